@@ -1,0 +1,98 @@
+// Shared device/host helpers for libnspeech_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/nspeech_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+// ---------------------------------------------------------------- errors
+void ns_set_error(const char* fmt, ...);
+
+#define NS_CHECK_ARG(cond, ...)                                   \
+  do {                                                            \
+    if (!(cond)) {                                                \
+      ns_set_error(__VA_ARGS__);                                  \
+      return NS_ERR_BAD_ARG;                                      \
+    }                                                             \
+  } while (0)
+
+#define NS_CHECK_LAUNCH(name)                                     \
+  do {                                                            \
+    hipError_t e__ = hipGetLastError();                           \
+    if (e__ != hipSuccess) {                                      \
+      ns_set_error("%s: launch failed: %s", name,                 \
+                   hipGetErrorString(e__));                       \
+      return NS_ERR_LAUNCH;                                       \
+    }                                                             \
+  } while (0)
+
+// ---------------------------------------------------------------- typed load/store
+template <typename T> struct dt_of;
+template <> struct dt_of<float> { static constexpr int v = NS_F32; };
+template <> struct dt_of<bf16_t> { static constexpr int v = NS_BF16; };
+
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
+__device__ __forceinline__ void stf(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) {
+  // accurate enough for fp32 parity (|err| ~1e-7) and cheap: tanh(x) = 1 - 2/(exp(2x)+1)
+  float ax = fabsf(x);
+  if (ax > 15.f) return copysignf(1.f, x);
+  float e = __expf(2.f * ax);
+  float t = 1.f - 2.f / (e + 1.f);
+  return copysignf(t, x);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case NS_ACT_RELU: return v > 0.f ? v : 0.f;
+    case NS_ACT_TANH: return tanhf_(v);
+    case NS_ACT_SIGMOID: return sigmoidf_(v);
+    default: return v;
+  }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-wide sum with 256..1024 threads; `red` is >= 32 floats of LDS scratch
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = 0.f;
+  for (int i = 0; i < nw; ++i) s += red[i];
+  return s;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float s = -INFINITY;
+  for (int i = 0; i < nw; ++i) s = fmaxf(s, red[i]);
+  return s;
+}
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,464 @@
+// GEMM family for the Tacotron hot path (dense, conv1d-as-strided-GEMM, LSTM/GRU gate
+// products and all of their data/weight gradients).  Three kernels behind ns_gemm():
+//   gemm_mfma_kernel   bf16 operands, 128x128x64 tiles, v_mfma_f32_16x16x32_bf16,
+//                      swizzled LDS images, k-slow operands read with ds_read_b64_tr_b16
+//   gemm_skinny_kernel bf16, M <= 32 rows (decoder / recurrent steps): fragments straight
+//                      from L2 to VGPRs, K split over the 4 waves of a workgroup
+//   gemm_generic_kernel any dtype / alignment (fp32 "exact" mode used by the parity tests,
+//                      and odd shapes)
+#include "common.h"
+
+// ------------------------------------------------------------------ shared epilogue
+struct Epi {
+  void* C; long ldc; int c_dtype; int accumulate;
+  const float* bias; int act; float alpha;
+  int row_period, row_lo, row_hi, row_shift;
+  int M, N;
+};
+
+__device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
+  Epi e;
+  e.C = p.C; e.ldc = p.ldc; e.c_dtype = p.c_dtype; e.accumulate = p.accumulate;
+  e.bias = p.bias; e.act = p.act; e.alpha = p.alpha;
+  e.row_period = p.row_period; e.row_lo = p.row_lo; e.row_hi = p.row_hi; e.row_shift = p.row_shift;
+  e.M = p.M; e.N = p.N;
+  return e;
+}
+
+__device__ __forceinline__ bool row_valid(const Epi& e, int m) {
+  if (e.row_period <= 0) return true;
+  int t = (m + e.row_shift) % e.row_period;
+  return t >= e.row_lo && t < e.row_hi;
+}
+
+// value after bias/act/mask (what BN statistics see)
+__device__ __forceinline__ float epi_value(const Epi& e, int m, int n, float acc, bool add_bias, bool valid) {
+  float v = e.alpha * acc;
+  if (add_bias && e.bias) v += e.bias[n];
+  v = apply_act(v, e.act);
+  return valid ? v : 0.f;
+}
+
+__device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float v) {
+  long off = (long)m * e.ldc + n;
+  if (e.accumulate == 2) {
+    atomicAdd((float*)e.C + off, v);
+  } else if (e.accumulate == 1) {
+    ((float*)e.C)[off] += v;
+  } else if (e.c_dtype == NS_BF16) {
+    ((bf16_t*)e.C)[off] = (bf16_t)v;
+  } else {
+    ((float*)e.C)[off] = v;
+  }
+}
+
+// ------------------------------------------------------------------ generic kernel
+template <typename T>
+__device__ __forceinline__ float ld_a(const ns_gemm_params& p, int m, int k) {
+  const T* A = (const T*)p.A;
+  return p.a_mode == 0 ? ldf(A + (long)m * p.lda + k) : ldf(A + (long)k * p.lda + m);
+}
+template <typename T>
+__device__ __forceinline__ float ld_b(const ns_gemm_params& p, int k, int n) {
+  const T* B = (const T*)p.B;
+  if (p.b_seg_len > 0) {
+    int s = k / p.b_seg_len;
+    B += (long)s * p.b_seg_stride;
+    k -= s * p.b_seg_len;
+  }
+  return p.b_mode == 0 ? ldf(B + (long)n * p.ldb + k) : ldf(B + (long)k * p.ldb + n);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
+  constexpr int BM = 64, BN = 64, BK = 16;
+  __shared__ float As[BK][BM + 1];
+  __shared__ float Bs[BK][BN + 1];
+  const int tid = threadIdx.x;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int tx = tid & 15, ty = tid >> 4;
+  // split-K over blockIdx.z
+  const int nk = (p.K + BK - 1) / BK;
+  const int per = (nk + p.split_k - 1) / p.split_k;
+  const int kt0 = blockIdx.z * per, kt1 = min(nk, kt0 + per);
+  float acc[4][4] = {};
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int k0 = kt * BK;
+    for (int i = tid; i < BK * BM; i += 256) {
+      int kk, mm;
+      if (p.a_mode == 0) { kk = i % BK; mm = i / BK; } else { mm = i % BM; kk = i / BM; }
+      int m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < p.M && k < p.K) ? ld_a<T>(p, m, k) : 0.f;
+    }
+    for (int i = tid; i < BK * BN; i += 256) {
+      int kk, nn;
+      if (p.b_mode == 0) { kk = i % BK; nn = i / BK; } else { nn = i % BN; kk = i / BN; }
+      int n = n0 + nn, k = k0 + kk;
+      Bs[kk][nn] = (n < p.N && k < p.K) ? ld_b<T>(p, k, n) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+  Epi e = make_epi(p);
+  const bool add_bias = (blockIdx.z == 0);
+  for (int i = 0; i < 4; ++i) {
+    int m = m0 + ty * 4 + i;
+    if (m >= p.M) continue;
+    bool valid = row_valid(e, m);
+    for (int j = 0; j < 4; ++j) {
+      int n = n0 + tx * 4 + j;
+      if (n >= p.N) continue;
+      float v = epi_value(e, m, n, acc[i][j], add_bias, valid);
+      epi_store(e, m, n, v);
+      if (valid && p.col_sum) {
+        // stats are taken on the value as the consumer will read it back
+        float vs = (p.c_dtype == NS_BF16 && p.accumulate == 0) ? (float)(bf16_t)v : v;
+        atomicAdd(p.col_sum + n, vs);
+        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, vs * vs);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ MFMA kernel
+// LDS images (bf16):
+//   k-contiguous operand ("row" image): [128 rows][64 k], 128 B rows, 16-B chunk index
+//       XOR ((row>>1)&7)  -> ds_read_b128 fragment reads are bank-conflict free
+//   k-slow operand ("col" image):       [64 k][128 cols], 256 B rows, 8-B unit index
+//       XOR (s(k)<<2), s(k) = (k&3)|((k>>1)&4) -> ds_read_b64_tr_b16 conflict free
+constexpr int GBM = 128, GBN = 128, GBK = 64;
+
+__device__ __forceinline__ int row_img_off(int row, int chunk) {  // bytes
+  return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+__device__ __forceinline__ int col_swz(int k) { return (k & 3) | ((k >> 1) & 4); }
+__device__ __forceinline__ int col_img_off_chunk(int k, int chunk) {  // 16-B chunk (write side)
+  return k * 256 + ((chunk ^ (col_swz(k) << 1)) << 4);
+}
+__device__ __forceinline__ int col_img_off_unit(int k, int unit) {  // 8-B unit (tr-read side)
+  return k * 256 + ((unit ^ (col_swz(k) << 2)) << 3);
+}
+
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+
+__device__ __forceinline__ bf16x8 frag_row(const char* img, int row, int chunk) {
+  return *(const bf16x8*)(img + row_img_off(row, chunk));
+}
+// 16x16x32 operand from a k-slow image: lane (i = l&15, g = l>>4) needs [k = kbase+8g+j][col0+i]
+__device__ __forceinline__ bf16x8 frag_col(const char* img, int kbase, int col0, int lane) {
+  const int i16 = lane & 15, g = lane >> 4;
+  const int q = i16 >> 2, pp = i16 & 3;
+  const int k = kbase + 8 * g + q;
+  const int unit = (col0 >> 2) + pp;
+  bf16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + col_img_off_unit(k, unit)));
+  bf16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + col_img_off_unit(k + 4, unit)));
+  return __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+struct Stage { uint4 v[4]; };
+
+// global -> registers for one 128x64 operand tile.  r0 = first row/col of the tile in the
+// non-contracted dim, extent = size of that dim, k0 = first k, K = contraction size.
+template <int MODE>
+__device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld, int r0, int extent,
+                                           int k0, int K, int tid) {
+  if (MODE == 0) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int r = r0 + row, k = k0 + c * 8;
+      if (r < extent && k < K) s.v[i] = *(const uint4*)(base + (long)r * ld + k);
+      else s.v[i] = make_uint4(0, 0, 0, 0);
+    }
+  } else {
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = (tid >> 4) + 16 * i;
+      const int k = k0 + kr, r = r0 + c * 8;
+      if (k < K && r < extent) s.v[i] = *(const uint4*)(base + (long)k * ld + r);
+      else s.v[i] = make_uint4(0, 0, 0, 0);
+    }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) {
+  if (MODE == 0) {
+    const int c = tid & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      *(uint4*)(img + row_img_off(row, c)) = s.v[i];
+    }
+  } else {
+    const int c = tid & 15;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = (tid >> 4) + 16 * i;
+      *(uint4*)(img + col_img_off_chunk(kr, c)) = s.v[i];
+    }
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [stage][A 16K | B 16K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + GBN - 1) / GBN;
+  const int tiles_m = (p.M + GBM - 1) / GBM;
+  // XCD-aware bijective remap: workgroups that share an XCD (id % 8) walk neighbouring tiles
+  const int nwg = tiles_m * tiles_n;
+  int wgid;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+
+  const int nk = (p.K + GBK - 1) / GBK;
+  const int per = (nk + p.split_k - 1) / p.split_k;
+  const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto b_tile_base = [&](int k0, int& kin) -> const bf16_t* {
+    if (p.b_seg_len > 0) {
+      int s = k0 / p.b_seg_len;
+      kin = k0 - s * p.b_seg_len;
+      return B + (long)s * p.b_seg_stride;
+    }
+    kin = k0;
+    return B;
+  };
+  const int KB = p.b_seg_len > 0 ? p.b_seg_len : p.K;
+
+  Stage sa, sb;
+  if (kt0 < kt1) {
+    int kin;
+    const bf16_t* bb = b_tile_base(kt0 * GBK, kin);
+    stage_load<AMODE>(sa, A, p.lda, m0, p.M, kt0 * GBK, p.K, tid);
+    stage_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+    stage_store<AMODE>(sa, smem, tid);
+    stage_store<BMODE>(sb, smem + 16384, tid);
+  }
+  __syncthreads();
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    char* imgA = smem + cur * 32768;
+    char* imgB = imgA + 16384;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      int kin;
+      const bf16_t* bb = b_tile_base((kt + 1) * GBK, kin);
+      stage_load<AMODE>(sa, A, p.lda, m0, p.M, (kt + 1) * GBK, p.K, tid);
+      stage_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bfr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (AMODE == 0) af[i] = frag_row(imgA, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        else af[i] = frag_col(imgA, ks * 32, wm * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (BMODE == 0) bfr[j] = frag_row(imgB, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        else bfr[j] = frag_col(imgB, ks * 32, wn * 64 + j * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      char* nA = smem + (cur ^ 1) * 32768;
+      stage_store<AMODE>(sa, nA, tid);
+      stage_store<BMODE>(sb, nA + 16384, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
+  Epi e = make_epi(p);
+  const bool add_bias = (blockIdx.y == 0);
+  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < p.M && n < p.N) {
+          const bool valid = row_valid(e, m);
+          float v = epi_value(e, m, n, acc[i][j][r], add_bias, valid);
+          epi_store(e, m, n, v);
+          if (valid) {
+            float vs = round_stats ? (float)(bf16_t)v : v;
+            s1 += vs;
+            s2 += vs * vs;
+          }
+        }
+      }
+    }
+    if (p.col_sum) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if ((lane >> 4) == 0 && n < p.N) {
+        atomicAdd(p.col_sum + n, s1);
+        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ skinny kernel (M <= 32)
+// Both operands k-contiguous (a_mode 0, b_mode 0).  One workgroup = 32 rows x 64 columns,
+// the 4 waves split K; fragments are 16-B global loads (weights stay L2 / MALL resident
+// across the time loop), partial sums meet in LDS.
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
+  __shared__ float red[4][32][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 64;
+  const bf16_t* A = (const bf16_t*)p.A;
+  const bf16_t* B = (const bf16_t*)p.B;
+  const int r16 = lane & 15, g = lane >> 4;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // K chunks of 32 dealt round-robin to waves
+  const int nkc = (p.K + 31) / 32;
+  for (int kc = wave; kc < nkc; kc += 4) {
+    const int k = kc * 32 + g * 8;
+    bf16x8 af[2], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = i * 16 + r16;
+      if (m < p.M && k < p.K) af[i] = *(const bf16x8*)(A + (long)m * p.lda + k);
+      else af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + j * 16 + r16;
+      if (n < p.N && k < p.K) bfr[j] = *(const bf16x8*)(B + (long)n * p.ldb + k);
+      else bfr[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
+  __syncthreads();
+  Epi e = make_epi(p);
+  for (int idx = tid; idx < 32 * 64; idx += 256) {
+    const int mm = idx >> 6, nn = idx & 63;
+    const int m = mm, n = n0 + nn;
+    if (m >= p.M || n >= p.N) continue;
+    float v = red[0][mm][nn] + red[1][mm][nn] + red[2][mm][nn] + red[3][mm][nn];
+    const bool valid = row_valid(e, m);
+    v = epi_value(e, m, n, v, true, valid);
+    epi_store(e, m, n, v);
+  }
+}
+
+// ------------------------------------------------------------------ host dispatch
+static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  NS_CHECK_ARG(pp != nullptr, "ns_gemm: null params");
+  ns_gemm_params p = *pp;
+  NS_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "ns_gemm: negative dims");
+  if (p.M == 0 || p.N == 0) return NS_OK;
+  NS_CHECK_ARG(p.A && p.B && p.C, "ns_gemm: null operand");
+  NS_CHECK_ARG(p.dtype == NS_F32 || p.dtype == NS_BF16, "ns_gemm: bad dtype %d", p.dtype);
+  NS_CHECK_ARG(p.c_dtype == NS_F32 || p.c_dtype == NS_BF16, "ns_gemm: bad c_dtype %d", p.c_dtype);
+  if (p.split_k < 1) p.split_k = 1;
+  NS_CHECK_ARG(p.accumulate >= 0 && p.accumulate <= 2, "ns_gemm: bad accumulate");
+  NS_CHECK_ARG(p.accumulate == 0 || p.c_dtype == NS_F32, "ns_gemm: accumulate needs fp32 C");
+  NS_CHECK_ARG(p.split_k == 1 || (p.accumulate == 2 && p.act == NS_ACT_NONE && !p.col_sum),
+               "ns_gemm: split_k>1 needs atomic accumulate, no activation, no stats");
+  NS_CHECK_ARG(p.b_seg_len == 0 || (p.b_seg_len > 0 && p.K % p.b_seg_len == 0),
+               "ns_gemm: K must be a multiple of b_seg_len");
+  if (p.alpha == 0.f) p.alpha = 1.f;
+
+  bool fast = (p.dtype == NS_BF16) && aligned16(p.A) && aligned16(p.B) && (p.lda % 8 == 0) &&
+              (p.ldb % 8 == 0) && (p.b_seg_stride % 8 == 0);
+  if (fast) {
+    // contiguous-dim extents must be whole 16-B chunks
+    if (p.a_mode == 0) fast = fast && (p.K % 8 == 0); else fast = fast && (p.M % 8 == 0);
+    if (p.b_mode == 0) fast = fast && (p.K % 8 == 0); else fast = fast && (p.N % 8 == 0);
+    if (p.b_seg_len > 0) fast = fast && (p.b_seg_len % GBK == 0);
+  }
+  if (fast && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 &&
+      !p.col_sum) {
+    dim3 grid(ceil_div(p.N, 64));
+    hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), 0, stream, p);
+    NS_CHECK_LAUNCH("gemm_skinny");
+    return NS_OK;
+  }
+  if (fast) {
+    const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
+    dim3 grid(tiles, p.split_k);
+    const size_t lds = 65536;
+#define LAUNCH_MFMA(AM, BM_)                                                                      \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<AM, BM_>,                               \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_>), grid, dim3(256), lds, stream, p);             \
+  } while (0)
+    if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
+    else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_MFMA(0, 1);
+    else if (p.a_mode == 1 && p.b_mode == 0) LAUNCH_MFMA(1, 0);
+    else LAUNCH_MFMA(1, 1);
+#undef LAUNCH_MFMA
+    NS_CHECK_LAUNCH("gemm_mfma");
+    return NS_OK;
+  }
+  dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k);
+  if (p.dtype == NS_F32) hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(gemm_generic_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
+  NS_CHECK_LAUNCH("gemm_generic");
+  return NS_OK;
+}
