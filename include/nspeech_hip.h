@@ -65,8 +65,189 @@ typedef struct {
   int row_period, row_lo, row_hi, row_shift;
   float* col_sum; float* col_sumsq;
   int split_k;
+  const float* addend; int64_t ld_add;   /* optional fp32 [M,N] added before the activation */
+  const void* gate; int64_t ld_gate;     /* optional (dtype of A) [M,N]: result *= (gate > 0)  (ReLU backward) */
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
+
+
+/* ------------------------------------------------------------------ element-wise / reductions */
+
+/* dst[i,j,c] (=|+=) src[i,j,c] with independent strides and dtypes (pack / pad / concat /
+ * cast).  Replaces tf.reshape / tf.concat / slicing glue (tacotron2.py:86, helpers.py:53,
+ * rnn_wrappers.py:58-64). */
+typedef struct {
+  const void* src; int src_dtype; int64_t src_si, src_sj;
+  void* dst; int dst_dtype; int64_t dst_si, dst_sj;
+  int I, J, Cc;
+  int accumulate;
+} ns_copy3d_params;
+int ns_copy3d(const ns_copy3d_params* p, ns_stream_t stream);
+
+/* tf.nn.embedding_lookup (modules.py:8-18) into the padded layout, and its scatter-add
+ * gradient. */
+typedef struct {
+  const int* ids;          /* [N,T] int32 */
+  const float* table;      /* [V,D] */
+  void* out; int out_dtype; /* [N,P,D] */
+  int N, T, P, padl, D, V;
+} ns_embedding_params;
+int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t stream);
+typedef struct {
+  const int* ids;
+  const float* dout;       /* fp32 [N,P,D] */
+  float* dtable;           /* [V,D] += */
+  int N, T, P, padl, D, V;
+} ns_embedding_bwd_params;
+int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t stream);
+
+/* tf.layers.batch_normalization (modules.py:198), axis -1, eps 1e-3, momentum 0.99.
+ * Training: statistics come from col_sum / col_sumsq (accumulated by the producing GEMM)
+ * over `count` rows; moving stats are updated in place.  Inference: moving stats.
+ * Rows failing the (period, lo, hi) test are written as zero. */
+typedef struct {
+  const void* z; void* y; int dtype;        /* [rows,C] both */
+  int rows, C;
+  const float* col_sum; const float* col_sumsq; float count;
+  const float* gamma; const float* beta;
+  float* moving_mean; float* moving_var;
+  float* mean_out; float* istd_out;         /* saved for backward, [C] each */
+  float eps, momentum;
+  int training;
+  int row_period, row_lo, row_hi;
+} ns_bn_fwd_params;
+int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t stream);
+
+/* BatchNorm + activation + bias backward of modules.py:194-198.
+ * dy fp32 [rows,C] (grad wrt BN output), z = activated pre-BN value saved by forward.
+ * Outputs: dpre (grad wrt conv output before the activation, operand dtype, pad rows 0),
+ * dgamma/dbeta/dbias += .  work = fp32[2*C] scratch, zeroed by the call. */
+typedef struct {
+  const float* dy; const void* z; void* dpre; int dtype;
+  int rows, C;
+  const float* mean; const float* istd; const float* gamma;
+  float* dgamma; float* dbeta; float* dbias;
+  float* work;
+  float count;
+  int act;
+  int row_period, row_lo, row_hi;
+} ns_bn_bwd_params;
+int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t stream);
+
+/* out[c] += sum over rows of x[row,c]  (bias gradients). */
+typedef struct {
+  const void* x; int dtype; int64_t ld;
+  int rows, C;
+  float* out;
+} ns_colsum_params;
+int ns_colsum(const ns_colsum_params* p, ns_stream_t stream);
+
+/* L1 losses of tacotron2.py:130-139 and their gradient in one pass.
+ * pred fp32 padded [N,P,ldp] (valid rows padl..padl+T), target fp32 [N,T,F].
+ * loss_acc[0] += sum|d| over all bins, loss_acc[1] += sum|d| over bins < n_prio.
+ * dpred[n,padl+t,f] = sign(pred-target) * (w_all + (f<n_prio ? w_prio : 0)). */
+typedef struct {
+  const float* pred; int64_t ldp;
+  const float* target;
+  void* dpred; int dpred_dtype; int64_t ldd;
+  int N, T, P, padl, F;
+  int n_prio; float w_all, w_prio;
+  float* loss_acc;
+} ns_l1_loss_params;
+int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * tf.clip_by_global_norm + tf.train.AdamOptimizer (tacotron2.py:150-161).
+ * ns_sumsq: out[0] += sum g^2.   ns_adam: scale = clip / max(sqrt(gnorm_sq[0]), clip);
+ * m,v,p updated in place with lr_t (bias-corrected on the host); optional bf16 shadow copy. */
+typedef struct { const float* x; int64_t n; float* out; } ns_sumsq_params;
+int ns_sumsq(const ns_sumsq_params* p, ns_stream_t stream);
+typedef struct {
+  float* p; const float* g; float* m; float* v; int64_t n;
+  const float* gnorm_sq; float clip; float grad_scale;
+  float lr_t, beta1, beta2, eps;
+  void* shadow_bf16;
+} ns_adam_params;
+int ns_adam(const ns_adam_params* p, ns_stream_t stream);
+
+/* dst[c,r] = (T)src[r,c]  (k-contiguous shadow copies of recurrent weights). */
+typedef struct {
+  const float* src; int rows, cols; int64_t ld_src;
+  void* dst; int dst_dtype; int64_t ld_dst;
+  int transpose;
+} ns_cast2d_params;
+int ns_cast2d(const ns_cast2d_params* p, ns_stream_t stream);
+
+/* ------------------------------------------------------------------ LSTM over time
+ * tf.contrib.rnn.LSTMBlockCell inside dynamic_rnn / bidirectional_dynamic_rnn / dynamic_decode
+ * (modules.py:40-49, tacotron2.py:67-83): gates [i,j,f,o] = xg[t] + h[t-1].Wh,
+ * c' = sig(f+forget_bias)*c + sig(i)*tanh(j), h' = sig(o)*tanh(c').
+ * xg = x.Wx + b is hoisted by the caller into one big ns_gemm.  All per-row buffers use the
+ * padded layout row(n,t) = n*P + padl + t; h and c of step t-1 (t+1 when reverse) are read
+ * back from hist buffers, whose pad rows must be zero (= zero initial state).
+ * lengths (optional): rows with t >= lengths[n] emit h = 0, c = 0 (state frozen at zero
+ * initial state for the reverse direction, unused afterwards for the forward one). */
+typedef struct {
+  int dtype;
+  int N, T, H, P, padl;
+  const float* xg; int64_t ld_xg;      /* [N*P, >=4H] fp32 */
+  const void* whT;                      /* [4H, H] (dtype) k-contiguous */
+  const void* wh;                       /* [H, 4H] (dtype) natural layout (backward) */
+  const int* lengths;
+  int reverse;
+  float forget_bias;
+  void* h; int64_t ld_h;                /* (dtype) [N*P, ld_h], this direction's H columns */
+  float* c;                             /* fp32 [N*P, H] */
+  void* gates;                          /* (dtype) [N*P, 4H] post-activation i,j,f,o */
+  /* backward only */
+  const float* dh; int64_t ld_dh;       /* fp32 [N*P, ld_dh] grad wrt h outputs */
+  void* dgates;                         /* (dtype) [N*P, 4H] out */
+  float* work;                          /* fp32 [2*N*H] + (dtype)[N*4H] scratch */
+} ns_lstm_seq_params;
+int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
+int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
+size_t ns_lstm_seq_work_bytes(const ns_lstm_seq_params* p);
+
+
+/* ------------------------------------------------------------------ Tacotron-2 attention RNN
+ * The part of the decoder loop that is recurrent through the attention state
+ * (tacotron2.py:63-83 with AttentionWrapper(PrenetWrapper(LSTMBlockCell(256)),
+ * LocationSensitiveAttention), modules.py:83-102, attention.py:30-60, rnn_wrappers.py:25-31):
+ *   p1 = relu(F1[s] + ctx[s-1].W1c)       (F1 = frame part of prenet dense_1 + bias, hoisted)
+ *   p2 = relu(p1.W2 + b2)
+ *   (c,h) = LSTM([p2, h[s-1]].Watt + b)
+ *   e[t] = sum_u v[u] tanh(keys[t,u] + (h.Wq)[u] + sum_k align[s-1][t+k-kw/2] Wcl[k,u])
+ *   align[s] = softmax over t < length;  ctx[s] = sum_t align[s][t] values[t]
+ * where Wcl = location_conv . location_layer folded into one [kw, A] filter.
+ * In training (teacher forcing, helpers.py:73-77) this chain does not depend on the two
+ * decoder LSTMs, so it runs first for all S steps and the big LSTMs get hoisted inputs.
+ * All per-step buffers are [N, S+1, X]: step s lives in slot s+1, slot 0 is the zero initial
+ * state and must be zero on entry.
+ */
+typedef struct {
+  int dtype;
+  int N, S, Ti, Pi, padl_i, Tia;   /* memory row(n,t) = n*Pi + padl_i + t; Tia = ld of align */
+  int A, E, D1, D2, kw;
+  const int* lengths;
+  const float* keys;               /* fp32 [N*Pi, A] */
+  const void* values;              /* (dtype) [N*Pi, E] */
+  const float* f1;                 /* fp32 [N,S+1,D1] */
+  const void* w1cT; const void* w2T; const void* wattT; const void* wqT;   /* k-contiguous (dtype) */
+  const float* b2; const float* batt; const float* wcl; const float* v;
+  void* p1; void* xa; void* hc;    /* (dtype) [N,S+1,D1], [N,S+1,D2+A], [N,S+1,A+E] */
+  float* ca; void* ga;             /* fp32 [N,S+1,A], (dtype) [N,S+1,4A] */
+  float* q; float* align;          /* fp32 [N,S+1,A], fp32 [N,S+1,Tia] */
+  /* backward */
+  const void* w1c; const void* w2; const void* watt; const void* wq;       /* natural layouts (dtype) */
+  const float* dhc;                /* fp32 [N,S+1,A+E] grad wrt hc from downstream */
+  void* df1; void* dp2; void* dga; void* dq;    /* (dtype) [N,S+1,D1|D2|4A|A] out */
+  float* dkeys; float* dvalues;    /* fp32 [N*Pi,A], [N*Pi,E] += */
+  float* dv; float* dwcl;          /* fp32 [A], [kw*A] += */
+  float* work;                     /* fp32 scratch, ns_taco2_attn_work_bytes() */
+} ns_taco2_attn_params;
+int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
+int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
+size_t ns_taco2_attn_work_bytes(const ns_taco2_attn_params* p);
 
 #ifdef __cplusplus
 }

@@ -1,13 +1,17 @@
 """ctypes binding of libnspeech_hip.so (the C ABI declared in include/nspeech_hip.h).
 
-The product path has NO CPU fallback: if the shared library is missing or a call
-fails, this module raises.  PyTorch only supplies device memory and streams.
+The parameter structs are generated from the header itself at import time, so the Python
+side cannot drift from the C side.  The product path has NO CPU fallback: if the shared
+library is missing or a call fails, this module raises.  PyTorch only supplies device
+memory and streams.
 """
 import ctypes as C
 import os
+import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libnspeech_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nspeech_hip.h")
 
 NS_F32, NS_BF16 = 0, 1
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3
@@ -17,6 +21,52 @@ _lib = None
 
 class NSError(RuntimeError):
     pass
+
+
+_CTYPES = {
+    "int": C.c_int, "float": C.c_float, "double": C.c_double, "int64_t": C.c_int64,
+    "int32_t": C.c_int32, "uint32_t": C.c_uint32, "uint64_t": C.c_uint64, "size_t": C.c_size_t,
+}
+
+
+def _parse_header():
+    """Return ({struct name: ctypes.Structure subclass}, [exported function names])."""
+    src = open(HEADER_PATH).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    structs = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(\w+)\s*;", src, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            m = re.match(r"(const\s+)?(\w+)\s*(\*?)\s*(.+)$", decl)
+            base, star, names = m.group(2), m.group(3), m.group(4)
+            for nm in names.split(","):
+                nm = nm.strip()
+                is_ptr = bool(star) or nm.startswith("*")
+                nm = nm.lstrip("* ")
+                arr = re.match(r"(\w+)\[(\d+)\]$", nm)
+                if is_ptr:
+                    ct = C.c_void_p
+                else:
+                    ct = _CTYPES[base]
+                if arr:
+                    nm = arr.group(1)
+                    ct = ct * int(arr.group(2))
+                fields.append((nm, ct))
+        structs[name] = type(name, (C.Structure,), {"_fields_": fields})
+    funcs = re.findall(r"\b(ns_\w+)\s*\(", src)
+    funcs = sorted(set(f for f in funcs if not f.endswith("_params")))
+    return structs, funcs
+
+
+STRUCTS, FUNCS = _parse_header()
+
+
+def struct(name):
+    return STRUCTS[name]()
 
 
 def lib():
@@ -46,18 +96,5 @@ def call(name, params, stream):
     check(rc, name)
 
 
-class GemmParams(C.Structure):
-    _fields_ = [
-        ("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
-        ("A", C.c_void_p), ("lda", C.c_int64), ("a_mode", C.c_int),
-        ("B", C.c_void_p), ("ldb", C.c_int64), ("b_mode", C.c_int),
-        ("b_seg_len", C.c_int), ("b_seg_stride", C.c_int64),
-        ("C", C.c_void_p), ("ldc", C.c_int64), ("c_dtype", C.c_int),
-        ("accumulate", C.c_int),
-        ("bias", C.c_void_p),
-        ("act", C.c_int),
-        ("alpha", C.c_float),
-        ("row_period", C.c_int), ("row_lo", C.c_int), ("row_hi", C.c_int), ("row_shift", C.c_int),
-        ("col_sum", C.c_void_p), ("col_sumsq", C.c_void_p),
-        ("split_k", C.c_int),
-    ]
+def GemmParams():
+    return struct("ns_gemm_params")

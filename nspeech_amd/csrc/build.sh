@@ -9,7 +9,7 @@ pids=()
 for f in *.hip; do
   o="${f%.hip}.o"
   OBJS="$OBJS $o"
-  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ common.h -nt "$o" ] || [ ../../include/nspeech_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find . -name "*.h" -newer "$o")" ] || [ ../../include/nspeech_hip.h -nt "$o" ]; then
     $HIPCC $FLAGS -c "$f" -o "$o" &
     pids+=($!)
   fi

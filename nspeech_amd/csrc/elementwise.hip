@@ -1,0 +1,348 @@
+// Bandwidth-bound kernels around the GEMMs: strided copy/cast, embedding, BatchNorm forward /
+// backward (+ activation and bias gradient), column sums, L1 loss + gradient, Adam with global
+// norm clipping, transposing casts.  All grid-stride, vectorised where layouts allow.
+#include "common.h"
+
+__device__ __forceinline__ float ld_dyn(const void* p, int dtype, long i) {
+  return dtype == NS_BF16 ? (float)((const bf16_t*)p)[i] : ((const float*)p)[i];
+}
+__device__ __forceinline__ void st_dyn(void* p, int dtype, long i, float v) {
+  if (dtype == NS_BF16) ((bf16_t*)p)[i] = (bf16_t)v;
+  else ((float*)p)[i] = v;
+}
+
+// ------------------------------------------------------------------ copy3d
+__global__ void copy3d_kernel(ns_copy3d_params p) {
+  const long total = (long)p.I * p.J * p.Cc;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = idx % p.Cc;
+    const long ij = idx / p.Cc;
+    const int j = ij % p.J;
+    const int i = ij / p.J;
+    const float v = ld_dyn(p.src, p.src_dtype, i * p.src_si + j * p.src_sj + c);
+    const long d = i * p.dst_si + j * p.dst_sj + c;
+    if (p.accumulate) st_dyn(p.dst, p.dst_dtype, d, ld_dyn(p.dst, p.dst_dtype, d) + v);
+    else st_dyn(p.dst, p.dst_dtype, d, v);
+  }
+}
+extern "C" int ns_copy3d(const ns_copy3d_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->src && p->dst, "ns_copy3d: null");
+  const long total = (long)p->I * p->J * p->Cc;
+  if (total <= 0) return NS_OK;
+  int grid = (int)min((long)4096, (total + 255) / 256);
+  hipLaunchKernelGGL(copy3d_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("copy3d");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ embedding
+__global__ void embedding_fwd_kernel(ns_embedding_params p) {
+  const int row = blockIdx.x;  // n*T + t
+  const int n = row / p.T, t = row % p.T;
+  int id = p.ids[row];
+  id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
+  const float* src = p.table + (long)id * p.D;
+  const long dst = ((long)n * p.P + p.padl + t) * p.D;
+  for (int d = threadIdx.x; d < p.D; d += blockDim.x) st_dyn(p.out, p.out_dtype, dst + d, src[d]);
+}
+extern "C" int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->ids && p->table && p->out, "ns_embedding_fwd: null");
+  if (p->N * p->T == 0) return NS_OK;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(p->N * p->T), dim3(64), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("embedding_fwd");
+  return NS_OK;
+}
+__global__ void embedding_bwd_kernel(ns_embedding_bwd_params p) {
+  const int row = blockIdx.x;
+  const int n = row / p.T, t = row % p.T;
+  int id = p.ids[row];
+  id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
+  const float* src = p.dout + ((long)n * p.P + p.padl + t) * p.D;
+  float* dst = p.dtable + (long)id * p.D;
+  for (int d = threadIdx.x; d < p.D; d += blockDim.x) atomicAdd(dst + d, src[d]);
+}
+extern "C" int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->ids && p->dout && p->dtable, "ns_embedding_bwd: null");
+  if (p->N * p->T == 0) return NS_OK;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(p->N * p->T), dim3(64), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("embedding_bwd");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm forward
+__global__ void bn_finalize_kernel(ns_bn_fwd_params p) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  float mean, var;
+  if (p.training) {
+    mean = p.col_sum[c] / p.count;
+    var = p.col_sumsq[c] / p.count - mean * mean;
+    var = var < 0.f ? 0.f : var;
+    if (p.moving_mean) {
+      p.moving_mean[c] = p.moving_mean[c] * p.momentum + mean * (1.f - p.momentum);
+      p.moving_var[c] = p.moving_var[c] * p.momentum + var * (1.f - p.momentum);
+    }
+  } else {
+    mean = p.moving_mean[c];
+    var = p.moving_var[c];
+  }
+  p.mean_out[c] = mean;
+  p.istd_out[c] = rsqrtf(var + p.eps);
+}
+
+template <typename T>
+__global__ void bn_apply_kernel(ns_bn_fwd_params p) {
+  const T* z = (const T*)p.z;
+  T* y = (T*)p.y;
+  const long total = (long)p.rows * p.C;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int c = idx % p.C;
+    const int row = idx / p.C;
+    bool valid = true;
+    if (p.row_period > 0) {
+      const int t = row % p.row_period;
+      valid = t >= p.row_lo && t < p.row_hi;
+    }
+    float v = 0.f;
+    if (valid) v = (ldf(z + idx) - p.mean_out[c]) * p.istd_out[c] * p.gamma[c] + p.beta[c];
+    stf(y + idx, v);
+  }
+}
+extern "C" int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->z && p->y && p->gamma && p->beta && p->mean_out && p->istd_out, "ns_bn_fwd: null");
+  NS_CHECK_ARG(!p->training || (p->col_sum && p->col_sumsq && p->count > 0), "ns_bn_fwd: training needs stats");
+  NS_CHECK_ARG(p->training || (p->moving_mean && p->moving_var), "ns_bn_fwd: inference needs moving stats");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(p->C, 256)), dim3(256), 0, (hipStream_t)s, *p);
+  const long total = (long)p->rows * p->C;
+  int grid = (int)min((long)8192, (total + 255) / 256);
+  if (p->dtype == NS_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("bn_fwd");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm backward
+// pass 1: work[c] = sum dy, work[C+c] = sum dy*xhat  over valid rows.  Block = 256 threads,
+// each block covers ROWS_PER_BLOCK rows; threads stride over channels (coalesced).
+constexpr int BN_ROWS_PER_BLOCK = 64;
+
+template <typename T>
+__global__ void bn_bwd_reduce_kernel(ns_bn_bwd_params p) {
+  const T* z = (const T*)p.z;
+  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
+  const int r1 = min(p.rows, r0 + BN_ROWS_PER_BLOCK);
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    const float mean = p.mean[c], istd = p.istd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      if (p.row_period > 0) {
+        const int t = row % p.row_period;
+        if (t < p.row_lo || t >= p.row_hi) continue;
+      }
+      const long idx = (long)row * p.C + c;
+      const float dy = p.dy[idx];
+      const float xh = (ldf(z + idx) - mean) * istd;
+      s1 += dy;
+      s2 += dy * xh;
+    }
+    atomicAdd(p.work + c, s1);
+    atomicAdd(p.work + p.C + c, s2);
+  }
+}
+
+// pass 2: dz = gamma*istd*(dy - s1/M - xhat*s2/M); dpre = dz*act'(z); dbias += colsum(dpre)
+template <typename T>
+__global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
+  const T* z = (const T*)p.z;
+  T* dpre = (T*)p.dpre;
+  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
+  const int r1 = min(p.rows, r0 + BN_ROWS_PER_BLOCK);
+  const float invM = 1.f / p.count;
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    const float mean = p.mean[c], istd = p.istd[c], g = p.gamma[c];
+    const float m1 = p.work[c] * invM, m2 = p.work[p.C + c] * invM;
+    float sb = 0.f;
+    for (int row = r0; row < r1; ++row) {
+      const long idx = (long)row * p.C + c;
+      bool valid = true;
+      if (p.row_period > 0) {
+        const int t = row % p.row_period;
+        valid = t >= p.row_lo && t < p.row_hi;
+      }
+      float d = 0.f;
+      if (valid) {
+        const float zv = ldf(z + idx);
+        const float xh = (zv - mean) * istd;
+        d = g * istd * (p.dy[idx] - m1 - xh * m2);
+        if (p.act == NS_ACT_RELU) d = zv > 0.f ? d : 0.f;
+        else if (p.act == NS_ACT_TANH) d *= (1.f - zv * zv);
+        else if (p.act == NS_ACT_SIGMOID) d *= zv * (1.f - zv);
+      }
+      stf(dpre + idx, d);
+      // bias gradient is taken on the value the weight-gradient GEMM will read
+      sb += (float)(T)d;
+    }
+    if (p.dbias) atomicAdd(p.dbias + c, sb);
+    if (blockIdx.x == 0) {
+      if (p.dgamma) p.dgamma[c] += p.work[p.C + c];
+      if (p.dbeta) p.dbeta[c] += p.work[c];
+    }
+  }
+}
+extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && p->dy && p->z && p->dpre && p->mean && p->istd && p->gamma && p->work, "ns_bn_bwd: null");
+  if (hipMemsetAsync(p->work, 0, sizeof(float) * 2 * p->C, s) != hipSuccess) {
+    ns_set_error("ns_bn_bwd: memset failed");
+    return NS_ERR_LAUNCH;
+  }
+  const int grid = ceil_div(p->rows, BN_ROWS_PER_BLOCK);
+  if (p->dtype == NS_BF16) {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *p);
+  } else {
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, dim3(grid), dim3(256), 0, s, *p);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, s, *p);
+  }
+  NS_CHECK_LAUNCH("bn_bwd");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ column sums
+__global__ void colsum_kernel(ns_colsum_params p) {
+  const int r0 = blockIdx.x * 64;
+  const int r1 = min(p.rows, r0 + 64);
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float s = 0.f;
+    for (int row = r0; row < r1; ++row) s += ld_dyn(p.x, p.dtype, (long)row * p.ld + c);
+    atomicAdd(p.out + c, s);
+  }
+}
+extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->x && p->out, "ns_colsum: null");
+  if (p->rows <= 0 || p->C <= 0) return NS_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(p->rows, 64)), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("colsum");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ L1 loss + gradient
+__global__ void l1_loss_kernel(ns_l1_loss_params p) {
+  __shared__ float red[32];
+  const long total = (long)p.N * p.T * p.F;
+  float s_all = 0.f, s_pr = 0.f;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const int f = idx % p.F;
+    const long nt = idx / p.F;
+    const int t = nt % p.T;
+    const int n = nt / p.T;
+    const long prow = (long)n * p.P + p.padl + t;
+    const float d = p.pred[prow * p.ldp + f] - p.target[idx];
+    const float a = fabsf(d);
+    s_all += a;
+    const bool pr = f < p.n_prio;
+    if (pr) s_pr += a;
+    if (p.dpred) {
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      st_dyn(p.dpred, p.dpred_dtype, prow * p.ldd + f, sg * (p.w_all + (pr ? p.w_prio : 0.f)));
+    }
+  }
+  s_all = block_sum(s_all, red);
+  s_pr = block_sum(s_pr, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(p.loss_acc, s_all);
+    atomicAdd(p.loss_acc + 1, s_pr);
+  }
+}
+extern "C" int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->pred && p->target && p->loss_acc, "ns_l1_loss: null");
+  const long total = (long)p->N * p->T * p->F;
+  if (total <= 0) return NS_OK;
+  int grid = (int)min((long)2048, (total + 255) / 256);
+  hipLaunchKernelGGL(l1_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("l1_loss");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ sum of squares / Adam
+__global__ void sumsq_kernel(ns_sumsq_params p) {
+  __shared__ float red[32];
+  float s = 0.f;
+  const long n4 = p.n / 4;
+  const float4* x4 = (const float4*)p.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x)
+    s += p.x[i] * p.x[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) atomicAdd(p.out, s);
+}
+extern "C" int ns_sumsq(const ns_sumsq_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->x && p->out, "ns_sumsq: null");
+  NS_CHECK_ARG((((uintptr_t)p->x) & 15) == 0, "ns_sumsq: x must be 16-byte aligned");
+  if (p->n <= 0) return NS_OK;
+  int grid = (int)min((long)1024, (p->n / 4 + 255) / 256 + 1);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("sumsq");
+  return NS_OK;
+}
+
+__global__ void adam_kernel(ns_adam_params p) {
+  float scale = p.grad_scale;
+  if (p.gnorm_sq) {
+    const float gn = sqrtf(p.gnorm_sq[0]) * p.grad_scale;
+    scale *= p.clip / fmaxf(gn, p.clip);
+  }
+  bf16_t* sh = (bf16_t*)p.shadow_bf16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x) {
+    const float g = p.g[i] * scale;
+    const float m = p.beta1 * p.m[i] + (1.f - p.beta1) * g;
+    const float v = p.beta2 * p.v[i] + (1.f - p.beta2) * g * g;
+    const float w = p.p[i] - p.lr_t * m / (sqrtf(v) + p.eps);
+    p.m[i] = m;
+    p.v[i] = v;
+    p.p[i] = w;
+    if (sh) sh[i] = (bf16_t)w;
+  }
+}
+extern "C" int ns_adam(const ns_adam_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->p && p->g && p->m && p->v, "ns_adam: null");
+  if (p->n <= 0) return NS_OK;
+  int grid = (int)min((long)4096, (p->n + 255) / 256);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("adam");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ cast / transpose 2-D
+__global__ void cast2d_kernel(ns_cast2d_params p) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx over cols, by over rows of src
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 32 x 8
+  for (int j = ty; j < 32; j += 8) {
+    const int r = by + j, c = bx + tx;
+    tile[j][tx] = (r < p.rows && c < p.cols) ? p.src[(long)r * p.ld_src + c] : 0.f;
+  }
+  __syncthreads();
+  if (p.transpose) {
+    for (int j = ty; j < 32; j += 8) {
+      const int c = bx + j, r = by + tx;  // dst[c][r]
+      if (r < p.rows && c < p.cols) st_dyn(p.dst, p.dst_dtype, (long)c * p.ld_dst + r, tile[tx][j]);
+    }
+  } else {
+    for (int j = ty; j < 32; j += 8) {
+      const int r = by + j, c = bx + tx;
+      if (r < p.rows && c < p.cols) st_dyn(p.dst, p.dst_dtype, (long)r * p.ld_dst + c, tile[j][tx]);
+    }
+  }
+}
+extern "C" int ns_cast2d(const ns_cast2d_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->src && p->dst, "ns_cast2d: null");
+  if (p->rows <= 0 || p->cols <= 0) return NS_OK;
+  dim3 grid(ceil_div(p->cols, 32), ceil_div(p->rows, 32));
+  hipLaunchKernelGGL(cast2d_kernel, grid, dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("cast2d");
+  return NS_OK;
+}

@@ -14,6 +14,8 @@ struct Epi {
   const float* bias; int act; float alpha;
   int row_period, row_lo, row_hi, row_shift;
   int M, N;
+  const float* addend; long ld_add;
+  const void* gate; long ld_gate; int gate_dtype;
 };
 
 __device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
@@ -22,6 +24,8 @@ __device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
   e.bias = p.bias; e.act = p.act; e.alpha = p.alpha;
   e.row_period = p.row_period; e.row_lo = p.row_lo; e.row_hi = p.row_hi; e.row_shift = p.row_shift;
   e.M = p.M; e.N = p.N;
+  e.addend = p.addend; e.ld_add = p.ld_add;
+  e.gate = p.gate; e.ld_gate = p.ld_gate; e.gate_dtype = p.dtype;
   return e;
 }
 
@@ -35,7 +39,13 @@ __device__ __forceinline__ bool row_valid(const Epi& e, int m) {
 __device__ __forceinline__ float epi_value(const Epi& e, int m, int n, float acc, bool add_bias, bool valid) {
   float v = e.alpha * acc;
   if (add_bias && e.bias) v += e.bias[n];
+  if (add_bias && e.addend) v += e.addend[(long)m * e.ld_add + n];
   v = apply_act(v, e.act);
+  if (e.gate) {
+    const long go = (long)m * e.ld_gate + n;
+    const float gv = e.gate_dtype == NS_BF16 ? (float)((const bf16_t*)e.gate)[go] : ((const float*)e.gate)[go];
+    if (!(gv > 0.f)) v = 0.f;
+  }
   return valid ? v : 0.f;
 }
 
@@ -344,23 +354,25 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
 // Both operands k-contiguous (a_mode 0, b_mode 0).  One workgroup = 32 rows x 64 columns,
 // the 4 waves split K; fragments are 16-B global loads (weights stay L2 / MALL resident
 // across the time loop), partial sums meet in LDS.
+template <int NT>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
-  __shared__ float red[4][32][65];
+  __shared__ float red[4][32][NT * 16 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 64;
+  const int n0 = blockIdx.x * (NT * 16);
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
   const int r16 = lane & 15, g = lane >> 4;
-  f32x4 acc[2][4];
+  f32x4 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   // K chunks of 32 dealt round-robin to waves
   const int nkc = (p.K + 31) / 32;
+#pragma unroll 2
   for (int kc = wave; kc < nkc; kc += 4) {
     const int k = kc * 32 + g * 8;
-    bf16x8 af[2], bfr[4];
+    bf16x8 af[2], bfr[NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = i * 16 + r16;
@@ -368,7 +380,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
       else af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NT; ++j) {
       const int n = n0 + j * 16 + r16;
       if (n < p.N && k < p.K) bfr[j] = *(const bf16x8*)(B + (long)n * p.ldb + k);
       else bfr[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
@@ -376,19 +388,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NT; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   __syncthreads();
   Epi e = make_epi(p);
-  for (int idx = tid; idx < 32 * 64; idx += 256) {
-    const int mm = idx >> 6, nn = idx & 63;
+  for (int idx = tid; idx < 32 * NT * 16; idx += 256) {
+    const int mm = idx / (NT * 16), nn = idx % (NT * 16);
     const int m = mm, n = n0 + nn;
     if (m >= p.M || n >= p.N) continue;
     float v = red[0][mm][nn] + red[1][mm][nn] + red[2][mm][nn] + red[3][mm][nn];
@@ -429,8 +441,10 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   }
   if (fast && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 &&
       !p.col_sum) {
-    dim3 grid(ceil_div(p.N, 64));
-    hipLaunchKernelGGL(gemm_skinny_kernel, grid, dim3(256), 0, stream, p);
+    // enough workgroups to spread the weight stream over the chip
+    if (p.N >= 64 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(ceil_div(p.N, 64)), dim3(256), 0, stream, p);
+    else if (p.N >= 32 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(ceil_div(p.N, 32)), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(256), 0, stream, p);
     NS_CHECK_LAUNCH("gemm_skinny");
     return NS_OK;
   }

@@ -1,0 +1,688 @@
+"""Tacotron-2 (as coded in the reference's neural_speech/models/tacotron2.py:15-161) on MI355X.
+
+Same surface as the reference class (initialize / add_loss / add_optimizer / add_stats and the
+attributes train.py / synthesizer.py read), but eager: every tensor op below is a call into
+libnspeech_hip.so (hand-written HIP for gfx950) through nspeech_amd.ops; torch only owns the
+device memory.  Forward AND backward are written out explicitly - there is no autograd tape.
+
+MI355X-first restructuring of the training step (results identical to the reference graph):
+  * conv1d 'same' = ONE strided GEMM over a zero-padded [N, T+4, C] layout (no im2col copy),
+    bias + activation + BatchNorm statistics fused in the GEMM epilogue;
+  * under teacher forcing the attention RNN (prenet -> LSTM(256) -> location-sensitive
+    attention) does not depend on the two 1024-unit decoder LSTMs, so it runs first for all
+    steps; the big LSTMs then take hoisted [N*S, K] x [K, 4096] input GEMMs and only their
+    recurrent halves stay in the time loop; the output projection is one GEMM;
+  * every weight gradient is a hoisted GEMM over all time steps.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU, ACT_TANH
+from ..utils.text.symbols import symbols
+from . import params as P_
+
+PADL = 2
+PADR = 2
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Tacotron2(object):
+    def __init__(self, hparams, device="cuda:0", dtype="bf16", seed=0, world_size=1):
+        self._hparams = hparams
+        self.device = torch.device(device)
+        assert dtype in ("bf16", "fp32")
+        self.T = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.vocab = len(symbols)
+        self.layout, self.stat_layout = P_.taco2_layout(hparams, self.vocab)
+        n = self.layout.size
+        dev = self.device
+        self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_s = self.flat_p if self.T == torch.float32 else torch.zeros(n, dtype=self.T, device=dev)
+        self.flat_stats = torch.zeros(self.stat_layout.size, dtype=torch.float32, device=dev)
+        self.scal = torch.zeros(16, dtype=torch.float32, device=dev)  # [0:2] mel, [2:4] lin loss, [8] gnorm^2
+        self.global_step = 0
+        self.world_size = world_size
+        self.gradient_clip = 1.0
+        self._bufs = {}
+        self._sig = None
+        self.timing = None
+        pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
+        self.load_numpy(pv, sv)
+        # attributes the reference exposes
+        self.inputs = self.input_lengths = self.mel_targets = self.linear_targets = None
+        self.mel_outputs = self.linear_outputs = self.alignments = self.audio = None
+        self.loss = self.mel_loss = self.linear_loss = self.learning_rate = None
+        self.gradients = self.flat_g
+        self.optimize = None
+        self.stats = None
+
+    # ------------------------------------------------------------------ parameters
+    def load_numpy(self, pvals, svals=None):
+        host = np.zeros(self.layout.size, np.float32)
+        for name, (off, shape) in self.layout.entries.items():
+            host[off:off + int(np.prod(shape))] = np.asarray(pvals[name], np.float32).reshape(-1)
+        self.flat_p.copy_(torch.from_numpy(host))
+        if svals is not None:
+            hs = np.zeros(self.stat_layout.size, np.float32)
+            for name, (off, shape) in self.stat_layout.entries.items():
+                hs[off:off + int(np.prod(shape))] = np.asarray(svals[name], np.float32).reshape(-1)
+            self.flat_stats.copy_(torch.from_numpy(hs))
+        self.refresh_shadows(full=True)
+
+    def numpy_params(self):
+        host = self.flat_p.cpu().numpy()
+        return {k: host[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in self.layout.entries.items()}
+
+    def numpy_grads(self):
+        host = self.flat_g.cpu().numpy()
+        return {k: host[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in self.layout.entries.items()}
+
+    def numpy_stats(self):
+        host = self.flat_stats.cpu().numpy()
+        return {k: host[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in self.stat_layout.entries.items()}
+
+    def state_dict(self):
+        """Checkpoint contents (train.py:60,96-97): trainables, BN moving stats, Adam slots, global_step."""
+        d = {"model/inference/" + k: torch.from_numpy(v) for k, v in self.numpy_params().items()}
+        d.update({"model/inference/" + k: torch.from_numpy(v) for k, v in self.numpy_stats().items()})
+        d["optimizer/adam_m"] = self.flat_m.cpu()
+        d["optimizer/adam_v"] = self.flat_v.cpu()
+        d["global_step"] = torch.tensor(self.global_step)
+        return d
+
+    def load_state_dict(self, d):
+        pv = {k: d["model/inference/" + k].numpy() for k in self.layout.entries}
+        sv = {k: d["model/inference/" + k].numpy() for k in self.stat_layout.entries}
+        self.load_numpy(pv, sv)
+        if "optimizer/adam_m" in d:
+            self.flat_m.copy_(d["optimizer/adam_m"])
+            self.flat_v.copy_(d["optimizer/adam_v"])
+        self.global_step = int(d.get("global_step", 0))
+
+    def _o(self, name):
+        return self.layout.off(name)
+
+    def refresh_shadows(self, full=False):
+        """Operand-dtype copies of the weights: k-contiguous (transposed) ones for the in-loop
+        products, the folded location filter, and the 16-byte padded linear head."""
+        hp = self._hparams
+        T = self.T
+        dev = self.device
+        if full and self.T != torch.float32:
+            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self.flat_s, self.layout.size, False)
+        if not hasattr(self, "tsh"):
+            self.tsh = {}
+
+        def tr(key, name, r0, rows, cols):
+            if key not in self.tsh:
+                self.tsh[key] = torch.zeros(cols * rows, dtype=T, device=dev)
+            ops.cast2d(self.flat_p, rows, cols, cols, self.tsh[key], rows, True, src_off=self._o(name) + r0 * cols)
+
+        M, E, A, D = hp.num_mels, 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
+        He, Hx = hp.encoder_lstm_units, hp.expand_lstm_units
+        C = hp.encoder_conv_channels
+        Cx = hp.expand_conv_channels
+        for d in ("fw", "bw"):
+            tr("enc_%s_whT" % d, "encoder/encoder_lstm/%s/lstm_cell/kernel" % d, C, He, 4 * He)
+            tr("exp_%s_whT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, Cx, Hx, 4 * Hx)
+        tr("l1_whT", "decoder/lstm_1/kernel", A + E, D, 4 * D)
+        tr("l2_whT", "decoder/lstm_2/kernel", D, D, 4 * D)
+        tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
+        tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
+        tr("wattT", "decoder/attention_lstm/kernel", 0, 128 + A, 4 * A)
+        tr("wqT", "decoder/attention/query_layer/kernel", 0, A, A)
+        # folded location filter Wcl[k,u] = sum_j Wc[k,0,j] Wl[j,u]  (fp32)
+        if "wcl" not in self.tsh:
+            self.tsh["wcl"] = torch.zeros(7 * A, dtype=torch.float32, device=dev)
+        ops.gemm(self.flat_p, self.flat_p, self.tsh["wcl"], 7, A, 20, 20, A, A, b_mode=1,
+                 a_off=self._o("decoder/attention/location_conv/kernel"),
+                 b_off=self._o("decoder/attention/location_layer/kernel"))
+        # linear head padded to a multiple of 16 columns
+        F = hp.num_freq
+        Fp = _round_up(F, 16)
+        if "wl_pad" not in self.tsh:
+            self.tsh["wl_pad"] = torch.zeros(2 * Hx * Fp, dtype=T, device=dev)
+            self.tsh["bl_pad"] = torch.zeros(Fp, dtype=torch.float32, device=dev)
+        ops.cast2d(self.flat_p, 2 * Hx, F, F, self.tsh["wl_pad"], Fp, False, src_off=self._o("dense/kernel"))
+        ops.cast2d(self.flat_p, 1, F, F, self.tsh["bl_pad"], Fp, False, src_off=self._o("dense/bias"))
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, numel, dtype, zero=True):
+        key = name
+        b = self._bufs.get(key)
+        if b is None or b.numel() < numel or b.dtype != dtype:
+            b = torch.zeros(numel, dtype=dtype, device=self.device)
+            self._bufs[key] = b
+        return b
+
+    def _tick(self, label):
+        if self.timing is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self.timing.append((label, ev))
+
+    # ------------------------------------------------------------------ reference API
+    def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
+        """tacotron2.py:15-128.  Training mode iff linear_targets is given.  Tensors may be numpy
+        arrays or torch tensors; they are moved to the GPU once and the forward pass runs."""
+        dev = self.device
+        self.inputs = torch.as_tensor(np.asarray(text_inputs) if not torch.is_tensor(text_inputs) else text_inputs
+                                      ).to(dev, torch.int32).contiguous()
+        self.input_lengths = torch.as_tensor(
+            np.asarray(input_lengths) if not torch.is_tensor(input_lengths) else input_lengths
+        ).to(dev, torch.int32).contiguous()
+        self.is_training = linear_targets is not None
+        if self.is_training:
+            self.mel_targets = torch.as_tensor(mel_targets).to(dev, torch.float32).contiguous()
+            self.linear_targets = torch.as_tensor(linear_targets).to(dev, torch.float32).contiguous()
+            self.forward_train()
+        else:
+            self.mel_targets = self.linear_targets = None
+            from .tacotron2_infer import forward_infer
+            forward_infer(self)
+        return self
+
+    def add_loss(self):
+        """tacotron2.py:130-139: the loss is evaluated together with its gradient in step()."""
+        return self
+
+    def learning_rate_at(self, step):
+        hp = self._hparams
+        return hp.initial_learning_rate * 0.5 ** (step / hp.learning_rate_decay_halflife)
+
+    def add_optimizer(self, global_step=0, gradient_clip=1.0):
+        """tacotron2.py:141-161: Adam(lr = lr0 * 0.5^(step/halflife)), clip_by_global_norm."""
+        self.global_step = int(global_step)
+        self.gradient_clip = float(gradient_clip)
+        self.optimize = self.step
+        return self
+
+    def add_stats(self):
+        self.stats = lambda: dict(loss=self.loss, loss_mel=self.mel_loss, loss_linear=self.linear_loss,
+                                  learning_rate=self.learning_rate)
+        return self
+
+    # ------------------------------------------------------------------ layer helpers
+    def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True):
+        """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198)."""
+        kl = (k - 1) // 2
+        rows = N * Pp
+        a_rows = PADL - kl
+        Mg = rows - (k - 1) - a_rows
+        z = self._buf(tag + "_z", rows * cout, self.T)
+        y = self._buf(tag + "_y", rows * cout, self.T)
+        st = self._buf(tag + "_st", 4 * cout, torch.float32)
+        st[:2 * cout].zero_()
+        ops.gemm(xin, self.flat_s, z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
+                 a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=PADL * cout,
+                 bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
+                 row_mask=(Pp, PADL, PADL + T, PADL),
+                 col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+        ops.bn_fwd(z, y, rows, cout, st, st[cout:], N * T, self.flat_p, self.flat_p, self.flat_stats,
+                   self.flat_stats, st[2 * cout:], st[3 * cout:], training, row_mask=(Pp, PADL, PADL + T),
+                   gamma_off=self._o(scope + "/batch_normalization/gamma"),
+                   beta_off=self._o(scope + "/batch_normalization/beta"),
+                   mm_off=self.stat_layout.off(scope + "/batch_normalization/moving_mean"),
+                   mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"))
+        return y
+
+    def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False):
+        """Backward of _conv_fwd.  dy fp32 [rows,cout] -> grads in flat_g, dx fp32 [rows,cin]."""
+        kl = (k - 1) // 2
+        kr = k - 1 - kl
+        rows = N * Pp
+        z = self._bufs[tag + "_z"]
+        st = self._bufs[tag + "_st"]
+        dpre = self._buf("dpre_%d" % cout, rows * cout, self.T)
+        work = self._buf("bn_work", 2 * 2048, torch.float32)
+        g = self.flat_g
+        ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
+                   row_mask=(Pp, PADL, PADL + T),
+                   gamma_off=self._o(scope + "/batch_normalization/gamma"),
+                   dgamma_off=self._o(scope + "/batch_normalization/gamma"),
+                   dbeta_off=self._o(scope + "/batch_normalization/beta"),
+                   dbias_off=self._o(scope + "/conv1d/bias"))
+        # weight gradient: dW[(k,ci),co] += sum_rows X[row+k, ci] * dpre[row, co]
+        a_rows = PADL - kl
+        Mg = rows - (k - 1) - a_rows
+        ops.gemm(xin, dpre, g, k * cin, cout, Mg, cin, cout, cout, a_mode=1, b_mode=1,
+                 a_off=a_rows * cin, b_off=PADL * cout, c_off=self._o(scope + "/conv1d/kernel"),
+                 accumulate=2, split_k=self._splitk(Mg, k * cin, cout))
+        if need_dx:
+            a2 = PADL - kr
+            Mg2 = rows - (k - 1) - a2
+            ops.gemm(dpre, self.flat_s, dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
+                     a_off=a2 * cout, b_off=self._o(scope + "/conv1d/kernel") + (k - 1) * cin * cout,
+                     b_seg=(cout, -cin * cout), c_off=PADL * cin, accumulate=1 if dx_accumulate else 0,
+                     row_mask=(Pp, PADL, PADL + T, PADL))
+
+    @staticmethod
+    def _splitk(K, M, N):
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        sk = max(1, min(32, 512 // max(tiles, 1)))
+        return max(1, min(sk, K // 512))
+
+    def _bilstm_fwd(self, scope, x, cin, H, N, T, Pp, lengths, tag, key):
+        rows = N * Pp
+        out = self._buf(tag + "_h", rows * 2 * H, self.T)
+        for di, d in enumerate(("fw", "bw")):
+            kname = "%s/%s/lstm_cell/kernel" % (scope, d)
+            xg = self._buf("%s_xg_%s" % (tag, d), rows * 4 * H, torch.float32)
+            ops.gemm(x, self.flat_s, xg, rows, 4 * H, cin, cin, 4 * H, 4 * H, b_mode=1, b_off=self._o(kname),
+                     bias=self.flat_p, bias_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
+            c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
+            gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, self.T)
+            ops.lstm_seq("fwd", self.T, N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
+                         lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H)
+        return out
+
+    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx):
+        """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients."""
+        rows = N * Pp
+        g = self.flat_g
+        hbuf = self._bufs[tag + "_h"]
+        work = self._buf("lstm_work", 2 * N * H + 64, torch.float32)
+        for di, d in enumerate(("fw", "bw")):
+            kname = "%s/%s/lstm_cell/kernel" % (scope, d)
+            ko = self._o(kname)
+            c = self._bufs["%s_c_%s" % (tag, d)]
+            gt = self._bufs["%s_g_%s" % (tag, d)]
+            dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, self.T)
+            ops.lstm_seq("bwd", self.T, N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
+                         self.flat_s, lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout, ld_dh=2 * H, dgates=dg,
+                         work=work, wh_off=ko + cin * 4 * H, h_off=di * H, dh_off=di * H)
+            # dWx += X^T dgates ; dWh += Hprev^T dgates ; db += colsum
+            ops.gemm(x, dg, g, cin, 4 * H, rows, cin, 4 * H, 4 * H, a_mode=1, b_mode=1, c_off=ko, accumulate=2,
+                     split_k=self._splitk(rows, cin, 4 * H))
+            if d == "fw":   # h_prev(row) = h(row-1)
+                ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
+                         a_off=di * H, b_off=4 * H, c_off=ko + cin * 4 * H, accumulate=2,
+                         split_k=self._splitk(rows, H, 4 * H))
+            else:           # h_prev(row) = h(row+1)
+                ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
+                         a_off=2 * H + di * H, b_off=0, c_off=ko + cin * 4 * H, accumulate=2,
+                         split_k=self._splitk(rows, H, 4 * H))
+            ops.colsum(dg, 4 * H, rows, 4 * H, g, out_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
+            # dx (+)= dgates . Wx^T
+            ops.gemm(dg, self.flat_s, dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
+                     accumulate=0 if di == 0 else 1)
+
+    # ------------------------------------------------------------------ training forward
+    def forward_train(self):
+        hp = self._hparams
+        T_ = self.T
+        N, Ti = self.inputs.shape
+        To = self.mel_targets.shape[1]
+        r = hp.outputs_per_step
+        assert To % r == 0, "T_out must be a multiple of outputs_per_step (datafeeder pads to it)"
+        S = To // r
+        assert S <= hp.max_iters, "targets longer than max_iters*outputs_per_step"
+        M, F = hp.num_mels, hp.num_freq
+        Fp = _round_up(F, 16)
+        E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
+        Pi, Po = Ti + PADL + PADR, To + PADL + PADR
+        S1 = S + 1
+        self.dims = dict(N=N, Ti=Ti, To=To, S=S, Pi=Pi, Po=Po, Fp=Fp)
+        sig = ("train", N, Ti, To)
+        if sig != self._sig:      # padded layouts depend on the shape: never reuse stale pad rows
+            self._bufs.clear()
+            self._sig = sig
+        self._tick("start")
+
+        # ---- encoder (tacotron2.py:37-60)
+        emb = hp.embedding_dim
+        x = self._buf("enc_x0", N * Pi * emb, T_)
+        ops.embedding_fwd(self.inputs, self.flat_p, x, N, Ti, Pi, PADL, emb, self.vocab,
+                          table_off=self._o("embedding/embedding"))
+        cin = emb
+        self._enc_in = [x]
+        for i in range(hp.encoder_conv_layers):
+            act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
+            x = self._conv_fwd("encoder/conv_%d" % i, x, cin, hp.encoder_conv_channels, hp.encoder_conv_width, act,
+                               N, Ti, Pi, "enc%d" % i)
+            cin = hp.encoder_conv_channels
+            self._enc_in.append(x)
+        enc = self._bilstm_fwd("encoder/encoder_lstm", x, cin, hp.encoder_lstm_units, N, Ti, Pi, self.input_lengths,
+                               "encl", "enc")
+        self._tick("encoder")
+        # keys = values . W_memory (values = encoder outputs, already zero past each length)
+        keys = self._buf("keys", N * Pi * A, torch.float32)
+        ops.gemm(enc, self.flat_s, keys, N * Pi, A, E, E, A, A, b_mode=1,
+                 b_off=self._o("attention_decoder/memory_layer/kernel"))
+
+        # ---- decoder, attention RNN for all steps (tacotron2.py:63-83, teacher forced)
+        fr = self._buf("dec_fr", N * S1 * M, T_)
+        if S > 1:   # slot s+1 <- mel_targets[:, s*r-1] for s >= 1 ; slot 1 stays <GO> = 0
+            ops.copy3d(self.mel_targets, fr, N, S - 1, M, (To * M, r * M), (S1 * M, M), src_off=(r - 1) * M,
+                       dst_off=2 * M)
+        f1 = self._buf("dec_f1", N * S1 * 256, torch.float32)
+        w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
+        ops.gemm(fr, self.flat_s, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p,
+                 bias_off=self._o("decoder/decoder_prenet/dense_1/bias"))
+        Tia = _round_up(Ti, 4)
+        p1 = self._buf("dec_p1", N * S1 * 256, T_)
+        xa = self._buf("dec_xa", N * S1 * (128 + A), T_)
+        hc = self._buf("dec_hc", N * S1 * (A + E), T_)
+        ca = self._buf("dec_ca", N * S1 * A, torch.float32)
+        ga = self._buf("dec_ga", N * S1 * 4 * A, T_)
+        q = self._buf("dec_q", N * S1 * A, torch.float32)
+        al = self._buf("dec_al", N * S1 * Tia, torch.float32)
+        self._attn_args = dict(
+            dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=PADL, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
+            lengths=self.input_lengths, keys=keys, values=enc, f1=f1,
+            w1cT=self.tsh["w1cT"], w2T=self.tsh["w2T"], wattT=self.tsh["wattT"], wqT=self.tsh["wqT"],
+            b2=(self.flat_p, self._o("decoder/decoder_prenet/dense_2/bias")),
+            batt=(self.flat_p, self._o("decoder/attention_lstm/bias")),
+            wcl=self.tsh["wcl"], v=(self.flat_p, self._o("decoder/attention/attention_v")),
+            p1=p1, xa=xa, hc=hc, ca=ca, ga=ga, q=q, align=al)
+        ops.taco2_attn("fwd", **self._attn_args)
+        self._tick("attn_rnn")
+
+        # ---- decoder LSTMs with hoisted inputs, then the projection (tacotron2.py:67-73)
+        rows = N * S1
+        k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
+        xg1 = self._buf("dec_xg1", rows * 4 * D, torch.float32)
+        ops.gemm(hc, self.flat_s, xg1, rows, 4 * D, A + E, A + E, 4 * D, 4 * D, b_mode=1, b_off=k1,
+                 bias=self.flat_p, bias_off=self._o("decoder/lstm_1/bias"))
+        h1 = self._buf("dec_h1", rows * D, T_)
+        c1 = self._buf("dec_c1", rows * D, torch.float32)
+        g1 = self._buf("dec_g1", rows * 4 * D, T_)
+        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1)
+        xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
+        ops.gemm(h1, self.flat_s, xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
+                 bias=self.flat_p, bias_off=self._o("decoder/lstm_2/bias"))
+        h2 = self._buf("dec_h2", rows * D, T_)
+        c2 = self._buf("dec_c2", rows * D, torch.float32)
+        g2 = self._buf("dec_g2", rows * 4 * D, T_)
+        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2)
+        dec = self._buf("dec_out", rows * M * r, torch.float32)
+        ops.gemm(h2, self.flat_s, dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
+                 b_off=self._o("decoder/output_projection/kernel"), bias=self.flat_p,
+                 bias_off=self._o("decoder/output_projection/bias"))
+        self._tick("dec_lstm")
+
+        # ---- postnet + residual (tacotron2.py:89-95)
+        decp = self._buf("decp", N * Po * M, torch.float32)
+        pin = self._buf("post_in", N * Po * M, T_)
+        ops.copy3d(dec, decp, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=PADL * M)
+        ops.copy3d(dec, pin, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=PADL * M)
+        x = pin
+        cin = M
+        self._post_in = [x]
+        Cp = hp.postnet_conv_channels
+        for i in range(hp.postnet_conv_layers):
+            act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
+            x = self._conv_fwd("decoder_postnet/postnet_conv_%d" % i, x, cin, Cp, hp.postnet_conv_width, act,
+                               N, To, Po, "post%d" % i)
+            cin = Cp
+            self._post_in.append(x)
+        mel = self._buf("mel_out", N * Po * M, torch.float32)
+        ops.gemm(x, self.flat_s, mel, N * Po, M, Cp, Cp, M, M, b_mode=1,
+                 b_off=self._o("decoder_postnet/dense/kernel"), bias=self.flat_p,
+                 bias_off=self._o("decoder_postnet/dense/bias"), row_mask=(Po, PADL, PADL + To, 0))
+        ops.copy3d(decp, mel, N, Po, M, (Po * M, M), (Po * M, M), accumulate=1)
+        self._tick("postnet")
+
+        # ---- expand net + linear head (tacotron2.py:97-107)
+        ein = self._buf("exp_in", N * Po * M, T_)
+        ops.copy3d(mel, ein, N, Po, M, (Po * M, M), (Po * M, M))
+        x = ein
+        cin = M
+        self._exp_in = [x]
+        Cx = hp.expand_conv_channels
+        for i in range(hp.expand_conv_layers):
+            act = ACT_RELU if i < hp.expand_conv_layers - 1 else ACT_NONE
+            x = self._conv_fwd("expand/conv_%d" % i, x, cin, Cx, hp.expand_conv_width, act, N, To, Po, "exp%d" % i)
+            cin = Cx
+            self._exp_in.append(x)
+        self._tick("expand_conv")
+        Hx = hp.expand_lstm_units
+        ex = self._bilstm_fwd("expand/encoder_lstm", x, cin, Hx, N, To, Po, None, "expl", "exp")
+        self._tick("expand_lstm")
+        lin = self._buf("lin_out", N * Po * Fp, torch.float32)
+        ops.gemm(ex, self.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=self.tsh["bl_pad"])
+        self._tick("linear")
+
+        self.mel_outputs = mel[:N * Po * M].view(N, Po, M)[:, PADL:PADL + To]
+        self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, PADL:PADL + To, :F]
+        self.decoder_outputs = dec[:rows * M * r].view(N, S1, M * r)[:, 1:].reshape(N, To, M)
+        self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:, :Ti].permute(0, 2, 1)
+        return self
+
+    # ------------------------------------------------------------------ loss + backward
+    def backward(self):
+        hp = self._hparams
+        T_ = self.T
+        d = self.dims
+        N, Ti, To, S, Pi, Po, Fp = d["N"], d["Ti"], d["To"], d["S"], d["Pi"], d["Po"], d["Fp"]
+        r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
+        E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
+        S1 = S + 1
+        g = self.flat_g
+        g.zero_()
+        self.scal.zero_()
+        B = self._bufs
+
+        # ---- losses (tacotron2.py:130-139) and their gradients
+        n_prio = int(2000 / (hp.sample_rate * 0.5) * F)
+        dmel = self._buf("d_mel", N * Po * M, torch.float32)
+        dlin = self._buf("d_lin", N * Po * Fp, T_)
+        ops.l1_loss(B["mel_out"], M, self.mel_targets, dmel, M, N, To, Po, PADL, M, 0, 1.0 / (N * To * M), 0.0,
+                    self.scal, acc_off=0)
+        ops.l1_loss(B["lin_out"], Fp, self.linear_targets, dlin, Fp, N, To, Po, PADL, F, n_prio,
+                    0.5 / (N * To * F), 0.5 / (N * To * n_prio), self.scal, acc_off=2)
+        self._n_prio = n_prio
+        self._tick("loss")
+
+        # ---- linear head
+        Hx = hp.expand_lstm_units
+        ex = B["expl_h"]
+        rows_o = N * Po
+        dwl = self._buf("d_wl_pad", 2 * Hx * Fp, torch.float32)
+        dwl.zero_()
+        ops.gemm(ex, dlin, dwl, 2 * Hx, Fp, rows_o, 2 * Hx, Fp, Fp, a_mode=1, b_mode=1, accumulate=2,
+                 split_k=self._splitk(rows_o, 2 * Hx, Fp))
+        ops.copy3d(dwl, g, 1, 2 * Hx, F, (0, Fp), (0, F), dst_off=self._o("dense/kernel"), accumulate=1)
+        ops.colsum(dlin, Fp, rows_o, F, g, out_off=self._o("dense/bias"))
+        dex = self._buf("d_exp_h", rows_o * 2 * Hx, torch.float32)
+        ops.gemm(dlin, self.tsh["wl_pad"], dex, rows_o, 2 * Hx, Fp, Fp, Fp, 2 * Hx, a_mode=0, b_mode=0)
+        self._tick("linear_bwd")
+        # ---- expand BiLSTM + convs
+        Cx = hp.expand_conv_channels
+        dx = self._buf("d_act_a", rows_o * 512, torch.float32)
+        dx2 = self._buf("d_act_b", rows_o * 512, torch.float32)
+        self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx)
+        self._tick("expand_lstm_bwd")
+        cur, nxt = dx, dx2
+        for i in range(hp.expand_conv_layers - 1, -1, -1):
+            act = ACT_RELU if i < hp.expand_conv_layers - 1 else ACT_NONE
+            cin = M if i == 0 else Cx
+            if i == 0:   # gradient lands on mel_outputs, on top of the mel-loss gradient
+                self._conv_bwd("expand/conv_0", self._exp_in[0], cur, cin, Cx, hp.expand_conv_width, act, N, To, Po,
+                               "exp0", dmel, dx_accumulate=True)
+            else:
+                self._conv_bwd("expand/conv_%d" % i, self._exp_in[i], cur, cin, Cx, hp.expand_conv_width, act, N, To,
+                               Po, "exp%d" % i, nxt)
+                cur, nxt = nxt, cur
+        self._tick("expand_conv_bwd")
+        # ---- postnet: mel = dec + dense(postnet(dec))
+        Cp = hp.postnet_conv_channels
+        dmel_t = self._buf("d_mel_t", rows_o * M, T_)
+        ops.copy3d(dmel, dmel_t, 1, rows_o, M, (0, M), (0, M))
+        ko = self._o("decoder_postnet/dense/kernel")
+        ops.gemm(self._post_in[-1], dmel_t, g, Cp, M, rows_o, Cp, M, M, a_mode=1, b_mode=1, c_off=ko, accumulate=2,
+                 split_k=self._splitk(rows_o, Cp, M))
+        ops.colsum(dmel_t, M, rows_o, M, g, out_off=self._o("decoder_postnet/dense/bias"))
+        cur, nxt = dx, dx2
+        ops.gemm(dmel_t, self.flat_s, cur, rows_o, Cp, M, M, M, Cp, a_mode=0, b_mode=0, b_off=ko)
+        for i in range(hp.postnet_conv_layers - 1, -1, -1):
+            act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
+            cin = M if i == 0 else Cp
+            if i == 0:   # accumulate into dmel: total gradient wrt decoder_outputs
+                self._conv_bwd("decoder_postnet/postnet_conv_0", self._post_in[0], cur, cin, Cp,
+                               hp.postnet_conv_width, act, N, To, Po, "post0", dmel, dx_accumulate=True)
+            else:
+                self._conv_bwd("decoder_postnet/postnet_conv_%d" % i, self._post_in[i], cur, cin, Cp,
+                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, nxt)
+                cur, nxt = nxt, cur
+        self._tick("postnet_bwd")
+        # ---- decoder output projection (grad wrt decoder_outputs sits in dmel, padded layout)
+        rows = N * S1
+        ddec = self._buf("d_dec", rows * M * r, T_)      # slot 0 rows stay zero
+        ops.copy3d(dmel, ddec, N, To, M, (Po * M, M), (S1 * M * r, M), src_off=PADL * M, dst_off=M * r)
+        h2, h1, hc = B["dec_h2"], B["dec_h1"], B["dec_hc"]
+        kp = self._o("decoder/output_projection/kernel")
+        ops.gemm(h2, ddec, g, D, M * r, rows, D, M * r, M * r, a_mode=1, b_mode=1, c_off=kp, accumulate=2,
+                 split_k=self._splitk(rows, D, M * r))
+        ops.colsum(ddec, M * r, rows, M * r, g, out_off=self._o("decoder/output_projection/bias"))
+        dh2 = self._buf("d_h2", rows * D, torch.float32)
+        ops.gemm(ddec, self.flat_s, dh2, rows, D, M * r, M * r, M * r, D, a_mode=0, b_mode=0, b_off=kp)
+        # ---- LSTM2, LSTM1 through time
+        work = self._buf("lstm_work_d", 2 * N * D + 64, torch.float32)
+        k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
+        dg2 = self._buf("d_g2", rows * 4 * D, T_)
+        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self.flat_s, None, False, h2, D, B["dec_c2"],
+                     B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D)
+        self._lstm_wgrads(h1, D, h2, D, dg2, rows, k2, "decoder/lstm_2/bias")
+        dh1 = self._buf("d_h1", rows * D, torch.float32)
+        ops.gemm(dg2, self.flat_s, dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
+        dg1 = self._buf("d_g1", rows * 4 * D, T_)
+        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self.flat_s, None, False, h1, D, B["dec_c1"],
+                     B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D)
+        self._lstm_wgrads(hc, A + E, h1, D, dg1, rows, k1, "decoder/lstm_1/bias")
+        dhc = self._buf("d_hc", rows * (A + E), torch.float32)
+        ops.gemm(dg1, self.flat_s, dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
+        self._tick("dec_lstm_bwd")
+        # ---- attention RNN through time
+        df1 = self._buf("d_f1", rows * 256, T_)
+        dp2 = self._buf("d_p2", rows * 128, T_)
+        dga = self._buf("d_ga", rows * 4 * A, T_)
+        dq = self._buf("d_q", rows * A, T_)
+        dkeys = self._buf("d_keys", N * Pi * A, torch.float32)
+        dvalues = self._buf("d_values", N * Pi * E, torch.float32)
+        dkeys.zero_()
+        dvalues.zero_()
+        dwcl = self._buf("d_wcl", 7 * A, torch.float32)
+        dwcl.zero_()
+        awork = self._buf("attn_work", N * (E + _round_up(Ti, 4) + 3 * A) + 64, torch.float32)
+        w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
+        w2 = self._o("decoder/decoder_prenet/dense_2/kernel")
+        wa = self._o("decoder/attention_lstm/kernel")
+        wq = self._o("decoder/attention/query_layer/kernel")
+        args = dict(self._attn_args)
+        args.update(w1c=(self.flat_s, w1 + M * 256), w2=(self.flat_s, w2), watt=(self.flat_s, wa),
+                    wq=(self.flat_s, wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
+                    dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork)
+        ops.taco2_attn("bwd", **args)
+        self._tick("attn_rnn_bwd")
+        # hoisted weight gradients of the attention RNN
+        p1, xa, fr = B["dec_p1"], B["dec_xa"], B["dec_fr"]
+        sk = self._splitk
+        ops.gemm(fr, df1, g, M, 256, rows, M, 256, 256, a_mode=1, b_mode=1, c_off=w1, accumulate=2,
+                 split_k=sk(rows, M, 256))
+        # ctx part: ctx of slot s pairs with df1 of slot s+1
+        ops.gemm(hc, df1, g, E, 256, rows - 1, A + E, 256, 256, a_mode=1, b_mode=1, a_off=A, b_off=256,
+                 c_off=w1 + M * 256, accumulate=2, split_k=sk(rows, E, 256))
+        ops.colsum(df1, 256, rows, 256, g, out_off=self._o("decoder/decoder_prenet/dense_1/bias"))
+        ops.gemm(p1, dp2, g, 256, 128, rows, 256, 128, 128, a_mode=1, b_mode=1, c_off=w2, accumulate=2,
+                 split_k=sk(rows, 256, 128))
+        ops.colsum(dp2, 128, rows, 128, g, out_off=self._o("decoder/decoder_prenet/dense_2/bias"))
+        ops.gemm(xa, dga, g, 128 + A, 4 * A, rows, 128 + A, 4 * A, 4 * A, a_mode=1, b_mode=1, c_off=wa, accumulate=2,
+                 split_k=sk(rows, 128 + A, 4 * A))
+        ops.colsum(dga, 4 * A, rows, 4 * A, g, out_off=self._o("decoder/attention_lstm/bias"))
+        ops.gemm(hc, dq, g, A, A, rows, A + E, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2,
+                 split_k=sk(rows, A, A))
+        # unfold dWcl[k,u] into location_conv [7,1,20] and location_layer [20,A]   (fp32, tiny)
+        oc = self._o("decoder/attention/location_conv/kernel")
+        ol = self._o("decoder/attention/location_layer/kernel")
+        ops.gemm(dwcl, self.flat_p, g, 7, 20, A, A, A, 20, a_mode=0, b_mode=0, b_off=ol, c_off=oc, accumulate=1)
+        ops.gemm(self.flat_p, dwcl, g, 20, A, 7, 20, A, A, a_mode=1, b_mode=1, a_off=oc, c_off=ol, accumulate=1)
+        # memory layer and encoder outputs
+        enc = B["encl_h"]
+        dkeys_t = self._buf("d_keys_t", N * Pi * A, T_)
+        ops.copy3d(dkeys, dkeys_t, 1, N * Pi, A, (0, A), (0, A))
+        om = self._o("attention_decoder/memory_layer/kernel")
+        ops.gemm(enc, dkeys_t, g, E, A, N * Pi, E, A, A, a_mode=1, b_mode=1, c_off=om, accumulate=2,
+                 split_k=sk(N * Pi, E, A))
+        ops.gemm(dkeys_t, self.flat_s, dvalues, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
+        self._tick("attn_wgrad")
+        # ---- encoder
+        He = hp.encoder_lstm_units
+        Ce = hp.encoder_conv_channels
+        rows_i = N * Pi
+        ea = self._buf("d_enc_a", rows_i * max(Ce, hp.embedding_dim), torch.float32)
+        eb = self._buf("d_enc_b", rows_i * max(Ce, hp.embedding_dim), torch.float32)
+        self._bilstm_bwd("encoder/encoder_lstm", self._enc_in[-1], dvalues, Ce, He, N, Ti, Pi, self.input_lengths,
+                         "encl", ea)
+        cur, nxt = ea, eb
+        for i in range(hp.encoder_conv_layers - 1, -1, -1):
+            act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
+            cin = hp.embedding_dim if i == 0 else Ce
+            self._conv_bwd("encoder/conv_%d" % i, self._enc_in[i], cur, cin, Ce, hp.encoder_conv_width, act, N, Ti, Pi,
+                           "enc%d" % i, nxt)
+            cur, nxt = nxt, cur
+        ops.embedding_bwd(self.inputs, cur, g, N, Ti, Pi, PADL, hp.embedding_dim, self.vocab,
+                          dtable_off=self._o("embedding/embedding"))
+        self._tick("encoder_bwd")
+
+    def _lstm_wgrads(self, x, ldx, h, H, dg, rows, koff, bias_name):
+        """dWx += X^T dg, dWh += Hprev^T dg (slot layout: h_prev(row) = h(row-1)), db += colsum(dg)."""
+        g = self.flat_g
+        cin = ldx
+        ops.gemm(x, dg, g, cin, 4 * H, rows, ldx, 4 * H, 4 * H, a_mode=1, b_mode=1, c_off=koff, accumulate=2,
+                 split_k=self._splitk(rows, cin, 4 * H))
+        ops.gemm(h, dg, g, H, 4 * H, rows - 1, H, 4 * H, 4 * H, a_mode=1, b_mode=1, b_off=4 * H,
+                 c_off=koff + cin * 4 * H, accumulate=2, split_k=self._splitk(rows, H, 4 * H))
+        ops.colsum(dg, 4 * H, rows, 4 * H, g, out_off=self._o(bias_name))
+
+    # ------------------------------------------------------------------ optimizer
+    def apply_gradients(self):
+        """clip_by_global_norm + Adam + refreshed operand shadows (tacotron2.py:150-161)."""
+        hp = self._hparams
+        t = self.global_step + 1
+        lr = self.learning_rate_at(self.global_step)
+        b1, b2 = hp.adam["beta1"], hp.adam["beta2"]
+        lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+        n = self.layout.size
+        ops.sumsq(self.flat_g, n, self.scal, out_off=8)
+        ops.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, n, self.scal[8:], self.gradient_clip,
+                 1.0 / self.world_size, lr_t, b1, b2, 1e-8,
+                 shadow=self.flat_s if self.T != torch.float32 else None)
+        self.refresh_shadows()
+        self.learning_rate = lr
+        self.global_step += 1
+        self._tick("optimizer")
+
+    def read_losses(self):
+        """Host read-back of the loss scalars (one small D2H copy, syncs the stream)."""
+        hp = self._hparams
+        d = self.dims
+        s = self.scal.cpu().numpy()
+        N, To = d["N"], d["To"]
+        self.mel_loss = float(s[0]) / (N * To * hp.num_mels)
+        self.linear_loss = 0.5 * float(s[2]) / (N * To * hp.num_freq) + 0.5 * float(s[3]) / (N * To * self._n_prio)
+        self.loss = self.mel_loss + self.linear_loss
+        self.grad_norm = math.sqrt(max(float(s[8]), 0.0)) / self.world_size
+        return self.loss
+
+    def step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, grad_hook=None,
+             read_loss=True):
+        """One training step = the reference's sess.run([global_step, loss, optimize]) (train.py:80)."""
+        if inputs is not None:
+            self.initialize(inputs, input_lengths, None, mel_targets, linear_targets)
+        else:
+            self.forward_train()
+        self.backward()
+        if grad_hook is not None:
+            grad_hook(self.flat_g)
+        self.apply_gradients()
+        return self.read_losses() if read_loss else None

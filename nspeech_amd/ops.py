@@ -54,3 +54,110 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     p.col_sumsq = ptr(col_sumsq)
     p.split_k = split_k
     L.call("ns_gemm", p, stream())
+
+
+def _fill(_st, **kw):
+    for k, v in kw.items():
+        setattr(_st, k, v)
+    return _st
+
+
+def copy3d(src, dst, I, J, Cc, src_strides, dst_strides, src_off=0, dst_off=0, accumulate=0):
+    p = L.struct("ns_copy3d_params")
+    _fill(p, src=ptr(src, src_off), src_dtype=dt(src), src_si=src_strides[0], src_sj=src_strides[1],
+          dst=ptr(dst, dst_off), dst_dtype=dt(dst), dst_si=dst_strides[0], dst_sj=dst_strides[1],
+          I=I, J=J, Cc=Cc, accumulate=accumulate)
+    L.call("ns_copy3d", p, stream())
+
+
+def embedding_fwd(ids, table, out, N, T, P, padl, D, V, table_off=0):
+    p = L.struct("ns_embedding_params")
+    _fill(p, ids=ptr(ids), table=ptr(table, table_off), out=ptr(out), out_dtype=dt(out), N=N, T=T, P=P,
+          padl=padl, D=D, V=V)
+    L.call("ns_embedding_fwd", p, stream())
+
+
+def embedding_bwd(ids, dout, dtable, N, T, P, padl, D, V, dtable_off=0):
+    p = L.struct("ns_embedding_bwd_params")
+    _fill(p, ids=ptr(ids), dout=ptr(dout), dtable=ptr(dtable, dtable_off), N=N, T=T, P=P, padl=padl, D=D, V=V)
+    L.call("ns_embedding_bwd", p, stream())
+
+
+def bn_fwd(z, y, rows, C, col_sum, col_sumsq, count, gamma, beta, moving_mean, moving_var, mean_out, istd_out,
+           training, row_mask=None, eps=1e-3, momentum=0.99, gamma_off=0, beta_off=0, mm_off=0, mv_off=0):
+    p = L.struct("ns_bn_fwd_params")
+    _fill(p, z=ptr(z), y=ptr(y), dtype=dt(z), rows=rows, C=C, col_sum=ptr(col_sum), col_sumsq=ptr(col_sumsq),
+          count=float(count), gamma=ptr(gamma, gamma_off), beta=ptr(beta, beta_off),
+          moving_mean=ptr(moving_mean, mm_off), moving_var=ptr(moving_var, mv_off),
+          mean_out=ptr(mean_out), istd_out=ptr(istd_out), eps=eps, momentum=momentum, training=int(training))
+    if row_mask is not None:
+        p.row_period, p.row_lo, p.row_hi = row_mask
+    L.call("ns_bn_fwd", p, stream())
+
+
+def bn_bwd(dy, z, dpre, rows, C, mean, istd, gamma, dgamma, dbeta, dbias, work, count, act, row_mask=None,
+           gamma_off=0, dgamma_off=0, dbeta_off=0, dbias_off=0):
+    p = L.struct("ns_bn_bwd_params")
+    _fill(p, dy=ptr(dy), z=ptr(z), dpre=ptr(dpre), dtype=dt(z), rows=rows, C=C, mean=ptr(mean), istd=ptr(istd),
+          gamma=ptr(gamma, gamma_off), dgamma=ptr(dgamma, dgamma_off), dbeta=ptr(dbeta, dbeta_off),
+          dbias=ptr(dbias, dbias_off), work=ptr(work), count=float(count), act=act)
+    if row_mask is not None:
+        p.row_period, p.row_lo, p.row_hi = row_mask
+    L.call("ns_bn_bwd", p, stream())
+
+
+def colsum(x, ld, rows, C, out, x_off=0, out_off=0):
+    p = L.struct("ns_colsum_params")
+    _fill(p, x=ptr(x, x_off), dtype=dt(x), ld=ld, rows=rows, C=C, out=ptr(out, out_off))
+    L.call("ns_colsum", p, stream())
+
+
+def l1_loss(pred, ldp, target, dpred, ldd, N, T, P, padl, F, n_prio, w_all, w_prio, loss_acc, acc_off=0):
+    p = L.struct("ns_l1_loss_params")
+    _fill(p, pred=ptr(pred), ldp=ldp, target=ptr(target), dpred=ptr(dpred),
+          dpred_dtype=dt(dpred) if dpred is not None else 0, ldd=ldd, N=N, T=T, P=P, padl=padl, F=F,
+          n_prio=n_prio, w_all=w_all, w_prio=w_prio, loss_acc=ptr(loss_acc, acc_off))
+    L.call("ns_l1_loss", p, stream())
+
+
+def sumsq(x, n, out, out_off=0):
+    p = L.struct("ns_sumsq_params")
+    _fill(p, x=ptr(x), n=n, out=ptr(out, out_off))
+    L.call("ns_sumsq", p, stream())
+
+
+def adam(pw, g, m, v, n, gnorm_sq, clip, grad_scale, lr_t, beta1, beta2, eps, shadow=None):
+    p = L.struct("ns_adam_params")
+    _fill(p, p=ptr(pw), g=ptr(g), m=ptr(m), v=ptr(v), n=n, gnorm_sq=ptr(gnorm_sq), clip=clip,
+          grad_scale=grad_scale, lr_t=lr_t, beta1=beta1, beta2=beta2, eps=eps, shadow_bf16=ptr(shadow))
+    L.call("ns_adam", p, stream())
+
+
+def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0):
+    p = L.struct("ns_cast2d_params")
+    _fill(p, src=ptr(src, src_off), rows=rows, cols=cols, ld_src=ld_src, dst=ptr(dst, dst_off),
+          dst_dtype=dt(dst), ld_dst=ld_dst, transpose=int(transpose))
+    L.call("ns_cast2d", p, stream())
+
+
+def lstm_seq(direction, dtype_t, N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
+             dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
+             forget_bias=1.0):
+    """direction: 'fwd' or 'bwd' (through-time gradient)."""
+    p = L.struct("ns_lstm_seq_params")
+    _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
+          whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
+          forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
+          dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work))
+    L.call("ns_lstm_seq_fwd" if direction == "fwd" else "ns_lstm_seq_bwd", p, stream())
+
+
+def taco2_attn(direction, **kw):
+    p = L.struct("ns_taco2_attn_params")
+    for k, v in kw.items():
+        if isinstance(v, tuple):        # (tensor, offset)
+            v = ptr(v[0], v[1])
+        elif hasattr(v, "data_ptr"):
+            v = ptr(v)
+        setattr(p, k, v)
+    L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", p, stream())

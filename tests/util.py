@@ -1,0 +1,54 @@
+"""Shared helpers for the parity tests: small Tacotron-2 configurations, synthetic batches and
+the oracle driver (torch-CPU float64 autograd over oracle/taco2_oracle.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from nspeech_amd import hparams as hparams_mod  # noqa: E402
+
+
+def small_hparams(**over):
+    hp = hparams_mod.load("taco2")
+    small = dict(num_mels=16, num_freq=65, embedding_dim=32, encoder_conv_channels=64, encoder_lstm_units=32,
+                 attention_dim=64, decoder_lstm_units=64, postnet_conv_channels=64, expand_conv_channels=64,
+                 expand_lstm_units=32, max_iters=50)
+    small.update(over)
+    for k, v in small.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def make_batch(hp, N, Ti, To, seed=0, vocab=149):
+    rng = np.random.RandomState(seed)
+    lengths = rng.randint(max(2, Ti // 2), Ti + 1, size=N).astype(np.int32)
+    lengths[0] = Ti
+    inputs = np.zeros((N, Ti), np.int32)
+    for n in range(N):
+        inputs[n, :lengths[n] - 1] = rng.randint(2, 64, size=lengths[n] - 1)
+        inputs[n, lengths[n] - 1] = 1
+    mel = rng.uniform(0, 1, size=(N, To, hp.num_mels)).astype(np.float32)
+    lin = rng.uniform(0, 1, size=(N, To, hp.num_freq)).astype(np.float32)
+    return inputs, lengths, mel, lin
+
+
+def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64, need_grad=True):
+    """Forward + loss + gradients with the CPU oracle.  Returns (out dict, loss tuple, grads dict)."""
+    sys.path.insert(0, os.path.join(ROOT))
+    from oracle import taco2_oracle as O
+    p = {k: torch.tensor(v, dtype=dtype, requires_grad=need_grad) for k, v in params.items()}
+    p.update({k: torch.tensor(v, dtype=dtype) for k, v in stats.items()})
+    hpd = hp.values()
+    out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths),
+                          torch.tensor(mel, dtype=dtype), torch.tensor(lin, dtype=dtype))
+    loss, mel_loss, lin_loss = O.taco2_loss(hpd, out, torch.tensor(mel, dtype=dtype), torch.tensor(lin, dtype=dtype))
+    grads = {}
+    if need_grad:
+        loss.backward()
+        grads = {k: (p[k].grad.numpy() if p[k].grad is not None else np.zeros_like(params[k])) for k in params}
+    return out, (float(loss.detach()), float(mel_loss.detach()), float(lin_loss.detach())), grads
