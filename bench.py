@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Tacotron-2 training step, LJSpeech shapes (batch 32/GPU, T_in 160,
+T_out 1000 mel frames, r=5), bf16 MFMA operands, synthetic data, data-parallel over N GPUs.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0 (Measurement)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nspeech_amd import hparams as hparams_mod  # noqa: E402
+from nspeech_amd.models import create_model  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def synthetic_batch(hp, N, Ti, To, seed):
+    rng = np.random.default_rng(seed)
+    lengths = rng.integers(Ti // 2, Ti + 1, size=N).astype(np.int32)
+    inputs = np.zeros((N, Ti), np.int32)
+    for n in range(N):
+        inputs[n, :lengths[n] - 1] = rng.integers(2, 64, size=lengths[n] - 1)
+        inputs[n, lengths[n] - 1] = 1
+    # spectrogram-like targets in [0,1] (saturating normalisation of the reference, Q1)
+    mel = np.clip(rng.normal(0.35, 0.25, size=(N, To, hp.num_mels)), 0, 1).astype(np.float32)
+    lin = np.clip(rng.normal(0.30, 0.25, size=(N, To, hp.num_freq)), 0, 1).astype(np.float32)
+    return inputs, lengths, mel, lin
+
+
+def cpu_baseline(hp, seed, budget_s=25.0):
+    """The CPU restatement of the reference (oracle/, torch-CPU fp32) timed on a bounded sample
+    of the same workload: one forward+backward at batch 4, T_in 160, T_out 250."""
+    from oracle import taco2_oracle as O
+    from nspeech_amd.models import params as P
+    from nspeech_amd.utils.text.symbols import symbols
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    lay, st = P.taco2_layout(hp, len(symbols))
+    pv, sv = P.init_values(lay, st, seed)
+    N, Ti, To = 4, 160, 250
+    inputs, lengths, mel, lin = synthetic_batch(hp, N, Ti, To, seed)
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in pv.items()}
+    p.update({k: torch.tensor(v) for k, v in sv.items()})
+    hpd = hp.values()
+    t0 = time.time()
+    out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin))
+    loss, _, _ = O.taco2_loss(hpd, out, torch.tensor(mel), torch.tensor(lin))
+    loss.backward()
+    dt = time.time() - t0
+    return {"value": N * To / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "1 train step (fwd+bwd, no Adam) at batch %d, T_in %d, T_out %d, fp32 torch-CPU oracle, %.1f s"
+                      % (N, Ti, To, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--t-in", type=int, default=160)
+    ap.add_argument("--t-out", type=int, default=1000)
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--phases", action="store_true", help="print a per-phase time table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    hp = hparams_mod.load("taco2")
+    model = create_model("taco2", hp, device="cuda:%d" % local, dtype=args.dtype, seed=1234, world_size=world)
+    if world > 1:
+        dist.broadcast(model.flat_p, 0)
+        model.refresh_shadows(full=True)
+    inputs, lengths, mel, lin = synthetic_batch(hp, args.batch, args.t_in, args.t_out, 1234 + rank)
+    model.add_optimizer(global_step=0)
+    model.initialize(inputs, lengths, None, mel, lin)
+
+    def hook(flat_g):
+        if world > 1:
+            dist.all_reduce(flat_g)
+
+    def one_step():
+        model.forward_train()
+        model.backward()
+        hook(model.flat_g)
+        model.apply_gradients()
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = model.read_losses()
+    ms = dt / args.steps * 1e3
+    frames = args.batch * args.t_out * world
+
+    phases = None
+    if args.phases and rank == 0:
+        model.timing = []
+        one_step()
+        torch.cuda.synchronize()
+        tm = model.timing
+        model.timing = None
+        phases = [(tm[i][0], tm[i - 1][1].elapsed_time(tm[i][1])) for i in range(1, len(tm))]
+        for name, v in phases:
+            sys.stderr.write("%-20s %8.3f ms\n" % (name, v))
+        sys.stderr.write("%-20s %8.3f ms\n" % ("total", sum(v for _, v in phases)))
+
+    if rank == 0:
+        from nspeech_amd import profiling
+        roof = profiling.roofline(model, one_step)
+        res = {
+            "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),
+            "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "Tacotron-2 train step (fwd+bwd+clip+Adam), batch %d/GPU, T_in %d, T_out %d, r=%d"
+                                   % (args.batch, args.t_in, args.t_out, hp.outputs_per_step),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss": loss},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(hp, 1234)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,40 @@
+"""Live roofline measurement for bench.py: wraps every ns_gemm call of one training step in
+HIP events (torch.cuda.Event on the stream the kernels are launched on) and reports the
+achieved bf16-MFMA rate of the GEMM family against the dense peak."""
+import torch
+
+from . import ops
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0
+
+
+def roofline(model, one_step):
+    rec = []
+    orig = ops.gemm
+
+    def timed(A, B, Cm, M, N, K, *a, **kw):
+        big = M > 32 and A.dtype == torch.bfloat16
+        if not big:
+            return orig(A, B, Cm, M, N, K, *a, **kw)
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(A, B, Cm, M, N, K, *a, **kw)
+        e1.record()
+        rec.append((2.0 * M * N * K, e0, e1))
+
+    ops.gemm = timed
+    try:
+        one_step()
+        torch.cuda.synchronize()
+    finally:
+        ops.gemm = orig
+    if not rec:
+        return None
+    flops = sum(r[0] for r in rec)
+    ms = sum(r[1].elapsed_time(r[2]) for r in rec)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv1d / dense / LSTM input + all weight and data gradients)",
+            "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+            "launches": len(rec), "avg_launch_us": ms * 1e3 / len(rec), "gflop_per_step": flops / 1e9,
+            "traffic": None}
