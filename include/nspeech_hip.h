@@ -202,11 +202,15 @@ typedef struct {
   /* backward only */
   const float* dh; int64_t ld_dh;       /* fp32 [N*P, ld_dh] grad wrt h outputs */
   void* dgates;                         /* (dtype) [N*P, 4H] out */
-  float* work;                          /* fp32 [2*N*H] + (dtype)[N*4H] scratch */
+  float* work;                          /* fp32 [N*H] scratch (cell-state gradient carry) */
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 size_t ns_lstm_seq_work_bytes(const ns_lstm_seq_params* p);
+/* Two independent recurrences with equal N/T/H (the fw and bw halves of
+ * tf.nn.bidirectional_dynamic_rnn, modules.py:40-46) advanced together: one launch per step. */
+int ns_lstm_seq2_fwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t stream);
+int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t stream);
 
 
 /* ------------------------------------------------------------------ Tacotron-2 attention RNN
@@ -237,6 +241,9 @@ typedef struct {
   void* p1; void* xa; void* hc;    /* (dtype) [N,S+1,D1], [N,S+1,D2+A], [N,S+1,A+E] */
   float* ca; void* ga;             /* fp32 [N,S+1,A], (dtype) [N,S+1,4A] */
   float* q; float* align;          /* fp32 [N,S+1,A], fp32 [N,S+1,Tia] */
+  float* keys_t;                   /* fp32 [N,A,Tia] scratch: keys transposed by fwd, re-read by bwd */
+  void* align_t;                   /* (dtype) [N,S+1,Tia] copy of align written by fwd (GEMM operand in bwd) */
+  float* de; void* dctx_t;         /* bwd scratch: fp32 [N,S+1,Tia] energy grads, (dtype) [N,S+1,E] context grads */
   /* backward */
   const void* w1c; const void* w2; const void* watt; const void* wq;       /* natural layouts (dtype) */
   const float* dhc;                /* fp32 [N,S+1,A+E] grad wrt hc from downstream */

@@ -1,238 +1,490 @@
 // Tacotron-2 attention RNN (prenet -> attention LSTM -> location-sensitive attention) for the
 // teacher-forced decoder, forward and backward through time.  The matrix products are M=batch
 // skinny GEMMs (ns_gemm), the LSTM cell is the fused step kernel of lstm.hip, and the
-// energies / masked softmax / context and their gradients are the two kernels below: one
-// workgroup per batch row, one wavefront per memory position, A/64 units per lane.
+// energies / masked softmax / context and their gradients are the kernels below.
+//
+// Layout choice that makes the energy kernels reduction-free: one memory position t per LANE
+// (keys are transposed once per call to [A][T_in]) and a serial loop over the attention units,
+// so e[t] = sum_u v[u] tanh(keys[t,u] + q[u] + loc[t,u]) and the location-filter gradient
+// accumulate in registers; quantities that are sums over t (dq, dv, dWcl) are computed by a
+// second sweep with one unit per lane over the original [T_in][A] layout.
 #include "common.h"
 #include "lstm_step.h"
 
-constexpr int MAXU = 4;   // units per lane (A <= 256)
 constexpr int MAXKW = 8;
+constexpr int PADK = 8;          // zero margin around the alignment vector in LDS
+constexpr int ATHREADS = 512;
+constexpr int AW = ATHREADS / 64;
+constexpr int UB = 32;           // units (or time steps) whose loads are in flight together
 
+__device__ __forceinline__ void ld8(const bf16_t* p, float* o) {
+  const bf16x8 v = *(const bf16x8*)p;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)v[i];
+}
+__device__ __forceinline__ void ld8(const float* p, float* o) {
+  const float4 a = *(const float4*)p, b = *(const float4*)(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+// keys [N, Pi, A] (valid rows padl..) <-> keys_t [N, A, Tia]
+__global__ void keys_transpose_kernel(const float* keys, float* keys_t, int Ti, int Tia, int Pi, int padl, int A,
+                                      int back) {
+  __shared__ float tile[32][33];
+  const int n = blockIdx.z, t0 = blockIdx.x * 32, u0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const float* kn = keys + ((long)n * Pi + padl) * A;
+  float* ktn = keys_t + (long)n * A * Tia;
+  if (!back) {
+    for (int j = ty; j < 32; j += 8) {
+      const int t = t0 + j, u = u0 + tx;
+      tile[j][tx] = (t < Ti && u < A) ? kn[(long)t * A + u] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int u = u0 + j, t = t0 + tx;
+      if (u < A && t < Tia) ktn[(long)u * Tia + t] = tile[tx][j];
+    }
+  } else {  // keys[t][u] += keys_t[u][t]
+    for (int j = ty; j < 32; j += 8) {
+      const int u = u0 + j, t = t0 + tx;
+      tile[j][tx] = (u < A && t < Ti) ? ktn[(long)u * Tia + t] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+      const int t = t0 + j, u = u0 + tx;
+      if (t < Ti && u < A) ((float*)kn)[(long)t * A + u] += tile[tx][j];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ forward, per step
+// Two launches so that every batch row spreads over many CUs: energies (grid = t-chunks x N),
+// then masked softmax + context (grid = column chunks x N).
 template <typename T>
 struct AttnStep {
   int Ti, A, E, kw, Tia;
-  int L;                         // unused (lengths read per row)
   const int* lengths;
-  const float* keys; long keys_sn;     // row n base: keys + n*keys_sn, [Ti, A]
-  const T* values; long values_sn;     // [Ti, E]
+  const float* keys_t;                 // [N, A, Tia]
+  const T* values; long values_sn;     // row-n base + [Ti, E]
   const float* q; long q_sn;           // [A]
   const float* aprev; long al_sn;      // [Tia]
+  float* e_raw;                        // [N, Tia] scratch
   float* aout;
+  T* aout_t;                           // operand-dtype copy of the alignments (same strides)
   T* ctx_out; long ctx_sn;             // [E]
   T* ctx_out2; long ctx2_sn;           // optional second destination
   const float* wcl; const float* v;
 };
 
+// x[t,u] = keys[t,u] + q[u] + sum_k align_prev[t+k-half] Wcl[k,u];  lane = t, wave = unit chunk.
+// q, v and Wcl are wave-uniform (scalar loads); tanh is v_exp + v_rcp.
 template <typename T>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnStep<T> a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ap = sm;                       // [Ti + 2*MAXKW]
-  float* e = ap + a.Ti + 2 * MAXKW;     // [Ti]
-  float* red = e + a.Ti;                // [32]
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = min(a.lengths ? a.lengths[n] : a.Ti, a.Ti);
-  const int upl = a.A / 64, half = a.kw / 2 - ((a.kw & 1) ? 0 : 1);  // 'same' left pad = (kw-1)/2
+__global__ __launch_bounds__(ATHREADS) void attn_energy_kernel(AttnStep<T> a) {
+  __shared__ float part[AW][64];
+  const int n = blockIdx.y, tc = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Ti = a.Ti, A = a.A, Tia = a.Tia;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const int half = (a.kw - 1) / 2;
+  const int t = tc * 64 + lane;
+  const bool act = t < L;
   const float* aprev = a.aprev + (long)n * a.al_sn;
-  for (int i = tid; i < a.Ti + 2 * MAXKW; i += 256) {
-    const int t = i - MAXKW;
-    ap[i] = (t >= 0 && t < a.Ti) ? aprev[t] : 0.f;
+  float apv[MAXKW];
+#pragma unroll
+  for (int k = 0; k < MAXKW; ++k) {
+    const int tt = t + k - half;
+    apv[k] = (k < a.kw && tt >= 0 && tt < Ti) ? aprev[tt] : 0.f;
   }
-  float q[MAXU], v[MAXU], w[MAXKW][MAXU];
+  const int upc = (A + AW - 1) / AW;
+  const int ub0 = wv * upc, ue = min(A, ub0 + upc);
+  const float* kt = a.keys_t + (long)n * A * Tia;
+  const float* qn = a.q + (long)n * a.q_sn;
+  float s = 0.f;
+  for (int ub = ub0; ub < ue; ub += UB) {
+    float kv[UB];
 #pragma unroll
-  for (int j = 0; j < MAXU; ++j) {
-    const int u = lane * upl + j;
-    const bool ok = j < upl;
-    q[j] = ok ? a.q[(long)n * a.q_sn + u] : 0.f;
-    v[j] = ok ? a.v[u] : 0.f;
+    for (int j = 0; j < UB; ++j) kv[j] = (act && ub + j < ue) ? kt[(long)(ub + j) * Tia + t] : 0.f;
 #pragma unroll
-    for (int k = 0; k < MAXKW; ++k) w[k][j] = (ok && k < a.kw) ? a.wcl[k * a.A + u] : 0.f;
-  }
-  __syncthreads();
-  const float* keys = a.keys + (long)n * a.keys_sn;
-  for (int t = wave; t < a.Ti; t += 4) {
-    if (t >= L) {
-      if (lane == 0) e[t] = -INFINITY;
-      continue;
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < MAXU; ++j) {
-      if (j < upl) {
-        float x = keys[(long)t * a.A + lane * upl + j] + q[j];
+    for (int j = 0; j < UB; ++j) {
+      const int u = ub + j;
+      if (u < ue) {
+        float x = kv[j] + qn[u];
 #pragma unroll
         for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) x = fmaf(ap[MAXKW + t + k - half], w[k][j], x);
-        s = fmaf(v[j], tanhf_(x), s);
+          if (k < a.kw) x = fmaf(apv[k], a.wcl[k * A + u], x);
+        s = fmaf(a.v[u], tanhf_(x), s);
       }
     }
-    s = wave_sum(s);
-    if (lane == 0) e[t] = s;
   }
+  part[wv][lane] = s;
   __syncthreads();
-  float mx = -INFINITY;
-  for (int t = tid; t < L; t += 256) mx = fmaxf(mx, e[t]);
-  mx = block_max(mx, red);
-  float sum = 0.f;
-  for (int t = tid; t < L; t += 256) sum += __expf(e[t] - mx);
-  sum = block_sum(sum, red);
-  const float inv = 1.f / sum;
-  __syncthreads();
-  float* aout = a.aout + (long)n * a.al_sn;
-  for (int t = tid; t < a.Tia; t += 256) {
-    const float al = t < L ? __expf(e[t] - mx) * inv : 0.f;
-    if (t < a.Ti) e[t] = al;
-    aout[t] = al;
-  }
-  __syncthreads();
-  const T* values = a.values + (long)n * a.values_sn;
-  for (int c = tid; c < a.E; c += 256) {
-    float s = 0.f;
-    for (int t = 0; t < L; ++t) s = fmaf(e[t], ldf(values + (long)t * a.E + c), s);
-    stf(a.ctx_out + (long)n * a.ctx_sn + c, s);
-    if (a.ctx_out2) stf(a.ctx_out2 + (long)n * a.ctx2_sn + c, s);
+  if (wv == 0 && t < Tia) {
+    float e = -INFINITY;
+    if (act) {
+      e = 0.f;
+#pragma unroll
+      for (int w = 0; w < AW; ++w) e += part[w][lane];
+    }
+    a.e_raw[(long)n * Tia + t] = e;
   }
 }
 
+constexpr int CCH = 128;   // context columns per workgroup
+// LDS (floats): al[Tia] | red[32] | cpart[4][CCH]
+template <typename T>
+__global__ __launch_bounds__(256) void attn_context_kernel(AttnStep<T> a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Ti = a.Ti, E = a.E, Tia = a.Tia;
+  float* al = sm;
+  float* red = al + Tia;
+  float* cpart = red + 32;
+  const int n = blockIdx.y, ch = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const float* er = a.e_raw + (long)n * Tia;
+  float mx = -INFINITY;
+  for (int t = tid; t < L; t += 256) mx = fmaxf(mx, er[t]);
+  mx = block_max(mx, red);
+  float sum = 0.f;
+  for (int t = tid; t < L; t += 256) sum += __expf(er[t] - mx);
+  sum = block_sum(sum, red);
+  const float inv = 1.f / sum;
+  for (int t = tid; t < Tia; t += 256) {
+    const float v = t < L ? __expf(er[t] - mx) * inv : 0.f;
+    al[t] = v;
+    if (ch == 0) {
+      a.aout[(long)n * a.al_sn + t] = v;
+      if (a.aout_t) stf(a.aout_t + (long)n * a.al_sn + t, v);
+    }
+  }
+  __syncthreads();
+  const T* values = a.values + (long)n * a.values_sn;
+  const int c = ch * CCH + (lane & 15) * 8;
+  const int rg = lane >> 4;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < E) {
+#pragma unroll 4
+    for (int t = wave * 4 + rg; t < L; t += 16) {
+      float x[8];
+      ld8(values + (long)t * E + c, x);
+      const float w = al[t];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc[i] = fmaf(w, x[i], acc[i]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    acc[i] += __shfl_xor(acc[i], 16, 64);
+    acc[i] += __shfl_xor(acc[i], 32, 64);
+  }
+  if (rg == 0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cpart[wave * CCH + (lane & 15) * 8 + i] = acc[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < CCH; i += 256) {
+    const int cc = ch * CCH + i;
+    if (cc < E) {
+      const float v = cpart[i] + cpart[CCH + i] + cpart[2 * CCH + i] + cpart[3 * CCH + i];
+      stf(a.ctx_out + (long)n * a.ctx_sn + cc, v);
+      if (a.ctx_out2) stf(a.ctx_out2 + (long)n * a.ctx2_sn + cc, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ backward, per step
 template <typename T>
 struct AttnBwdStep {
   int Ti, A, E, kw, Tia;
   const int* lengths;
-  const float* keys; long keys_sn;
+  const float* keys; long keys_sn;         // [Ti, A] original layout (row-n base = keys + n*keys_sn)
+  const float* keys_t;                     // [N, A, Tia]
   const T* values; long values_sn;
   const float* q; long q_sn;
   const float* acur; const float* aprev; long al_sn;
   const float* dctx_ext; long dce_sn;      // [E] from downstream (dhc columns A..)
   const float* dctx_carry;                 // [N,E] or null
-  float* dalign_carry;                     // [N,Tia] in: grad wrt acur from step s+1, out: grad wrt aprev
-  int has_carry;
+  float* gk;                               // [N,Tia,MAXKW] location-filter gradients of the step after
+  int has_carry;                           //   (read by da, then overwritten by the energy kernel)
+  float* da;                               // [N,Tia] scratch
   T* dq_out; long dq_sn;
-  float* dkeys; float* dvalues;            // row-n bases use keys_sn / values_sn
-  float* dv; float* dwcl;
+  float* de_out;                           // [Tia] per row (stride al_sn): energy gradients of this step
+  T* dctx_out; long dco_sn;                // [E] total context gradient of this step (operand dtype)
   const float* wcl; const float* v;
 };
 
+// (1) da[t] = dctx . values[t] + sum_k G_next[t-k+half][k];  grid (t-chunks of 32, N)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdStep<T> a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ap = sm;                         // [Ti + 2*MAXKW]  previous alignments, padded
-  float* dap = ap + a.Ti + 2 * MAXKW;     // [Ti + 2*MAXKW]  grad wrt previous alignments
-  float* ac = dap + a.Ti + 2 * MAXKW;     // [Ti] current alignments
-  float* da = ac + a.Ti;                  // [Ti]
-  float* dctx = da + a.Ti;                // [E]
-  float* red = dctx + a.E;                // [32]
-  float* xr = red + 32;                   // [4][(2+MAXKW)*A] cross-wave reduction
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int L = min(a.lengths ? a.lengths[n] : a.Ti, a.Ti);
-  const int upl = a.A / 64, half = a.kw / 2 - ((a.kw & 1) ? 0 : 1);
-  const float* aprev = a.aprev + (long)n * a.al_sn;
-  const float* acur = a.acur + (long)n * a.al_sn;
-  float* dal = a.dalign_carry + (long)n * a.Tia;
-  for (int i = tid; i < a.Ti + 2 * MAXKW; i += 256) {
-    const int t = i - MAXKW;
-    ap[i] = (t >= 0 && t < a.Ti) ? aprev[t] : 0.f;
-    dap[i] = 0.f;
-  }
-  for (int t = tid; t < a.Ti; t += 256) ac[t] = acur[t];
-  for (int c = tid; c < a.E; c += 256) {
+__global__ __launch_bounds__(256) void attn_bwd_da_kernel(AttnBwdStep<T> a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // dctx[E]
+  const int Ti = a.Ti, E = a.E, Tia = a.Tia;
+  const int n = blockIdx.y, t0 = blockIdx.x * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const int half = (a.kw - 1) / 2;
+  for (int c = tid; c < E; c += 256) {
     float d = a.dctx_ext[(long)n * a.dce_sn + c];
-    if (a.dctx_carry) d += a.dctx_carry[(long)n * a.E + c];
-    dctx[c] = d;
+    if (a.dctx_carry) d += a.dctx_carry[(long)n * E + c];
+    sm[c] = d;
+    if (blockIdx.x == 0) stf(a.dctx_out + (long)n * a.dco_sn + c, d);
   }
   __syncthreads();
-  // (1) context: da[t] = dctx . values[t] (+ carry);  dvalues[t] += a[t] * dctx
   const T* values = a.values + (long)n * a.values_sn;
-  float* dvalues = a.dvalues + (long)n * a.values_sn;
-  for (int t = wave; t < L; t += 4) {
+  const float* gk = a.gk + (long)n * Tia * MAXKW;
+#pragma unroll 4
+  for (int j = 0; j < 8; ++j) {
+    const int t = t0 + wave * 8 + j;
+    if (t >= Tia) break;
     float s = 0.f;
-    const float at = ac[t];
-    for (int c = lane; c < a.E; c += 64) {
-      const float dc = dctx[c];
-      s = fmaf(dc, ldf(values + (long)t * a.E + c), s);
-      dvalues[(long)t * a.E + c] += at * dc;
+    if (t < L) {
+      for (int c = lane * 8; c < E; c += 512) {
+        float x[8];
+        ld8(values + (long)t * E + c, x);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s = fmaf(sm[c + i], x[i], s);
+      }
+      s = wave_sum(s);
     }
-    s = wave_sum(s);
-    if (lane == 0) da[t] = s + (a.has_carry ? dal[t] : 0.f);
+    if (lane == 0) {
+      float carry = 0.f;
+      if (a.has_carry && t < L) {
+        for (int k = 0; k < a.kw; ++k) {
+          const int ts = t - k + half;
+          if (ts >= 0 && ts < Ti) carry += gk[(long)ts * MAXKW + k];
+        }
+      }
+      a.da[(long)n * Tia + t] = t < L ? s + carry : 0.f;
+    }
+  }
+}
+
+// (2) softmax backward + gradient wrt the previous alignments (as per-tap terms G[t][k]);
+//     grid (t-chunks of 64, N), lane = t, wave = unit chunk
+template <typename T>
+__global__ __launch_bounds__(ATHREADS) void attn_bwd_energy_kernel(AttnBwdStep<T> a) {
+  __shared__ float part[AW][64][MAXKW + 1];
+  __shared__ float red[32];
+  const int n = blockIdx.y, tc = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int Ti = a.Ti, A = a.A, Tia = a.Tia;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const int half = (a.kw - 1) / 2;
+  const float* acur = a.acur + (long)n * a.al_sn;
+  const float* aprev = a.aprev + (long)n * a.al_sn;
+  const float* da = a.da + (long)n * Tia;
+  float dot = 0.f;
+  for (int t = tid; t < L; t += ATHREADS) dot += acur[t] * da[t];
+  dot = block_sum(dot, red);
+  const int t = tc * 64 + lane;
+  const bool act = t < L;
+  const float de = act ? acur[t] * (da[t] - dot) : 0.f;
+  if (wv == 0 && t < Tia) a.de_out[(long)n * a.al_sn + t] = de;
+  float apv[MAXKW], g[MAXKW];
+#pragma unroll
+  for (int k = 0; k < MAXKW; ++k) {
+    const int tt = t + k - half;
+    apv[k] = (k < a.kw && tt >= 0 && tt < Ti) ? aprev[tt] : 0.f;
+    g[k] = 0.f;
+  }
+  const int upc = (A + AW - 1) / AW;
+  const int ub0 = wv * upc, ue = min(A, ub0 + upc);
+  const float* kt = a.keys_t + (long)n * A * Tia;
+  const float* qn = a.q + (long)n * a.q_sn;
+  for (int ub = ub0; ub < ue; ub += UB) {
+    float kv[UB];
+#pragma unroll
+    for (int j = 0; j < UB; ++j) kv[j] = (act && ub + j < ue) ? kt[(long)(ub + j) * Tia + t] : 0.f;
+#pragma unroll
+    for (int j = 0; j < UB; ++j) {
+      const int u = ub + j;
+      if (u < ue) {
+        float x = kv[j] + qn[u];
+#pragma unroll
+        for (int k = 0; k < MAXKW; ++k)
+          if (k < a.kw) x = fmaf(apv[k], a.wcl[k * A + u], x);
+        const float th = tanhf_(x);
+        const float dpre = de * a.v[u] * (1.f - th * th);
+#pragma unroll
+        for (int k = 0; k < MAXKW; ++k)
+          if (k < a.kw) g[k] = fmaf(dpre, a.wcl[k * A + u], g[k]);
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < MAXKW; ++k) part[wv][lane][k] = g[k];
+  __syncthreads();
+  float* gk = a.gk + (long)n * Tia * MAXKW;
+  for (int i = tid; i < 64 * MAXKW; i += ATHREADS) {
+    const int l = i / MAXKW, k = i % MAXKW;
+    const int tt = tc * 64 + l;
+    if (tt < Tia) {
+      float sacc = 0.f;
+#pragma unroll
+      for (int w = 0; w < AW; ++w) sacc += part[w][l][k];
+      gk[(long)tt * MAXKW + k] = sacc;
+    }
+  }
+}
+
+// (3) dq[u] = sum_t dpre[t,u];  grid (unit chunks of 64, N), lane = unit, wave = time slice
+template <typename T>
+__global__ __launch_bounds__(ATHREADS) void attn_bwd_dq_kernel(AttnBwdStep<T> a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // ap[Ti+2P] | de[Tia] | part[AW][64]
+  const int Ti = a.Ti, A = a.A, Tia = a.Tia;
+  float* ap = sm;
+  float* de = ap + Ti + 2 * PADK;
+  float* part = de + Tia;
+  const int n = blockIdx.y, uw = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, ts = tid >> 6;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const int half = (a.kw - 1) / 2;
+  const float* aprev = a.aprev + (long)n * a.al_sn;
+  const float* den = a.de_out + (long)n * a.al_sn;
+  for (int i = tid; i < Ti + 2 * PADK; i += ATHREADS) {
+    const int t = i - PADK;
+    ap[i] = (t >= 0 && t < Ti) ? aprev[t] : 0.f;
+  }
+  for (int t = tid; t < Tia; t += ATHREADS) de[t] = t < L ? den[t] : 0.f;
+  __syncthreads();
+  const int u = uw * 64 + lane;
+  float dq = 0.f;
+  if (u < A) {
+    const float* keys = a.keys + (long)n * a.keys_sn;
+    const float qu = a.q[(long)n * a.q_sn + u], vu = a.v[u];
+    float w[MAXKW];
+#pragma unroll
+    for (int k = 0; k < MAXKW; ++k) w[k] = (k < a.kw) ? a.wcl[k * A + u] : 0.f;
+    for (int tb = ts; tb < L; tb += AW * UB) {
+      float kv[UB];
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int t = tb + j * AW;
+        kv[j] = t < L ? keys[(long)t * A + u] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < UB; ++j) {
+        const int t = tb + j * AW;
+        if (t < L) {
+          float x = kv[j] + qu;
+#pragma unroll
+          for (int k = 0; k < MAXKW; ++k)
+            if (k < a.kw) x = fmaf(ap[PADK + t + k - half], w[k], x);
+          const float th = tanhf_(x);
+          dq = fmaf(de[t] * vu, 1.f - th * th, dq);
+        }
+      }
+    }
+  }
+  part[ts * 64 + lane] = dq;
+  __syncthreads();
+  if (ts == 0 && u < A) {
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < AW; ++w) s += part[w * 64 + lane];
+    stf(a.dq_out + (long)n * a.dq_sn + u, s);
+  }
+}
+
+// Hoisted part of the attention backward: sums over all decoder steps that no recurrence needs.
+//   dkeys[t,u] = sum_s dpre_s[t,u],  dv[u] = sum_{s,t} de_s[t] th_s[t,u],
+//   dWcl[k,u]  = sum_{s,t} align_{s-1}[t+k-half] dpre_s[t,u]
+// One wave = 64 memory positions x PU units, looping over the S steps with everything in
+// registers (th is recomputed; nothing is read-modify-written in memory).
+constexpr int PU = 16;
+struct AttnPost {
+  int S, Ti, A, kw, Tia;
+  const int* lengths;
+  const float* keys_t;     // [N,A,Tia]
+  const float* q;          // [N,S+1,A]
+  const float* align;      // [N,S+1,Tia]
+  const float* de;         // [N,S+1,Tia]
+  const float* wcl; const float* v;
+  float* dkeys_t;          // [N,A,Tia] out (plain store)
+  float* dv; float* dwcl;  // +=
+};
+__global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
+  __shared__ float wl[4][(1 + MAXKW) * PU];
+  const int n = blockIdx.z, tc = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int u0 = (blockIdx.y * 4 + wave) * PU;
+  const int t = tc * 64 + lane;
+  const int Ti = a.Ti, A = a.A, Tia = a.Tia, S1 = a.S + 1;
+  const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
+  const int half = (a.kw - 1) / 2;
+  if (u0 < A) {
+    for (int i = lane; i < (1 + MAXKW) * PU; i += 64) {
+      const int j = i % PU, k = i / PU;   // k = 0: v, k >= 1: wcl[k-1]
+      float val = 0.f;
+      if (u0 + j < A) {
+        if (k == 0) val = a.v[u0 + j];
+        else if (k - 1 < a.kw) val = a.wcl[(k - 1) * A + u0 + j];
+      }
+      wl[wave][i] = val;
+    }
   }
   __syncthreads();
-  // (2) softmax backward
-  float dot = 0.f;
-  for (int t = tid; t < L; t += 256) dot += ac[t] * da[t];
-  dot = block_sum(dot, red);
-  __syncthreads();
-  for (int t = tid; t < L; t += 256) da[t] = ac[t] * (da[t] - dot);   // da now holds de
-  __syncthreads();
-  // (3) energies backward
-  float q[MAXU], v[MAXU], w[MAXKW][MAXU];
-  float dv[MAXU], dq[MAXU], dw[MAXKW][MAXU];
+  if (u0 >= A) return;
+  const bool act = t < L;
+  float kv[PU], dk[PU], dvp[PU], dwp[MAXKW][PU];
 #pragma unroll
-  for (int j = 0; j < MAXU; ++j) {
-    const int u = lane * upl + j;
-    const bool ok = j < upl;
-    q[j] = ok ? a.q[(long)n * a.q_sn + u] : 0.f;
-    v[j] = ok ? a.v[u] : 0.f;
-    dv[j] = 0.f; dq[j] = 0.f;
+  for (int j = 0; j < PU; ++j) {
+    kv[j] = (act && u0 + j < A) ? a.keys_t[((long)n * A + u0 + j) * Tia + t] : 0.f;
+    dk[j] = 0.f; dvp[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < MAXKW; ++k) dwp[k][j] = 0.f;
+  }
+  const float* alb = a.align + (long)n * S1 * Tia;
+  const float* deb = a.de + (long)n * S1 * Tia;
+  const float* qb = a.q + (long)n * S1 * A + u0;
+  // one-step-ahead register prefetch of the per-step operands
+  float apn[MAXKW], den;
+  auto fetch = [&](int slot, float* apo, float& deo) {
 #pragma unroll
     for (int k = 0; k < MAXKW; ++k) {
-      w[k][j] = (ok && k < a.kw) ? a.wcl[k * a.A + u] : 0.f;
-      dw[k][j] = 0.f;
+      const int tt = t + k - half;
+      apo[k] = (k < a.kw && tt >= 0 && tt < Ti) ? alb[(long)(slot - 1) * Tia + tt] : 0.f;
+    }
+    deo = act ? deb[(long)slot * Tia + t] : 0.f;
+  };
+  fetch(1, apn, den);
+  for (int slot = 1; slot <= a.S; ++slot) {
+    float apv[MAXKW], de = den;
+#pragma unroll
+    for (int k = 0; k < MAXKW; ++k) apv[k] = apn[k];
+    if (slot < a.S) fetch(slot + 1, apn, den);
+    const float* qs = qb + (long)slot * A;
+#pragma unroll
+    for (int j = 0; j < PU; ++j) {
+      float x = kv[j] + qs[j];
+#pragma unroll
+      for (int k = 0; k < MAXKW; ++k)
+        if (k < a.kw) x = fmaf(apv[k], wl[wave][(1 + k) * PU + j], x);
+      const float th = tanhf_(x);
+      const float dpre = de * wl[wave][j] * (1.f - th * th);
+      dk[j] += dpre;
+      dvp[j] = fmaf(de, th, dvp[j]);
+#pragma unroll
+      for (int k = 0; k < MAXKW; ++k)
+        if (k < a.kw) dwp[k][j] = fmaf(apv[k], dpre, dwp[k][j]);
     }
   }
-  const float* keys = a.keys + (long)n * a.keys_sn;
-  float* dkeys = a.dkeys + (long)n * a.keys_sn;
-  for (int t = wave; t < L; t += 4) {
-    const float de = da[t];
-    float g[MAXKW];
 #pragma unroll
-    for (int k = 0; k < MAXKW; ++k) g[k] = 0.f;
+  for (int j = 0; j < PU; ++j) {
+    if (u0 + j < A) {
+      if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = dk[j];
+      const float sv = wave_sum(dvp[j]);
+      if (lane == 0) atomicAdd(a.dv + u0 + j, sv);
 #pragma unroll
-    for (int j = 0; j < MAXU; ++j) {
-      if (j < upl) {
-        const long ko = (long)t * a.A + lane * upl + j;
-        float x = keys[ko] + q[j];
-#pragma unroll
-        for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) x = fmaf(ap[MAXKW + t + k - half], w[k][j], x);
-        const float th = tanhf_(x);
-        const float dpre = de * v[j] * (1.f - th * th);
-        dv[j] = fmaf(de, th, dv[j]);
-        dq[j] += dpre;
-        dkeys[ko] += dpre;
-#pragma unroll
-        for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) {
-            dw[k][j] = fmaf(ap[MAXKW + t + k - half], dpre, dw[k][j]);
-            g[k] = fmaf(dpre, w[k][j], g[k]);
-          }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < MAXKW; ++k)
-      if (k < a.kw) {
-        const float gs = wave_sum(g[k]);
-        if (lane == 0) atomicAdd(&dap[MAXKW + t + k - half], gs);
-      }
-  }
-  // cross-wave reduction of dv, dq, dw
-  const int RS = (2 + MAXKW) * a.A;
-#pragma unroll
-  for (int j = 0; j < MAXU; ++j) {
-    if (j < upl) {
-      const int u = lane * upl + j;
-      xr[wave * RS + u] = dv[j];
-      xr[wave * RS + a.A + u] = dq[j];
-#pragma unroll
-      for (int k = 0; k < MAXKW; ++k) xr[wave * RS + (2 + k) * a.A + u] = dw[k][j];
+      for (int k = 0; k < MAXKW; ++k)
+        if (k < a.kw) {
+          const float sw = wave_sum(dwp[k][j]);
+          if (lane == 0) atomicAdd(a.dwcl + k * A + u0 + j, sw);
+        }
     }
   }
-  __syncthreads();
-  for (int i = tid; i < (2 + a.kw) * a.A; i += 256) {
-    const float s = xr[i] + xr[RS + i] + xr[2 * RS + i] + xr[3 * RS + i];
-    if (i < a.A) atomicAdd(a.dv + i, s);
-    else if (i < 2 * a.A) stf(a.dq_out + (long)n * a.dq_sn + (i - a.A), s);
-    else atomicAdd(a.dwcl + (i - 2 * a.A), s);
-  }
-  for (int t = tid; t < a.Tia; t += 256) dal[t] = t < a.Ti ? dap[MAXKW + t] : 0.f;
 }
 
 // ------------------------------------------------------------------ host loops
@@ -251,17 +503,23 @@ static int gemm_small(int dtype, int M, int N, int K, const void* A, long lda, c
 
 extern "C" size_t ns_taco2_attn_work_bytes(const ns_taco2_attn_params* p) {
   if (!p) return 0;
-  // dctx_carry [N,E] + dalign_carry [N,Tia] + dhq [N,A] + dh_carry [N,A] + dc_carry [N,A]
-  return sizeof(float) * ((size_t)p->N * (p->E + p->Tia + 3 * p->A)) + 256;
+  // dctx_carry [N,E] + e_raw/da [N,Tia] + G [N,Tia,MAXKW] + dhq [N,A] + dc_carry [N,A] + dkeys_t [N,A,Tia]
+  return sizeof(float) * ((size_t)p->N * (p->E + (1 + MAXKW) * p->Tia + 2 * p->A + (size_t)p->A * p->Tia)) + 256;
 }
 
 static int check_attn(const ns_taco2_attn_params* p, const char* who) {
   NS_CHECK_ARG(p != nullptr, "%s: null params", who);
-  NS_CHECK_ARG(p->A % 64 == 0 && p->A <= 64 * MAXU, "%s: attention units must be a multiple of 64, <= 256", who);
+  NS_CHECK_ARG(p->A % 8 == 0 && p->A <= 256, "%s: attention units must be a multiple of 8, <= 256", who);
+  NS_CHECK_ARG(p->E % 8 == 0, "%s: memory depth must be a multiple of 8", who);
   NS_CHECK_ARG(p->kw >= 1 && p->kw <= MAXKW, "%s: location filter width must be 1..%d", who, MAXKW);
-  NS_CHECK_ARG(p->Tia >= p->Ti, "%s: Tia < Ti", who);
-  NS_CHECK_ARG(p->N <= 32, "%s: batch per call must be <= 32 (shard the batch)", who);
+  NS_CHECK_ARG(p->Tia >= p->Ti && p->Tia % 4 == 0, "%s: Tia must be >= Ti and a multiple of 4", who);
+  NS_CHECK_ARG(p->keys_t != nullptr, "%s: keys_t scratch missing", who);
   return NS_OK;
+}
+
+static size_t ctx_lds(const ns_taco2_attn_params& p) { return sizeof(float) * ((size_t)p.Tia + 32 + 4 * CCH); }
+static size_t dq_lds(const ns_taco2_attn_params& p) {
+  return sizeof(float) * ((size_t)p.Ti + 2 * PADK + p.Tia + AW * 64);
 }
 
 template <typename T>
@@ -269,19 +527,28 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
   const long XA = D2 + A, HC = A + E;
   const int dt = p.dtype;
-  const size_t lds = sizeof(float) * (2 * p.Ti + 2 * MAXKW + 32);
+  const size_t lds = ctx_lds(p);
+  NS_CHECK_ARG(lds <= 64 * 1024, "ns_taco2_attn_fwd: T_in too long for LDS (%zu bytes)", lds);
+  NS_CHECK_ARG(p.work != nullptr, "ns_taco2_attn_fwd: work buffer missing");
+  float* e_raw = p.work + (size_t)p.N * p.E;
+  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(p.Tia, 32), ceil_div(p.A, 32), p.N), dim3(256), 0, s,
+                     p.keys, p.keys_t, p.Ti, p.Tia, p.Pi, p.padl_i, p.A, 0);
+  NS_CHECK_LAUNCH("keys_transpose");
   for (int st = 0; st < p.S; ++st) {
     const long slot = st + 1, prev = st;
     T* hc = (T*)p.hc; T* xa = (T*)p.xa; T* p1 = (T*)p.p1;
     int rc;
-    // p1 = relu(ctx_prev . W1c + F1)
-    rc = gemm_small(dt, p.N, D1, E, hc + prev * HC + A, S1 * HC, p.w1cT, E, p1 + slot * D1, S1 * D1, dt,
-                    nullptr, NS_ACT_RELU, p.f1 + slot * D1, S1 * D1, nullptr, 0, s);
-    if (rc) return rc;
-    // p2 = relu(p1 . W2 + b2) -> xa[:, 0:D2]
-    rc = gemm_small(dt, p.N, D2, D1, p1 + slot * D1, S1 * D1, p.w2T, D1, xa + slot * XA, S1 * XA, dt, p.b2,
-                    NS_ACT_RELU, nullptr, 0, nullptr, 0, s);
-    if (rc) return rc;
+    for (int nb = 0; nb < p.N; nb += 32) {
+      const int nn = min(32, p.N - nb);
+      // p1 = relu(ctx_prev . W1c + F1)
+      rc = gemm_small(dt, nn, D1, E, hc + (nb * S1 + prev) * HC + A, S1 * HC, p.w1cT, E, p1 + (nb * S1 + slot) * D1,
+                      S1 * D1, dt, nullptr, NS_ACT_RELU, p.f1 + (nb * S1 + slot) * D1, S1 * D1, nullptr, 0, s);
+      if (rc) return rc;
+      // p2 = relu(p1 . W2 + b2) -> xa[:, 0:D2]
+      rc = gemm_small(dt, nn, D2, D1, p1 + (nb * S1 + slot) * D1, S1 * D1, p.w2T, D1, xa + (nb * S1 + slot) * XA,
+                      S1 * XA, dt, p.b2, NS_ACT_RELU, nullptr, 0, nullptr, 0, s);
+      if (rc) return rc;
+    }
     // attention LSTM on [p2 | h_prev]
     LstmStep<T> l = {};
     l.N = p.N; l.H = p.A; l.K = (int)XA; l.forget_bias = 1.0f;
@@ -294,18 +561,23 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     rc = lstm_step_launch<T>(l, s);
     if (rc) return rc;
     // q = h . Wq
-    rc = gemm_small(dt, p.N, (int)A, (int)A, hc + slot * HC, S1 * HC, p.wqT, A, p.q + slot * A, S1 * A, NS_F32,
-                    nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
-    if (rc) return rc;
+    for (int nb = 0; nb < p.N; nb += 32) {
+      const int nn = min(32, p.N - nb);
+      rc = gemm_small(dt, nn, (int)A, (int)A, hc + (nb * S1 + slot) * HC, S1 * HC, p.wqT, A,
+                      p.q + (nb * S1 + slot) * A, S1 * A, NS_F32, nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
+      if (rc) return rc;
+    }
     AttnStep<T> a = {};
     a.Ti = p.Ti; a.A = p.A; a.E = p.E; a.kw = p.kw; a.Tia = p.Tia; a.lengths = p.lengths;
-    a.keys = p.keys + (long)p.padl_i * A; a.keys_sn = (long)p.Pi * A;
+    a.keys_t = p.keys_t;
     a.values = (const T*)p.values + (long)p.padl_i * E; a.values_sn = (long)p.Pi * E;
     a.q = p.q + slot * A; a.q_sn = S1 * A;
     a.aprev = p.align + prev * p.Tia; a.aout = p.align + slot * p.Tia; a.al_sn = S1 * p.Tia;
+    a.aout_t = p.align_t ? (T*)p.align_t + slot * p.Tia : nullptr;
     a.ctx_out = hc + slot * HC + A; a.ctx_sn = S1 * HC;
-    a.wcl = p.wcl; a.v = p.v;
-    hipLaunchKernelGGL(attn_fwd_kernel<T>, dim3(p.N), dim3(256), lds, s, a);
+    a.wcl = p.wcl; a.v = p.v; a.e_raw = e_raw;
+    hipLaunchKernelGGL(attn_energy_kernel<T>, dim3(ceil_div(p.Ti, 64), p.N), dim3(ATHREADS), 0, s, a);
+    hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div(p.E, CCH), p.N), dim3(256), lds, s, a);
     NS_CHECK_LAUNCH("attn_fwd");
   }
   return NS_OK;
@@ -327,18 +599,15 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long XA = D2 + A, HC = A + E;
   const int dt = p.dtype;
   float* dctx_carry = p.work;
-  float* dalign_carry = dctx_carry + (size_t)p.N * E;
-  float* dhq = dalign_carry + (size_t)p.N * p.Tia;
-  float* dh_carry = dhq + (size_t)p.N * A;
-  float* dc_carry = dh_carry + (size_t)p.N * A;
-  const size_t lds = sizeof(float) * (2 * (p.Ti + 2 * MAXKW) + 2 * p.Ti + p.E + 32 + 4 * (2 + MAXKW) * p.A);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
-  NS_CHECK_ARG(lds <= 160 * 1024, "ns_taco2_attn_bwd: T_in too long for LDS (%zu bytes)", lds);
-  T* hc = (T*)p.hc; T* xa = (T*)p.xa; T* p1 = (T*)p.p1;
+  float* da = dctx_carry + (size_t)p.N * E;
+  float* gk = da + (size_t)p.N * p.Tia;
+  float* dhq = gk + (size_t)p.N * p.Tia * MAXKW;
+  float* dc_carry = dhq + (size_t)p.N * A;
+  float* dkeys_t = dc_carry + (size_t)p.N * A;
+  const size_t lds = dq_lds(p);
+  NS_CHECK_ARG(lds <= 64 * 1024 && sizeof(float) * p.E <= 64 * 1024,
+               "ns_taco2_attn_bwd: T_in / memory depth too large for LDS");
+  T* xa = (T*)p.xa; T* p1 = (T*)p.p1;
   for (int st = p.S - 1; st >= 0; --st) {
     const long slot = st + 1, prev = st;
     const bool last = (st == p.S - 1);
@@ -346,55 +615,87 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     AttnBwdStep<T> a = {};
     a.Ti = p.Ti; a.A = p.A; a.E = p.E; a.kw = p.kw; a.Tia = p.Tia; a.lengths = p.lengths;
     a.keys = p.keys + (long)p.padl_i * A; a.keys_sn = (long)p.Pi * A;
+    a.keys_t = p.keys_t;
     a.values = (const T*)p.values + (long)p.padl_i * E; a.values_sn = (long)p.Pi * E;
     a.q = p.q + slot * A; a.q_sn = S1 * A;
     a.acur = p.align + slot * p.Tia; a.aprev = p.align + prev * p.Tia; a.al_sn = S1 * p.Tia;
     a.dctx_ext = p.dhc + slot * HC + A; a.dce_sn = S1 * HC;
     a.dctx_carry = last ? nullptr : dctx_carry;
-    a.dalign_carry = dalign_carry; a.has_carry = last ? 0 : 1;
+    a.gk = gk; a.da = da; a.has_carry = last ? 0 : 1;
     a.dq_out = (T*)p.dq + slot * A; a.dq_sn = S1 * A;
-    a.dkeys = p.dkeys + (long)p.padl_i * A; a.dvalues = p.dvalues + (long)p.padl_i * E;
-    a.dv = p.dv; a.dwcl = p.dwcl; a.wcl = p.wcl; a.v = p.v;
-    hipLaunchKernelGGL(attn_bwd_kernel<T>, dim3(p.N), dim3(256), lds, s, a);
+    a.de_out = p.de + slot * p.Tia;
+    a.dctx_out = (T*)p.dctx_t + slot * E; a.dco_sn = S1 * E;
+    a.wcl = p.wcl; a.v = p.v;
+    hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p.Tia, 32), p.N), dim3(256), sizeof(float) * p.E, s, a);
+    hipLaunchKernelGGL(attn_bwd_energy_kernel<T>, dim3(ceil_div(p.Ti, 64), p.N), dim3(ATHREADS), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(ceil_div(p.A, 64), p.N), dim3(ATHREADS), lds, s, a);
     NS_CHECK_LAUNCH("attn_bwd");
     // dhq = dq . Wq^T
-    rc = gemm_small(dt, p.N, (int)A, (int)A, (T*)p.dq + slot * A, S1 * A, p.wq, A, dhq, A, NS_F32, nullptr,
-                    NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
-    if (rc) return rc;
-    LstmBwdCell<T> c = {};
-    c.N = p.N; c.H = p.A; c.t = st; c.first = last ? 1 : 0; c.lengths = nullptr;
+    for (int nb = 0; nb < p.N; nb += 32) {
+      const int nn = min(32, p.N - nb);
+      rc = gemm_small(dt, nn, (int)A, (int)A, (T*)p.dq + (nb * S1 + slot) * A, S1 * A, p.wq, A, dhq + (long)nb * A, A,
+                      NS_F32, nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
+      if (rc) return rc;
+    }
+    // attention LSTM cell: dh = dhc[:, :A] + dhq + dga[s+1] . Watt[D2:]^T
+    LstmBwdStep<T> c = {};
+    c.N = p.N; c.H = p.A; c.t = st; c.lengths = nullptr; c.K = (int)(4 * A);
+    c.first = last ? 1 : 0;
+    c.dg_next = last ? nullptr : (const T*)p.dga + (slot + 1) * 4 * A; c.dgn_sn = S1 * 4 * A;
+    c.w = (const T*)p.watt + D2 * 4 * A;
     c.dh_out = p.dhc + slot * HC; c.dho_sn = S1 * HC;
     c.dh_out2 = dhq; c.dho2_sn = A;
-    c.dh_carry = last ? nullptr : dh_carry; c.dhc_sn = A;
     c.gates = (const T*)p.ga + slot * 4 * A; c.g_sn = S1 * 4 * A;
     c.c = p.ca + slot * A; c.c_prev = st > 0 ? p.ca + prev * A : nullptr; c.c_sn = S1 * A;
     c.dc_carry = dc_carry;
     c.dgates = (T*)p.dga + slot * 4 * A; c.dg_sn = S1 * 4 * A;
-    rc = lstm_bwd_cell_launch<T>(c, s);
+    rc = lstm_bwd_step_launch<T>(c, s);
     if (rc) return rc;
-    const T* dga = (const T*)p.dga + slot * 4 * A;
-    // dp2pre = (dga . Watt[0:D2]^T) * (p2 > 0)
-    rc = gemm_small(dt, p.N, (int)D2, (int)(4 * A), dga, S1 * 4 * A, p.watt, 4 * A, (T*)p.dp2 + slot * D2, S1 * D2,
-                    dt, nullptr, NS_ACT_NONE, nullptr, 0, xa + slot * XA, S1 * XA, s);
-    if (rc) return rc;
-    // dh_carry = dga . Watt[D2:]^T
-    if (st > 0) {
-      rc = gemm_small(dt, p.N, (int)A, (int)(4 * A), dga, S1 * 4 * A, (const T*)p.watt + D2 * 4 * A, 4 * A, dh_carry,
-                      A, NS_F32, nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
+    for (int nb = 0; nb < p.N; nb += 32) {
+      const int nn = min(32, p.N - nb);
+      const T* dga = (const T*)p.dga + (nb * S1 + slot) * 4 * A;
+      // dp2pre = (dga . Watt[0:D2]^T) * (p2 > 0)
+      rc = gemm_small(dt, nn, (int)D2, (int)(4 * A), dga, S1 * 4 * A, p.watt, 4 * A, (T*)p.dp2 + (nb * S1 + slot) * D2,
+                      S1 * D2, dt, nullptr, NS_ACT_NONE, nullptr, 0, xa + (nb * S1 + slot) * XA, S1 * XA, s);
       if (rc) return rc;
-    }
-    // dp1pre = (dp2pre . W2^T) * (p1 > 0)
-    rc = gemm_small(dt, p.N, (int)D1, (int)D2, (T*)p.dp2 + slot * D2, S1 * D2, p.w2, D2, (T*)p.df1 + slot * D1,
-                    S1 * D1, dt, nullptr, NS_ACT_NONE, nullptr, 0, p1 + slot * D1, S1 * D1, s);
-    if (rc) return rc;
-    // dctx_carry = dp1pre . W1c^T
-    if (st > 0) {
-      rc = gemm_small(dt, p.N, (int)E, (int)D1, (T*)p.df1 + slot * D1, S1 * D1, p.w1c, D1, dctx_carry, E, NS_F32,
-                      nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
+      // dp1pre = (dp2pre . W2^T) * (p1 > 0)
+      rc = gemm_small(dt, nn, (int)D1, (int)D2, (T*)p.dp2 + (nb * S1 + slot) * D2, S1 * D2, p.w2, D2,
+                      (T*)p.df1 + (nb * S1 + slot) * D1, S1 * D1, dt, nullptr, NS_ACT_NONE, nullptr, 0,
+                      p1 + (nb * S1 + slot) * D1, S1 * D1, s);
       if (rc) return rc;
+      // dctx_carry = dp1pre . W1c^T
+      if (st > 0) {
+        rc = gemm_small(dt, nn, (int)E, (int)D1, (T*)p.df1 + (nb * S1 + slot) * D1, S1 * D1, p.w1c, D1,
+                        dctx_carry + (long)nb * E, E, NS_F32, nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
+        if (rc) return rc;
+      }
     }
   }
-  (void)hc;
+  // ---- hoisted sums over all steps
+  {
+    AttnPost q = {};
+    q.S = p.S; q.Ti = p.Ti; q.A = p.A; q.kw = p.kw; q.Tia = p.Tia; q.lengths = p.lengths;
+    q.keys_t = p.keys_t; q.q = p.q; q.align = p.align; q.de = p.de; q.wcl = p.wcl; q.v = p.v;
+    q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl;
+    dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
+    hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, s, q);
+    NS_CHECK_LAUNCH("attn_post");
+  }
+  // dvalues[n] += align[n]^T . dctx[n]   (contraction over the decoder steps)
+  for (int n = 0; n < p.N; ++n) {
+    ns_gemm_params g = {};
+    g.dtype = dt; g.M = p.Ti; g.N = (int)E; g.K = (int)S1;
+    g.A = (const T*)p.align_t + (long)n * S1 * p.Tia; g.lda = p.Tia; g.a_mode = 1;
+    g.B = (const T*)p.dctx_t + (long)n * S1 * E; g.ldb = E; g.b_mode = 1;
+    g.C = p.dvalues + ((long)n * p.Pi + p.padl_i) * E; g.ldc = E; g.c_dtype = NS_F32;
+    g.accumulate = 1; g.alpha = 1.f; g.split_k = 1;
+    int rc = ns_gemm(&g, s);
+    if (rc) return rc;
+  }
+  // dkeys[t][u] += dkeys_t[u][t]
+  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(p.Tia, 32), ceil_div(p.A, 32), p.N), dim3(256), 0, s,
+                     (const float*)p.dkeys, dkeys_t, p.Ti, p.Tia, p.Pi, p.padl_i, p.A, 1);
+  NS_CHECK_LAUNCH("keys_transpose_back");
   return NS_OK;
 }
 
@@ -403,7 +704,7 @@ extern "C" int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   if (rc) return rc;
   NS_CHECK_ARG(p->keys && p->values && p->w1c && p->w2 && p->watt && p->wq && p->wcl && p->v && p->p1 && p->xa &&
                    p->ca && p->ga && p->q && p->align && p->dhc && p->df1 && p->dp2 && p->dga && p->dq &&
-                   p->dkeys && p->dvalues && p->dv && p->dwcl && p->work,
+                   p->dkeys && p->dvalues && p->dv && p->dwcl && p->work && p->align_t && p->de && p->dctx_t,
                "ns_taco2_attn_bwd: null pointer");
   if (p->dtype == NS_BF16) return attn_bwd_t<bf16_t>(*p, (hipStream_t)s);
   return attn_bwd_t<float>(*p, (hipStream_t)s);

@@ -43,14 +43,13 @@ __device__ __forceinline__ float ldf(const bf16_t* p) { return (float)*p; }
 __device__ __forceinline__ void stf(float* p, float v) { *p = v; }
 __device__ __forceinline__ void stf(bf16_t* p, float v) { *p = (bf16_t)v; }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 forms (absolute error ~1e-7): sigmoid(x) = 1/(1+2^(-x log2 e)),
+// tanh(x) = 1 - 2/(2^(2x log2 e) + 1); both saturate correctly through exp -> 0 / inf.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float tanhf_(float x) {
-  // accurate enough for fp32 parity (|err| ~1e-7) and cheap: tanh(x) = 1 - 2/(exp(2x)+1)
-  float ax = fabsf(x);
-  if (ax > 15.f) return copysignf(1.f, x);
-  float e = __expf(2.f * ax);
-  float t = 1.f - 2.f / (e + 1.f);
-  return copysignf(t, x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.0f);
 }
 
 __device__ __forceinline__ float apply_act(float v, int act) {

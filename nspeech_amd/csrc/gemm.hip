@@ -354,42 +354,48 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
 // Both operands k-contiguous (a_mode 0, b_mode 0).  One workgroup = 32 rows x 64 columns,
 // the 4 waves split K; fragments are 16-B global loads (weights stay L2 / MALL resident
 // across the time loop), partial sums meet in LDS.
+constexpr int SKW = 8;      // waves per workgroup
+constexpr int SKG = 4;      // K chunks in flight per wave
 template <int NT>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
-  __shared__ float red[4][32][NT * 16 + 1];
+__global__ __launch_bounds__(SKW * 64) void gemm_skinny_kernel(ns_gemm_params p) {
+  __shared__ float red[SKW][32][NT * 16 + 1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * (NT * 16);
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
   const int r16 = lane & 15, g = lane >> 4;
+  const bf16x8 z8 = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
   f32x4 acc[2][NT];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  // K chunks of 32 dealt round-robin to waves
+  // K chunks of 32 dealt round-robin to waves; each wave keeps SKG chunks of loads in flight
   const int nkc = (p.K + 31) / 32;
-#pragma unroll 2
-  for (int kc = wave; kc < nkc; kc += 4) {
-    const int k = kc * 32 + g * 8;
-    bf16x8 af[2], bfr[NT];
+  const bf16_t* arow0 = A + (long)r16 * p.lda;
+  const bf16_t* arow1 = A + (long)(16 + r16) * p.lda;
+  const bool ok0 = r16 < p.M, ok1 = 16 + r16 < p.M;
+  for (int kc0 = wave; kc0 < nkc; kc0 += SKW * SKG) {
+    bf16x8 af[SKG][2], bfr[SKG][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = i * 16 + r16;
-      if (m < p.M && k < p.K) af[i] = *(const bf16x8*)(A + (long)m * p.lda + k);
-      else af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < SKG; ++q) {
+      const int k = (kc0 + q * SKW) * 32 + g * 8;
+      const bool okk = k < p.K;
+      af[q][0] = (ok0 && okk) ? *(const bf16x8*)(arow0 + k) : z8;
+      af[q][1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : z8;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 16 + r16;
+        bfr[q][j] = (n < p.N && okk) ? *(const bf16x8*)(B + (long)n * p.ldb + k) : z8;
+      }
     }
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + j * 16 + r16;
-      if (n < p.N && k < p.K) bfr[j] = *(const bf16x8*)(B + (long)n * p.ldb + k);
-      else bfr[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    }
+    for (int q = 0; q < SKG; ++q)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q][j], acc[i][j], 0, 0, 0);
   }
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -399,11 +405,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(ns_gemm_params p) {
       for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   __syncthreads();
   Epi e = make_epi(p);
-  for (int idx = tid; idx < 32 * NT * 16; idx += 256) {
+  for (int idx = tid; idx < 32 * NT * 16; idx += SKW * 64) {
     const int mm = idx / (NT * 16), nn = idx % (NT * 16);
     const int m = mm, n = n0 + nn;
     if (m >= p.M || n >= p.N) continue;
-    float v = red[0][mm][nn] + red[1][mm][nn] + red[2][mm][nn] + red[3][mm][nn];
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SKW; ++w) v += red[w][mm][nn];
     const bool valid = row_valid(e, m);
     v = epi_value(e, m, n, v, true, valid);
     epi_store(e, m, n, v);
@@ -442,9 +450,8 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   if (fast && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 &&
       !p.col_sum) {
     // enough workgroups to spread the weight stream over the chip
-    if (p.N >= 64 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<4>, dim3(ceil_div(p.N, 64)), dim3(256), 0, stream, p);
-    else if (p.N >= 32 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(ceil_div(p.N, 32)), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(256), 0, stream, p);
+    if (p.N >= 32 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(ceil_div(p.N, 32)), dim3(SKW * 64), 0, stream, p);
+    else hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
     NS_CHECK_LAUNCH("gemm_skinny");
     return NS_OK;
   }

@@ -1,18 +1,46 @@
 // LSTM recurrences (LSTMBlockCell semantics: gate order i,j,f,o, forget_bias added at compute
-// time).  One fused kernel per time step: the recurrent product h[t-1].Wh for 16 hidden units
-// (= 64 gate columns) x 32 batch rows per workgroup, K split over the 4 waves, then the cell
-// update in the same launch.  The input product x.Wx is hoisted by the caller into one big GEMM.
+// time).  One fused kernel per time step and direction pair:
+//   forward : gates = xg[t] + h[t-1].Wh for 16 hidden units (= 64 gate columns) x 32 batch rows
+//             per workgroup, K dealt in 32-wide chunks to 8 wavefronts that issue all of their
+//             16-byte fragment loads before the first MFMA (the step is L2-latency bound), partial
+//             sums meet in LDS, then the cell update;
+//   backward: dh = dh_out + dgates[t+1].Wh^T for 16 units, then the cell gradient, same shape.
+// The input products x.Wx and every weight gradient are hoisted by the caller into big GEMMs.
 #include "common.h"
 #include "lstm_step.h"
 
+constexpr int LW = 8;          // waves per workgroup
+constexpr int LTHREADS = LW * 64;
+constexpr int GROUP = 4;       // K chunks whose loads are in flight together, per wave
+
+__device__ __forceinline__ bf16x8 zero8() { return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
+
 // ------------------------------------------------------------------ fused forward step
 template <typename T>
-__global__ __launch_bounds__(256) void lstm_step_kernel(LstmStep<T> a) {
-  __shared__ float red[4][32][65];
+__global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp) {
+  __shared__ float red[LW][32][65];
+  const LstmStep<T>& a = pp.s[blockIdx.z];
   const int tid = threadIdx.x;
   const int u0 = blockIdx.x * 16;
   const int nb = blockIdx.y * 32;
   const int H = a.H;
+  // epilogue operands of this thread's (row, unit): issued now so that their memory latency
+  // overlaps the weight / state fragment loads instead of following the LDS reduction
+  const int er = tid >> 4, euu = tid & 15;
+  const int en = nb + er, eu = u0 + euu;
+  const bool eok = en < a.N && eu < H;
+  float pz[4] = {0.f, 0.f, 0.f, 0.f};
+  float pcp = 0.f;
+  bool pmask = false;
+  if (eok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (a.xg) pz[j] = a.xg[(long)en * a.xg_sn + (long)j * H + eu];
+      if (a.bias) pz[j] += a.bias[j * H + eu];
+    }
+    if (a.c_prev) pcp = a.c_prev[(long)en * a.c_sn + eu];
+    pmask = a.lengths && a.t >= a.lengths[en];
+  }
 
   if constexpr (sizeof(T) == 2) {
     const int lane = tid & 63, wave = tid >> 6;
@@ -24,27 +52,30 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStep<T> a) {
       for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.a) {
       const int nkc = (a.K + 31) / 32;
-#pragma unroll 2
-      for (int kc = wave; kc < nkc; kc += 4) {
-        const int k = kc * 32 + g * 8;
-        bf16x8 af[2], bfr[4];
+      const bf16_t* arow0 = a.a + (long)(nb + r16) * a.a_sn;
+      const bf16_t* arow1 = a.a + (long)(nb + 16 + r16) * a.a_sn;
+      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
+      const bool oku = u0 + r16 < H;
+      const bf16_t* brow = a.wT + (long)(u0 + r16) * a.K;
+      const long gstride = (long)H * a.K;
+      for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
+        bf16x8 af[GROUP][2], bfr[GROUP][4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int n = nb + i * 16 + r16;
-          if (n < a.N && k < a.K) af[i] = *(const bf16x8*)(a.a + (long)n * a.a_sn + k);
-          else af[i] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < GROUP; ++q) {
+          const int k = (kc0 + q * LW) * 32 + g * 8;
+          const bool okk = k < a.K;
+          af[q][0] = (ok0 && okk) ? *(const bf16x8*)(arow0 + k) : zero8();
+          af[q][1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bfr[q][j] = (oku && okk) ? *(const bf16x8*)(brow + j * gstride + k) : zero8();
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int u = u0 + r16;
-          if (u < H && k < a.K) bfr[j] = *(const bf16x8*)(a.wT + ((long)j * H + u) * a.K + k);
-          else bfr[j] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-        }
+        for (int q = 0; q < GROUP; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q][j], acc[i][j], 0, 0, 0);
       }
     }
 #pragma unroll
@@ -54,43 +85,42 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStep<T> a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   } else {
-    // exact fp32 path (parity tests): thread = (row, 8 gate columns)
-    const int r = tid >> 3, cb = (tid & 7) * 8;
+    // exact fp32 path (parity tests): thread = (row, 4 gate columns)
+    const int r = tid >> 4, cb = (tid & 15) * 4;
     const int n = nb + r;
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float s[4] = {0, 0, 0, 0};
     if (a.a && n < a.N) {
       const float* arow = (const float*)a.a + (long)n * a.a_sn;
       for (int k = 0; k < a.K; ++k) {
         const float av = arow[k];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
+        for (int q = 0; q < 4; ++q) {
           const int col = cb + q, j = col >> 4, u = u0 + (col & 15);
           if (u < H) s[q] = fmaf(av, ((const float*)a.wT)[((long)j * H + u) * a.K + k], s[q]);
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < 4; ++q) {
       red[0][r][cb + q] = s[q];
-      red[1][r][cb + q] = 0.f; red[2][r][cb + q] = 0.f; red[3][r][cb + q] = 0.f;
+#pragma unroll
+      for (int w = 1; w < LW; ++w) red[w][r][cb + q] = 0.f;
     }
   }
   __syncthreads();
 
-  for (int idx = tid; idx < 32 * 16; idx += 256) {
-    const int r = idx >> 4, uu = idx & 15;
-    const int n = nb + r, u = u0 + uu;
-    if (n >= a.N || u >= H) continue;
+  if (eok) {
+    const int r = er, uu = euu, n = en, u = eu;
     float z[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float v = red[0][r][j * 16 + uu] + red[1][r][j * 16 + uu] + red[2][r][j * 16 + uu] + red[3][r][j * 16 + uu];
-      if (a.xg) v += a.xg[(long)n * a.xg_sn + (long)j * H + u];
-      if (a.bias) v += a.bias[j * H + u];
+      float v = pz[j];
+#pragma unroll
+      for (int w = 0; w < LW; ++w) v += red[w][r][j * 16 + uu];
       z[j] = v;
     }
-    const bool masked = a.lengths && a.t >= a.lengths[n];
-    const float cp = a.c_prev ? a.c_prev[(long)n * a.c_sn + u] : 0.f;
+    const bool masked = pmask;
+    const float cp = pcp;
     const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + a.forget_bias), go = sigmoidf_(z[3]);
     float c = gf * cp + gi * gj;
     float h = go * tanhf_(c);
@@ -109,140 +139,255 @@ __global__ __launch_bounds__(256) void lstm_step_kernel(LstmStep<T> a) {
 }
 
 template <typename T>
-int lstm_step_launch(const LstmStep<T>& a, hipStream_t s) {
-  dim3 grid(ceil_div(a.H, 16), ceil_div(a.N, 32));
-  hipLaunchKernelGGL(lstm_step_kernel<T>, grid, dim3(256), 0, s, a);
+int lstm_step_launch2(const LstmStepPair<T>& a, hipStream_t s) {
+  dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
+  hipLaunchKernelGGL(lstm_step_kernel<T>, grid, dim3(LTHREADS), 0, s, a);
   NS_CHECK_LAUNCH("lstm_step");
   return NS_OK;
 }
+template <typename T>
+int lstm_step_launch(const LstmStep<T>& a, hipStream_t s) {
+  LstmStepPair<T> pp;
+  pp.s[0] = a; pp.s[1] = a; pp.n = 1;
+  return lstm_step_launch2<T>(pp, s);
+}
 template int lstm_step_launch<float>(const LstmStep<float>&, hipStream_t);
 template int lstm_step_launch<bf16_t>(const LstmStep<bf16_t>&, hipStream_t);
+template int lstm_step_launch2<float>(const LstmStepPair<float>&, hipStream_t);
+template int lstm_step_launch2<bf16_t>(const LstmStepPair<bf16_t>&, hipStream_t);
 
-// ------------------------------------------------------------------ backward cell update
+// ------------------------------------------------------------------ fused backward step
 template <typename T>
-__global__ void lstm_bwd_cell_kernel(LstmBwdCell<T> a) {
-  const int total = a.N * a.H;
-  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
-    const int n = idx / a.H, u = idx % a.H;
-    const int H = a.H;
-    T* dg = a.dgates + (long)n * a.dg_sn;
-    const bool masked = a.lengths && a.t >= a.lengths[n];
-    if (masked) {
-      stf(dg + u, 0.f); stf(dg + H + u, 0.f); stf(dg + 2 * H + u, 0.f); stf(dg + 3 * H + u, 0.f);
-      a.dc_carry[idx] = 0.f;
-      continue;
-    }
-    float dh = 0.f;
-    if (a.dh_out) dh += a.dh_out[(long)n * a.dho_sn + u];
-    if (a.dh_out2) dh += a.dh_out2[(long)n * a.dho2_sn + u];
-    if (a.dh_carry) dh += a.dh_carry[(long)n * a.dhc_sn + u];
-    const T* gp = a.gates + (long)n * a.g_sn;
-    const float gi = ldf(gp + u), gj = ldf(gp + H + u), gf = ldf(gp + 2 * H + u), go = ldf(gp + 3 * H + u);
-    const float c = a.c[(long)n * a.c_sn + u];
-    const float cp = a.c_prev ? a.c_prev[(long)n * a.c_sn + u] : 0.f;
-    const float tc = tanhf_(c);
-    const float d_o = dh * tc * go * (1.f - go);
-    float dc = dh * go * (1.f - tc * tc);
-    if (!a.first) dc += a.dc_carry[idx];
-    const float d_i = dc * gj * gi * (1.f - gi);
-    const float d_j = dc * gi * (1.f - gj * gj);
-    const float d_f = dc * cp * gf * (1.f - gf);
-    a.dc_carry[idx] = dc * gf;
-    stf(dg + u, d_i); stf(dg + H + u, d_j); stf(dg + 2 * H + u, d_f); stf(dg + 3 * H + u, d_o);
+__global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair<T> pp) {
+  __shared__ float red[LW][32][17];
+  const LstmBwdStep<T>& a = pp.s[blockIdx.z];
+  const int tid = threadIdx.x;
+  const int u0 = blockIdx.x * 16;
+  const int nb = blockIdx.y * 32;
+  const int H = a.H;
+  // epilogue operands first (see the forward kernel)
+  const int er = tid >> 4, euu = tid & 15;
+  const int en = nb + er, eu = u0 + euu;
+  const bool eok = en < a.N && eu < H;
+  float pdh = 0.f, pgi = 0.f, pgj = 0.f, pgf = 0.f, pgo = 0.f, pc = 0.f, pcp = 0.f, pdc = 0.f;
+  bool pmask = false;
+  if (eok) {
+    pmask = a.lengths && a.t >= a.lengths[en];
+    if (a.dh_out) pdh += a.dh_out[(long)en * a.dho_sn + eu];
+    if (a.dh_out2) pdh += a.dh_out2[(long)en * a.dho2_sn + eu];
+    const T* gp = a.gates + (long)en * a.g_sn;
+    pgi = ldf(gp + eu); pgj = ldf(gp + H + eu); pgf = ldf(gp + 2 * H + eu); pgo = ldf(gp + 3 * H + eu);
+    pc = a.c[(long)en * a.c_sn + eu];
+    if (a.c_prev) pcp = a.c_prev[(long)en * a.c_sn + eu];
+    if (!a.first) pdc = a.dc_carry[(long)en * H + eu];
   }
+
+  if constexpr (sizeof(T) == 2) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.dg_next) {
+      const int nkc = (a.K + 31) / 32;
+      const bf16_t* arow0 = a.dg_next + (long)(nb + r16) * a.dgn_sn;
+      const bf16_t* arow1 = a.dg_next + (long)(nb + 16 + r16) * a.dgn_sn;
+      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
+      const bool oku = u0 + r16 < H;
+      const bf16_t* brow = a.w + (long)(u0 + r16) * a.K;
+      for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
+        bf16x8 af[GROUP][2], bfr[GROUP];
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+          const int k = (kc0 + q * LW) * 32 + g * 8;
+          const bool okk = k < a.K;
+          af[q][0] = (ok0 && okk) ? *(const bf16x8*)(arow0 + k) : zero8();
+          af[q][1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
+          bfr[q] = (oku && okk) ? *(const bf16x8*)(brow + k) : zero8();
+        }
+#pragma unroll
+        for (int q = 0; q < GROUP; ++q) {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][0], bfr[q], acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][1], bfr[q], acc[1], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
+  } else {
+    const int r = tid >> 4, uu = tid & 15;
+    const int n = nb + r, u = u0 + uu;
+    float s = 0.f;
+    if (a.dg_next && n < a.N && u < H) {
+      const float* arow = (const float*)a.dg_next + (long)n * a.dgn_sn;
+      const float* brow = (const float*)a.w + (long)u * a.K;
+      for (int k = 0; k < a.K; ++k) s = fmaf(arow[k], brow[k], s);
+    }
+    red[0][r][uu] = s;
+#pragma unroll
+    for (int w = 1; w < LW; ++w) red[w][r][uu] = 0.f;
+  }
+  __syncthreads();
+
+  if (!eok) return;
+  const int r = er, uu = euu, n = en, u = eu;
+  T* dg = a.dgates + (long)n * a.dg_sn;
+  const long ci = (long)n * H + u;
+  if (pmask) {
+    stf(dg + u, 0.f); stf(dg + H + u, 0.f); stf(dg + 2 * H + u, 0.f); stf(dg + 3 * H + u, 0.f);
+    a.dc_carry[ci] = 0.f;
+    return;
+  }
+  float dh = pdh;
+#pragma unroll
+  for (int w = 0; w < LW; ++w) dh += red[w][r][uu];
+  const float gi = pgi, gj = pgj, gf = pgf, go = pgo, c = pc, cp = pcp;
+  const float tc = tanhf_(c);
+  const float d_o = dh * tc * go * (1.f - go);
+  const float dc = dh * go * (1.f - tc * tc) + pdc;
+  const float d_i = dc * gj * gi * (1.f - gi);
+  const float d_j = dc * gi * (1.f - gj * gj);
+  const float d_f = dc * cp * gf * (1.f - gf);
+  a.dc_carry[ci] = dc * gf;
+  stf(dg + u, d_i); stf(dg + H + u, d_j); stf(dg + 2 * H + u, d_f); stf(dg + 3 * H + u, d_o);
 }
+
 template <typename T>
-int lstm_bwd_cell_launch(const LstmBwdCell<T>& a, hipStream_t s) {
-  const int total = a.N * a.H;
-  hipLaunchKernelGGL(lstm_bwd_cell_kernel<T>, dim3(ceil_div(total, 256)), dim3(256), 0, s, a);
-  NS_CHECK_LAUNCH("lstm_bwd_cell");
+int lstm_bwd_step_launch2(const LstmBwdStepPair<T>& a, hipStream_t s) {
+  dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
+  hipLaunchKernelGGL(lstm_bwd_step_kernel<T>, grid, dim3(LTHREADS), 0, s, a);
+  NS_CHECK_LAUNCH("lstm_bwd_step");
   return NS_OK;
 }
-template int lstm_bwd_cell_launch<float>(const LstmBwdCell<float>&, hipStream_t);
-template int lstm_bwd_cell_launch<bf16_t>(const LstmBwdCell<bf16_t>&, hipStream_t);
+template <typename T>
+int lstm_bwd_step_launch(const LstmBwdStep<T>& a, hipStream_t s) {
+  LstmBwdStepPair<T> pp;
+  pp.s[0] = a; pp.s[1] = a; pp.n = 1;
+  return lstm_bwd_step_launch2<T>(pp, s);
+}
+template int lstm_bwd_step_launch<float>(const LstmBwdStep<float>&, hipStream_t);
+template int lstm_bwd_step_launch<bf16_t>(const LstmBwdStep<bf16_t>&, hipStream_t);
+template int lstm_bwd_step_launch2<float>(const LstmBwdStepPair<float>&, hipStream_t);
+template int lstm_bwd_step_launch2<bf16_t>(const LstmBwdStepPair<bf16_t>&, hipStream_t);
 
 // ------------------------------------------------------------------ host time loops
 extern "C" size_t ns_lstm_seq_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
-  return sizeof(float) * 2 * (size_t)p->N * p->H + 256;
+  return sizeof(float) * (size_t)p->N * p->H + 256;
 }
 
 template <typename T>
-static int lstm_seq_fwd_t(const ns_lstm_seq_params& p, hipStream_t s) {
+static void fill_fwd(LstmStep<T>& a, const ns_lstm_seq_params& p, int step) {
   const long P = p.P, H = p.H;
-  for (int step = 0; step < p.T; ++step) {
-    const int t = p.reverse ? p.T - 1 - step : step;
-    const int tp = p.reverse ? t + 1 : t - 1;
-    const long row = p.padl + t, rowp = p.padl + tp;
-    const bool has_prev = rowp >= 0 && rowp < P && step > 0;
-    LstmStep<T> a = {};
-    a.N = p.N; a.H = p.H; a.K = p.H; a.forget_bias = p.forget_bias;
-    a.a = has_prev ? (const T*)p.h + rowp * p.ld_h : nullptr;
-    a.a_sn = P * p.ld_h;
-    a.wT = (const T*)p.whT;
-    a.xg = p.xg + row * p.ld_xg; a.xg_sn = P * p.ld_xg;
-    a.c_prev = has_prev ? p.c + rowp * H : nullptr; a.c_sn = P * H;
-    a.h_out = (T*)p.h + row * p.ld_h; a.h_sn = P * p.ld_h;
-    a.c_out = p.c + row * H; a.co_sn = P * H;
-    a.gates_out = p.gates ? (T*)p.gates + row * 4 * H : nullptr; a.g_sn = P * 4 * H;
-    a.lengths = p.lengths; a.t = t;
-    int rc = lstm_step_launch<T>(a, s);
+  const int t = p.reverse ? p.T - 1 - step : step;
+  const int tp = p.reverse ? t + 1 : t - 1;
+  const long row = p.padl + t, rowp = p.padl + tp;
+  const bool has_prev = rowp >= 0 && rowp < P && step > 0;
+  a = LstmStep<T>{};
+  a.N = p.N; a.H = p.H; a.K = p.H; a.forget_bias = p.forget_bias;
+  a.a = has_prev ? (const T*)p.h + rowp * p.ld_h : nullptr;
+  a.a_sn = P * p.ld_h;
+  a.wT = (const T*)p.whT;
+  a.xg = p.xg + row * p.ld_xg; a.xg_sn = P * p.ld_xg;
+  a.c_prev = has_prev ? p.c + rowp * H : nullptr; a.c_sn = P * H;
+  a.h_out = (T*)p.h + row * p.ld_h; a.h_sn = P * p.ld_h;
+  a.c_out = p.c + row * H; a.co_sn = P * H;
+  a.gates_out = p.gates ? (T*)p.gates + row * 4 * H : nullptr; a.g_sn = P * 4 * H;
+  a.lengths = p.lengths; a.t = t;
+}
+
+template <typename T>
+static void fill_bwd(LstmBwdStep<T>& a, const ns_lstm_seq_params& p, int step, float* dc_carry) {
+  const long P = p.P, H = p.H;
+  const int t = p.reverse ? p.T - 1 - step : step;
+  const int tp = p.reverse ? t + 1 : t - 1;   // forward-pass predecessor
+  const int tn = p.reverse ? t - 1 : t + 1;   // forward-pass successor (whose dgates feed dh)
+  const long row = p.padl + t, rowp = p.padl + tp, rown = p.padl + tn;
+  const bool has_prev = step > 0 && rowp >= 0 && rowp < P;
+  const bool has_next = step < p.T - 1;
+  a = LstmBwdStep<T>{};
+  a.N = p.N; a.H = p.H; a.t = t; a.lengths = p.lengths; a.K = 4 * p.H;
+  a.first = has_next ? 0 : 1;
+  a.dg_next = has_next ? (const T*)p.dgates + rown * 4 * H : nullptr; a.dgn_sn = P * 4 * H;
+  a.w = (const T*)p.wh;
+  a.dh_out = p.dh + row * p.ld_dh; a.dho_sn = P * p.ld_dh;
+  a.gates = (const T*)p.gates + row * 4 * H; a.g_sn = P * 4 * H;
+  a.c = p.c + row * H; a.c_sn = P * H;
+  a.c_prev = has_prev ? p.c + rowp * H : nullptr;
+  a.dc_carry = dc_carry;
+  a.dgates = (T*)p.dgates + row * 4 * H; a.dg_sn = P * 4 * H;
+}
+
+static int check_fwd(const ns_lstm_seq_params* p, const char* who) {
+  NS_CHECK_ARG(p && p->xg && p->whT && p->h && p->c, "%s: null", who);
+  NS_CHECK_ARG(p->H % 16 == 0 && p->ld_h % 8 == 0, "%s: H %% 16 and ld_h %% 8 required", who);
+  NS_CHECK_ARG(p->padl + p->T <= p->P, "%s: P too small", who);
+  return NS_OK;
+}
+static int check_bwd(const ns_lstm_seq_params* p, const char* who) {
+  NS_CHECK_ARG(p && p->wh && p->gates && p->c && p->dh && p->dgates && p->work, "%s: null", who);
+  NS_CHECK_ARG(p->H % 16 == 0, "%s: H %% 16 required", who);
+  return NS_OK;
+}
+
+template <typename T>
+static int seq_fwd_t(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, hipStream_t s) {
+  for (int step = 0; step < p0->T; ++step) {
+    LstmStepPair<T> pp;
+    pp.n = p1 ? 2 : 1;
+    fill_fwd<T>(pp.s[0], *p0, step);
+    if (p1) fill_fwd<T>(pp.s[1], *p1, step); else pp.s[1] = pp.s[0];
+    int rc = lstm_step_launch2<T>(pp, s);
+    if (rc) return rc;
+  }
+  return NS_OK;
+}
+template <typename T>
+static int seq_bwd_t(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, hipStream_t s) {
+  for (int step = p0->T - 1; step >= 0; --step) {
+    LstmBwdStepPair<T> pp;
+    pp.n = p1 ? 2 : 1;
+    fill_bwd<T>(pp.s[0], *p0, step, p0->work);
+    if (p1) fill_bwd<T>(pp.s[1], *p1, step, p1->work); else pp.s[1] = pp.s[0];
+    int rc = lstm_bwd_step_launch2<T>(pp, s);
     if (rc) return rc;
   }
   return NS_OK;
 }
 
 extern "C" int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t s) {
-  NS_CHECK_ARG(p && p->xg && p->whT && p->h && p->c, "ns_lstm_seq_fwd: null");
-  NS_CHECK_ARG(p->H % 16 == 0 && p->ld_h % 8 == 0, "ns_lstm_seq_fwd: H %% 16 and ld_h %% 8 required");
-  NS_CHECK_ARG(p->padl + p->T <= p->P, "ns_lstm_seq_fwd: P too small");
-  if (p->dtype == NS_BF16) return lstm_seq_fwd_t<bf16_t>(*p, (hipStream_t)s);
-  return lstm_seq_fwd_t<float>(*p, (hipStream_t)s);
+  int rc = check_fwd(p, "ns_lstm_seq_fwd");
+  if (rc) return rc;
+  if (p->dtype == NS_BF16) return seq_fwd_t<bf16_t>(p, nullptr, (hipStream_t)s);
+  return seq_fwd_t<float>(p, nullptr, (hipStream_t)s);
 }
-
-template <typename T>
-static int lstm_seq_bwd_t(const ns_lstm_seq_params& p, hipStream_t s) {
-  const long P = p.P, H = p.H;
-  float* dh_carry = p.work;
-  float* dc_carry = p.work + (size_t)p.N * H;
-  // walk the forward order backwards
-  for (int step = p.T - 1; step >= 0; --step) {
-    const int t = p.reverse ? p.T - 1 - step : step;
-    const int tp = p.reverse ? t + 1 : t - 1;  // forward-pass predecessor
-    const long row = p.padl + t, rowp = p.padl + tp;
-    const bool has_prev = step > 0 && rowp >= 0 && rowp < P;
-    LstmBwdCell<T> a = {};
-    a.N = p.N; a.H = p.H; a.t = t; a.lengths = p.lengths;
-    a.first = (step == p.T - 1);
-    a.dh_out = p.dh + row * p.ld_dh; a.dho_sn = P * p.ld_dh;
-    a.dh_carry = a.first ? nullptr : dh_carry; a.dhc_sn = H;
-    a.gates = (const T*)p.gates + row * 4 * H; a.g_sn = P * 4 * H;
-    a.c = p.c + row * H; a.c_sn = P * H;
-    a.c_prev = has_prev ? p.c + rowp * H : nullptr;
-    a.dc_carry = dc_carry;
-    a.dgates = (T*)p.dgates + row * 4 * H; a.dg_sn = P * 4 * H;
-    int rc = lstm_bwd_cell_launch<T>(a, s);
-    if (rc) return rc;
-    if (step > 0) {
-      // dh_carry[N,H] = dgates[t] . Wh^T   (Wh natural [H,4H] is k-contiguous for this product)
-      for (int nb = 0; nb < p.N; nb += 32) {
-        ns_gemm_params g = {};
-        g.dtype = p.dtype; g.M = min(32, p.N - nb); g.N = p.H; g.K = 4 * p.H;
-        g.A = (const T*)p.dgates + (row + (long)nb * P) * 4 * H; g.lda = P * 4 * H; g.a_mode = 0;
-        g.B = p.wh; g.ldb = 4 * H; g.b_mode = 0;
-        g.C = dh_carry + (size_t)nb * H; g.ldc = H; g.c_dtype = NS_F32;
-        g.alpha = 1.f; g.split_k = 1;
-        rc = ns_gemm(&g, s);
-        if (rc) return rc;
-      }
-    }
-  }
-  return NS_OK;
-}
-
 extern "C" int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t s) {
-  NS_CHECK_ARG(p && p->wh && p->gates && p->c && p->dh && p->dgates && p->work, "ns_lstm_seq_bwd: null");
-  NS_CHECK_ARG(p->H % 16 == 0, "ns_lstm_seq_bwd: H %% 16 required");
-  if (p->dtype == NS_BF16) return lstm_seq_bwd_t<bf16_t>(*p, (hipStream_t)s);
-  return lstm_seq_bwd_t<float>(*p, (hipStream_t)s);
+  int rc = check_bwd(p, "ns_lstm_seq_bwd");
+  if (rc) return rc;
+  if (p->dtype == NS_BF16) return seq_bwd_t<bf16_t>(p, nullptr, (hipStream_t)s);
+  return seq_bwd_t<float>(p, nullptr, (hipStream_t)s);
+}
+// Two independent recurrences with identical N/T/H (the two directions of a BiLSTM) advanced
+// together, one launch per time step.
+extern "C" int ns_lstm_seq2_fwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t s) {
+  int rc = check_fwd(p0, "ns_lstm_seq2_fwd");
+  if (rc) return rc;
+  rc = check_fwd(p1, "ns_lstm_seq2_fwd");
+  if (rc) return rc;
+  NS_CHECK_ARG(p0->N == p1->N && p0->T == p1->T && p0->H == p1->H && p0->dtype == p1->dtype,
+               "ns_lstm_seq2_fwd: the two recurrences must share N, T, H, dtype");
+  if (p0->dtype == NS_BF16) return seq_fwd_t<bf16_t>(p0, p1, (hipStream_t)s);
+  return seq_fwd_t<float>(p0, p1, (hipStream_t)s);
+}
+extern "C" int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t s) {
+  int rc = check_bwd(p0, "ns_lstm_seq2_bwd");
+  if (rc) return rc;
+  rc = check_bwd(p1, "ns_lstm_seq2_bwd");
+  if (rc) return rc;
+  NS_CHECK_ARG(p0->N == p1->N && p0->T == p1->T && p0->H == p1->H && p0->dtype == p1->dtype,
+               "ns_lstm_seq2_bwd: the two recurrences must share N, T, H, dtype");
+  if (p0->dtype == NS_BF16) return seq_bwd_t<bf16_t>(p0, p1, (hipStream_t)s);
+  return seq_bwd_t<float>(p0, p1, (hipStream_t)s);
 }

@@ -18,18 +18,27 @@ struct LstmStep {
   int N, H;
   float forget_bias;
 };
-template <typename T> int lstm_step_launch(const LstmStep<T>& a, hipStream_t s);
-
+// up to two independent cells (the two directions of a BiLSTM) in one launch: blockIdx.z
 template <typename T>
-struct LstmBwdCell {
-  int N, H, t, first;
+struct LstmStepPair { LstmStep<T> s[2]; int n; };
+template <typename T> int lstm_step_launch(const LstmStep<T>& a, hipStream_t s);
+template <typename T> int lstm_step_launch2(const LstmStepPair<T>& a, hipStream_t s);
+
+// Backward step: dh = dh_out (+dh_out2) + dgates_next . Wh^T, then the cell gradient.
+template <typename T>
+struct LstmBwdStep {
+  int N, H, t;
   const int* lengths;
-  const float* dh_out; long dho_sn;    // optional
-  const float* dh_out2; long dho2_sn;  // optional
-  const float* dh_carry; long dhc_sn;  // optional
+  const T* dg_next; long dgn_sn; int K;   // [N, K] gate gradients of the step after (null = none)
+  const T* w;                              // [H, K] rows = this cell's units, k-contiguous
+  const float* dh_out; long dho_sn;        // optional
+  const float* dh_out2; long dho2_sn;      // optional
   const T* gates; long g_sn;
   const float* c; const float* c_prev; long c_sn;
-  float* dc_carry;                     // [N,H] in/out
-  T* dgates; long dg_sn;
+  float* dc_carry; int first;              // [N,H] in/out (ignored on input when first)
+  T* dgates; long dg_sn;                   // out [N, 4H]
 };
-template <typename T> int lstm_bwd_cell_launch(const LstmBwdCell<T>& a, hipStream_t s);
+template <typename T>
+struct LstmBwdStepPair { LstmBwdStep<T> s[2]; int n; };
+template <typename T> int lstm_bwd_step_launch(const LstmBwdStep<T>& a, hipStream_t s);
+template <typename T> int lstm_bwd_step_launch2(const LstmBwdStepPair<T>& a, hipStream_t s);

@@ -274,6 +274,7 @@ class Tacotron2(object):
     def _bilstm_fwd(self, scope, x, cin, H, N, T, Pp, lengths, tag, key):
         rows = N * Pp
         out = self._buf(tag + "_h", rows * 2 * H, self.T)
+        pair = []
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             xg = self._buf("%s_xg_%s" % (tag, d), rows * 4 * H, torch.float32)
@@ -281,8 +282,9 @@ class Tacotron2(object):
                      bias=self.flat_p, bias_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
             gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, self.T)
-            ops.lstm_seq("fwd", self.T, N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
-                         lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H)
+            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
+                                            lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H))
+        ops.lstm_seq2("fwd", pair[0], pair[1])
         return out
 
     def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx):
@@ -290,16 +292,23 @@ class Tacotron2(object):
         rows = N * Pp
         g = self.flat_g
         hbuf = self._bufs[tag + "_h"]
-        work = self._buf("lstm_work", 2 * N * H + 64, torch.float32)
+        pair = []
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             ko = self._o(kname)
             c = self._bufs["%s_c_%s" % (tag, d)]
             gt = self._bufs["%s_g_%s" % (tag, d)]
             dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, self.T)
-            ops.lstm_seq("bwd", self.T, N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
-                         self.flat_s, lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout, ld_dh=2 * H, dgates=dg,
-                         work=work, wh_off=ko + cin * 4 * H, h_off=di * H, dh_off=di * H)
+            work = self._buf("lstm_work_%s" % d, N * H + 64, torch.float32)
+            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
+                                            self.flat_s, lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
+                                            ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
+                                            h_off=di * H, dh_off=di * H))
+        ops.lstm_seq2("bwd", pair[0], pair[1])
+        for di, d in enumerate(("fw", "bw")):
+            kname = "%s/%s/lstm_cell/kernel" % (scope, d)
+            ko = self._o(kname)
+            dg = self._bufs["%s_dg_%s" % (tag, d)]
             # dWx += X^T dgates ; dWh += Hprev^T dgates ; db += colsum
             ops.gemm(x, dg, g, cin, 4 * H, rows, cin, 4 * H, 4 * H, a_mode=1, b_mode=1, c_off=ko, accumulate=2,
                      split_k=self._splitk(rows, cin, 4 * H))
@@ -368,7 +377,7 @@ class Tacotron2(object):
         w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
         ops.gemm(fr, self.flat_s, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p,
                  bias_off=self._o("decoder/decoder_prenet/dense_1/bias"))
-        Tia = _round_up(Ti, 4)
+        Tia = _round_up(Ti, 8)
         p1 = self._buf("dec_p1", N * S1 * 256, T_)
         xa = self._buf("dec_xa", N * S1 * (128 + A), T_)
         hc = self._buf("dec_hc", N * S1 * (A + E), T_)
@@ -383,7 +392,10 @@ class Tacotron2(object):
             b2=(self.flat_p, self._o("decoder/decoder_prenet/dense_2/bias")),
             batt=(self.flat_p, self._o("decoder/attention_lstm/bias")),
             wcl=self.tsh["wcl"], v=(self.flat_p, self._o("decoder/attention/attention_v")),
-            p1=p1, xa=xa, hc=hc, ca=ca, ga=ga, q=q, align=al)
+            p1=p1, xa=xa, hc=hc, ca=ca, ga=ga, q=q, align=al,
+            keys_t=self._buf("dec_keys_t", N * A * Tia, torch.float32),
+            work=self._buf("attn_work", N * (E + 9 * Tia + 2 * A + A * Tia) + 64, torch.float32),
+            align_t=self._buf("dec_al_t", N * S1 * Tia, T_))
         ops.taco2_attn("fwd", **self._attn_args)
         self._tick("attn_rnn")
 
@@ -573,7 +585,8 @@ class Tacotron2(object):
         dvalues.zero_()
         dwcl = self._buf("d_wcl", 7 * A, torch.float32)
         dwcl.zero_()
-        awork = self._buf("attn_work", N * (E + _round_up(Ti, 4) + 3 * A) + 64, torch.float32)
+        Tia = _round_up(Ti, 8)
+        awork = self._buf("attn_work", N * (E + 9 * Tia + 2 * A + A * Tia) + 64, torch.float32)
         w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
         w2 = self._o("decoder/decoder_prenet/dense_2/kernel")
         wa = self._o("decoder/attention_lstm/kernel")
@@ -581,7 +594,9 @@ class Tacotron2(object):
         args = dict(self._attn_args)
         args.update(w1c=(self.flat_s, w1 + M * 256), w2=(self.flat_s, w2), watt=(self.flat_s, wa),
                     wq=(self.flat_s, wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
-                    dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork)
+                    dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork,
+                    de=self._buf("d_energy", rows * Tia, torch.float32),
+                    dctx_t=self._buf("d_ctx_t", rows * E, T_))
         ops.taco2_attn("bwd", **args)
         self._tick("attn_rnn_bwd")
         # hoisted weight gradients of the attention RNN

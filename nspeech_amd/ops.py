@@ -140,16 +140,27 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
     L.call("ns_cast2d", p, stream())
 
 
-def lstm_seq(direction, dtype_t, N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
-             dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
-             forget_bias=1.0):
-    """direction: 'fwd' or 'bwd' (through-time gradient)."""
+def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
+                    dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
+                    forget_bias=1.0):
     p = L.struct("ns_lstm_seq_params")
     _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
           dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work))
+    return p
+
+
+def lstm_seq(direction, dtype_t, *a, **kw):
+    """direction: 'fwd' or 'bwd' (through-time gradient)."""
+    p = lstm_seq_params(*a, **kw)
     L.call("ns_lstm_seq_fwd" if direction == "fwd" else "ns_lstm_seq_bwd", p, stream())
+
+
+def lstm_seq2(direction, p0, p1):
+    """Two independent recurrences (BiLSTM directions) advanced together, one launch per step."""
+    fn = getattr(L.lib(), "ns_lstm_seq2_fwd" if direction == "fwd" else "ns_lstm_seq2_bwd")
+    L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(stream())), "ns_lstm_seq2_" + direction)
 
 
 def taco2_attn(direction, **kw):

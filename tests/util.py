@@ -52,3 +52,26 @@ def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64
         loss.backward()
         grads = {k: (p[k].grad.numpy() if p[k].grad is not None else np.zeros_like(params[k])) for k in params}
     return out, (float(loss.detach()), float(mel_loss.detach()), float(lin_loss.detach())), grads
+
+
+def stabilise_targets(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3, rounds=4):
+    """The L1 losses have a sign() gradient: an element whose prediction sits within rounding
+    noise of its target flips sign between fp32-on-GPU and float64-on-CPU and perturbs every
+    upstream gradient by a finite amount.  Move such targets away from the oracle's prediction
+    (mel targets also feed the teacher-forced decoder, hence a few rounds)."""
+    from oracle import taco2_oracle as O
+    mel, lin = mel.copy(), lin.copy()
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in stats.items()})
+    for _ in range(rounds):
+        with torch.no_grad():
+            out = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
+                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+        dm = out["mel_outputs"].numpy() - mel
+        dl = out["linear_outputs"].numpy() - lin
+        bm, bl = np.abs(dm) < margin, np.abs(dl) < margin
+        if not bm.any() and not bl.any():
+            break
+        mel[bm] -= 10 * margin
+        lin[bl] -= 10 * margin
+    return mel.astype(np.float32), lin.astype(np.float32)
