@@ -62,6 +62,46 @@ def cpu_baseline(hp, seed, budget_s=25.0):
                       % (N, Ti, To, dt)}
 
 
+def griffin_lim_bench(hp, with_cpu):
+    """Second headline metric: Griffin-Lim real-time factor on 10 s of audio (60 iterations)."""
+    from nspeech_amd.utils import audio as A
+    from oracle import audio_oracle as AO
+    hpd = hp.values()
+    rng = np.random.default_rng(1234)
+    L = 200000
+    t = np.arange(L) / hp.sample_rate
+    f0 = rng.uniform(90, 250)
+    y = sum(np.sin(2 * np.pi * f0 * (h + 1) * t) / (h + 1) for h in range(5)) * (0.5 + 0.5 * np.sin(2 * np.pi * 4 * t))
+    y = (0.8 * y / np.abs(y).max() + rng.normal(0, 0.01, L)).astype(np.float32)
+    # normalised linear spectrogram with real dynamics (the shipped +100 min_level_db saturates, SURVEY Q1)
+    spec = AO.spectrogram(y, dict(hpd, min_level_db=-100)).T[:797].copy()
+    st = torch.tensor(spec, device="cuda")
+    for _ in range(2):
+        A.griffin_lim_gpu(st)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        wav = A.griffin_lim_gpu(st)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    audio_s = wav.numel() / hp.sample_rate
+    # algorithmic HBM bytes per call (SURVEY 8d): per iteration read S + read y + write y, plus the init pass
+    T, F, win = 797, hp.num_freq, 1000
+    alg = 60 * (T * F * 4 + 2 * wav.numel() * 4) + (T * F * 4 + wav.numel() * 4)
+    res = {"rtf": ms * 1e-3 / audio_s, "ms": ms, "audio_s": audio_s, "iters": int(hp.griffin_lim_iters),
+           "algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
+    if with_cpu:
+        t0 = time.time()
+        AO.inv_spectrogram_tensorflow(spec[:200], hpd)       # bounded sample: 200 frames, 60 iterations
+        dt = time.time() - t0
+        res["cpu_rtf"] = dt / ((199 * 250 + 1000) / hp.sample_rate)
+        res["cpu_sample"] = "float64 NumPy oracle, 200 frames (2.5 s of audio), 60 iterations, %.1f s" % dt
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,6 +189,8 @@ def main():
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss": loss},
             "roofline": roof,
         }
+        if world == 1:
+            res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hp, 1234)
         print(json.dumps(res))

@@ -256,6 +256,45 @@ int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 size_t ns_taco2_attn_work_bytes(const ns_taco2_attn_params* p);
 
+
+/* ------------------------------------------------------------------ audio DSP (utils/audio.py)
+ * Radix-2 Stockham FFTs of n_fft points run inside LDS, one workgroup per frame; no MFMA,
+ * the kernels are bandwidth / latency bound.  window = periodic Hann(win) and
+ * twiddle[m] = (cos, -sin)(2*pi*m/n_fft), m < n_fft/2, are supplied by the caller (immutable). */
+
+/* audio.spectrogram + audio.melspectrogram in ONE pass over the waveform (audio.py:39-42,61-64
+ * with librosa.stft(center=True, reflect) framing, _amp_to_db, _normalize; preemphasis fused).
+ * lin_out [T, n_fft/2+1], mel_out [T, n_mels], both normalised, T = 1 + L/hop. */
+typedef struct {
+  const float* wav; int L;
+  float preemph;
+  int n_fft, hop, win, T;
+  const float* window; const float* twiddle;
+  const float* mel_basis; int n_mels;
+  float ref_level_db, min_level_db;
+  float* lin_out; float* mel_out;
+} ns_spectrogram_params;
+int ns_spectrogram(const ns_spectrogram_params* p, ns_stream_t stream);
+
+/* audio.inv_spectrogram_tensorflow (audio.py:51-58,90-123): denormalise -> dB to amplitude ->
+ * ^power -> Griffin-Lim with zero initial phase and TF-style (un-centred, un-normalised)
+ * STFT / inverse STFT.  spec [N, T, F] normalised, wav [N, (T-1)*hop + win]. */
+typedef struct {
+  const float* spec; int N, T;
+  int n_fft, hop, win, iters;
+  float power, ref_level_db, min_level_db;
+  const float* window; const float* twiddle;
+  float* wav;
+  float* work;   /* ns_griffin_lim_work_bytes() */
+} ns_griffin_lim_params;
+int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t stream);
+size_t ns_griffin_lim_work_bytes(const ns_griffin_lim_params* p);
+
+/* audio.preemphasis (inverse=0: y[n] = x[n] - c x[n-1]) and audio.inv_preemphasis
+ * (inverse=1: y[n] = x[n] + c y[n-1]), scipy.signal.lfilter with zero initial state. */
+typedef struct { const float* x; float* y; int64_t n; float coef; int inverse; } ns_preemphasis_params;
+int ns_preemphasis(const ns_preemphasis_params* p, ns_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,233 @@
+"""Drop-in for neural_speech/utils/audio.py: same functions, NumPy in / NumPy out, hyper-parameters
+read from the global get_hparams() at call time - but the DSP runs in hand-written HIP kernels
+(csrc/audio.hip) through the C ABI.  Spectrograms are [F, T] exactly like the reference.
+
+Host-side here: wav file I/O, the immutable tables (Hann window, FFT twiddles, Slaney mel basis,
+built once per configuration in float64 NumPy and uploaded), and find_endpoint's threshold scan.
+"""
+import wave
+
+import numpy as np
+import torch
+
+from .. import ops
+from .. import _lib as L
+from ..hparams import get_hparams
+
+_tables = {}
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise L.NSError("nspeech_amd.utils.audio needs a GPU: the DSP kernels have no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _stft_parameters():
+    hp = get_hparams()
+    n_fft = (hp.num_freq - 1) * 2
+    hop_length = int(hp.frame_shift_ms / 1000 * hp.sample_rate)
+    win_length = int(hp.frame_length_ms / 1000 * hp.sample_rate)
+    return n_fft, hop_length, win_length
+
+
+def _hz_to_mel(f):
+    f = np.atleast_1d(np.asarray(f, np.float64))
+    out = f / (200.0 / 3)
+    big = f >= 1000.0
+    out[big] = 15.0 + np.log(f[big] / 1000.0) * (27.0 / np.log(6.4))
+    return out
+
+
+def _mel_to_hz(m):
+    m = np.atleast_1d(np.asarray(m, np.float64))
+    out = m * (200.0 / 3)
+    big = m >= 15.0
+    out[big] = 1000.0 * np.exp((m[big] - 15.0) * (np.log(6.4) / 27.0))
+    return out
+
+
+def _build_mel_basis():
+    """librosa.filters.mel(sr, n_fft, n_mels) of librosa 0.6.0: Slaney mel scale, triangular
+    filters between n_mels+2 band edges from 0 to sr/2, each scaled by 2/(f[i+2]-f[i])."""
+    hp = get_hparams()
+    n_fft = (hp.num_freq - 1) * 2
+    freqs = np.arange(hp.num_freq, dtype=np.float64) * (hp.sample_rate / float(n_fft))
+    edges = _mel_to_hz(np.linspace(_hz_to_mel(0.0)[0], _hz_to_mel(hp.sample_rate / 2.0)[0], hp.num_mels + 2))
+    basis = np.zeros((hp.num_mels, hp.num_freq))
+    for i in range(hp.num_mels):
+        lo, mid, hi = edges[i], edges[i + 1], edges[i + 2]
+        up = (freqs - lo) / (mid - lo)
+        down = (hi - freqs) / (hi - mid)
+        basis[i] = np.maximum(0.0, np.minimum(up, down)) * (2.0 / (hi - lo))
+    return basis
+
+
+def _get_tables():
+    hp = get_hparams()
+    n_fft, hop, win = _stft_parameters()
+    key = (n_fft, win, hp.num_mels, hp.sample_rate, torch.cuda.current_device())
+    if key not in _tables:
+        dev = _dev()
+        w = 0.5 - 0.5 * np.cos(2.0 * np.pi * np.arange(win) / win)
+        m = np.arange(n_fft // 2)
+        tw = np.stack([np.cos(2 * np.pi * m / n_fft), -np.sin(2 * np.pi * m / n_fft)], axis=1)
+        _tables[key] = dict(
+            window=torch.tensor(w, dtype=torch.float32, device=dev),
+            twiddle=torch.tensor(tw, dtype=torch.float32, device=dev).contiguous(),
+            mel_basis=torch.tensor(_build_mel_basis(), dtype=torch.float32, device=dev).contiguous())
+    return _tables[key]
+
+
+# ---------------------------------------------------------------- wav I/O (host)
+def load_wav(path, offset=0.0, duration=None):
+    """PCM16 / float32 RIFF reader.  The reference resamples through librosa (resampy); here the
+    file must already be at hparams.sample_rate (SURVEY F2 keeps resampling out of the hot path)."""
+    with wave.open(path, "rb") as f:
+        sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
+        raw = f.readframes(n)
+    hp = get_hparams()
+    if sr != hp.sample_rate:
+        raise ValueError("%s is %d Hz, expected %d Hz" % (path, sr, hp.sample_rate))
+    if width == 2:
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+    elif width == 4:
+        x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+    else:
+        raise ValueError("unsupported sample width %d" % width)
+    if ch > 1:
+        x = x.reshape(-1, ch).mean(axis=1)
+    s = int(offset * sr)
+    e = None if duration is None else s + int(duration * sr)
+    return x[s:e]
+
+
+def save_wav(wav, path):
+    """audio.py:17-19 scales to +-32767 (in place in the reference); written as int16 PCM."""
+    wav = np.asarray(wav, np.float64) * (32767 / max(0.01, np.max(np.abs(wav))))
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1)
+        f.setsampwidth(2)
+        f.setframerate(get_hparams().sample_rate)
+        f.writeframes(wav.astype("<i2").tobytes())
+
+
+def load_spectrogram(path):
+    spec = np.load(path)
+    return spec, spec.shape[1]
+
+
+def save_spectrogram(spec, path):
+    np.save(path, spec, allow_pickle=False)
+
+
+# ---------------------------------------------------------------- filters
+def _preemph(x, inverse):
+    xt = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32)).to(_dev())
+    y = torch.empty_like(xt)
+    p = L.struct("ns_preemphasis_params")
+    p.x, p.y, p.n, p.coef, p.inverse = ops.ptr(xt), ops.ptr(y), xt.numel(), float(get_hparams().preemphasis), inverse
+    L.call("ns_preemphasis", p, ops.stream())
+    return y.cpu().numpy()
+
+
+def preemphasis(x):
+    return _preemph(x, 0)
+
+
+def inv_preemphasis(x):
+    return _preemph(x, 1)
+
+
+# ---------------------------------------------------------------- spectrograms
+def _spectrograms(y, want_lin, want_mel):
+    hp = get_hparams()
+    n_fft, hop, win = _stft_parameters()
+    tb = _get_tables()
+    dev = _dev()
+    wav = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32)).to(dev)
+    Lw = wav.numel()
+    T = 1 + Lw // hop
+    lin = torch.empty(T * hp.num_freq, dtype=torch.float32, device=dev) if want_lin else None
+    mel = torch.empty(T * hp.num_mels, dtype=torch.float32, device=dev) if want_mel else None
+    p = L.struct("ns_spectrogram_params")
+    p.wav, p.L, p.preemph = ops.ptr(wav), Lw, float(hp.preemphasis)
+    p.n_fft, p.hop, p.win, p.T = n_fft, hop, win, T
+    p.window, p.twiddle = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"])
+    p.mel_basis, p.n_mels = ops.ptr(tb["mel_basis"]), hp.num_mels
+    p.ref_level_db, p.min_level_db = float(hp.ref_level_db), float(hp.min_level_db)
+    p.lin_out, p.mel_out = ops.ptr(lin), ops.ptr(mel)
+    L.call("ns_spectrogram", p, ops.stream())
+    out_lin = lin.view(T, hp.num_freq).t().cpu().numpy() if want_lin else None
+    out_mel = mel.view(T, hp.num_mels).t().cpu().numpy() if want_mel else None
+    return out_lin, out_mel
+
+
+def spectrogram(y):
+    return np.ascontiguousarray(_spectrograms(y, True, False)[0])
+
+
+def melspectrogram(y):
+    return np.ascontiguousarray(_spectrograms(y, False, True)[1])
+
+
+def spectrogram_and_mel(y):
+    """Both features from ONE STFT (the reference recomputes the STFT for each, process.py:28-33)."""
+    a, b = _spectrograms(y, True, True)
+    return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def griffin_lim_gpu(spec, iters=None):
+    """spec: torch CUDA tensor or array [T, F] / [N, T, F] (normalised).  Returns a CUDA tensor
+    [L] / [N, L], L = (T-1)*hop + win, before inv_preemphasis (audio.py:51-58)."""
+    hp = get_hparams()
+    n_fft, hop, win = _stft_parameters()
+    tb = _get_tables()
+    dev = _dev()
+    st = spec if torch.is_tensor(spec) else torch.as_tensor(np.asarray(spec, dtype=np.float32))
+    st = st.to(dev, torch.float32).contiguous()
+    single = st.dim() == 2
+    if single:
+        st = st.unsqueeze(0)
+    N, T, F = st.shape
+    assert F == hp.num_freq
+    Lout = (T - 1) * hop + win
+    wav = torch.empty(N * Lout, dtype=torch.float32, device=dev)
+    p = L.struct("ns_griffin_lim_params")
+    p.spec, p.N, p.T = ops.ptr(st), N, T
+    p.n_fft, p.hop, p.win = n_fft, hop, win
+    p.iters = int(hp.griffin_lim_iters if iters is None else iters)
+    p.power, p.ref_level_db, p.min_level_db = float(hp.power), float(hp.ref_level_db), float(hp.min_level_db)
+    p.window, p.twiddle, p.wav = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"]), ops.ptr(wav)
+    nbytes = L.lib().ns_griffin_lim_work_bytes
+    nbytes.restype = __import__("ctypes").c_size_t
+    work = torch.empty((nbytes(__import__("ctypes").byref(p)) + 3) // 4, dtype=torch.float32, device=dev)
+    p.work = ops.ptr(work)
+    L.call("ns_griffin_lim", p, ops.stream())
+    out = wav.view(N, Lout)
+    return out[0] if single else out
+
+
+def inv_spectrogram_tensorflow(spectrogram):
+    """Name kept from the reference (audio.py:51): Griffin-Lim on the GPU; [T,F] in, waveform out,
+    pre-emphasis NOT inverted (the caller applies inv_preemphasis, as in the reference)."""
+    out = griffin_lim_gpu(spectrogram)
+    return out if torch.is_tensor(spectrogram) else out.cpu().numpy()
+
+
+def inv_spectrogram(spectrogram):
+    """audio.py:45-48 takes [F, T]; the live path of the reference is the TF variant,
+    so this uses the same deterministic zero-phase Griffin-Lim, then inverts the pre-emphasis."""
+    wav = griffin_lim_gpu(np.asarray(spectrogram, dtype=np.float32).T).cpu().numpy()
+    return inv_preemphasis(wav)
+
+
+def find_endpoint(wav, threshold_db=-40, min_silence_sec=0.8):
+    hp = get_hparams()
+    window_length = int(hp.sample_rate * min_silence_sec)
+    hop_length = int(window_length / 4)
+    threshold = np.power(10.0, threshold_db * 0.05)
+    for x in range(hop_length, len(wav) - window_length, hop_length):
+        if np.max(wav[x:x + window_length]) < threshold:
+            return x + hop_length
+    return len(wav)

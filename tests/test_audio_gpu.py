@@ -1,0 +1,86 @@
+"""GPU parity of the audio kernels (STFT/mel features, Griffin-Lim, pre-emphasis) against the
+float64 NumPy oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import audio_oracle as AO
+from test_audio_oracle import HP, _speechlike
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def audio(dev):
+    from nspeech_amd import hparams
+    from nspeech_amd.utils import audio as A
+    hp = hparams.load("taco2")
+    return A, hp
+
+
+def test_features_match_oracle(audio):
+    A, hp = audio
+    for L, seed in ((20000, 0), (12345, 1), (2600, 2)):
+        y = _speechlike(L, seed)
+        lin = A.spectrogram(y)
+        mel = A.melspectrogram(y)
+        rl, rm = AO.spectrogram(y, HP), AO.melspectrogram(y, HP)
+        assert lin.shape == rl.shape and mel.shape == rm.shape
+        # tolerance: fp32 FFT + log10 on the GPU vs float64; values live in [0, 1]
+        assert np.abs(lin - rl).max() < 2e-4, np.abs(lin - rl).max()
+        assert np.abs(mel - rm).max() < 2e-4, np.abs(mel - rm).max()
+        l2, m2 = A.spectrogram_and_mel(y)
+        assert np.array_equal(l2, lin) and np.array_equal(m2, mel)
+
+
+def test_min_level_db_both_signs(audio):
+    A, hp = audio
+    y = _speechlike(6000, 4)
+    hp.min_level_db = -100
+    try:
+        got = A.spectrogram(y)
+    finally:
+        hp.min_level_db = 100
+    assert np.abs(got - AO.spectrogram(y, dict(HP, min_level_db=-100))).max() < 2e-4
+
+
+def test_preemphasis_roundtrip(audio):
+    A, hp = audio
+    y = _speechlike(50001, 5)
+    p = A.preemphasis(y)
+    assert np.abs(p - AO.preemphasis(y, 0.97)).max() < 1e-6
+    q = A.inv_preemphasis(y)
+    ref = AO.inv_preemphasis(y, 0.97)
+    assert np.abs(q - ref).max() < 2e-4 * np.abs(ref).max()
+    assert np.abs(A.inv_preemphasis(p) - y).max() < 1e-4
+
+
+def test_griffin_lim_matches_oracle(audio):
+    A, hp = audio
+    y = _speechlike(30 * 250 + 1000, 6)
+    # a spectrogram with real dynamics: under the shipped min_level_db=+100 the
+    # features of this signal saturate at 1.0, which Griffin-Lim maps to an all-zero waveform
+    spec = AO.spectrogram(y, dict(HP, min_level_db=-100)).T[:31]            # [T, F] in [0, 1]
+    assert spec.std() > 0.05
+    for iters in (0, 1, 5):
+        got = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
+        ref = AO.inv_spectrogram_tensorflow(spec, HP, iters=iters)
+        assert got.shape == ref.shape == ((31 - 1) * 250 + 1000,)
+        # relative to the signal's peak; phase normalisation E/|E| is ill-conditioned where |E| ~ 0,
+        # so the error grows with the iteration count
+        tol = 2e-4 if iters <= 1 else 5e-3
+        assert np.abs(got - ref).max() < tol * np.abs(ref).max(), (iters, np.abs(got - ref).max(), np.abs(ref).max())
+
+
+def test_griffin_lim_batched_and_roundtrip_gain(audio):
+    A, hp = audio
+    ys = [_speechlike(20 * 250 + 1000, s) for s in (7, 8)]
+    specs = np.stack([AO.spectrogram(y, dict(HP, min_level_db=-100)).T[:21] for y in ys])
+    out = A.griffin_lim_gpu(specs, iters=3).cpu().numpy()
+    for i in range(2):
+        single = A.griffin_lim_gpu(specs[i], iters=3).cpu().numpy()
+        assert np.array_equal(out[i], single)
+    assert np.isfinite(out).all() and np.abs(out).max() > 0
+    # saturated input (all ones) -> constant magnitude, zero phase -> impulse at n=0 where Hann is 0
+    z = A.griffin_lim_gpu(np.ones((21, 1025), np.float32), iters=2).cpu().numpy()
+    assert np.abs(z).max() < 1e-3
