@@ -43,8 +43,14 @@ def cpu_baseline(hp, seed, budget_s=25.0):
     from oracle import taco2_oracle as O
     from nspeech_amd.models import params as P
     from nspeech_amd.utils.text.symbols import symbols
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box grants a 16-core share per GPU
     torch.set_num_threads(cores)
+    sys.stderr.write("[bench] cpu baseline on %d threads...\n" % cores)
+    sys.stderr.flush()
     lay, st = P.taco2_layout(hp, len(symbols))
     pv, sv = P.init_values(lay, st, seed)
     N, Ti, To = 4, 160, 250
@@ -94,6 +100,8 @@ def griffin_lim_bench(hp, with_cpu):
     res = {"rtf": ms * 1e-3 / audio_s, "ms": ms, "audio_s": audio_s, "iters": int(hp.griffin_lim_iters),
            "algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
     if with_cpu:
+        sys.stderr.write("[bench] griffin-lim cpu sample...\n")
+        sys.stderr.flush()
         t0 = time.time()
         AO.inv_spectrogram_tensorflow(spec[:200], hpd)       # bounded sample: 200 frames, 60 iterations
         dt = time.time() - t0
