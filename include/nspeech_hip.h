@@ -67,6 +67,8 @@ typedef struct {
   int split_k;
   const float* addend; int64_t ld_add;   /* optional fp32 [M,N] added before the activation */
   const void* gate; int64_t ld_gate;     /* optional (dtype of A) [M,N]: result *= (gate > 0)  (ReLU backward) */
+  int f32_passes;   /* fp32 operands only: 0 = exact fp32 FMA kernel; 3 = split-bf16 on MFMA
+                       (x = hi + lo, hi*hi + hi*lo + lo*hi, ~2^-17 relative); 1 = hi*hi only */
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
 
@@ -203,6 +205,7 @@ typedef struct {
   const float* dh; int64_t ld_dh;       /* fp32 [N*P, ld_dh] grad wrt h outputs */
   void* dgates;                         /* (dtype) [N*P, 4H] out */
   float* work;                          /* fp32 [N*H] scratch (cell-state gradient carry) */
+  int f32_passes;                       /* as in ns_gemm_params, for the recurrent product */
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -251,6 +254,7 @@ typedef struct {
   float* dkeys; float* dvalues;    /* fp32 [N*Pi,A], [N*Pi,E] += */
   float* dv; float* dwcl;          /* fp32 [A], [kw*A] += */
   float* work;                     /* fp32 scratch, ns_taco2_attn_work_bytes() */
+  int f32_passes;                  /* as in ns_gemm_params, for the in-loop products */
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

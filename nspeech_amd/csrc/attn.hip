@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
 }
 
 // ------------------------------------------------------------------ host loops
+static thread_local int g_f32_passes = 0;   // set per call from ns_taco2_attn_params
 static int gemm_small(int dtype, int M, int N, int K, const void* A, long lda, const void* B, long ldb,
                       void* C, long ldc, int c_dtype, const float* bias, int act, const float* addend,
                       long ld_add, const void* gate, long ld_gate, hipStream_t s) {
@@ -498,6 +499,7 @@ static int gemm_small(int dtype, int M, int N, int K, const void* A, long lda, c
   g.C = C; g.ldc = ldc; g.c_dtype = c_dtype;
   g.bias = bias; g.act = act; g.alpha = 1.f; g.split_k = 1;
   g.addend = addend; g.ld_add = ld_add; g.gate = gate; g.ld_gate = ld_gate;
+  g.f32_passes = g_f32_passes;
   return ns_gemm(&g, s);
 }
 
@@ -558,6 +560,7 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     if (st + 1 < p.S) { l.h_out2 = xa + (slot + 1) * XA + D2; l.h2_sn = S1 * XA; }
     l.c_out = p.ca + slot * A; l.co_sn = S1 * A;
     l.gates_out = (T*)p.ga + slot * 4 * A; l.g_sn = S1 * 4 * A;
+    l.passes = p.f32_passes;
     rc = lstm_step_launch<T>(l, s);
     if (rc) return rc;
     // q = h . Wq
@@ -589,6 +592,7 @@ extern "C" int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p->keys && p->values && p->f1 && p->w1cT && p->w2T && p->wattT && p->wqT && p->b2 && p->batt &&
                    p->wcl && p->v && p->p1 && p->xa && p->hc && p->ca && p->ga && p->q && p->align,
                "ns_taco2_attn_fwd: null pointer");
+  g_f32_passes = p->f32_passes;
   if (p->dtype == NS_BF16) return attn_fwd_t<bf16_t>(*p, (hipStream_t)s);
   return attn_fwd_t<float>(*p, (hipStream_t)s);
 }
@@ -649,6 +653,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     c.c = p.ca + slot * A; c.c_prev = st > 0 ? p.ca + prev * A : nullptr; c.c_sn = S1 * A;
     c.dc_carry = dc_carry;
     c.dgates = (T*)p.dga + slot * 4 * A; c.dg_sn = S1 * 4 * A;
+    c.passes = p.f32_passes;
     rc = lstm_bwd_step_launch<T>(c, s);
     if (rc) return rc;
     for (int nb = 0; nb < p.N; nb += 32) {
@@ -688,7 +693,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     g.A = (const T*)p.align_t + (long)n * S1 * p.Tia; g.lda = p.Tia; g.a_mode = 1;
     g.B = (const T*)p.dctx_t + (long)n * S1 * E; g.ldb = E; g.b_mode = 1;
     g.C = p.dvalues + ((long)n * p.Pi + p.padl_i) * E; g.ldc = E; g.c_dtype = NS_F32;
-    g.accumulate = 1; g.alpha = 1.f; g.split_k = 1;
+    g.accumulate = 1; g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
     int rc = ns_gemm(&g, s);
     if (rc) return rc;
   }
@@ -706,6 +711,7 @@ extern "C" int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t s) {
                    p->ca && p->ga && p->q && p->align && p->dhc && p->df1 && p->dp2 && p->dga && p->dq &&
                    p->dkeys && p->dvalues && p->dv && p->dwcl && p->work && p->align_t && p->de && p->dctx_t,
                "ns_taco2_attn_bwd: null pointer");
+  g_f32_passes = p->f32_passes;
   if (p->dtype == NS_BF16) return attn_bwd_t<bf16_t>(*p, (hipStream_t)s);
   return attn_bwd_t<float>(*p, (hipStream_t)s);
 }

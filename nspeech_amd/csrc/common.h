@@ -94,4 +94,28 @@ __device__ __forceinline__ float block_max(float v, float* red) {
   return s;
 }
 
+// ---------------------------------------------------------------- split-bf16 helpers
+// fp32 value x = hi + lo (hi = bf16(x), lo = bf16(x - hi)); products hi*hi + hi*lo + lo*hi
+__device__ __forceinline__ void ldsplit8(const float* p, bool ok, bf16x8& hi, bf16x8& lo) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (ok) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+  const float f[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const bf16_t h = (bf16_t)f[i];
+    hi[i] = h;
+    lo[i] = (bf16_t)(f[i] - (float)h);
+  }
+}
+template <int PASSES>
+__device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl,
+                                            f32x4 acc) {
+  if (PASSES > 1) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+  }
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+}
+
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

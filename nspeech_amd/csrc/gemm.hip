@@ -223,6 +223,43 @@ __device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) 
   }
 }
 
+// C/D map of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg; each wave owns 64x64
+__device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
+                                              int wn, int lane, bool add_bias) {
+  Epi e = make_epi(p);
+  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+        if (m < p.M && n < p.N) {
+          const bool valid = row_valid(e, m);
+          float v = epi_value(e, m, n, acc[i][j][r], add_bias, valid);
+          epi_store(e, m, n, v);
+          if (valid) {
+            float vs = round_stats ? (float)(bf16_t)v : v;
+            s1 += vs;
+            s2 += vs * vs;
+          }
+        }
+      }
+    }
+    if (p.col_sum) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if ((lane >> 4) == 0 && n < p.N) {
+        atomicAdd(p.col_sum + n, s1);
+        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
+      }
+    }
+  }
+}
+
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -314,40 +351,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D map of 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg
-  Epi e = make_epi(p);
-  const bool add_bias = (blockIdx.y == 0);
-  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int n = n0 + wn * 64 + j * 16 + (lane & 15);
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
-        if (m < p.M && n < p.N) {
-          const bool valid = row_valid(e, m);
-          float v = epi_value(e, m, n, acc[i][j][r], add_bias, valid);
-          epi_store(e, m, n, v);
-          if (valid) {
-            float vs = round_stats ? (float)(bf16_t)v : v;
-            s1 += vs;
-            s2 += vs * vs;
-          }
-        }
-      }
-    }
-    if (p.col_sum) {
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if ((lane >> 4) == 0 && n < p.N) {
-        atomicAdd(p.col_sum + n, s1);
-        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
-      }
-    }
-  }
+  mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
 // ------------------------------------------------------------------ skinny kernel (M <= 32)
@@ -418,6 +422,219 @@ __global__ __launch_bounds__(SKW * 64) void gemm_skinny_kernel(ns_gemm_params p)
   }
 }
 
+// ------------------------------------------------------------------ fp32 operands on bf16 MFMA
+// x = hi + lo with hi = bf16(x), lo = bf16(x - hi): a.b ~ hi.hi + hi.lo + lo.hi (PASSES = 3) keeps
+// ~16 mantissa bits at 3/16 of the bf16 MFMA rate - 3x faster than the native fp32 MFMA (1/16).
+// 128x128x32 tiles; per stage four 8 KB images (A hi/lo, B hi/lo); same tr-read scheme for
+// k-slow operands.
+constexpr int FBK = 32;
+__device__ __forceinline__ int row32_img_off(int row, int chunk16) {   // 64-B rows, 4 chunks of 16 B
+  return row * 64 + ((chunk16 ^ ((row >> 2) & 3)) << 4);
+}
+struct StageF { float4 v[4]; };
+
+template <int MODE>
+__device__ __forceinline__ void stagef_load(StageF& s, const float* base, long ld, int r0, int extent, int k0,
+                                            int K, int tid) {
+  if (MODE == 0) {
+    const int c = tid & 7;            // 8 float4 per 32-float row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 32 * i;
+      const int r = r0 + row, k = k0 + c * 4;
+      if (r < extent && k < K) s.v[i] = *(const float4*)(base + (long)r * ld + k);
+      else s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    const int c = tid & 31;           // 32 float4 per 128-float row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kr = (tid >> 5) + 8 * i;
+      const int k = k0 + kr, r = r0 + c * 4;
+      if (k < K && r < extent) s.v[i] = *(const float4*)(base + (long)k * ld + r);
+      else s.v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+}
+__device__ __forceinline__ void split4(const float4& x, bf16x4& hi, bf16x4& lo) {
+  const float f[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const bf16_t h = (bf16_t)f[i];
+    hi[i] = h;
+    lo[i] = (bf16_t)(f[i] - (float)h);
+  }
+}
+template <int MODE, int PASSES>
+__device__ __forceinline__ void stagef_store(const StageF& s, char* img_hi, char* img_lo, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    bf16x4 hi, lo;
+    split4(s.v[i], hi, lo);
+    int off;
+    if (MODE == 0) {
+      const int c = tid & 7, row = (tid >> 3) + 32 * i;
+      off = row32_img_off(row, c >> 1) + (c & 1) * 8;
+    } else {
+      const int c = tid & 31, kr = (tid >> 5) + 8 * i;
+      off = col_img_off_unit(kr, c);
+    }
+    *(bf16x4*)(img_hi + off) = hi;
+    if (PASSES > 1) *(bf16x4*)(img_lo + off) = lo;
+  }
+}
+
+template <int AMODE, int BMODE, int PASSES>
+__global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // [stage][A hi 8K | A lo 8K | B hi 8K | B lo 8K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int tiles_n = (p.N + GBN - 1) / GBN;
+  const int tiles_m = (p.M + GBM - 1) / GBM;
+  const int nwg = tiles_m * tiles_n;
+  int wgid;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int nk = (p.K + FBK - 1) / FBK;
+  const int per = (nk + p.split_k - 1) / p.split_k;
+  const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+  const float* A = (const float*)p.A;
+  const float* B = (const float*)p.B;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  auto b_tile_base = [&](int k0, int& kin) -> const float* {
+    if (p.b_seg_len > 0) {
+      int sg = k0 / p.b_seg_len;
+      kin = k0 - sg * p.b_seg_len;
+      return B + (long)sg * p.b_seg_stride;
+    }
+    kin = k0;
+    return B;
+  };
+  const int KB = p.b_seg_len > 0 ? p.b_seg_len : p.K;
+  StageF sa, sb;
+  if (kt0 < kt1) {
+    int kin;
+    const float* bb = b_tile_base(kt0 * FBK, kin);
+    stagef_load<AMODE>(sa, A, p.lda, m0, p.M, kt0 * FBK, p.K, tid);
+    stagef_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+    stagef_store<AMODE, PASSES>(sa, smem, smem + 8192, tid);
+    stagef_store<BMODE, PASSES>(sb, smem + 16384, smem + 24576, tid);
+  }
+  __syncthreads();
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const int cur = (kt - kt0) & 1;
+    char* iAh = smem + cur * 32768;
+    char* iAl = iAh + 8192;
+    char* iBh = iAh + 16384;
+    char* iBl = iAh + 24576;
+    const bool more = kt + 1 < kt1;
+    if (more) {
+      int kin;
+      const float* bb = b_tile_base((kt + 1) * FBK, kin);
+      stagef_load<AMODE>(sa, A, p.lda, m0, p.M, (kt + 1) * FBK, p.K, tid);
+      stagef_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+    }
+    bf16x8 ah[4], al[4], bh[4], bl[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (AMODE == 0) {
+        const int off = row32_img_off(wm * 64 + i * 16 + (lane & 15), lane >> 4);
+        ah[i] = *(const bf16x8*)(iAh + off);
+        if (PASSES > 1) al[i] = *(const bf16x8*)(iAl + off);
+      } else {
+        ah[i] = frag_col(iAh, 0, wm * 64 + i * 16, lane);
+        if (PASSES > 1) al[i] = frag_col(iAl, 0, wm * 64 + i * 16, lane);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (BMODE == 0) {
+        const int off = row32_img_off(wn * 64 + j * 16 + (lane & 15), lane >> 4);
+        bh[j] = *(const bf16x8*)(iBh + off);
+        if (PASSES > 1) bl[j] = *(const bf16x8*)(iBl + off);
+      } else {
+        bh[j] = frag_col(iBh, 0, wn * 64 + j * 16, lane);
+        if (PASSES > 1) bl[j] = frag_col(iBl, 0, wn * 64 + j * 16, lane);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (PASSES > 1) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    if (more) {
+      char* nb = smem + (cur ^ 1) * 32768;
+      stagef_store<AMODE, PASSES>(sa, nb, nb + 8192, tid);
+      stagef_store<BMODE, PASSES>(sb, nb + 16384, nb + 24576, tid);
+    }
+    __syncthreads();
+  }
+  mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+}
+
+// skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h)
+template <int PASSES>
+__global__ __launch_bounds__(SKW * 64) void gemm_skinny_f32_kernel(ns_gemm_params p) {
+  __shared__ float red[SKW][32][17];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 16;
+  const float* A = (const float*)p.A;
+  const float* B = (const float*)p.B;
+  const int r16 = lane & 15, g = lane >> 4;
+  f32x4 acc[2];
+  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nkc = (p.K + 31) / 32;
+  const bool ok0 = r16 < p.M, ok1 = 16 + r16 < p.M, okn = n0 + r16 < p.N;
+  for (int kc0 = wave; kc0 < nkc; kc0 += SKW * 2) {
+    bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int k = (kc0 + q * SKW) * 32 + g * 8;
+      const bool okk = k < p.K;
+      ldsplit8(A + (long)r16 * p.lda + k, ok0 && okk, ah[q][0], al[q][0]);
+      ldsplit8(A + (long)(16 + r16) * p.lda + k, ok1 && okk, ah[q][1], al[q][1]);
+      ldsplit8(B + (long)(n0 + r16) * p.ldb + k, okn && okk, bh[q], bl[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      acc[0] = mfma_split<PASSES>(ah[q][0], al[q][0], bh[q], bl[q], acc[0]);
+      acc[1] = mfma_split<PASSES>(ah[q][1], al[q][1], bh[q], bl[q], acc[1]);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
+  __syncthreads();
+  Epi e = make_epi(p);
+  for (int idx = tid; idx < 32 * 16; idx += SKW * 64) {
+    const int mm = idx >> 4, nn = idx & 15;
+    const int m = mm, n = n0 + nn;
+    if (m >= p.M || n >= p.N) continue;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < SKW; ++w) v += red[w][mm][nn];
+    const bool valid = row_valid(e, m);
+    v = epi_value(e, m, n, v, true, valid);
+    epi_store(e, m, n, v);
+  }
+}
+
 // ------------------------------------------------------------------ host dispatch
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -476,6 +693,47 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
 #undef LAUNCH_MFMA
     NS_CHECK_LAUNCH("gemm_mfma");
     return NS_OK;
+  }
+  if (p.dtype == NS_F32 && p.f32_passes > 0) {
+    bool ok = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && (p.b_seg_stride % 4 == 0);
+    if (p.a_mode == 0) ok = ok && (p.K % 4 == 0); else ok = ok && (p.M % 4 == 0);
+    if (p.b_mode == 0) ok = ok && (p.K % 4 == 0); else ok = ok && (p.N % 4 == 0);
+    if (p.b_seg_len > 0) ok = ok && (p.b_seg_len % FBK == 0);
+    const bool three = p.f32_passes >= 3;
+    if (ok && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 && !p.col_sum &&
+        p.K % 8 == 0 && p.lda % 4 == 0) {
+      if (three) hipLaunchKernelGGL(gemm_skinny_f32_kernel<3>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
+      else hipLaunchKernelGGL(gemm_skinny_f32_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
+      NS_CHECK_LAUNCH("gemm_skinny_f32");
+      return NS_OK;
+    }
+    if (ok) {
+      const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
+      dim3 grid(tiles, p.split_k);
+      const size_t lds = 65536;
+#define LAUNCH_F32(AM, BM_, PS)                                                                     \
+  do {                                                                                              \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_f32_kernel<AM, BM_, PS>,                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS>), grid, dim3(256), lds, stream, p);       \
+  } while (0)
+#define LAUNCH_F32_MODES(PS)                                                   \
+  do {                                                                         \
+    if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_F32(0, 0, PS);                  \
+    else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_F32(0, 1, PS);             \
+    else if (p.a_mode == 1 && p.b_mode == 0) LAUNCH_F32(1, 0, PS);             \
+    else LAUNCH_F32(1, 1, PS);                                                 \
+  } while (0)
+      if (three) LAUNCH_F32_MODES(3); else LAUNCH_F32_MODES(1);
+#undef LAUNCH_F32_MODES
+#undef LAUNCH_F32
+      NS_CHECK_LAUNCH("gemm_mfma_f32");
+      return NS_OK;
+    }
   }
   dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k);
   if (p.dtype == NS_F32) hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, p);

@@ -84,6 +84,46 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
       for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
+  } else if (a.passes > 0) {
+    // fp32 state / weights on the bf16 MFMA via the hi/lo split (common.h)
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool three = a.passes >= 3;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.a) {
+      const int nkc = (a.K + 31) / 32;
+      const float* arow0 = (const float*)a.a + (long)(nb + r16) * a.a_sn;
+      const float* arow1 = (const float*)a.a + (long)(nb + 16 + r16) * a.a_sn;
+      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
+      const bool oku = u0 + r16 < H;
+      const float* brow = (const float*)a.wT + (long)(u0 + r16) * a.K;
+      const long gstride = (long)H * a.K;
+      for (int kc = wave; kc < nkc; kc += LW) {
+        const int k = kc * 32 + g * 8;
+        const bool okk = k < a.K;
+        bf16x8 ah[2], al[2], bh[4], bl[4];
+        ldsplit8(arow0 + k, ok0 && okk, ah[0], al[0]);
+        ldsplit8(arow1 + k, ok1 && okk, ah[1], al[1]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ldsplit8(brow + j * gstride + k, oku && okk, bh[j], bl[j]);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            acc[i][j] = three ? mfma_split<3>(ah[i], al[i], bh[j], bl[j], acc[i][j])
+                              : mfma_split<1>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   } else {
     // exact fp32 path (parity tests): thread = (row, 4 gate columns)
     const int r = tid >> 4, cb = (tid & 15) * 4;
@@ -216,6 +256,42 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
+  } else if (a.passes > 0) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const bool three = a.passes >= 3;
+    f32x4 acc[2];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (a.dg_next) {
+      const int nkc = (a.K + 31) / 32;
+      const float* arow0 = (const float*)a.dg_next + (long)(nb + r16) * a.dgn_sn;
+      const float* arow1 = (const float*)a.dg_next + (long)(nb + 16 + r16) * a.dgn_sn;
+      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
+      const bool oku = u0 + r16 < H;
+      const float* brow = (const float*)a.w + (long)(u0 + r16) * a.K;
+      for (int kc0 = wave; kc0 < nkc; kc0 += LW * 2) {
+        bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const int k = (kc0 + q * LW) * 32 + g * 8;
+          const bool okk = k < a.K;
+          ldsplit8(arow0 + k, ok0 && okk, ah[q][0], al[q][0]);
+          ldsplit8(arow1 + k, ok1 && okk, ah[q][1], al[q][1]);
+          ldsplit8(brow + k, oku && okk, bh[q], bl[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            acc[i] = three ? mfma_split<3>(ah[q][i], al[q][i], bh[q], bl[q], acc[i])
+                           : mfma_split<1>(ah[q][i], al[q][i], bh[q], bl[q], acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
   } else {
     const int r = tid >> 4, uu = tid & 15;
     const int n = nb + r, u = u0 + uu;
@@ -296,6 +372,7 @@ static void fill_fwd(LstmStep<T>& a, const ns_lstm_seq_params& p, int step) {
   a.c_out = p.c + row * H; a.co_sn = P * H;
   a.gates_out = p.gates ? (T*)p.gates + row * 4 * H : nullptr; a.g_sn = P * 4 * H;
   a.lengths = p.lengths; a.t = t;
+  a.passes = p.f32_passes;
 }
 
 template <typename T>
@@ -318,6 +395,7 @@ static void fill_bwd(LstmBwdStep<T>& a, const ns_lstm_seq_params& p, int step, f
   a.c_prev = has_prev ? p.c + rowp * H : nullptr;
   a.dc_carry = dc_carry;
   a.dgates = (T*)p.dgates + row * 4 * H; a.dg_sn = P * 4 * H;
+  a.passes = p.f32_passes;
 }
 
 static int check_fwd(const ns_lstm_seq_params* p, const char* who) {

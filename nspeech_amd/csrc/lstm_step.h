@@ -17,6 +17,7 @@ struct LstmStep {
   const int* lengths; int t;
   int N, H;
   float forget_bias;
+  int passes;                        // fp32 operands: 0 exact FMA, 1/3 split-bf16 MFMA
 };
 // up to two independent cells (the two directions of a BiLSTM) in one launch: blockIdx.z
 template <typename T>
@@ -37,6 +38,7 @@ struct LstmBwdStep {
   const float* c; const float* c_prev; long c_sn;
   float* dc_carry; int first;              // [N,H] in/out (ignored on input when first)
   T* dgates; long dg_sn;                   // out [N, 4H]
+  int passes;
 };
 template <typename T>
 struct LstmBwdStepPair { LstmBwdStep<T> s[2]; int n; };

@@ -36,8 +36,18 @@ class Tacotron2(object):
     def __init__(self, hparams, device="cuda:0", dtype="bf16", seed=0, world_size=1):
         self._hparams = hparams
         self.device = torch.device(device)
-        assert dtype in ("bf16", "fp32")
+        # precision modes:
+        #   bf16   - bf16 operands everywhere (single MFMA pass)
+        #   fp32   - exact fp32 FMA kernels (parity tests)
+        #   bf16x3 - fp32 storage, every product as 3 split-bf16 MFMA passes (~fp32 accuracy)
+        #   mixed  - the path that decides mel_outputs (encoder, decoder, postnet) in bf16x3 forward /
+        #            1-pass backward; the mel->linear expand net, which cannot affect mel_outputs, in bf16
+        assert dtype in ("bf16", "fp32", "bf16x3", "mixed")
+        self.mode = dtype
         self.T = torch.bfloat16 if dtype == "bf16" else torch.float32
+        self.Tx = torch.bfloat16 if dtype in ("bf16", "mixed") else torch.float32
+        self.passes_fwd = {"bf16": 0, "fp32": 0, "bf16x3": 3, "mixed": 3}[dtype]
+        self.passes_bwd = {"bf16": 0, "fp32": 0, "bf16x3": 3, "mixed": 1}[dtype]
         self.vocab = len(symbols)
         self.layout, self.stat_layout = P_.taco2_layout(hparams, self.vocab)
         n = self.layout.size
@@ -46,7 +56,8 @@ class Tacotron2(object):
         self.flat_g = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.flat_s = self.flat_p if self.T == torch.float32 else torch.zeros(n, dtype=self.T, device=dev)
+        need_shadow = torch.bfloat16 in (self.T, self.Tx)
+        self.flat_s = torch.zeros(n, dtype=torch.bfloat16, device=dev) if need_shadow else self.flat_p
         self.flat_stats = torch.zeros(self.stat_layout.size, dtype=torch.float32, device=dev)
         self.scal = torch.zeros(16, dtype=torch.float32, device=dev)  # [0:2] mel, [2:4] lin loss, [8] gnorm^2
         self.global_step = 0
@@ -111,20 +122,24 @@ class Tacotron2(object):
     def _o(self, name):
         return self.layout.off(name)
 
+    def _W(self, D):
+        """Flat weight buffer to use as a GEMM operand of dtype D."""
+        return self.flat_p if D == torch.float32 else self.flat_s
+
     def refresh_shadows(self, full=False):
         """Operand-dtype copies of the weights: k-contiguous (transposed) ones for the in-loop
         products, the folded location filter, and the 16-byte padded linear head."""
         hp = self._hparams
         T = self.T
         dev = self.device
-        if full and self.T != torch.float32:
-            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self.flat_s, self.layout.size, False)
+        if full and self.flat_s is not self.flat_p:
+            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self._W(self.T), self.layout.size, False)
         if not hasattr(self, "tsh"):
             self.tsh = {}
 
-        def tr(key, name, r0, rows, cols):
+        def tr(key, name, r0, rows, cols, D=None):
             if key not in self.tsh:
-                self.tsh[key] = torch.zeros(cols * rows, dtype=T, device=dev)
+                self.tsh[key] = torch.zeros(cols * rows, dtype=D or T, device=dev)
             ops.cast2d(self.flat_p, rows, cols, cols, self.tsh[key], rows, True, src_off=self._o(name) + r0 * cols)
 
         M, E, A, D = hp.num_mels, 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
@@ -133,7 +148,7 @@ class Tacotron2(object):
         Cx = hp.expand_conv_channels
         for d in ("fw", "bw"):
             tr("enc_%s_whT" % d, "encoder/encoder_lstm/%s/lstm_cell/kernel" % d, C, He, 4 * He)
-            tr("exp_%s_whT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, Cx, Hx, 4 * Hx)
+            tr("exp_%s_whT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, Cx, Hx, 4 * Hx, self.Tx)
         tr("l1_whT", "decoder/lstm_1/kernel", A + E, D, 4 * D)
         tr("l2_whT", "decoder/lstm_2/kernel", D, D, 4 * D)
         tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
@@ -150,7 +165,7 @@ class Tacotron2(object):
         F = hp.num_freq
         Fp = _round_up(F, 16)
         if "wl_pad" not in self.tsh:
-            self.tsh["wl_pad"] = torch.zeros(2 * Hx * Fp, dtype=T, device=dev)
+            self.tsh["wl_pad"] = torch.zeros(2 * Hx * Fp, dtype=self.Tx, device=dev)
             self.tsh["bl_pad"] = torch.zeros(Fp, dtype=torch.float32, device=dev)
         ops.cast2d(self.flat_p, 2 * Hx, F, F, self.tsh["wl_pad"], Fp, False, src_off=self._o("dense/kernel"))
         ops.cast2d(self.flat_p, 1, F, F, self.tsh["bl_pad"], Fp, False, src_off=self._o("dense/bias"))
@@ -158,6 +173,8 @@ class Tacotron2(object):
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, numel, dtype, zero=True):
         key = name
+        if name.startswith("dpre_") or name.startswith("lstm_work"):
+            key = "%s_%s" % (name, str(dtype))
         b = self._bufs.get(key)
         if b is None or b.numel() < numel or b.dtype != dtype:
             b = torch.zeros(numel, dtype=dtype, device=self.device)
@@ -212,17 +229,18 @@ class Tacotron2(object):
         return self
 
     # ------------------------------------------------------------------ layer helpers
-    def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True):
+    def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None):
         """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198)."""
         kl = (k - 1) // 2
         rows = N * Pp
         a_rows = PADL - kl
         Mg = rows - (k - 1) - a_rows
-        z = self._buf(tag + "_z", rows * cout, self.T)
-        y = self._buf(tag + "_y", rows * cout, self.T)
+        D = D or self.T
+        z = self._buf(tag + "_z", rows * cout, D)
+        y = self._buf(tag + "_y", rows * cout, D)
         st = self._buf(tag + "_st", 4 * cout, torch.float32)
         st[:2 * cout].zero_()
-        ops.gemm(xin, self.flat_s, z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
+        ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
                  a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=PADL * cout,
                  bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
                  row_mask=(Pp, PADL, PADL + T, PADL),
@@ -235,14 +253,16 @@ class Tacotron2(object):
                    mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"))
         return y
 
-    def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False):
+    def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False,
+                  D=None):
         """Backward of _conv_fwd.  dy fp32 [rows,cout] -> grads in flat_g, dx fp32 [rows,cin]."""
         kl = (k - 1) // 2
         kr = k - 1 - kl
         rows = N * Pp
         z = self._bufs[tag + "_z"]
         st = self._bufs[tag + "_st"]
-        dpre = self._buf("dpre_%d" % cout, rows * cout, self.T)
+        D = D or self.T
+        dpre = self._buf("dpre_%d" % cout, rows * cout, D)
         work = self._buf("bn_work", 2 * 2048, torch.float32)
         g = self.flat_g
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
@@ -260,7 +280,7 @@ class Tacotron2(object):
         if need_dx:
             a2 = PADL - kr
             Mg2 = rows - (k - 1) - a2
-            ops.gemm(dpre, self.flat_s, dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
+            ops.gemm(dpre, self._W(D), dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
                      a_off=a2 * cout, b_off=self._o(scope + "/conv1d/kernel") + (k - 1) * cin * cout,
                      b_seg=(cout, -cin * cout), c_off=PADL * cin, accumulate=1 if dx_accumulate else 0,
                      row_mask=(Pp, PADL, PADL + T, PADL))
@@ -271,25 +291,27 @@ class Tacotron2(object):
         sk = max(1, min(32, 512 // max(tiles, 1)))
         return max(1, min(sk, K // 512))
 
-    def _bilstm_fwd(self, scope, x, cin, H, N, T, Pp, lengths, tag, key):
+    def _bilstm_fwd(self, scope, x, cin, H, N, T, Pp, lengths, tag, key, D=None):
         rows = N * Pp
-        out = self._buf(tag + "_h", rows * 2 * H, self.T)
+        D = D or self.T
+        out = self._buf(tag + "_h", rows * 2 * H, D)
         pair = []
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             xg = self._buf("%s_xg_%s" % (tag, d), rows * 4 * H, torch.float32)
-            ops.gemm(x, self.flat_s, xg, rows, 4 * H, cin, cin, 4 * H, 4 * H, b_mode=1, b_off=self._o(kname),
+            ops.gemm(x, self._W(D), xg, rows, 4 * H, cin, cin, 4 * H, 4 * H, b_mode=1, b_off=self._o(kname),
                      bias=self.flat_p, bias_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
-            gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, self.T)
+            gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
             pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
                                             lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H))
         ops.lstm_seq2("fwd", pair[0], pair[1])
         return out
 
-    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx):
+    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None):
         """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients."""
         rows = N * Pp
+        D = D or self.T
         g = self.flat_g
         hbuf = self._bufs[tag + "_h"]
         pair = []
@@ -298,10 +320,10 @@ class Tacotron2(object):
             ko = self._o(kname)
             c = self._bufs["%s_c_%s" % (tag, d)]
             gt = self._bufs["%s_g_%s" % (tag, d)]
-            dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, self.T)
+            dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, D)
             work = self._buf("lstm_work_%s" % d, N * H + 64, torch.float32)
             pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
-                                            self.flat_s, lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
+                                            self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
                                             ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
                                             h_off=di * H, dh_off=di * H))
         ops.lstm_seq2("bwd", pair[0], pair[1])
@@ -322,7 +344,7 @@ class Tacotron2(object):
                          split_k=self._splitk(rows, H, 4 * H))
             ops.colsum(dg, 4 * H, rows, 4 * H, g, out_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
             # dx (+)= dgates . Wx^T
-            ops.gemm(dg, self.flat_s, dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
+            ops.gemm(dg, self._W(D), dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
                      accumulate=0 if di == 0 else 1)
 
     # ------------------------------------------------------------------ training forward
@@ -346,6 +368,8 @@ class Tacotron2(object):
             self._bufs.clear()
             self._sig = sig
         self._tick("start")
+        ops.F32_PASSES = self.passes_fwd
+        Tx = self.Tx
 
         # ---- encoder (tacotron2.py:37-60)
         emb = hp.embedding_dim
@@ -365,7 +389,7 @@ class Tacotron2(object):
         self._tick("encoder")
         # keys = values . W_memory (values = encoder outputs, already zero past each length)
         keys = self._buf("keys", N * Pi * A, torch.float32)
-        ops.gemm(enc, self.flat_s, keys, N * Pi, A, E, E, A, A, b_mode=1,
+        ops.gemm(enc, self._W(self.T), keys, N * Pi, A, E, E, A, A, b_mode=1,
                  b_off=self._o("attention_decoder/memory_layer/kernel"))
 
         # ---- decoder, attention RNN for all steps (tacotron2.py:63-83, teacher forced)
@@ -375,7 +399,7 @@ class Tacotron2(object):
                        dst_off=2 * M)
         f1 = self._buf("dec_f1", N * S1 * 256, torch.float32)
         w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
-        ops.gemm(fr, self.flat_s, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p,
+        ops.gemm(fr, self._W(self.T), f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p,
                  bias_off=self._o("decoder/decoder_prenet/dense_1/bias"))
         Tia = _round_up(Ti, 8)
         p1 = self._buf("dec_p1", N * S1 * 256, T_)
@@ -403,21 +427,21 @@ class Tacotron2(object):
         rows = N * S1
         k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
         xg1 = self._buf("dec_xg1", rows * 4 * D, torch.float32)
-        ops.gemm(hc, self.flat_s, xg1, rows, 4 * D, A + E, A + E, 4 * D, 4 * D, b_mode=1, b_off=k1,
+        ops.gemm(hc, self._W(self.T), xg1, rows, 4 * D, A + E, A + E, 4 * D, 4 * D, b_mode=1, b_off=k1,
                  bias=self.flat_p, bias_off=self._o("decoder/lstm_1/bias"))
         h1 = self._buf("dec_h1", rows * D, T_)
         c1 = self._buf("dec_c1", rows * D, torch.float32)
         g1 = self._buf("dec_g1", rows * 4 * D, T_)
         ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1)
         xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
-        ops.gemm(h1, self.flat_s, xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
+        ops.gemm(h1, self._W(self.T), xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
                  bias=self.flat_p, bias_off=self._o("decoder/lstm_2/bias"))
         h2 = self._buf("dec_h2", rows * D, T_)
         c2 = self._buf("dec_c2", rows * D, torch.float32)
         g2 = self._buf("dec_g2", rows * 4 * D, T_)
         ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2)
         dec = self._buf("dec_out", rows * M * r, torch.float32)
-        ops.gemm(h2, self.flat_s, dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
+        ops.gemm(h2, self._W(self.T), dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
                  b_off=self._o("decoder/output_projection/kernel"), bias=self.flat_p,
                  bias_off=self._o("decoder/output_projection/bias"))
         self._tick("dec_lstm")
@@ -438,14 +462,14 @@ class Tacotron2(object):
             cin = Cp
             self._post_in.append(x)
         mel = self._buf("mel_out", N * Po * M, torch.float32)
-        ops.gemm(x, self.flat_s, mel, N * Po, M, Cp, Cp, M, M, b_mode=1,
+        ops.gemm(x, self._W(self.T), mel, N * Po, M, Cp, Cp, M, M, b_mode=1,
                  b_off=self._o("decoder_postnet/dense/kernel"), bias=self.flat_p,
                  bias_off=self._o("decoder_postnet/dense/bias"), row_mask=(Po, PADL, PADL + To, 0))
         ops.copy3d(decp, mel, N, Po, M, (Po * M, M), (Po * M, M), accumulate=1)
         self._tick("postnet")
 
         # ---- expand net + linear head (tacotron2.py:97-107)
-        ein = self._buf("exp_in", N * Po * M, T_)
+        ein = self._buf("exp_in", N * Po * M, Tx)
         ops.copy3d(mel, ein, N, Po, M, (Po * M, M), (Po * M, M))
         x = ein
         cin = M
@@ -453,12 +477,13 @@ class Tacotron2(object):
         Cx = hp.expand_conv_channels
         for i in range(hp.expand_conv_layers):
             act = ACT_RELU if i < hp.expand_conv_layers - 1 else ACT_NONE
-            x = self._conv_fwd("expand/conv_%d" % i, x, cin, Cx, hp.expand_conv_width, act, N, To, Po, "exp%d" % i)
+            x = self._conv_fwd("expand/conv_%d" % i, x, cin, Cx, hp.expand_conv_width, act, N, To, Po, "exp%d" % i,
+                               D=Tx)
             cin = Cx
             self._exp_in.append(x)
         self._tick("expand_conv")
         Hx = hp.expand_lstm_units
-        ex = self._bilstm_fwd("expand/encoder_lstm", x, cin, Hx, N, To, Po, None, "expl", "exp")
+        ex = self._bilstm_fwd("expand/encoder_lstm", x, cin, Hx, N, To, Po, None, "expl", "exp", D=Tx)
         self._tick("expand_lstm")
         lin = self._buf("lin_out", N * Po * Fp, torch.float32)
         ops.gemm(ex, self.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=self.tsh["bl_pad"])
@@ -483,11 +508,13 @@ class Tacotron2(object):
         g.zero_()
         self.scal.zero_()
         B = self._bufs
+        ops.F32_PASSES = self.passes_bwd
+        Tx = self.Tx
 
         # ---- losses (tacotron2.py:130-139) and their gradients
         n_prio = int(2000 / (hp.sample_rate * 0.5) * F)
         dmel = self._buf("d_mel", N * Po * M, torch.float32)
-        dlin = self._buf("d_lin", N * Po * Fp, T_)
+        dlin = self._buf("d_lin", N * Po * Fp, Tx)
         ops.l1_loss(B["mel_out"], M, self.mel_targets, dmel, M, N, To, Po, PADL, M, 0, 1.0 / (N * To * M), 0.0,
                     self.scal, acc_off=0)
         ops.l1_loss(B["lin_out"], Fp, self.linear_targets, dlin, Fp, N, To, Po, PADL, F, n_prio,
@@ -512,7 +539,7 @@ class Tacotron2(object):
         Cx = hp.expand_conv_channels
         dx = self._buf("d_act_a", rows_o * 512, torch.float32)
         dx2 = self._buf("d_act_b", rows_o * 512, torch.float32)
-        self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx)
+        self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx, D=Tx)
         self._tick("expand_lstm_bwd")
         cur, nxt = dx, dx2
         for i in range(hp.expand_conv_layers - 1, -1, -1):
@@ -520,10 +547,10 @@ class Tacotron2(object):
             cin = M if i == 0 else Cx
             if i == 0:   # gradient lands on mel_outputs, on top of the mel-loss gradient
                 self._conv_bwd("expand/conv_0", self._exp_in[0], cur, cin, Cx, hp.expand_conv_width, act, N, To, Po,
-                               "exp0", dmel, dx_accumulate=True)
+                               "exp0", dmel, dx_accumulate=True, D=Tx)
             else:
                 self._conv_bwd("expand/conv_%d" % i, self._exp_in[i], cur, cin, Cx, hp.expand_conv_width, act, N, To,
-                               Po, "exp%d" % i, nxt)
+                               Po, "exp%d" % i, nxt, D=Tx)
                 cur, nxt = nxt, cur
         self._tick("expand_conv_bwd")
         # ---- postnet: mel = dec + dense(postnet(dec))
@@ -535,7 +562,7 @@ class Tacotron2(object):
                  split_k=self._splitk(rows_o, Cp, M))
         ops.colsum(dmel_t, M, rows_o, M, g, out_off=self._o("decoder_postnet/dense/bias"))
         cur, nxt = dx, dx2
-        ops.gemm(dmel_t, self.flat_s, cur, rows_o, Cp, M, M, M, Cp, a_mode=0, b_mode=0, b_off=ko)
+        ops.gemm(dmel_t, self._W(self.T), cur, rows_o, Cp, M, M, M, Cp, a_mode=0, b_mode=0, b_off=ko)
         for i in range(hp.postnet_conv_layers - 1, -1, -1):
             act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
             cin = M if i == 0 else Cp
@@ -557,22 +584,22 @@ class Tacotron2(object):
                  split_k=self._splitk(rows, D, M * r))
         ops.colsum(ddec, M * r, rows, M * r, g, out_off=self._o("decoder/output_projection/bias"))
         dh2 = self._buf("d_h2", rows * D, torch.float32)
-        ops.gemm(ddec, self.flat_s, dh2, rows, D, M * r, M * r, M * r, D, a_mode=0, b_mode=0, b_off=kp)
+        ops.gemm(ddec, self._W(self.T), dh2, rows, D, M * r, M * r, M * r, D, a_mode=0, b_mode=0, b_off=kp)
         # ---- LSTM2, LSTM1 through time
         work = self._buf("lstm_work_d", 2 * N * D + 64, torch.float32)
         k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
         dg2 = self._buf("d_g2", rows * 4 * D, T_)
-        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self.flat_s, None, False, h2, D, B["dec_c2"],
+        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D, B["dec_c2"],
                      B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D)
         self._lstm_wgrads(h1, D, h2, D, dg2, rows, k2, "decoder/lstm_2/bias")
         dh1 = self._buf("d_h1", rows * D, torch.float32)
-        ops.gemm(dg2, self.flat_s, dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
+        ops.gemm(dg2, self._W(self.T), dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
         dg1 = self._buf("d_g1", rows * 4 * D, T_)
-        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self.flat_s, None, False, h1, D, B["dec_c1"],
+        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D, B["dec_c1"],
                      B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D)
         self._lstm_wgrads(hc, A + E, h1, D, dg1, rows, k1, "decoder/lstm_1/bias")
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
-        ops.gemm(dg1, self.flat_s, dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
+        ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
         self._tick("dec_lstm_bwd")
         # ---- attention RNN through time
         df1 = self._buf("d_f1", rows * 256, T_)
@@ -592,8 +619,8 @@ class Tacotron2(object):
         wa = self._o("decoder/attention_lstm/kernel")
         wq = self._o("decoder/attention/query_layer/kernel")
         args = dict(self._attn_args)
-        args.update(w1c=(self.flat_s, w1 + M * 256), w2=(self.flat_s, w2), watt=(self.flat_s, wa),
-                    wq=(self.flat_s, wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
+        args.update(w1c=(self._W(self.T), w1 + M * 256), w2=(self._W(self.T), w2), watt=(self._W(self.T), wa),
+                    wq=(self._W(self.T), wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
                     dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork,
                     de=self._buf("d_energy", rows * Tia, torch.float32),
                     dctx_t=self._buf("d_ctx_t", rows * E, T_))
@@ -628,7 +655,7 @@ class Tacotron2(object):
         om = self._o("attention_decoder/memory_layer/kernel")
         ops.gemm(enc, dkeys_t, g, E, A, N * Pi, E, A, A, a_mode=1, b_mode=1, c_off=om, accumulate=2,
                  split_k=sk(N * Pi, E, A))
-        ops.gemm(dkeys_t, self.flat_s, dvalues, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
+        ops.gemm(dkeys_t, self._W(self.T), dvalues, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
         self._tick("attn_wgrad")
         # ---- encoder
         He = hp.encoder_lstm_units
@@ -671,7 +698,7 @@ class Tacotron2(object):
         ops.sumsq(self.flat_g, n, self.scal, out_off=8)
         ops.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, n, self.scal[8:], self.gradient_clip,
                  1.0 / self.world_size, lr_t, b1, b2, 1e-8,
-                 shadow=self.flat_s if self.T != torch.float32 else None)
+                 shadow=self.flat_s if self.flat_s is not self.flat_p else None)
         self.refresh_shadows()
         self.learning_rate = lr
         self.global_step += 1

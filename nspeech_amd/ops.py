@@ -11,6 +11,10 @@ from . import _lib as L
 from ._lib import NS_BF16, NS_F32
 
 
+# fp32-operand GEMM precision (see ns_gemm_params.f32_passes); models set it per call
+F32_PASSES = 0
+
+
 def stream():
     return torch.cuda.current_stream().cuda_stream
 
@@ -33,7 +37,7 @@ def ptr(t, off=0):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0, c_off=0,
          bias=None, bias_off=0, act=0, alpha=1.0, accumulate=0, row_mask=None, col_sum=None,
-         col_sumsq=None, split_k=1, b_seg=None):
+         col_sumsq=None, split_k=1, b_seg=None, addend=None, addend_off=0, ld_add=0, f32_passes=None):
     """C = act(alpha * A.B + bias); see ns_gemm in include/nspeech_hip.h."""
     assert A.dtype == B.dtype
     p = L.GemmParams()
@@ -53,6 +57,9 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     p.col_sum = ptr(col_sum)
     p.col_sumsq = ptr(col_sumsq)
     p.split_k = split_k
+    if addend is not None:
+        p.addend, p.ld_add = ptr(addend, addend_off), ld_add
+    p.f32_passes = F32_PASSES if f32_passes is None else f32_passes
     L.call("ns_gemm", p, stream())
 
 
@@ -147,7 +154,7 @@ def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, l
     _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
-          dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work))
+          dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES)
     return p
 
 
@@ -171,4 +178,5 @@ def taco2_attn(direction, **kw):
         elif hasattr(v, "data_ptr"):
             v = ptr(v)
         setattr(p, k, v)
+    p.f32_passes = F32_PASSES
     L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", p, stream())

@@ -13,15 +13,16 @@ def roofline(model, one_step):
     orig = ops.gemm
 
     def timed(A, B, Cm, M, N, K, *a, **kw):
-        big = M > 32 and A.dtype == torch.bfloat16
+        big = M > 32 and (A.dtype == torch.bfloat16 or ops.F32_PASSES > 0)
         if not big:
             return orig(A, B, Cm, M, N, K, *a, **kw)
+        passes = 1 if A.dtype == torch.bfloat16 else max(1, ops.F32_PASSES)
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
         e0.record()
         orig(A, B, Cm, M, N, K, *a, **kw)
         e1.record()
-        rec.append((2.0 * M * N * K, e0, e1))
+        rec.append((2.0 * M * N * K, e0, e1, passes))
 
     ops.gemm = timed
     try:
@@ -31,10 +32,12 @@ def roofline(model, one_step):
         ops.gemm = orig
     if not rec:
         return None
-    flops = sum(r[0] for r in rec)
+    flops = sum(r[0] for r in rec)                 # algorithmic (one product per multiply-add)
+    issued = sum(r[0] * r[3] for r in rec)         # MFMA work actually issued (x3 for split-bf16)
     ms = sum(r[1].elapsed_time(r[2]) for r in rec)
     ach = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv1d / dense / LSTM input + all weight and data gradients)",
             "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
             "launches": len(rec), "avg_launch_us": ms * 1e3 / len(rec), "gflop_per_step": flops / 1e9,
+            "issued_mfma_tflops": issued / (ms * 1e-3) / 1e12,
             "traffic": None}

@@ -90,3 +90,23 @@ def test_gemm_splitk_atomic_and_segments(dev, dtype):
     for j in range(taps):
         ref += dy[j:j + Mr] @ w[taps - 1 - j].t()
     assert (dX.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("passes,tol", [(3, 3e-5), (1, 2e-2)])
+@pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 320), (32, 256, 512), (260, 72, 1000)])
+def test_gemm_fp32_split_bf16(dev, passes, tol, a_mode, b_mode, M, N, K):
+    """fp32 operands on the bf16 MFMA: x = hi + lo, three products (or hi*hi only)."""
+    from nspeech_amd import ops
+    A = _mk((M, K) if a_mode == 0 else (K, M), torch.float32, dev, 11)
+    B = _mk((N, K) if b_mode == 0 else (K, N), torch.float32, dev, 12)
+    Cm = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+    ops.gemm(A, B, Cm, M, N, K, A.shape[1], B.shape[1], N, a_mode=a_mode, b_mode=b_mode, f32_passes=passes)
+    torch.cuda.synchronize()
+    ref = _ref(A, B, a_mode, b_mode)
+    # error model: sum of K products each off by ~2^-17 (3 passes) or ~2^-8 (1 pass) relative
+    bound = tol * (A.double().abs().cpu().max() * B.double().abs().cpu().max() * K ** 0.5).item()
+    err = (Cm.double().cpu() - ref).abs().max().item()
+    assert err <= bound, (err, bound)
+    if passes == 3:   # and it is clearly better than single-pass bf16
+        assert err <= 1e-4 * ref.abs().max().item()

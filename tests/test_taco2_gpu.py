@@ -108,3 +108,49 @@ def test_taco2_adam_step_matches_oracle(dev):
         if mask.any():
             assert np.abs(upd_got[mask] - upd_ref[mask]).max() < 2e-4, k
     assert m.global_step == 1
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "mixed"])
+def test_taco2_split_bf16_meets_north_star_tolerance(dev, mode):
+    """north_star: mel outputs within 1e-3 (mean L1) of the reference arithmetic, on bf16 MFMA.
+    Products on the mel path run as three split-bf16 MFMA passes (x = hi + lo)."""
+    N, Ti, To = 4, 16, 40
+    hp = small_hparams()
+    m = _model(hp, mode)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=7)
+    params, stats = m.numpy_params(), m.numpy_stats()
+    mel, lin = stabilise_targets(hp, params, stats, inputs, lengths, mel, lin)
+    out, (loss, mel_loss, _), grads = oracle_run(hp, params, stats, inputs, lengths, mel, lin)
+    m.initialize(inputs, lengths, None, mel, lin)
+    m.backward()
+    m.read_losses()
+    l1 = np.abs(m.mel_outputs.float().cpu().numpy() - out["mel_outputs"].detach().numpy()).mean()
+    assert l1 < 1e-3, l1
+    assert np.abs(m.alignments.cpu().numpy() - out["alignments"].detach().numpy()).max() < 1e-3
+    assert abs(m.mel_loss - mel_loss) < 2e-3 * abs(mel_loss)
+    # in 'mixed' the mel->linear expand net runs single-pass bf16, so the linear loss moves by ~1e-2
+    assert abs(m.loss - loss) < (2e-3 if mode == "bf16x3" else 3e-2) * abs(loss)
+    got = m.numpy_grads()
+    for k in grads:
+        a, b = got[k].ravel().astype(np.float64), grads[k].ravel()
+        if np.linalg.norm(b) < 1e-6 or k.endswith("conv1d/bias"):
+            continue
+        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+        # 'mixed' back-propagates with single-pass bf16 products: direction only
+        assert cos > (0.999 if mode == "bf16x3" else 0.8), (k, cos)
+
+
+def test_taco2_mixed_full_width_forward(dev):
+    """The shipped layer widths (512-channel convs, 1024-unit decoder LSTMs, 1025 bins) at a short
+    length: mel L1 < 1e-3 against the float64 oracle in the benchmarked precision mode."""
+    from nspeech_amd import hparams as hparams_mod
+    hp = hparams_mod.load("taco2")
+    N, Ti, To = 2, 24, 40
+    m = _model(hp, "mixed", seed=5)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=9)
+    out, _, _ = oracle_run(hp, m.numpy_params(), m.numpy_stats(), inputs, lengths, mel, lin, need_grad=False)
+    m.initialize(inputs, lengths, None, mel, lin)
+    l1 = np.abs(m.mel_outputs.float().cpu().numpy() - out["mel_outputs"].detach().numpy()).mean()
+    assert l1 < 1e-3, l1
+    l1d = np.abs(m.decoder_outputs.float().cpu().numpy() - out["decoder_outputs"].detach().numpy()).mean()
+    assert l1d < 1e-3, l1d
