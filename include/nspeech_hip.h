@@ -216,6 +216,43 @@ int ns_lstm_seq2_fwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1,
 int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t stream);
 
 
+/* One LSTMBlockCell step on an explicit input row: gates = [a].W^T + xg + bias with a = the
+ * concatenated [input | h_prev] rows (the free-running decoder of tacotron2.py:67-83 with
+ * TacoTestHelper feedback, helpers.py:32-38, where nothing can be hoisted).
+ * wT is the whole TF kernel transposed, [4H, K] k-contiguous. */
+typedef struct {
+  int dtype, N, H, K;
+  const void* a; int64_t a_sn;
+  const void* wT;
+  const float* xg; int64_t xg_sn;
+  const float* bias;
+  const float* c_prev; int64_t c_sn;
+  void* h_out; int64_t h_sn;
+  void* h_out2; int64_t h2_sn;
+  float* c_out; int64_t co_sn;
+  float forget_bias;
+  int f32_passes;
+} ns_lstm_step_params;
+int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t stream);
+
+/* One location-sensitive attention step (attention.py:30-60): energies, masked softmax, context. */
+typedef struct {
+  int dtype, N, Ti, Pi, padl_i, Tia, A, E, kw;
+  const int* lengths;
+  const float* keys_t;              /* fp32 [N,A,Tia] (see ns_taco2_keys_transpose) */
+  const void* values;               /* (dtype) [N*Pi, E] */
+  const float* q; int64_t q_sn;     /* fp32 [N, A] rows */
+  const float* aprev; float* aout; int64_t al_sn;   /* fp32 [N, Tia] rows */
+  void* ctx_out; int64_t ctx_sn;    /* (dtype) [N, E] rows */
+  void* ctx_out2; int64_t ctx2_sn;  /* optional */
+  const float* wcl; const float* v;
+  float* e_raw;                     /* fp32 [N,Tia] scratch */
+} ns_attention_step_params;
+int ns_attention_step(const ns_attention_step_params* p, ns_stream_t stream);
+/* keys_t[n,u,t] = keys[n, padl+t, u] */
+int ns_taco2_keys_transpose(const float* keys, float* keys_t, int N, int Ti, int Tia, int Pi, int padl, int A,
+                            ns_stream_t stream);
+
 /* ------------------------------------------------------------------ Tacotron-2 attention RNN
  * The part of the decoder loop that is recurrent through the attention state
  * (tacotron2.py:63-83 with AttentionWrapper(PrenetWrapper(LSTMBlockCell(256)),

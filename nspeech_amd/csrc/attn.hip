@@ -715,3 +715,39 @@ extern "C" int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   if (p->dtype == NS_BF16) return attn_bwd_t<bf16_t>(*p, (hipStream_t)s);
   return attn_bwd_t<float>(*p, (hipStream_t)s);
 }
+
+extern "C" int ns_taco2_keys_transpose(const float* keys, float* keys_t, int N, int Ti, int Tia, int Pi, int padl,
+                                       int A, ns_stream_t s) {
+  NS_CHECK_ARG(keys && keys_t, "ns_taco2_keys_transpose: null");
+  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(Tia, 32), ceil_div(A, 32), N), dim3(256), 0, (hipStream_t)s,
+                     keys, keys_t, Ti, Tia, Pi, padl, A, 0);
+  NS_CHECK_LAUNCH("keys_transpose");
+  return NS_OK;
+}
+
+extern "C" int ns_attention_step(const ns_attention_step_params* p, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && p->keys_t && p->values && p->q && p->aprev && p->aout && p->ctx_out && p->wcl && p->v && p->e_raw,
+               "ns_attention_step: null");
+  NS_CHECK_ARG(p->A % 8 == 0 && p->A <= 256 && p->E % 8 == 0 && p->kw >= 1 && p->kw <= MAXKW && p->Tia >= p->Ti,
+               "ns_attention_step: unsupported shape");
+  const size_t lds = sizeof(float) * ((size_t)p->Tia + 32 + 4 * CCH);
+  NS_CHECK_ARG(lds <= 64 * 1024, "ns_attention_step: T_in too long for LDS");
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    AttnStep<T> a = {};
+    a.Ti = p->Ti; a.A = p->A; a.E = p->E; a.kw = p->kw; a.Tia = p->Tia; a.lengths = p->lengths;
+    a.keys_t = p->keys_t;
+    a.values = (const T*)p->values + (long)p->padl_i * p->E; a.values_sn = (long)p->Pi * p->E;
+    a.q = p->q; a.q_sn = p->q_sn;
+    a.aprev = p->aprev; a.aout = p->aout; a.al_sn = p->al_sn; a.aout_t = nullptr;
+    a.ctx_out = (T*)p->ctx_out; a.ctx_sn = p->ctx_sn; a.ctx_out2 = (T*)p->ctx_out2; a.ctx2_sn = p->ctx2_sn;
+    a.wcl = p->wcl; a.v = p->v; a.e_raw = p->e_raw;
+    hipLaunchKernelGGL(attn_energy_kernel<T>, dim3(ceil_div(p->Ti, 64), p->N), dim3(ATHREADS), 0, s, a);
+    hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div(p->E, CCH), p->N), dim3(256), lds, s, a);
+    NS_CHECK_LAUNCH("attention_step");
+    return NS_OK;
+  };
+  if (p->dtype == NS_BF16) return run(bf16_t{});
+  return run(float{});
+}

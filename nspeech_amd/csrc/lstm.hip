@@ -469,3 +469,21 @@ extern "C" int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_
   if (p0->dtype == NS_BF16) return seq_bwd_t<bf16_t>(p0, p1, (hipStream_t)s);
   return seq_bwd_t<float>(p0, p1, (hipStream_t)s);
 }
+
+extern "C" int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->a && p->wT && p->h_out && p->c_out, "ns_lstm_step: null");
+  NS_CHECK_ARG(p->H % 16 == 0 && p->K % 8 == 0 && p->a_sn % 8 == 0, "ns_lstm_step: H %% 16, K %% 8, a_sn %% 8 required");
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    LstmStep<T> a = {};
+    a.N = p->N; a.H = p->H; a.K = p->K; a.forget_bias = p->forget_bias; a.passes = p->f32_passes;
+    a.a = (const T*)p->a; a.a_sn = p->a_sn; a.wT = (const T*)p->wT;
+    a.xg = p->xg; a.xg_sn = p->xg_sn; a.bias = p->bias;
+    a.c_prev = p->c_prev; a.c_sn = p->c_sn;
+    a.h_out = (T*)p->h_out; a.h_sn = p->h_sn; a.h_out2 = (T*)p->h_out2; a.h2_sn = p->h2_sn;
+    a.c_out = p->c_out; a.co_sn = p->co_sn;
+    return lstm_step_launch<T>(a, (hipStream_t)s);
+  };
+  if (p->dtype == NS_BF16) return run(bf16_t{});
+  return run(float{});
+}
