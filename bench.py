@@ -135,21 +135,17 @@ def main():
     hp = hparams_mod.load("taco2")
     model = create_model("taco2", hp, device="cuda:%d" % local, dtype=args.dtype, seed=1234, world_size=world)
     if world > 1:
-        dist.broadcast(model.flat_p, 0)
-        model.refresh_shadows(full=True)
+        from nspeech_amd import parallel
+        parallel.broadcast_parameters(model, 0)
+        model.reducer = parallel.GradReducer(model.flat_g, parallel.bucket_ranges(model.layout))
     inputs, lengths, mel, lin = synthetic_batch(hp, args.batch, args.t_in, args.t_out, 1234 + rank)
     model.add_optimizer(global_step=0)
     model.initialize(inputs, lengths, None, mel, lin)
 
-    def hook(flat_g):
-        if world > 1:
-            dist.all_reduce(flat_g)
-
     def one_step():
         model.forward_train()
-        model.backward()
-        hook(model.flat_g)
-        model.apply_gradients()
+        model.backward()          # hands each gradient bucket to RCCL as soon as it is final
+        model.apply_gradients()   # waits for the reductions, then clip + Adam on the summed gradients
 
     for _ in range(args.warmup):
         one_step()

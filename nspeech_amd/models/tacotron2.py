@@ -66,6 +66,7 @@ class Tacotron2(object):
         self._bufs = {}
         self._sig = None
         self.timing = None
+        self.reducer = None       # parallel.GradReducer when data-parallel
         pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
         self.load_numpy(pv, sv)
         # attributes the reference exposes
@@ -181,7 +182,12 @@ class Tacotron2(object):
             self._bufs[key] = b
         return b
 
+    _BUCKET_AFTER = {"expand_conv_bwd": "head", "postnet_bwd": "postnet", "attn_wgrad": "decoder",
+                     "encoder_bwd": "encoder"}
+
     def _tick(self, label):
+        if self.reducer is not None and label in self._BUCKET_AFTER:
+            self.reducer.bucket_ready(self._BUCKET_AFTER[label])   # gradients of this group are final
         if self.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -690,6 +696,8 @@ class Tacotron2(object):
     def apply_gradients(self):
         """clip_by_global_norm + Adam + refreshed operand shadows (tacotron2.py:150-161)."""
         hp = self._hparams
+        if self.reducer is not None:
+            self.reducer.wait()
         t = self.global_step + 1
         lr = self.learning_rate_at(self.global_step)
         b1, b2 = hp.adam["beta1"], hp.adam["beta2"]

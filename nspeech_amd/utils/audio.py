@@ -64,6 +64,7 @@ def _build_mel_basis():
 
 
 def _get_tables():
+    _dev()
     hp = get_hparams()
     n_fft, hop, win = _stft_parameters()
     key = (n_fft, win, hp.num_mels, hp.sample_rate, torch.cuda.current_device())

@@ -1,0 +1,64 @@
+"""world_size-2 gloo rehearsal of the data-parallel path on CPU: bucket layout, asynchronous
+bucketed all-reduce, parameter broadcast semantics.  (The HIP kernels need a GPU; what is tested
+here is the host logic that bench.py / train.py run per rank.)"""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from nspeech_amd import hparams as hparams_mod
+from nspeech_amd import parallel
+from nspeech_amd.models import params as P
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_bucket_ranges_tile_the_flat_buffer():
+    hp = hparams_mod.load("taco2")
+    lay, _ = P.taco2_layout(hp, 149)
+    b = parallel.bucket_ranges(lay)
+    assert [n for n, _, _ in b] == ["head", "postnet", "decoder", "encoder"]   # backward completion order
+    covered = sum(hi - lo for _, lo, hi in b)
+    assert covered == lay.size
+    sizes = {n: hi - lo for n, lo, hi in b}
+    # 7.56 M (head) / 5.50 M (postnet) / 16.93 M (decoder) / 4.89 M (encoder) parameters
+    assert abs(sizes["head"] - 7556097) < 2000 and abs(sizes["postnet"] - 5496400) < 2000
+    assert abs(sizes["decoder"] - 16927900) < 2000 and abs(sizes["encoder"] - 4894464) < 2000
+
+
+def _worker(rank, world, port, size, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, _, w = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.arange(size, dtype=torch.float32) * (rank + 1)
+    buckets = [("head", 600, size), ("postnet", 400, 600), ("decoder", 100, 400), ("encoder", 0, 100)]
+    red = parallel.GradReducer(g, buckets)
+    for name, _, _ in buckets:          # the order the backward pass releases them
+        red.bucket_ready(name)
+    red.wait()
+    expect = torch.arange(size, dtype=torch.float32) * sum(range(1, world + 1))
+    ok = torch.equal(g, expect)
+    # parameter broadcast: every rank ends with rank 0's values
+    p = torch.full((16,), float(rank + 7))
+    dist.broadcast(p, 0)
+    ok = ok and bool((p == 7).all())
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_world2_gloo():
+    world, size = 2, 1000
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, size, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
