@@ -1,0 +1,140 @@
+#!/usr/bin/env python3
+"""Training CLI with the reference's flags (train.py:133-164) on the MI355X-native model.
+
+  python3 train.py --ljspeech DIR --model taco2 [--hparams k=v,...] [--restore-step N]
+  torchrun --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 train.py ...     (data parallel)
+
+Outputs follow the reference: LOGDIR/RUN/train.log, model.ckpt-STEP (torch.save of a name->tensor
+dict whose names mirror the TF scopes), step-%06d-audio.wav every --checkpoint-interval."""
+import argparse
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nspeech_amd import hparams as hparams_mod  # noqa: E402
+from nspeech_amd import parallel  # noqa: E402
+from nspeech_amd.models import create_model  # noqa: E402
+from nspeech_amd.utils import audio  # noqa: E402
+
+
+class ValueWindow(object):
+    """100-step moving average (utils/__init__.py:8-29)."""
+
+    def __init__(self, size=100):
+        self.size, self.v = size, []
+
+    def append(self, x):
+        self.v = self.v[-(self.size - 1):] + [x]
+
+    @property
+    def average(self):
+        return sum(self.v) / max(1, len(self.v))
+
+
+def log(msg, path=None):
+    print(msg, flush=True)
+    if path:
+        with open(path, "a") as f:
+            f.write("[%s]  %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), msg))
+
+
+def save_checkpoint(model, log_dir, step, keep=5):
+    path = os.path.join(log_dir, "model.ckpt-%d" % step)
+    torch.save(model.state_dict(), path)
+    with open(os.path.join(log_dir, "checkpoint"), "w") as f:
+        f.write('model_checkpoint_path: "model.ckpt-%d"\n' % step)
+    ck = sorted((int(n.split("-")[-1]), n) for n in os.listdir(log_dir) if n.startswith("model.ckpt-"))
+    for _, n in ck[:-keep]:            # tf.train.Saver(max_to_keep=5), train.py:60
+        os.remove(os.path.join(log_dir, n))
+    return path
+
+
+def train(log_dir, args):
+    rank, local, world = parallel.init_distributed()
+    torch.cuda.set_device(local)
+    hp = hparams_mod.get_hparams()
+    logf = os.path.join(log_dir, "train.log") if rank == 0 else None
+    log("Checkpoint path: %s" % os.path.join(log_dir, "model.ckpt"), logf)
+    log(hparams_mod.debug_string(hp), logf)
+    from nspeech_amd.datasets.datafeeder import DataFeeder
+    feeder = DataFeeder(hp, ljspeech=args.ljspeech, seed=1234 + rank)
+    model = create_model(args.model, hp, device="cuda:%d" % local, dtype=args.precision, world_size=world)
+    step0 = 0
+    if args.restore_step:
+        path = "%s-%d" % (os.path.join(log_dir, "model.ckpt"), args.restore_step)
+        model.load_state_dict(torch.load(path, map_location="cpu"))
+        step0 = model.global_step
+        log("Resuming from checkpoint: %s" % path, logf)
+    if world > 1:
+        parallel.broadcast_parameters(model, 0)
+        model.reducer = parallel.GradReducer(model.flat_g, parallel.bucket_ranges(model.layout))
+    model.add_loss()
+    model.add_optimizer(step0)
+    model.add_stats()
+    time_window, loss_window = ValueWindow(100), ValueWindow(100)
+    while args.max_steps is None or model.global_step < args.max_steps:
+        t0 = time.time()
+        inputs, lengths, mel, lin = feeder.next_batch()
+        loss = model.step(inputs, lengths, mel, lin)
+        if world > 1:   # every rank must agree on the abort decision
+            t = torch.tensor([loss], device="cuda")
+            torch.distributed.all_reduce(t)
+            loss = float(t.item()) / world
+        step = model.global_step
+        time_window.append(time.time() - t0)
+        loss_window.append(loss)
+        frames = mel.shape[0] * mel.shape[1] * world
+        log("Step %-7d [%.03f sec/step, loss=%.05f, avg_loss=%.05f, %.0f mel_frames/s]" %
+            (step, time_window.average, loss, loss_window.average, frames / time_window.average), logf)
+        if loss > 100 or math.isnan(loss):          # train.py:87-89
+            log("Loss exploded to %.05f at step %d!" % (loss, step), logf)
+            raise Exception("Loss Exploded")
+        if rank == 0 and step % args.checkpoint_interval == 0:
+            path = save_checkpoint(model, log_dir, step)
+            log("Saved checkpoint %s" % path, logf)
+            wav = audio.inv_spectrogram_tensorflow(model.linear_outputs[0].float().contiguous())
+            wav = audio.inv_preemphasis(wav.cpu().numpy())
+            audio.save_wav(wav[:audio.find_endpoint(wav)], os.path.join(log_dir, "step-%06d-audio.wav" % step))
+    return model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-dir", "--log_dir", default=os.path.expanduser("~/nspeech-logs"))
+    ap.add_argument("--input", default="training/train.txt")
+    ap.add_argument("--vctk", default=None)
+    ap.add_argument("--ljspeech", default=None)
+    ap.add_argument("--librispeech", default=None)
+    ap.add_argument("--model", default="taco2")
+    ap.add_argument("--name", default=None)
+    ap.add_argument("--hparams", default="")
+    ap.add_argument("--restore-step", "--restore_step", type=int, default=None)
+    ap.add_argument("--summary-interval", "--summary_interval", type=int, default=100)
+    ap.add_argument("--checkpoint-interval", "--checkpoint_interval", type=int, default=1000)
+    ap.add_argument("--slack-url", "--slack_url", default=None)
+    ap.add_argument("--tf-log-level", "--tf_log_level", type=int, default=1)
+    ap.add_argument("--git", action="store_true")
+    ap.add_argument("--gpu", default="0")
+    ap.add_argument("--threads", type=int, default=1)
+    ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "bf16x3", "fp32"])
+    ap.add_argument("--max-steps", "--max_steps", type=int, default=None)
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ:
+        os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
+    run_name = args.name or args.model
+    log_dir = os.path.join(args.log_dir, "logs-%s" % run_name)
+    os.makedirs(log_dir, exist_ok=True)
+    hp = hparams_mod.load(args.model)
+    hp.parse(args.hparams)
+    train(log_dir, args)
+
+
+if __name__ == "__main__":
+    main()
