@@ -216,6 +216,15 @@ int ns_lstm_seq2_fwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1,
 int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, ns_stream_t stream);
 
 
+/* Persistent variant of ns_lstm_seq2_*: ONE launch for the whole sequence.  Each (direction,
+ * 16-row group) recurrence runs on a cluster of H/64 workgroups that keep their W_h slice and the
+ * cell state in registers and exchange h (backward: the gate gradients) through `work` with
+ * tagged 8-byte granules.  bf16 only, H %% 64 == 0, H <= 512.  work[0] (int) is a status word:
+ * non-zero after the call completes = an exchange timed out and the outputs are invalid. */
+size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p);
+int ns_lstm_cluster_fwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
+int ns_lstm_cluster_bwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
+
 /* One LSTMBlockCell step on an explicit input row: gates = [a].W^T + xg + bias with a = the
  * concatenated [input | h_prev] rows (the free-running decoder of tacotron2.py:67-83 with
  * TacoTestHelper feedback, helpers.py:32-38, where nothing can be hoisted).

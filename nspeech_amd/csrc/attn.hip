@@ -79,9 +79,13 @@ struct AttnStep {
 
 // x[t,u] = keys[t,u] + q[u] + sum_k align_prev[t+k-half] Wcl[k,u];  lane = t, wave = unit chunk.
 // q, v and Wcl are wave-uniform (scalar loads); tanh is v_exp + v_rcp.
+// per-unit constants of one wave's unit chunk, packed for broadcast ds_read_b128:
+// cst[u] = {q, v, w0, w1 | w2, w3, w4, w5 | w6, w7, 0, 0}
+constexpr int CPU = 12;
 template <typename T>
 __global__ __launch_bounds__(ATHREADS) void attn_energy_kernel(AttnStep<T> a) {
   __shared__ float part[AW][64];
+  __shared__ __attribute__((aligned(16))) float cst[AW][UB * CPU];
   const int n = blockIdx.y, tc = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -106,17 +110,30 @@ __global__ __launch_bounds__(ATHREADS) void attn_energy_kernel(AttnStep<T> a) {
     float kv[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) kv[j] = (act && ub + j < ue) ? kt[(long)(ub + j) * Tia + t] : 0.f;
+    // stage this block's constants (wave-private LDS region, no block barrier needed)
+    for (int i = lane; i < UB * CPU; i += 64) {
+      const int j = i / CPU, f = i % CPU, u = ub + j;
+      float val = 0.f;
+      if (u < ue) {
+        if (f == 0) val = qn[u];
+        else if (f == 1) val = a.v[u];
+        else if (f - 2 < a.kw) val = a.wcl[(f - 2) * A + u];
+      }
+      cst[wv][i] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      const int u = ub + j;
-      if (u < ue) {
-        float x = kv[j] + qn[u];
-#pragma unroll
-        for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) x = fmaf(apv[k], a.wcl[k * A + u], x);
-        s = fmaf(a.v[u], tanhf_(x), s);
-      }
+      const float4 c0 = *(const float4*)&cst[wv][j * CPU];
+      const float4 c1 = *(const float4*)&cst[wv][j * CPU + 4];
+      const float4 c2 = *(const float4*)&cst[wv][j * CPU + 8];
+      float x = kv[j] + c0.x;
+      x = fmaf(apv[0], c0.z, x); x = fmaf(apv[1], c0.w, x);
+      x = fmaf(apv[2], c1.x, x); x = fmaf(apv[3], c1.y, x); x = fmaf(apv[4], c1.z, x); x = fmaf(apv[5], c1.w, x);
+      x = fmaf(apv[6], c2.x, x); x = fmaf(apv[7], c2.y, x);
+      s = fmaf(c0.y, tanhf_(x), s);     // v = 0 for units past the chunk end
     }
+    __builtin_amdgcn_wave_barrier();
   }
   part[wv][lane] = s;
   __syncthreads();
@@ -217,14 +234,14 @@ struct AttnBwdStep {
 
 // (1) da[t] = dctx . values[t] + sum_k G_next[t-k+half][k];  grid (t-chunks of 32, N)
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_da_kernel(AttnBwdStep<T> a) {
+__global__ __launch_bounds__(ATHREADS) void attn_bwd_da_kernel(AttnBwdStep<T> a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // dctx[E]
   const int Ti = a.Ti, E = a.E, Tia = a.Tia;
   const int n = blockIdx.y, t0 = blockIdx.x * 32;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
   const int half = (a.kw - 1) / 2;
-  for (int c = tid; c < E; c += 256) {
+  for (int c = tid; c < E; c += ATHREADS) {
     float d = a.dctx_ext[(long)n * a.dce_sn + c];
     if (a.dctx_carry) d += a.dctx_carry[(long)n * E + c];
     sm[c] = d;
@@ -233,21 +250,28 @@ __global__ __launch_bounds__(256) void attn_bwd_da_kernel(AttnBwdStep<T> a) {
   __syncthreads();
   const T* values = a.values + (long)n * a.values_sn;
   const float* gk = a.gk + (long)n * Tia * MAXKW;
-#pragma unroll 4
-  for (int j = 0; j < 8; ++j) {
-    const int t = t0 + wave * 8 + j;
-    if (t >= Tia) break;
-    float s = 0.f;
-    if (t < L) {
-      for (int c = lane * 8; c < E; c += 512) {
-        float x[8];
-        ld8(values + (long)t * E + c, x);
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane * 8; c < E; c += 512) {
+    float x[4][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s = fmaf(sm[c + i], x[i], s);
+    for (int j = 0; j < 4; ++j) {
+      const int t = t0 + wave * 4 + j;
+      if (t < L) ld8(values + (long)t * E + c, x[j]);
+      else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[j][i] = 0.f;
       }
-      s = wave_sum(s);
     }
-    if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[j] = fmaf(sm[c + i], x[j][i], s[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int t = t0 + wave * 4 + j;
+    const float sv = wave_sum(s[j]);
+    if (lane == 0 && t < Tia) {
       float carry = 0.f;
       if (a.has_carry && t < L) {
         for (int k = 0; k < a.kw; ++k) {
@@ -255,7 +279,7 @@ __global__ __launch_bounds__(256) void attn_bwd_da_kernel(AttnBwdStep<T> a) {
           if (ts >= 0 && ts < Ti) carry += gk[(long)ts * MAXKW + k];
         }
       }
-      a.da[(long)n * Tia + t] = t < L ? s + carry : 0.f;
+      a.da[(long)n * Tia + t] = t < L ? sv + carry : 0.f;
     }
   }
 }
@@ -266,6 +290,7 @@ template <typename T>
 __global__ __launch_bounds__(ATHREADS) void attn_bwd_energy_kernel(AttnBwdStep<T> a) {
   __shared__ float part[AW][64][MAXKW + 1];
   __shared__ float red[32];
+  __shared__ __attribute__((aligned(16))) float cst[AW][UB * CPU];
   const int n = blockIdx.y, tc = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -297,21 +322,33 @@ __global__ __launch_bounds__(ATHREADS) void attn_bwd_energy_kernel(AttnBwdStep<T
     float kv[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) kv[j] = (act && ub + j < ue) ? kt[(long)(ub + j) * Tia + t] : 0.f;
+    for (int i = lane; i < UB * CPU; i += 64) {
+      const int j = i / CPU, f = i % CPU, u = ub + j;
+      float val = 0.f;
+      if (u < ue) {
+        if (f == 0) val = qn[u];
+        else if (f == 1) val = a.v[u];
+        else if (f - 2 < a.kw) val = a.wcl[(f - 2) * A + u];
+      }
+      cst[wv][i] = val;
+    }
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int j = 0; j < UB; ++j) {
-      const int u = ub + j;
-      if (u < ue) {
-        float x = kv[j] + qn[u];
-#pragma unroll
-        for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) x = fmaf(apv[k], a.wcl[k * A + u], x);
-        const float th = tanhf_(x);
-        const float dpre = de * a.v[u] * (1.f - th * th);
-#pragma unroll
-        for (int k = 0; k < MAXKW; ++k)
-          if (k < a.kw) g[k] = fmaf(dpre, a.wcl[k * A + u], g[k]);
-      }
+      const float4 c0 = *(const float4*)&cst[wv][j * CPU];
+      const float4 c1 = *(const float4*)&cst[wv][j * CPU + 4];
+      const float4 c2 = *(const float4*)&cst[wv][j * CPU + 8];
+      float x = kv[j] + c0.x;
+      x = fmaf(apv[0], c0.z, x); x = fmaf(apv[1], c0.w, x);
+      x = fmaf(apv[2], c1.x, x); x = fmaf(apv[3], c1.y, x); x = fmaf(apv[4], c1.z, x); x = fmaf(apv[5], c1.w, x);
+      x = fmaf(apv[6], c2.x, x); x = fmaf(apv[7], c2.y, x);
+      const float th = tanhf_(x);
+      const float dpre = de * c0.y * (1.f - th * th);
+      g[0] = fmaf(dpre, c0.z, g[0]); g[1] = fmaf(dpre, c0.w, g[1]);
+      g[2] = fmaf(dpre, c1.x, g[2]); g[3] = fmaf(dpre, c1.y, g[3]); g[4] = fmaf(dpre, c1.z, g[4]); g[5] = fmaf(dpre, c1.w, g[5]);
+      g[6] = fmaf(dpre, c2.x, g[6]); g[7] = fmaf(dpre, c2.y, g[7]);
     }
+    __builtin_amdgcn_wave_barrier();
   }
 #pragma unroll
   for (int k = 0; k < MAXKW; ++k) part[wv][lane][k] = g[k];
@@ -630,7 +667,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     a.de_out = p.de + slot * p.Tia;
     a.dctx_out = (T*)p.dctx_t + slot * E; a.dco_sn = S1 * E;
     a.wcl = p.wcl; a.v = p.v;
-    hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p.Tia, 32), p.N), dim3(256), sizeof(float) * p.E, s, a);
+    hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p.Tia, 32), p.N), dim3(ATHREADS), sizeof(float) * p.E, s, a);
     hipLaunchKernelGGL(attn_bwd_energy_kernel<T>, dim3(ceil_div(p.Ti, 64), p.N), dim3(ATHREADS), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(ceil_div(p.A, 64), p.N), dim3(ATHREADS), lds, s, a);
     NS_CHECK_LAUNCH("attn_bwd");

@@ -67,6 +67,7 @@ class Tacotron2(object):
         self._sig = None
         self.timing = None
         self.reducer = None       # parallel.GradReducer when data-parallel
+        self._status_words = {}
         pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
         self.load_numpy(pv, sv)
         # attributes the reference exposes
@@ -134,7 +135,7 @@ class Tacotron2(object):
         T = self.T
         dev = self.device
         if full and self.flat_s is not self.flat_p:
-            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self._W(self.T), self.layout.size, False)
+            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self.flat_s, self.layout.size, False)
         if not hasattr(self, "tsh"):
             self.tsh = {}
 
@@ -311,8 +312,26 @@ class Tacotron2(object):
             gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
             pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
                                             lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H))
-        ops.lstm_seq2("fwd", pair[0], pair[1])
+        self._run_bilstm("fwd", pair, tag)
         return out
+
+    use_cluster = True      # persistent whole-sequence BiLSTM kernels where the shape allows
+
+    def _run_bilstm(self, direction, pair, tag):
+        if self.use_cluster and ops.lstm_cluster_supported(pair[0]):
+            work = self._buf("lstm_cluster_work_%s_%s" % (tag, direction), ops.lstm_cluster_work_floats(pair[0]),
+                             torch.float32)
+            ops.lstm_cluster(direction, pair[0], pair[1], work)
+            self._status_words[(tag, direction)] = work
+        else:
+            ops.lstm_seq2(direction, pair[0], pair[1])
+
+    def check_status(self):
+        """Raise if a persistent kernel reported an exchange timeout (host sync)."""
+        for key, w in self._status_words.items():
+            v = int(w[:1].view(torch.int32).item())
+            if v != 0:
+                raise RuntimeError("persistent LSTM kernel %s timed out (status %d)" % (key, v))
 
     def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None):
         """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients."""
@@ -332,7 +351,7 @@ class Tacotron2(object):
                                             self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
                                             ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
                                             h_off=di * H, dh_off=di * H))
-        ops.lstm_seq2("bwd", pair[0], pair[1])
+        self._run_bilstm("bwd", pair, tag)
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             ko = self._o(kname)
@@ -717,6 +736,7 @@ class Tacotron2(object):
         hp = self._hparams
         d = self.dims
         s = self.scal.cpu().numpy()
+        self.check_status()
         N, To = d["N"], d["To"]
         self.mel_loss = float(s[0]) / (N * To * hp.num_mels)
         self.linear_loss = 0.5 * float(s[2]) / (N * To * hp.num_freq) + 0.5 * float(s[3]) / (N * To * self._n_prio)

@@ -180,3 +180,19 @@ def taco2_attn(direction, **kw):
         setattr(p, k, v)
     p.f32_passes = F32_PASSES
     L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", p, stream())
+
+
+def lstm_cluster_supported(p0):
+    return p0.dtype == NS_BF16 and p0.H % 64 == 0 and p0.H <= 512 and p0.T >= 2
+
+
+def lstm_cluster_work_floats(p0):
+    fn = L.lib().ns_lstm_cluster_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(p0)) + 3) // 4
+
+
+def lstm_cluster(direction, p0, p1, work):
+    """Persistent whole-sequence BiLSTM (one launch); work[0] is the status word."""
+    fn = getattr(L.lib(), "ns_lstm_cluster_fwd" if direction == "fwd" else "ns_lstm_cluster_bwd")
+    L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_cluster_" + direction)

@@ -1,0 +1,78 @@
+"""The persistent whole-sequence BiLSTM kernels (cluster of workgroups, register-resident W_h,
+tagged-granule exchange) against the one-launch-per-step kernels on the same bf16 inputs,
+forward and backward, with per-row lengths, partial row groups and repeated launches."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, N, T, H, seed, masked):
+    from nspeech_amd import ops
+    g = torch.Generator().manual_seed(seed)
+    P, padl = T + 4, 2
+    rows = N * P
+    bf = torch.bfloat16
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc)
+    data = dict(N=N, T=T, H=H, P=P, padl=padl)
+    data["lengths"] = (torch.randint(1, T + 1, (N,), generator=g, dtype=torch.int32).to(dev) if masked else None)
+    if masked:
+        data["lengths"][0] = T
+    for d in ("fw", "bw"):
+        data["xg_" + d] = mk(rows, 4 * H).to(dev)
+        w = mk(H, 4 * H, sc=1.0 / H ** 0.5)
+        data["wh_" + d] = w.to(bf).to(dev).contiguous()
+        data["whT_" + d] = w.t().contiguous().to(bf).to(dev)
+        data["dh"] = mk(rows, 2 * H, sc=0.1).to(dev)
+    return data
+
+
+def _run(dev, data, cluster):
+    from nspeech_amd import ops
+    N, T, H, P, padl = (data[k] for k in ("N", "T", "H", "P", "padl"))
+    rows = N * P
+    bf = torch.bfloat16
+    out = dict(h=torch.zeros(rows * 2 * H, dtype=bf, device=dev))
+    fp, bp = [], []
+    for di, d in enumerate(("fw", "bw")):
+        out["c_" + d] = torch.zeros(rows * H, device=dev)
+        out["g_" + d] = torch.zeros(rows * 4 * H, dtype=bf, device=dev)
+        out["dg_" + d] = torch.zeros(rows * 4 * H, dtype=bf, device=dev)
+        work = torch.zeros(N * H + 64, device=dev)
+        common = dict(h_off=di * H)
+        fp.append(ops.lstm_seq_params(N, T, H, P, padl, data["xg_" + d], 4 * H, data["whT_" + d], None, data["lengths"],
+                                      d == "bw", out["h"], 2 * H, out["c_" + d], out["g_" + d], **common))
+        bp.append(ops.lstm_seq_params(N, T, H, P, padl, data["xg_" + d], 4 * H, None, data["wh_" + d], data["lengths"],
+                                      d == "bw", out["h"], 2 * H, out["c_" + d], out["g_" + d], dh=data["dh"],
+                                      ld_dh=2 * H, dgates=out["dg_" + d], work=work, dh_off=di * H, **common))
+        out["_w" + d] = work
+    if cluster:
+        assert ops.lstm_cluster_supported(fp[0])
+        w = torch.zeros(ops.lstm_cluster_work_floats(fp[0]), device=dev)
+        for _ in range(2):      # second launch re-initialises the exchange state itself
+            ops.lstm_cluster("fwd", fp[0], fp[1], w)
+        torch.cuda.synchronize()
+        assert int(w[:1].view(torch.int32).item()) == 0
+        for _ in range(2):
+            ops.lstm_cluster("bwd", bp[0], bp[1], w)
+        torch.cuda.synchronize()
+        assert int(w[:1].view(torch.int32).item()) == 0
+    else:
+        ops.lstm_seq2("fwd", fp[0], fp[1])
+        ops.lstm_seq2("bwd", bp[0], bp[1])
+        torch.cuda.synchronize()
+    return out
+
+
+@pytest.mark.parametrize("N,T,H,masked", [(16, 9, 64, False), (20, 33, 256, True), (32, 61, 256, False), (5, 12, 128, True)])
+def test_cluster_matches_per_step_kernels(dev, N, T, H, masked):
+    data = _setup(dev, N, T, H, seed=N + T, masked=masked)
+    ref = _run(dev, data, cluster=False)
+    got = _run(dev, data, cluster=True)
+    for k in ("h", "c_fw", "c_bw", "g_fw", "g_bw", "dg_fw", "dg_bw"):
+        a, b = got[k].float(), ref[k].float()
+        scale = b.abs().max().item() + 1e-6
+        err = (a - b).abs().max().item()
+        # same bf16 operands, different fp32 summation order; bf16 rounding of stored states
+        assert err <= 3e-2 * scale, (k, err, scale)
+        assert (a - b).abs().mean().item() <= 2e-3 * scale, k
