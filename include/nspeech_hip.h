@@ -172,6 +172,10 @@ typedef struct {
 } ns_adam_params;
 int ns_adam(const ns_adam_params* p, ns_stream_t stream);
 
+/* hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - hi[i]): pre-split operands for f32_passes = 3. */
+typedef struct { const float* src; void* hi; void* lo; int64_t n; } ns_split_params;
+int ns_split_hi_lo(const ns_split_params* p, ns_stream_t stream);
+
 /* dst[c,r] = (T)src[r,c]  (k-contiguous shadow copies of recurrent weights). */
 typedef struct {
   const float* src; int rows, cols; int64_t ld_src;
@@ -206,6 +210,9 @@ typedef struct {
   void* dgates;                         /* (dtype) [N*P, 4H] out */
   float* work;                          /* fp32 [N*H] scratch (cell-state gradient carry) */
   int f32_passes;                       /* as in ns_gemm_params, for the recurrent product */
+  /* optional pre-split bf16 copies of fp32 weights (dtype NS_F32 only): whT = whT_hi + whT_lo
+   * spares the in-kernel split for f32_passes = 3; wh_bf16 serves f32_passes = 1 at half the bytes */
+  const void* whT_hi; const void* whT_lo; const void* wh_bf16;
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -241,6 +248,7 @@ typedef struct {
   float* c_out; int64_t co_sn;
   float forget_bias;
   int f32_passes;
+  const void* wT_hi; const void* wT_lo;   /* optional pre-split weights (dtype NS_F32) */
 } ns_lstm_step_params;
 int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t stream);
 
@@ -301,6 +309,7 @@ typedef struct {
   float* dv; float* dwcl;          /* fp32 [A], [kw*A] += */
   float* work;                     /* fp32 scratch, ns_taco2_attn_work_bytes() */
   int f32_passes;                  /* as in ns_gemm_params, for the in-loop products */
+  const void* wattT_hi; const void* wattT_lo; const void* watt_bf16;   /* optional, as in ns_lstm_seq_params */
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

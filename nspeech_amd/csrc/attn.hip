@@ -598,6 +598,7 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     l.c_out = p.ca + slot * A; l.co_sn = S1 * A;
     l.gates_out = (T*)p.ga + slot * 4 * A; l.g_sn = S1 * 4 * A;
     l.passes = p.f32_passes;
+    l.wT_hi = (const bf16_t*)p.wattT_hi; l.wT_lo = (const bf16_t*)p.wattT_lo;
     rc = lstm_step_launch<T>(l, s);
     if (rc) return rc;
     // q = h . Wq
@@ -691,6 +692,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     c.dc_carry = dc_carry;
     c.dgates = (T*)p.dga + slot * 4 * A; c.dg_sn = S1 * 4 * A;
     c.passes = p.f32_passes;
+    c.w_bf16 = p.watt_bf16 ? (const bf16_t*)p.watt_bf16 + D2 * 4 * A : nullptr;
     rc = lstm_bwd_step_launch<T>(c, s);
     if (rc) return rc;
     for (int nb = 0; nb < p.N; nb += 32) {

@@ -346,3 +346,23 @@ extern "C" int ns_cast2d(const ns_cast2d_params* p, ns_stream_t s) {
   NS_CHECK_LAUNCH("cast2d");
   return NS_OK;
 }
+
+// ------------------------------------------------------------------ hi/lo split
+__global__ void split_kernel(ns_split_params p) {
+  bf16_t* hi = (bf16_t*)p.hi;
+  bf16_t* lo = (bf16_t*)p.lo;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x) {
+    const float x = p.src[i];
+    const bf16_t h = (bf16_t)x;
+    hi[i] = h;
+    lo[i] = (bf16_t)(x - (float)h);
+  }
+}
+extern "C" int ns_split_hi_lo(const ns_split_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->src && p->hi && p->lo, "ns_split_hi_lo: null");
+  if (p->n <= 0) return NS_OK;
+  int grid = (int)min((long)4096, (long)((p->n + 255) / 256));
+  hipLaunchKernelGGL(split_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("split_hi_lo");
+  return NS_OK;
+}

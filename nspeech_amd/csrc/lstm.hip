@@ -102,20 +102,34 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
       const bool oku = u0 + r16 < H;
       const float* brow = (const float*)a.wT + (long)(u0 + r16) * a.K;
       const long gstride = (long)H * a.K;
-      for (int kc = wave; kc < nkc; kc += LW) {
-        const int k = kc * 32 + g * 8;
-        const bool okk = k < a.K;
-        bf16x8 ah[2], al[2], bh[4], bl[4];
-        ldsplit8(arow0 + k, ok0 && okk, ah[0], al[0]);
-        ldsplit8(arow1 + k, ok1 && okk, ah[1], al[1]);
+      for (int kc0 = wave; kc0 < nkc; kc0 += LW * 2) {
+        bf16x8 ah[2][2], al[2][2], bh[2][4], bl[2][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) ldsplit8(brow + j * gstride + k, oku && okk, bh[j], bl[j]);
+        for (int q = 0; q < 2; ++q) {
+          const int k = (kc0 + q * LW) * 32 + g * 8;
+          const bool okk = k < a.K;
+          ldsplit8(arow0 + k, ok0 && okk, ah[q][0], al[q][0]);
+          ldsplit8(arow1 + k, ok1 && okk, ah[q][1], al[q][1]);
+          if (a.wT_hi) {
+            const long bo = (long)(u0 + r16) * a.K + k;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 4; ++j) {
+              bh[q][j] = (oku && okk) ? *(const bf16x8*)(a.wT_hi + bo + j * gstride) : zero8();
+              bl[q][j] = (oku && okk && three) ? *(const bf16x8*)(a.wT_lo + bo + j * gstride) : zero8();
+            }
+          } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            acc[i][j] = three ? mfma_split<3>(ah[i], al[i], bh[j], bl[j], acc[i][j])
-                              : mfma_split<1>(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+            for (int j = 0; j < 4; ++j) ldsplit8(brow + j * gstride + k, oku && okk, bh[q][j], bl[q][j]);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[i][j] = three ? mfma_split<3>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j])
+                                : mfma_split<1>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j]);
       }
     }
 #pragma unroll
@@ -270,6 +284,26 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
       const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
       const bool oku = u0 + r16 < H;
       const float* brow = (const float*)a.w + (long)(u0 + r16) * a.K;
+      if (a.w_bf16 && !three) {
+        const bf16_t* wrow = a.w_bf16 + (long)(u0 + r16) * a.K;
+        for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
+          bf16x8 af[GROUP][2], bfr[GROUP];
+#pragma unroll
+          for (int q = 0; q < GROUP; ++q) {
+            const int k = (kc0 + q * LW) * 32 + g * 8;
+            const bool okk = k < a.K;
+            bf16x8 dummy;
+            ldsplit8(arow0 + k, ok0 && okk, af[q][0], dummy);
+            ldsplit8(arow1 + k, ok1 && okk, af[q][1], dummy);
+            bfr[q] = (oku && okk) ? *(const bf16x8*)(wrow + k) : zero8();
+          }
+#pragma unroll
+          for (int q = 0; q < GROUP; ++q) {
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][0], bfr[q], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][1], bfr[q], acc[1], 0, 0, 0);
+          }
+        }
+      } else
       for (int kc0 = wave; kc0 < nkc; kc0 += LW * 2) {
         bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
 #pragma unroll
@@ -278,7 +312,12 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
           const bool okk = k < a.K;
           ldsplit8(arow0 + k, ok0 && okk, ah[q][0], al[q][0]);
           ldsplit8(arow1 + k, ok1 && okk, ah[q][1], al[q][1]);
-          ldsplit8(brow + k, oku && okk, bh[q], bl[q]);
+          if (false) {
+            bh[q] = (oku && okk) ? *(const bf16x8*)(a.w_bf16 + (long)(u0 + r16) * a.K + k) : zero8();
+            bl[q] = zero8();
+          } else {
+            ldsplit8(brow + k, oku && okk, bh[q], bl[q]);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
@@ -373,6 +412,7 @@ static void fill_fwd(LstmStep<T>& a, const ns_lstm_seq_params& p, int step) {
   a.gates_out = p.gates ? (T*)p.gates + row * 4 * H : nullptr; a.g_sn = P * 4 * H;
   a.lengths = p.lengths; a.t = t;
   a.passes = p.f32_passes;
+  a.wT_hi = (const bf16_t*)p.whT_hi; a.wT_lo = (const bf16_t*)p.whT_lo;
 }
 
 template <typename T>
@@ -396,6 +436,7 @@ static void fill_bwd(LstmBwdStep<T>& a, const ns_lstm_seq_params& p, int step, f
   a.dc_carry = dc_carry;
   a.dgates = (T*)p.dgates + row * 4 * H; a.dg_sn = P * 4 * H;
   a.passes = p.f32_passes;
+  a.w_bf16 = (const bf16_t*)p.wh_bf16;
 }
 
 static int check_fwd(const ns_lstm_seq_params* p, const char* who) {
@@ -482,6 +523,7 @@ extern "C" int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t s) {
     a.c_prev = p->c_prev; a.c_sn = p->c_sn;
     a.h_out = (T*)p->h_out; a.h_sn = p->h_sn; a.h_out2 = (T*)p->h_out2; a.h2_sn = p->h2_sn;
     a.c_out = p->c_out; a.co_sn = p->co_sn;
+    a.wT_hi = (const bf16_t*)p->wT_hi; a.wT_lo = (const bf16_t*)p->wT_lo;
     return lstm_step_launch<T>(a, (hipStream_t)s);
   };
   if (p->dtype == NS_BF16) return run(bf16_t{});

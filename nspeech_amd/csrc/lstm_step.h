@@ -18,6 +18,7 @@ struct LstmStep {
   int N, H;
   float forget_bias;
   int passes;                        // fp32 operands: 0 exact FMA, 1/3 split-bf16 MFMA
+  const bf16_t* wT_hi; const bf16_t* wT_lo;   // optional pre-split copies of an fp32 wT
 };
 // up to two independent cells (the two directions of a BiLSTM) in one launch: blockIdx.z
 template <typename T>
@@ -39,6 +40,7 @@ struct LstmBwdStep {
   float* dc_carry; int first;              // [N,H] in/out (ignored on input when first)
   T* dgates; long dg_sn;                   // out [N, 4H]
   int passes;
+  const bf16_t* w_bf16;                    // optional bf16 copy of an fp32 w (passes == 1)
 };
 template <typename T>
 struct LstmBwdStepPair { LstmBwdStep<T> s[2]; int n; };

@@ -124,6 +124,12 @@ class Tacotron2(object):
     def _o(self, name):
         return self.layout.off(name)
 
+    def _bf16_w(self, D):
+        """bf16 shadow of the flat weights for single-pass backward products on fp32 storage."""
+        if D == torch.float32 and self.passes_bwd == 1 and self.flat_s is not self.flat_p:
+            return self.flat_s
+        return None
+
     def _W(self, D):
         """Flat weight buffer to use as a GEMM operand of dtype D."""
         return self.flat_p if D == torch.float32 else self.flat_s
@@ -139,10 +145,18 @@ class Tacotron2(object):
         if not hasattr(self, "tsh"):
             self.tsh = {}
 
+        split = self.passes_fwd > 0     # fp32 storage: also keep pre-split bf16 (hi, lo) copies
+
         def tr(key, name, r0, rows, cols, D=None):
+            D = D or T
             if key not in self.tsh:
-                self.tsh[key] = torch.zeros(cols * rows, dtype=D or T, device=dev)
+                self.tsh[key] = torch.zeros(cols * rows, dtype=D, device=dev)
             ops.cast2d(self.flat_p, rows, cols, cols, self.tsh[key], rows, True, src_off=self._o(name) + r0 * cols)
+            if split and D == torch.float32:
+                if key + "_hi" not in self.tsh:
+                    self.tsh[key + "_hi"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
+                    self.tsh[key + "_lo"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
+                ops.split_hi_lo(self.tsh[key], self.tsh[key + "_hi"], self.tsh[key + "_lo"], cols * rows)
 
         M, E, A, D = hp.num_mels, 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
         He, Hx = hp.encoder_lstm_units, hp.expand_lstm_units
@@ -310,8 +324,11 @@ class Tacotron2(object):
                      bias=self.flat_p, bias_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
             gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
-            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh["%s_%s_whT" % (key, d)], None,
-                                            lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H))
+            wk = "%s_%s_whT" % (key, d)
+            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh[wk], None,
+                                            lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H,
+                                            whT_hi=self.tsh.get(wk + "_hi") if D == torch.float32 else None,
+                                            whT_lo=self.tsh.get(wk + "_lo") if D == torch.float32 else None))
         self._run_bilstm("fwd", pair, tag)
         return out
 
@@ -350,7 +367,8 @@ class Tacotron2(object):
             pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
                                             self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
                                             ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
-                                            h_off=di * H, dh_off=di * H))
+                                            h_off=di * H, dh_off=di * H,
+                                            wh_bf16=self._bf16_w(D), wh_bf16_off=ko + cin * 4 * H))
         self._run_bilstm("bwd", pair, tag)
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
@@ -444,6 +462,7 @@ class Tacotron2(object):
             p1=p1, xa=xa, hc=hc, ca=ca, ga=ga, q=q, align=al,
             keys_t=self._buf("dec_keys_t", N * A * Tia, torch.float32),
             work=self._buf("attn_work", N * (E + 9 * Tia + 2 * A + A * Tia) + 64, torch.float32),
+            wattT_hi=self.tsh.get("wattT_hi"), wattT_lo=self.tsh.get("wattT_lo"),
             align_t=self._buf("dec_al_t", N * S1 * Tia, T_))
         ops.taco2_attn("fwd", **self._attn_args)
         self._tick("attn_rnn")
@@ -457,14 +476,16 @@ class Tacotron2(object):
         h1 = self._buf("dec_h1", rows * D, T_)
         c1 = self._buf("dec_c1", rows * D, torch.float32)
         g1 = self._buf("dec_g1", rows * 4 * D, T_)
-        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1)
+        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1,
+                     whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"))
         xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
         ops.gemm(h1, self._W(self.T), xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
                  bias=self.flat_p, bias_off=self._o("decoder/lstm_2/bias"))
         h2 = self._buf("dec_h2", rows * D, T_)
         c2 = self._buf("dec_c2", rows * D, torch.float32)
         g2 = self._buf("dec_g2", rows * 4 * D, T_)
-        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2)
+        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2,
+                     whT_hi=self.tsh.get("l2_whT_hi"), whT_lo=self.tsh.get("l2_whT_lo"))
         dec = self._buf("dec_out", rows * M * r, torch.float32)
         ops.gemm(h2, self._W(self.T), dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
                  b_off=self._o("decoder/output_projection/kernel"), bias=self.flat_p,
@@ -615,13 +636,15 @@ class Tacotron2(object):
         k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
         dg2 = self._buf("d_g2", rows * 4 * D, T_)
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D, B["dec_c2"],
-                     B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D)
+                     B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
+                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D)
         self._lstm_wgrads(h1, D, h2, D, dg2, rows, k2, "decoder/lstm_2/bias")
         dh1 = self._buf("d_h1", rows * D, torch.float32)
         ops.gemm(dg2, self._W(self.T), dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
         dg1 = self._buf("d_g1", rows * 4 * D, T_)
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D, B["dec_c1"],
-                     B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D)
+                     B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
+                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D)
         self._lstm_wgrads(hc, A + E, h1, D, dg1, rows, k1, "decoder/lstm_1/bias")
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
         ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
@@ -647,6 +670,7 @@ class Tacotron2(object):
         args.update(w1c=(self._W(self.T), w1 + M * 256), w2=(self._W(self.T), w2), watt=(self._W(self.T), wa),
                     wq=(self._W(self.T), wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
                     dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork,
+                    watt_bf16=(self._bf16_w(T_), wa) if self._bf16_w(T_) is not None else None,
                     de=self._buf("d_energy", rows * Tia, torch.float32),
                     dctx_t=self._buf("d_ctx_t", rows * E, T_))
         ops.taco2_attn("bwd", **args)

@@ -149,12 +149,13 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
 
 def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
                     dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
-                    forget_bias=1.0):
+                    forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0):
     p = L.struct("ns_lstm_seq_params")
     _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
-          dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES)
+          dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES,
+          whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off))
     return p
 
 
@@ -173,6 +174,8 @@ def lstm_seq2(direction, p0, p1):
 def taco2_attn(direction, **kw):
     p = L.struct("ns_taco2_attn_params")
     for k, v in kw.items():
+        if v is None:
+            continue
         if isinstance(v, tuple):        # (tensor, offset)
             v = ptr(v[0], v[1])
         elif hasattr(v, "data_ptr"):
@@ -196,3 +199,10 @@ def lstm_cluster(direction, p0, p1, work):
     """Persistent whole-sequence BiLSTM (one launch); work[0] is the status word."""
     fn = getattr(L.lib(), "ns_lstm_cluster_fwd" if direction == "fwd" else "ns_lstm_cluster_bwd")
     L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_cluster_" + direction)
+
+
+def split_hi_lo(src, hi, lo, n):
+    """hi = bf16(src), lo = bf16(src - hi)  (pre-split operands of the 3-pass products)."""
+    p = L.struct("ns_split_params")
+    _fill(p, src=ptr(src), hi=ptr(hi), lo=ptr(lo), n=n)
+    L.call("ns_split_hi_lo", p, stream())
