@@ -270,6 +270,77 @@ int ns_attention_step(const ns_attention_step_params* p, ns_stream_t stream);
 int ns_taco2_keys_transpose(const float* keys, float* keys_t, int N, int Ti, int Tia, int Pi, int padl, int A,
                             ns_stream_t stream);
 
+/* Backward of ns_attention_step for one decoder step (the three kernels of the training loop):
+ * da = dctx.values + carry, softmax backward, gradient wrt the previous alignments (as per-tap
+ * terms gk) and dq.  de_out / dctx_out feed ns_attention_post_bwd. */
+typedef struct {
+  int dtype, N, Ti, Pi, padl_i, Tia, A, E, kw;
+  const int* lengths;
+  const float* keys; const float* keys_t; const void* values;
+  const float* q; int64_t q_sn;
+  const float* acur; const float* aprev; int64_t al_sn;
+  const float* dctx_ext; int64_t dce_sn;
+  const float* dctx_carry;          /* fp32 [N,E] or NULL */
+  float* gk; float* da; int has_carry;   /* fp32 [N,Tia,8] in/out, fp32 [N,Tia] scratch */
+  void* dq_out; int64_t dq_sn;      /* (dtype) [N, A] rows */
+  float* de_out;                    /* fp32 rows, stride al_sn */
+  void* dctx_out; int64_t dco_sn;   /* (dtype) [N, E] rows */
+  const float* wcl; const float* v;
+} ns_attention_step_bwd_params;
+int ns_attention_step_bwd(const ns_attention_step_bwd_params* p, ns_stream_t stream);
+/* Sums over all S decoder steps that no recurrence needs: dkeys_t (plain store), dv +=, dwcl +=. */
+typedef struct {
+  int N, S, Ti, Tia, A, kw;
+  const int* lengths;
+  const float* keys_t; const float* q; const float* align; const float* de;   /* [N,S+1,...] slot layout */
+  const float* wcl; const float* v;
+  float* dkeys_t; float* dv; float* dwcl;
+} ns_attention_post_bwd_params;
+int ns_attention_post_bwd(const ns_attention_post_bwd_params* p, ns_stream_t stream);
+/* keys[n, padl+t, u] += keys_t[n,u,t] */
+int ns_taco2_keys_transpose_add(float* keys, const float* keys_t, int N, int Ti, int Tia, int Pi, int padl, int A,
+                                ns_stream_t stream);
+
+/* ------------------------------------------------------------------ GRU / highway element-wise
+ * tf.contrib.rnn.GRUCell pieces (modules.py:92,172-181; tacotron.py:69-76) around the gate GEMMs:
+ *  mode 0: rh = r * h_prev                         (ru = [r | u] fp32 [N,2H])
+ *  mode 1: h = u*h_prev + (1-u)*c  (0 past length) -> h_out (dtype) (+ h_out2)
+ *  mode 2: backward A: dzc = dh*(1-u)*(1-c^2); dzu = dh*(h_prev-c)*u*(1-u) -> dzg[:,H:]; carry = dh*u
+ *  mode 3: backward B: dzr = drh*h_prev*r*(1-r) -> dzg[:,:H]; carry += drh*r
+ * rows with t >= lengths[n] produce zeros (modes 1-3). */
+typedef struct {
+  int mode, dtype, N, H, t;
+  const int* lengths;
+  const float* ru; int64_t ru_sn;
+  const float* c; int64_t c_sn;
+  const void* h_prev; int64_t hp_sn;      /* (dtype), NULL = zeros */
+  void* out; int64_t out_sn;              /* mode 0: rh; mode 1: h_out; mode 2: dzc (dtype) */
+  void* out2; int64_t out2_sn;            /* mode 1: optional second h destination */
+  void* dzg; int64_t dzg_sn;              /* (dtype) [N,2H] rows (modes 2, 3) */
+  const float* dh; int64_t dh_sn;         /* modes 2: total grad wrt h (fp32); mode 3: drh */
+  float* carry; int64_t carry_sn;         /* fp32 [N,H] */
+} ns_gru_pointwise_params;
+int ns_gru_pointwise(const ns_gru_pointwise_params* p, ns_stream_t stream);
+
+/* dpre = dy * act'(y) for a dense layer whose output y = act(pre) was stored (ReLU / tanh /
+ * sigmoid / none); rows failing the (period, lo, hi) test give 0. */
+typedef struct {
+  const float* dy; const void* y; void* dpre; int dtype;
+  int rows, C; int act;
+  int row_period, row_lo, row_hi;
+} ns_act_bwd_params;
+int ns_act_bwd(const ns_act_bwd_params* p, ns_stream_t stream);
+
+/* modules.py:185-191 highway combine y = H*T + x*(1-T) and its backward
+ * (dHpre = dy*T*(H>0), dTpre = dy*(H-x)*T*(1-T), dx = dy*(1-T)). */
+typedef struct {
+  int backward, dtype; int64_t n;
+  const void* h; const void* t; const void* x;
+  void* y;                               /* forward out (dtype) */
+  const float* dy; void* dhpre; void* dtpre; float* dx;   /* backward */
+} ns_highway_params;
+int ns_highway(const ns_highway_params* p, ns_stream_t stream);
+
 /* ------------------------------------------------------------------ Tacotron-2 attention RNN
  * The part of the decoder loop that is recurrent through the attention state
  * (tacotron2.py:63-83 with AttentionWrapper(PrenetWrapper(LSTMBlockCell(256)),

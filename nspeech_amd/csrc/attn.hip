@@ -790,3 +790,57 @@ extern "C" int ns_attention_step(const ns_attention_step_params* p, ns_stream_t 
   if (p->dtype == NS_BF16) return run(bf16_t{});
   return run(float{});
 }
+
+extern "C" int ns_taco2_keys_transpose_add(float* keys, const float* keys_t, int N, int Ti, int Tia, int Pi, int padl,
+                                           int A, ns_stream_t s) {
+  NS_CHECK_ARG(keys && keys_t, "ns_taco2_keys_transpose_add: null");
+  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(Tia, 32), ceil_div(A, 32), N), dim3(256), 0, (hipStream_t)s,
+                     (const float*)keys, (float*)keys_t, Ti, Tia, Pi, padl, A, 1);
+  NS_CHECK_LAUNCH("keys_transpose_add");
+  return NS_OK;
+}
+
+extern "C" int ns_attention_step_bwd(const ns_attention_step_bwd_params* p, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && p->keys && p->keys_t && p->values && p->q && p->acur && p->aprev && p->dctx_ext && p->gk && p->da &&
+                   p->dq_out && p->de_out && p->dctx_out && p->wcl && p->v, "ns_attention_step_bwd: null");
+  NS_CHECK_ARG(p->A % 8 == 0 && p->A <= 256 && p->E % 8 == 0 && p->kw >= 1 && p->kw <= MAXKW && p->Tia >= p->Ti,
+               "ns_attention_step_bwd: unsupported shape");
+  const size_t lds = sizeof(float) * ((size_t)p->Ti + 2 * PADK + p->Tia + AW * 64);
+  NS_CHECK_ARG(lds <= 64 * 1024 && sizeof(float) * p->E <= 64 * 1024, "ns_attention_step_bwd: too large for LDS");
+  auto run = [&](auto tag) -> int {
+    using T = decltype(tag);
+    AttnBwdStep<T> a = {};
+    a.Ti = p->Ti; a.A = p->A; a.E = p->E; a.kw = p->kw; a.Tia = p->Tia; a.lengths = p->lengths;
+    a.keys = p->keys + (long)p->padl_i * p->A; a.keys_sn = (long)p->Pi * p->A;
+    a.keys_t = p->keys_t;
+    a.values = (const T*)p->values + (long)p->padl_i * p->E; a.values_sn = (long)p->Pi * p->E;
+    a.q = p->q; a.q_sn = p->q_sn;
+    a.acur = p->acur; a.aprev = p->aprev; a.al_sn = p->al_sn;
+    a.dctx_ext = p->dctx_ext; a.dce_sn = p->dce_sn; a.dctx_carry = p->dctx_carry;
+    a.gk = p->gk; a.da = p->da; a.has_carry = p->has_carry;
+    a.dq_out = (T*)p->dq_out; a.dq_sn = p->dq_sn; a.de_out = p->de_out;
+    a.dctx_out = (T*)p->dctx_out; a.dco_sn = p->dco_sn;
+    a.wcl = p->wcl; a.v = p->v;
+    hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p->Tia, 32), p->N), dim3(ATHREADS), sizeof(float) * p->E, s, a);
+    hipLaunchKernelGGL(attn_bwd_energy_kernel<T>, dim3(ceil_div(p->Ti, 64), p->N), dim3(ATHREADS), 0, s, a);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(ceil_div(p->A, 64), p->N), dim3(ATHREADS), lds, s, a);
+    NS_CHECK_LAUNCH("attention_step_bwd");
+    return NS_OK;
+  };
+  if (p->dtype == NS_BF16) return run(bf16_t{});
+  return run(float{});
+}
+
+extern "C" int ns_attention_post_bwd(const ns_attention_post_bwd_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->keys_t && p->q && p->align && p->de && p->wcl && p->v && p->dkeys_t && p->dv && p->dwcl,
+               "ns_attention_post_bwd: null");
+  AttnPost q = {};
+  q.S = p->S; q.Ti = p->Ti; q.A = p->A; q.kw = p->kw; q.Tia = p->Tia; q.lengths = p->lengths;
+  q.keys_t = p->keys_t; q.q = p->q; q.align = p->align; q.de = p->de; q.wcl = p->wcl; q.v = p->v;
+  q.dkeys_t = p->dkeys_t; q.dv = p->dv; q.dwcl = p->dwcl;
+  dim3 grid(ceil_div(p->Tia, 64), ceil_div(p->A, 4 * PU), p->N);
+  hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, (hipStream_t)s, q);
+  NS_CHECK_LAUNCH("attention_post_bwd");
+  return NS_OK;
+}

@@ -366,3 +366,103 @@ extern "C" int ns_split_hi_lo(const ns_split_params* p, ns_stream_t s) {
   NS_CHECK_LAUNCH("split_hi_lo");
   return NS_OK;
 }
+
+// ------------------------------------------------------------------ GRU element-wise pieces
+template <typename T>
+__global__ void gru_pointwise_kernel(ns_gru_pointwise_params p) {
+  const int total = p.N * p.H;
+  const int H = p.H;
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+    const int n = idx / H, u = idx % H;
+    const bool masked = p.lengths && p.t >= p.lengths[n];
+    const float hp = p.h_prev ? ldf((const T*)p.h_prev + (long)n * p.hp_sn + u) : 0.f;
+    const float r = p.ru ? p.ru[(long)n * p.ru_sn + u] : 0.f;
+    const float uu = p.ru ? p.ru[(long)n * p.ru_sn + H + u] : 0.f;
+    if (p.mode == 0) {
+      stf((T*)p.out + (long)n * p.out_sn + u, r * hp);
+    } else if (p.mode == 1) {
+      const float c = p.c[(long)n * p.c_sn + u];
+      const float h = masked ? 0.f : uu * hp + (1.f - uu) * c;
+      stf((T*)p.out + (long)n * p.out_sn + u, h);
+      if (p.out2) stf((T*)p.out2 + (long)n * p.out2_sn + u, h);
+    } else if (p.mode == 2) {
+      const float c = p.c[(long)n * p.c_sn + u];
+      const float dh = masked ? 0.f : p.dh[(long)n * p.dh_sn + u];
+      stf((T*)p.out + (long)n * p.out_sn + u, dh * (1.f - uu) * (1.f - c * c));
+      stf((T*)p.dzg + (long)n * p.dzg_sn + H + u, dh * (hp - c) * uu * (1.f - uu));
+      p.carry[(long)n * p.carry_sn + u] = dh * uu;
+    } else {
+      const float drh = masked ? 0.f : p.dh[(long)n * p.dh_sn + u];
+      stf((T*)p.dzg + (long)n * p.dzg_sn + u, drh * hp * r * (1.f - r));
+      p.carry[(long)n * p.carry_sn + u] += drh * r;
+    }
+  }
+}
+extern "C" int ns_gru_pointwise(const ns_gru_pointwise_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->mode >= 0 && p->mode <= 3, "ns_gru_pointwise: bad mode");
+  const int total = p->N * p->H;
+  if (total <= 0) return NS_OK;
+  const int grid = min(1024, ceil_div(total, 256));
+  if (p->dtype == NS_BF16) hipLaunchKernelGGL(gru_pointwise_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  else hipLaunchKernelGGL(gru_pointwise_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("gru_pointwise");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ highway combine
+template <typename T>
+__global__ void highway_kernel(ns_highway_params p) {
+  const T* h = (const T*)p.h; const T* t = (const T*)p.t; const T* x = (const T*)p.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x) {
+    const float hv = ldf(h + i), tv = ldf(t + i), xv = ldf(x + i);
+    if (!p.backward) {
+      stf((T*)p.y + i, hv * tv + xv * (1.f - tv));
+    } else {
+      const float dy = p.dy[i];
+      stf((T*)p.dhpre + i, hv > 0.f ? dy * tv : 0.f);
+      stf((T*)p.dtpre + i, dy * (hv - xv) * tv * (1.f - tv));
+      p.dx[i] = dy * (1.f - tv);
+    }
+  }
+}
+extern "C" int ns_highway(const ns_highway_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->h && p->t && p->x, "ns_highway: null");
+  if (p->n <= 0) return NS_OK;
+  const int grid = (int)min((long)4096, (long)((p->n + 255) / 256));
+  if (p->dtype == NS_BF16) hipLaunchKernelGGL(highway_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  else hipLaunchKernelGGL(highway_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("highway");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ activation backward
+template <typename T>
+__global__ void act_bwd_kernel(ns_act_bwd_params p) {
+  const long total = (long)p.rows * p.C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    bool valid = true;
+    if (p.row_period > 0) {
+      const int t = (int)((i / p.C) % p.row_period);
+      valid = t >= p.row_lo && t < p.row_hi;
+    }
+    float d = 0.f;
+    if (valid) {
+      d = p.dy[i];
+      const float y = ldf((const T*)p.y + i);
+      if (p.act == NS_ACT_RELU) d = y > 0.f ? d : 0.f;
+      else if (p.act == NS_ACT_TANH) d *= (1.f - y * y);
+      else if (p.act == NS_ACT_SIGMOID) d *= y * (1.f - y);
+    }
+    stf((T*)p.dpre + i, d);
+  }
+}
+extern "C" int ns_act_bwd(const ns_act_bwd_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->dy && p->y && p->dpre, "ns_act_bwd: null");
+  const long total = (long)p->rows * p->C;
+  if (total <= 0) return NS_OK;
+  const int grid = (int)min((long)4096, (total + 255) / 256);
+  if (p->dtype == NS_BF16) hipLaunchKernelGGL(act_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  else hipLaunchKernelGGL(act_bwd_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("act_bwd");
+  return NS_OK;
+}

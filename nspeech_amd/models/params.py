@@ -125,6 +125,57 @@ def taco2_layout(hp, vocab_size):
     return tr, st
 
 
+def _gru(trainable, scope, nin, units):
+    trainable.add(scope + "/gates/kernel", (nin + units, 2 * units))
+    trainable.add(scope + "/gates/bias", (2 * units,))
+    trainable.add(scope + "/candidate/kernel", (nin + units, units))
+    trainable.add(scope + "/candidate/bias", (units,))
+
+
+def _cbhg(tr, st, scope, K, cin, proj, gru_units=128, highways=4):
+    for k in range(1, K + 1):
+        _conv_bn(tr, st, "%s/conv_bank/conv1d_%d" % (scope, k), k, cin, 128)
+    c = K * 128
+    for i, size in enumerate(proj):
+        _conv_bn(tr, st, "%s/proj_%d" % (scope, i + 1), 3, c, size)
+        c = size
+    if c != 128:
+        tr.add(scope + "/dense/kernel", (c, 128))
+        tr.add(scope + "/dense/bias", (128,))
+    for i in range(highways):
+        for g in ("H", "T"):
+            tr.add("%s/highway_%d/highway/%s/kernel" % (scope, i, g), (128, 128))
+            tr.add("%s/highway_%d/highway/%s/bias" % (scope, i, g), (128,))
+    for d in ("fw", "bw"):
+        _gru(tr, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), 128, gru_units)
+
+
+def taco1_layout(hp, vocab_size):
+    """Variables of tacotron.py:36-98 (names relative to 'model/inference/')."""
+    tr, st = Layout(), Layout()
+    M, emb = hp.num_mels, hp.embedding_dim
+    tr.add("embedding/embedding", (vocab_size, emb))
+    pn = list(hp.encoder_prenet)
+    tr.add("prenet/dense_1/kernel", (emb, pn[0])); tr.add("prenet/dense_1/bias", (pn[0],))
+    tr.add("prenet/dense_2/kernel", (pn[0], pn[1])); tr.add("prenet/dense_2/bias", (pn[1],))
+    _cbhg(tr, st, "encoder_cbhg", hp.encoder_cbhg_banks, pn[1], list(hp.encoder_cbhg_bank_sizes))
+    E, A, D = 256, hp.attention_dim, hp.decoder_dim
+    tr.add("attention_decoder/memory_layer/kernel", (E, A))
+    tr.add("decoder/decoder_prenet/dense_1/kernel", (M + E, 256)); tr.add("decoder/decoder_prenet/dense_1/bias", (256,))
+    tr.add("decoder/decoder_prenet/dense_2/kernel", (256, 128)); tr.add("decoder/decoder_prenet/dense_2/bias", (128,))
+    _gru(tr, "decoder/attention_gru", 128, A)
+    tr.add("decoder/attention/query_layer/kernel", (A, A))
+    tr.add("decoder/attention/attention_v", (A,))
+    tr.add("decoder/attention_projection/kernel", (A + E, D)); tr.add("decoder/attention_projection/bias", (D,))
+    _gru(tr, "decoder/gru_1", D, D)
+    _gru(tr, "decoder/gru_2", D, D)
+    tr.add("decoder/output_projection/kernel", (D, M * hp.outputs_per_step))
+    tr.add("decoder/output_projection/bias", (M * hp.outputs_per_step,))
+    _cbhg(tr, st, "post_cbhg", hp.post_cbhg_banks, M, list(hp.post_cbhg_bank_sizes) + [M])
+    tr.add("dense/kernel", (256, hp.num_freq)); tr.add("dense/bias", (hp.num_freq,))
+    return tr, st
+
+
 def init_values(trainable, stats, seed=0):
     """numpy dicts (name -> array) with the reference's initial values."""
     rng = np.random.RandomState(seed)
@@ -132,6 +183,10 @@ def init_values(trainable, stats, seed=0):
     for name, (_, shape) in trainable.entries.items():
         if name == "embedding/embedding":
             p[name] = truncated_normal(rng, shape, 0.01)
+        elif name.endswith("/gates/bias"):          # GRUCell: gate bias starts at 1.0
+            p[name] = np.ones(shape, np.float32)
+        elif name.endswith("/highway/T/bias"):      # modules.py:189-190
+            p[name] = np.full(shape, -1.0, np.float32)
         elif name.endswith("/bias") or name.endswith("/beta"):
             p[name] = np.zeros(shape, np.float32)
         elif name.endswith("/gamma"):

@@ -1,0 +1,549 @@
+"""Tacotron-1 (neural_speech/models/tacotron.py:16-190) on the same HIP kernels as Tacotron-2:
+embedding -> prenet -> CBHG(K=16) encoder -> Bahdanau attention with a GRU(256) attention cell
+behind the decoder prenet -> Dense(256) -> 2 x residual GRU(256) -> r frames -> post CBHG(K=8)
+-> Dense(num_freq); Griffin-Lim audio attribute; Noam learning-rate schedule.
+
+Conv banks (k = 1..16) use the padded layout with 7 / 8 pad rows, so every bank conv is the same
+strided GEMM as in Tacotron-2.  Bahdanau attention is the location-sensitive kernel with a zero
+location filter.  GRU recurrences run one launch per gate product from this file (skinny GEMMs with
+sigmoid / tanh epilogues + small element-wise kernels); this is the reference's CPU "plumbing"
+configuration (BASELINE configs[0]), so the time loops are plain Python, not fused kernels.
+
+Forward ops record their backward on a tape; gradients wrt activations are fp32 and accumulate.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from .._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from . import params as P_
+from .tacotron2 import Tacotron2, _round_up
+
+
+class Act(object):
+    """A [N, P, C] activation in the padded layout plus its (lazily created) fp32 gradient."""
+
+    def __init__(self, model, name, N, P, padl, T, C, dtype=None, buf=None):
+        self.m, self.name, self.N, self.P, self.padl, self.T, self.C = model, name, N, P, padl, T, C
+        self.rows = N * P
+        self.buf = buf if buf is not None else model._buf("a:" + name, self.rows * C, dtype or model.T)
+        self._grad = None
+
+    @property
+    def mask(self):
+        return (self.P, self.padl, self.padl + self.T)
+
+    @property
+    def grad(self):
+        if self._grad is None:
+            self._grad = self.m._buf("g:" + self.name, self.rows * self.C, torch.float32)
+            self._grad.zero_()
+        return self._grad
+
+
+class Tacotron(Tacotron2):
+    padl, padr = 8, 8     # bank widths up to 16: 'same' needs 7 left / 8 right; the data gradient the mirror
+    LAYOUT = staticmethod(P_.taco1_layout)
+    KW = 1    # Bahdanau = location-sensitive kernel with a 1-tap zero filter
+
+    # ------------------------------------------------------------------ shadows
+    def refresh_shadows(self, full=False):
+        if full and self.flat_s is not self.flat_p:
+            ops.cast2d(self.flat_p, 1, self.layout.size, self.layout.size, self.flat_s, self.layout.size, False)
+        if not hasattr(self, "tsh"):
+            self.tsh = {}
+        hp = self._hparams
+        dev, T = self.device, self.T
+
+        def tr(key, name, r0, rows, cols):
+            if key not in self.tsh:
+                self.tsh[key] = torch.zeros(cols * rows, dtype=T, device=dev)
+            ops.cast2d(self.flat_p, rows, cols, cols, self.tsh[key], rows, True, src_off=self._o(name) + r0 * cols)
+
+        def gru(key, scope, cin, H):
+            tr(key + "_gT", scope + "/gates/kernel", cin, H, 2 * H)
+            tr(key + "_cT", scope + "/candidate/kernel", cin, H, H)
+
+        for cb in ("encoder_cbhg", "post_cbhg"):
+            for d in ("fw", "bw"):
+                gru("%s_%s" % (cb, d), "%s/bidirectional_rnn/%s/gru_cell" % (cb, d), 128, 128)
+        A, D, M, E = hp.attention_dim, hp.decoder_dim, hp.num_mels, 256
+        gru("gru_1", "decoder/gru_1", D, D)
+        gru("gru_2", "decoder/gru_2", D, D)
+        # attention GRU: the whole [x | h] kernels transposed (x = prenet output is not hoistable)
+        tr("att_gT", "decoder/attention_gru/gates/kernel", 0, 128 + A, 2 * A)
+        tr("att_cT", "decoder/attention_gru/candidate/kernel", 0, 128 + A, A)
+        tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
+        tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
+        tr("wqT", "decoder/attention/query_layer/kernel", 0, A, A)
+        if "wcl" not in self.tsh:
+            self.tsh["wcl"] = torch.zeros(A, dtype=torch.float32, device=dev)      # zero location term
+        F = hp.num_freq
+        Fp = _round_up(F, 16)
+        if "wl_pad" not in self.tsh:
+            self.tsh["wl_pad"] = torch.zeros(256 * Fp, dtype=T, device=dev)
+            self.tsh["bl_pad"] = torch.zeros(Fp, dtype=torch.float32, device=dev)
+        ops.cast2d(self.flat_p, 256, F, F, self.tsh["wl_pad"], Fp, False, src_off=self._o("dense/kernel"))
+        ops.cast2d(self.flat_p, 1, F, F, self.tsh["bl_pad"], Fp, False, src_off=self._o("dense/bias"))
+
+    # ------------------------------------------------------------------ schedule (tacotron.py:143-146,186-190)
+    def learning_rate_at(self, step):
+        hp = self._hparams
+        if not hp.decay_learning_rate:
+            return hp.initial_learning_rate
+        warm = 4000.0
+        s = float(step + 1)
+        return hp.initial_learning_rate * warm ** 0.5 * min(s * warm ** -1.5, s ** -0.5)
+
+    # ------------------------------------------------------------------ taped layer ops
+    def _new(self, name, like, C, dtype=None):
+        return Act(self, name, like.N, like.P, like.padl, like.T, C, dtype)
+
+    def _dense(self, name, x, scope, cout, act, mask=True, W=None, woff=None, boff=None, ldw=None):
+        """y = act(x . W + b) per row (tf.layers.dense); pad rows forced to 0 when mask."""
+        y = self._new(name, x, cout)
+        woff = self._o(scope + "/kernel") if woff is None else woff
+        boff = self._o(scope + "/bias") if boff is None else boff
+        Wb = self._W(self.T) if W is None else W
+        rm = (x.P, x.padl, x.padl + x.T, 0) if mask else None
+        ops.gemm(x.buf, Wb, y.buf, x.rows, cout, x.C, x.C, cout, cout, b_mode=1, b_off=woff, bias=self.flat_p,
+                 bias_off=boff, act=act, row_mask=rm)
+
+        def bwd():
+            dpre = self._buf("t:dpre", x.rows * cout, self.T)
+            ops.act_bwd(y.grad, y.buf, dpre, x.rows, cout, act, row_mask=x.mask if mask else None)
+            g = self.flat_g
+            ops.gemm(x.buf, dpre, g, x.C, cout, x.rows, x.C, cout, cout, a_mode=1, b_mode=1, c_off=woff, accumulate=2,
+                     split_k=self._splitk(x.rows, x.C, cout))
+            ops.colsum(dpre, cout, x.rows, cout, g, out_off=boff)
+            ops.gemm(dpre, Wb, x.grad, x.rows, x.C, cout, cout, cout, x.C, a_mode=0, b_mode=0, b_off=woff, accumulate=1)
+        self._tape.append(bwd)
+        return y
+
+    def _conv(self, name, x, scope, k, cout, act, training):
+        yb = self._conv_fwd(scope, x.buf, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, training=training)
+        y = Act(self, name, x.N, x.P, x.padl, x.T, cout, buf=yb)
+
+        def bwd():
+            self._conv_bwd(scope, x.buf, y.grad, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, x.grad,
+                           dx_accumulate=True)
+        self._tape.append(bwd)
+        return y
+
+    def _concat(self, name, parts):
+        C = sum(p.C for p in parts)
+        y = self._new(name, parts[0], C)
+        off = 0
+        for p in parts:
+            ops.copy3d(p.buf, y.buf, 1, p.rows, p.C, (0, p.C), (0, C), dst_off=off)
+            off += p.C
+
+        def bwd():
+            o = 0
+            for p in parts:
+                ops.copy3d(y.grad, p.grad, 1, p.rows, p.C, (0, C), (0, p.C), src_off=o, accumulate=1)
+                o += p.C
+        self._tape.append(bwd)
+        return y
+
+    def _add(self, name, a, b):
+        y = self._new(name, a, a.C)
+        ops.copy3d(a.buf, y.buf, 1, a.rows, a.C, (0, a.C), (0, a.C))
+        ops.copy3d(b.buf, y.buf, 1, a.rows, a.C, (0, a.C), (0, a.C), accumulate=1)
+
+        def bwd():
+            for t in (a, b):
+                ops.copy3d(y.grad, t.grad, 1, a.rows, a.C, (0, a.C), (0, a.C), accumulate=1)
+        self._tape.append(bwd)
+        return y
+
+    def _highway(self, name, x, scope):
+        C = x.C
+        h = self._new(name + "_h", x, C)
+        t = self._new(name + "_t", x, C)
+        y = self._new(name, x, C)
+        W = self._W(self.T)
+        oh, ot = self._o(scope + "/H/kernel"), self._o(scope + "/T/kernel")
+        bh, bt = self._o(scope + "/H/bias"), self._o(scope + "/T/bias")
+        ops.gemm(x.buf, W, h.buf, x.rows, C, C, C, C, C, b_mode=1, b_off=oh, bias=self.flat_p, bias_off=bh, act=ACT_RELU)
+        ops.gemm(x.buf, W, t.buf, x.rows, C, C, C, C, C, b_mode=1, b_off=ot, bias=self.flat_p, bias_off=bt,
+                 act=ACT_SIGMOID)
+        ops.highway(h.buf, t.buf, x.buf, x.rows * C, y=y.buf)
+
+        def bwd():
+            dh = self._buf("t:hw_dh", x.rows * C, self.T)
+            dt_ = self._buf("t:hw_dt", x.rows * C, self.T)
+            dx = self._buf("t:hw_dx", x.rows * C, torch.float32)
+            ops.highway(h.buf, t.buf, x.buf, x.rows * C, dy=y.grad, dhpre=dh, dtpre=dt_, dx=dx)
+            g = self.flat_g
+            for dpre, ow, ob in ((dh, oh, bh), (dt_, ot, bt)):
+                ops.gemm(x.buf, dpre, g, C, C, x.rows, C, C, C, a_mode=1, b_mode=1, c_off=ow, accumulate=2,
+                         split_k=self._splitk(x.rows, C, C))
+                ops.colsum(dpre, C, x.rows, C, g, out_off=ob)
+                ops.gemm(dpre, W, dx, x.rows, C, C, C, C, C, a_mode=0, b_mode=0, b_off=ow, accumulate=1)
+            ops.copy3d(dx, x.grad, 1, x.rows, C, (0, C), (0, C), accumulate=1)
+        self._tape.append(bwd)
+        return y
+
+    # ---- GRU over time (tf GRUCell); h history lives in out.buf columns [col, col+H)
+    def _gru_seq(self, tag, x, scope, key, H, lengths, reverse, out, col):
+        N, P, padl, T = x.N, x.P, x.padl, x.T
+        rows, cin, ldh = x.rows, x.C, out.C
+        W, g = self._W(self.T), self.flat_g
+        og, oc = self._o(scope + "/gates/kernel"), self._o(scope + "/candidate/kernel")
+        bg, bc = self._o(scope + "/gates/bias"), self._o(scope + "/candidate/bias")
+        xg = self._buf("gru:%s_xg" % tag, rows * 2 * H, torch.float32)
+        xc = self._buf("gru:%s_xc" % tag, rows * H, torch.float32)
+        ops.gemm(x.buf, W, xg, rows, 2 * H, cin, cin, 2 * H, 2 * H, b_mode=1, b_off=og, bias=self.flat_p, bias_off=bg)
+        ops.gemm(x.buf, W, xc, rows, H, cin, cin, H, H, b_mode=1, b_off=oc, bias=self.flat_p, bias_off=bc)
+        ru = self._buf("gru:%s_ru" % tag, rows * 2 * H, torch.float32)
+        cc = self._buf("gru:%s_c" % tag, rows * H, torch.float32)
+        rh = self._buf("gru:%s_rh" % tag, rows * H, self.T)
+        gT, cT = self.tsh[key + "_gT"], self.tsh[key + "_cT"]
+        hb = out.buf
+        order = range(T - 1, -1, -1) if reverse else range(T)
+        for t in order:
+            row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
+            ops.gemm(hb, gT, ru, N, 2 * H, H, P * ldh, H, P * 2 * H, a_off=prow * ldh + col, c_off=row * 2 * H,
+                     act=ACT_SIGMOID, addend=xg, addend_off=row * 2 * H, ld_add=P * 2 * H)
+            ops.gru_pointwise(0, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
+                              h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(rh, row * H), out_sn=P * H)
+            ops.gemm(rh, cT, cc, N, H, H, P * H, H, P * H, a_off=row * H, c_off=row * H, act=ACT_TANH, addend=xc,
+                     addend_off=row * H, ld_add=P * H)
+            ops.gru_pointwise(1, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
+                              c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(hb, row * ldh + col),
+                              out_sn=P * ldh)
+
+        def bwd():
+            dzg = self._buf("gru:%s_dzg" % tag, rows * 2 * H, self.T)
+            dzc = self._buf("gru:%s_dzc" % tag, rows * H, self.T)
+            carry = self._buf("gru:carry", N * H, torch.float32)
+            drh = self._buf("gru:drh", N * H, torch.float32)
+            carry.zero_()
+            dzg.zero_()
+            dzc.zero_()
+            dh = out.grad
+            for t in (range(T) if reverse else range(T - 1, -1, -1)):
+                row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
+                ops.copy3d(dh, carry, N, 1, H, (P * ldh, 0), (H, 0), src_off=row * ldh + col, accumulate=1)
+                ops.gru_pointwise(2, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
+                                  c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(dzc, row * H),
+                                  out_sn=P * H, dzg=(dzg, row * 2 * H), dzg_sn=P * 2 * H, dh=(carry, 0), dh_sn=H,
+                                  carry=(carry, 0), carry_sn=H)
+                ops.gemm(dzc, W, drh, N, H, H, P * H, H, H, a_off=row * H, b_off=oc + cin * H)
+                ops.gru_pointwise(3, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
+                                  h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, dzg=(dzg, row * 2 * H),
+                                  dzg_sn=P * 2 * H, dh=(drh, 0), dh_sn=H, carry=(carry, 0), carry_sn=H)
+                ops.gemm(dzg, W, carry, N, H, 2 * H, P * 2 * H, 2 * H, H, a_off=row * 2 * H, b_off=og + cin * 2 * H,
+                         accumulate=1)
+            sk = self._splitk
+            # hoisted weight gradients: x parts, h parts (h_prev = history shifted by one row), biases
+            ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
+                     split_k=sk(rows, cin, 2 * H))
+            ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
+                     split_k=sk(rows, cin, H))
+            if reverse:
+                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + col,
+                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+            else:
+                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=col, b_off=2 * H,
+                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+            ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
+                     split_k=sk(rows, H, H))
+            ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=bg)
+            ops.colsum(dzc, H, rows, H, g, out_off=bc)
+            ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
+            ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
+        self._tape.append(bwd)
+
+    def _cbhg(self, name, x, lengths, scope, K, proj, training):
+        banks = [self._conv("%s_b%d" % (name, k), x, "%s/conv_bank/conv1d_%d" % (scope, k), k, 128, ACT_RELU, training)
+                 for k in range(1, K + 1)]
+        bank = self._concat(name + "_bank", banks)
+        y = bank
+        for i, size in enumerate(proj[:-1]):      # each reads the bank, the last one wins
+            y = self._conv("%s_p%d" % (name, i + 1), bank, "%s/proj_%d" % (scope, i + 1), 3, size, ACT_RELU, training)
+        y = self._conv("%s_p%d" % (name, len(proj)), y, "%s/proj_%d" % (scope, len(proj)), 3, proj[-1], ACT_NONE,
+                       training)
+        hw = self._add(name + "_res", y, x)
+        if hw.C != 128:
+            hw = self._dense(name + "_dense", hw, scope + "/dense", 128, ACT_NONE)
+        for i in range(4):
+            hw = self._highway("%s_hw%d" % (name, i), hw, "%s/highway_%d/highway" % (scope, i))
+        out = self._new(name + "_out", hw, 256)
+        out.buf.zero_()
+        for di, d in enumerate(("fw", "bw")):
+            self._gru_seq("%s_%s" % (name, d), hw, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), "%s_%s" % (scope, d),
+                          128, lengths, d == "bw", out, di * 128)
+        return out
+
+    def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
+        if linear_targets is None:
+            raise NotImplementedError("Tacotron-1 free-running synthesis is not built yet (training path only)")
+        return Tacotron2.initialize(self, text_inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
+
+    # ------------------------------------------------------------------ forward (training)
+    def forward_train(self):
+        hp = self._hparams
+        T_ = self.T
+        N, Ti = self.inputs.shape
+        To = self.mel_targets.shape[1]
+        r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
+        assert To % r == 0
+        S = To // r
+        Fp = _round_up(F, 16)
+        A, D, E = hp.attention_dim, hp.decoder_dim, 256
+        Pi, Po, S1 = Ti + self.padl + self.padr, To + self.padl + self.padr, S + 1
+        sig = ("train1", N, Ti, To)
+        if sig != self._sig:
+            self._bufs.clear()
+            self._sig = sig
+        self.dims = dict(N=N, Ti=Ti, To=To, S=S, Pi=Pi, Po=Po, Fp=Fp)
+        self._tape = []
+        ops.F32_PASSES = self.passes_fwd
+        W, g = self._W(T_), self.flat_g
+        o = self._o
+        lengths = self.input_lengths
+
+        # ---- encoder: embedding -> prenet -> CBHG (tacotron.py:38-62)
+        emb = Act(self, "emb", N, Pi, self.padl, Ti, hp.embedding_dim)
+        ops.embedding_fwd(self.inputs, self.flat_p, emb.buf, N, Ti, Pi, self.padl, hp.embedding_dim, self.vocab,
+                          table_off=o("embedding/embedding"))
+        self._tape.append(lambda: ops.embedding_bwd(self.inputs, emb.grad, g, N, Ti, Pi, self.padl, hp.embedding_dim,
+                                                    self.vocab, dtable_off=o("embedding/embedding")))
+        pn = list(hp.encoder_prenet)
+        x = self._dense("pre1", emb, "prenet/dense_1", pn[0], ACT_RELU)
+        x = self._dense("pre2", x, "prenet/dense_2", pn[1], ACT_RELU)
+        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), True)
+        self._enc = enc
+
+        # ---- attention memory
+        keys = self._buf("keys", N * Pi * A, torch.float32)
+        om = o("attention_decoder/memory_layer/kernel")
+        ops.gemm(enc.buf, W, keys, N * Pi, A, E, E, A, A, b_mode=1, b_off=om)
+        Tia = _round_up(Ti, 8)
+        keys_t = self._buf("keys_t", N * A * Tia, torch.float32)
+        ops.keys_transpose(keys, keys_t, N, Ti, Tia, Pi, self.padl, A)
+
+        # ---- attention RNN over all steps (teacher forced): prenet -> GRU(A) -> Bahdanau
+        XA, HC = 128 + A, A + E
+        fr = self._buf("dec_fr", N * S1 * M, T_)
+        if S > 1:
+            ops.copy3d(self.mel_targets, fr, N, S - 1, M, (To * M, r * M), (S1 * M, M), src_off=(r - 1) * M, dst_off=2 * M)
+        f1 = self._buf("dec_f1", N * S1 * 256, torch.float32)
+        w1, w2 = o("decoder/decoder_prenet/dense_1/kernel"), o("decoder/decoder_prenet/dense_2/kernel")
+        b1, b2 = o("decoder/decoder_prenet/dense_1/bias"), o("decoder/decoder_prenet/dense_2/bias")
+        ops.gemm(fr, W, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p, bias_off=b1)
+        p1 = self._buf("dec_p1", N * S1 * 256, T_)
+        xa = self._buf("dec_xa", N * S1 * XA, T_)     # [p2 | h_prev]
+        xc = self._buf("dec_xc", N * S1 * XA, T_)     # [p2 | r*h_prev]
+        hc = self._buf("dec_hc", N * S1 * HC, T_)     # [h | ctx]
+        ru = self._buf("dec_ru", N * S1 * 2 * A, torch.float32)
+        cc = self._buf("dec_cc", N * S1 * A, torch.float32)
+        q = self._buf("dec_q", N * S1 * A, torch.float32)
+        al = self._buf("dec_al", N * S1 * Tia, torch.float32)
+        al_t = self._buf("dec_al_t", N * S1 * Tia, T_)
+        er = self._buf("dec_eraw", N * Tia, torch.float32)
+        for b in (xa, xc, hc, al):
+            b.zero_()
+        tsh = self.tsh
+        ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
+        abg, abc = o("decoder/attention_gru/gates/bias"), o("decoder/attention_gru/candidate/bias")
+        ov = o("decoder/attention/attention_v")
+        for s in range(S):
+            sl, pv = s + 1, s
+            ops.gemm(hc, tsh["w1cT"], p1, N, 256, E, S1 * HC, E, S1 * 256, a_off=pv * HC + A, c_off=sl * 256, act=ACT_RELU,
+                     addend=f1, addend_off=sl * 256, ld_add=S1 * 256)
+            ops.gemm(p1, tsh["w2T"], xa, N, 128, 256, S1 * 256, 256, S1 * XA, a_off=sl * 256, c_off=sl * XA,
+                     bias=self.flat_p, bias_off=b2, act=ACT_RELU)
+            ops.copy3d(xa, xc, N, 1, 128, (S1 * XA, 0), (S1 * XA, 0), src_off=sl * XA, dst_off=sl * XA)
+            ops.gemm(xa, tsh["att_gT"], ru, N, 2 * A, XA, S1 * XA, XA, S1 * 2 * A, a_off=sl * XA, c_off=sl * 2 * A,
+                     bias=self.flat_p, bias_off=abg, act=ACT_SIGMOID)
+            ops.gru_pointwise(0, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + 128),
+                              hp_sn=S1 * XA, out=(xc, sl * XA + 128), out_sn=S1 * XA)
+            ops.gemm(xc, tsh["att_cT"], cc, N, A, XA, S1 * XA, XA, S1 * A, a_off=sl * XA, c_off=sl * A, bias=self.flat_p,
+                     bias_off=abc, act=ACT_TANH)
+            ops.gru_pointwise(1, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
+                              h_prev=(xa, sl * XA + 128), hp_sn=S1 * XA, out=(hc, sl * HC), out_sn=S1 * HC,
+                              out2=(xa, (sl + 1) * XA + 128) if s + 1 < S else None, out2_sn=S1 * XA)
+            ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, S1 * A, a_off=sl * HC, c_off=sl * A)
+            ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, sl * A), S1 * A,
+                               (al, pv * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, None, 0,
+                               tsh["wcl"], (self.flat_p, ov), er)
+        ops.copy3d(al, al_t, 1, N * S1, Tia, (0, Tia), (0, Tia))
+        hcA = Act(self, "hc", N, S1, 1, S, HC, buf=hc)
+        self._tape.append(self._attention_backward)
+
+        # ---- projection, residual GRUs, output projection (tacotron.py:69-76)
+        x1 = self._dense("attproj", hcA, "decoder/attention_projection", D, ACT_NONE, mask=True)
+        h1 = self._new("dec_h1", x1, D); h1.buf.zero_()
+        self._gru_seq("gru_1", x1, "decoder/gru_1", "gru_1", D, None, False, h1, 0)
+        y1 = self._add("dec_y1", x1, h1)
+        h2 = self._new("dec_h2", y1, D); h2.buf.zero_()
+        self._gru_seq("gru_2", y1, "decoder/gru_2", "gru_2", D, None, False, h2, 0)
+        y2 = self._add("dec_y2", y1, h2)
+        decA = Act(self, "dec_out", N, S1, 1, S, M * r, dtype=torch.float32)
+        op_, ob_ = o("decoder/output_projection/kernel"), o("decoder/output_projection/bias")
+        ops.gemm(y2.buf, W, decA.buf, y2.rows, M * r, D, D, M * r, M * r, b_mode=1, b_off=op_, bias=self.flat_p, bias_off=ob_)
+        dec = decA.buf
+
+        def out_proj_bwd():
+            dd = self._buf("t:ddec", y2.rows * M * r, T_)
+            ops.copy3d(decA.grad, dd, 1, y2.rows, M * r, (0, M * r), (0, M * r))     # slot-0 rows are zero
+            ops.gemm(y2.buf, dd, g, D, M * r, y2.rows, D, M * r, M * r, a_mode=1, b_mode=1, c_off=op_, accumulate=2,
+                     split_k=self._splitk(y2.rows, D, M * r))
+            ops.colsum(dd, M * r, y2.rows, M * r, g, out_off=ob_)
+            ops.gemm(dd, W, y2.grad, y2.rows, D, M * r, M * r, M * r, D, a_mode=0, b_mode=0, b_off=op_, accumulate=1)
+        self._tape.append(out_proj_bwd)
+
+        # ---- post CBHG + linear head (tacotron.py:92-98)
+        melp = Act(self, "mel_pad", N, Po, self.padl, To, M)
+        ops.copy3d(dec, melp.buf, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=self.padl * M)
+        self._tape.append(lambda: ops.copy3d(melp.grad, decA.grad, N, To, M, (Po * M, M), (S1 * M * r, M),
+                                             src_off=self.padl * M, dst_off=M * r, accumulate=1))
+        post = self._cbhg("post", melp, None, "post_cbhg", hp.post_cbhg_banks, list(hp.post_cbhg_bank_sizes) + [M], True)
+        lin = self._buf("lin_out", N * Po * Fp, torch.float32)
+        ops.gemm(post.buf, tsh["wl_pad"], lin, N * Po, Fp, 256, 256, Fp, Fp, b_mode=1, bias=tsh["bl_pad"])
+
+        self._state = dict(keys=keys, keys_t=keys_t, fr=fr, f1=f1, p1=p1, xa=xa, xc=xc, hc=hc, ru=ru, cc=cc, q=q, al=al,
+                           al_t=al_t, hcA=hcA, y2=y2, decA=decA, melp=melp, post=post, lin=lin, Tia=Tia)
+        self.mel_outputs = dec[:N * S1 * M * r].view(N, S1, M * r)[:, 1:].reshape(N, To, M)
+        self.decoder_outputs = self.mel_outputs
+        self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
+        self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:, :Ti].permute(0, 2, 1)
+        return self
+
+    # ------------------------------------------------------------------ loss + backward
+    def backward(self):
+        hp = self._hparams
+        T_ = self.T
+        d, st = self.dims, self._state
+        N, Ti, To, S, Pi, Po, Fp = d["N"], d["Ti"], d["To"], d["S"], d["Pi"], d["Po"], d["Fp"]
+        r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
+        A, D, E = hp.attention_dim, hp.decoder_dim, 256
+        S1, Tia = S + 1, st["Tia"]
+        XA, HC = 128 + A, A + E
+        g = self.flat_g
+        g.zero_()
+        self.scal.zero_()
+        for k, b in self._bufs.items():     # activation gradients accumulate: start from zero
+            if k.startswith("g:"):
+                b.zero_()
+        ops.F32_PASSES = self.passes_bwd
+        W, o, tsh = self._W(T_), self._o, self.tsh
+        sk = self._splitk
+
+        # ---- losses (tacotron.py:124-133): mel on the decoder output, linear with the 3 kHz band
+        n_prio = int(3000 / (hp.sample_rate * 0.5) * F)
+        self._n_prio = n_prio
+        decA, melp, post, lin = st["decA"], st["melp"], st["post"], st["lin"]
+        dlin = self._buf("d_lin", N * Po * Fp, T_)
+        ops.l1_loss(lin, Fp, self.linear_targets, dlin, Fp, N, To, Po, self.padl, F, n_prio, 0.5 / (N * To * F),
+                    0.5 / (N * To * n_prio), self.scal, acc_off=2)
+        # mel loss gradient lands directly in the decoder-output gradient ([N, S1*r, M] row view)
+        ops.l1_loss(decA.buf, M, self.mel_targets, decA.grad, M, N, To, S1 * r, r, M, 0, 1.0 / (N * To * M), 0.0,
+                    self.scal, acc_off=0)
+        # linear head
+        dwl = self._buf("d_wl_pad", 256 * Fp, torch.float32)
+        dwl.zero_()
+        rows_o = N * Po
+        ops.gemm(post.buf, dlin, dwl, 256, Fp, rows_o, 256, Fp, Fp, a_mode=1, b_mode=1, accumulate=2,
+                 split_k=sk(rows_o, 256, Fp))
+        ops.copy3d(dwl, g, 1, 256, F, (0, Fp), (0, F), dst_off=o("dense/kernel"), accumulate=1)
+        ops.colsum(dlin, Fp, rows_o, F, g, out_off=o("dense/bias"))
+        ops.gemm(dlin, tsh["wl_pad"], post.grad, rows_o, 256, Fp, Fp, Fp, 256, a_mode=0, b_mode=0, accumulate=1)
+        # ---- everything else: the tape, newest first
+        while self._tape:
+            self._tape.pop()()
+        self._tick("backward")
+
+    def _attention_backward(self):
+        """Backward through the attention RNN loop (prenet -> GRU -> Bahdanau), newest step first."""
+        hp = self._hparams
+        T_ = self.T
+        d, st = self.dims, self._state
+        N, Ti, S, Pi = d["N"], d["Ti"], d["S"], d["Pi"]
+        M = hp.num_mels
+        A, E = hp.attention_dim, 256
+        S1, Tia = S + 1, st["Tia"]
+        XA, HC = 128 + A, A + E
+        g, W, o, tsh, sk = self.flat_g, self._W(T_), self._o, self.tsh, self._splitk
+        enc, lengths = self._enc, self.input_lengths
+        keys, keys_t, fr, p1, xa, xc, hc, ru, cc, q, al, al_t = (st[k] for k in (
+            "keys", "keys_t", "fr", "p1", "xa", "xc", "hc", "ru", "cc", "q", "al", "al_t"))
+        dhc = st["hcA"].grad
+        rows = N * S1
+        buf = self._buf
+        dzg = buf("att_dzg", rows * 2 * A, T_); dzc = buf("att_dzc", rows * A, T_)
+        dp2 = buf("att_dp2", rows * 128, T_); df1 = buf("att_df1", rows * 256, T_)
+        dq = buf("att_dq", rows * A, T_); de = buf("att_de", rows * Tia, torch.float32)
+        dctx_t = buf("att_dctx_t", rows * E, T_)
+        for b in (dzg, dzc, dp2, df1, dq, de, dctx_t):
+            b.zero_()
+        carry_h = buf("att_carry_h", N * A, torch.float32); carry_h.zero_()
+        dctx_carry = buf("att_dctx_carry", N * E, torch.float32)
+        drh = buf("att_drh", N * A, torch.float32)
+        tmp128 = buf("att_tmp128", N * 128, torch.float32)
+        gk = buf("att_gk", N * Tia * 8, torch.float32); gk.zero_()
+        da = buf("att_da", N * Tia, torch.float32)
+        ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
+        w1, w2 = o("decoder/decoder_prenet/dense_1/kernel"), o("decoder/decoder_prenet/dense_2/kernel")
+        wq, ov = o("decoder/attention/query_layer/kernel"), o("decoder/attention/attention_v")
+        for s in range(S - 1, -1, -1):
+            sl, pv = s + 1, s
+            last = s == S - 1
+            ops.attention_step_bwd(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys, keys_t, enc.buf,
+                                   (q, sl * A), S1 * A, (al, sl * Tia), (al, pv * Tia), S1 * Tia, (dhc, sl * HC + A), S1 * HC,
+                                   None if last else dctx_carry, gk, da, 0 if last else 1, (dq, sl * A), S1 * A,
+                                   (de, sl * Tia), (dctx_t, sl * E), S1 * E, tsh["wcl"], (self.flat_p, ov))
+            # dh_total = dhc[:, :A] + carry + dq . Wq^T
+            ops.copy3d(dhc, carry_h, N, 1, A, (S1 * HC, 0), (A, 0), src_off=sl * HC, accumulate=1)
+            ops.gemm(dq, W, carry_h, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=wq, accumulate=1)
+            ops.gru_pointwise(2, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
+                              h_prev=(xa, sl * XA + 128), hp_sn=S1 * XA, out=(dzc, sl * A), out_sn=S1 * A,
+                              dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(carry_h, 0), dh_sn=A, carry=(carry_h, 0), carry_sn=A)
+            ops.gemm(dzc, W, drh, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=ac_ + 128 * A)
+            ops.gru_pointwise(3, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + 128),
+                              hp_sn=S1 * XA, dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(drh, 0), dh_sn=A,
+                              carry=(carry_h, 0), carry_sn=A)
+            ops.gemm(dzg, W, carry_h, N, A, 2 * A, S1 * 2 * A, 2 * A, A, a_off=sl * 2 * A, b_off=ag + 128 * 2 * A, accumulate=1)
+            # dp2pre = (dzg . Wg[:128]^T + dzc . Wc[:128]^T) * (p2 > 0)
+            ops.gemm(dzg, W, tmp128, N, 128, 2 * A, S1 * 2 * A, 2 * A, 128, a_off=sl * 2 * A, b_off=ag,
+                     gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
+            ops.gemm(dzc, W, tmp128, N, 128, A, S1 * A, A, 128, a_off=sl * A, b_off=ac_, accumulate=1,
+                     gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
+            ops.copy3d(tmp128, dp2, N, 1, 128, (128, 0), (S1 * 128, 0), dst_off=sl * 128)
+            ops.gemm(dp2, W, df1, N, 256, 128, S1 * 128, 128, S1 * 256, a_off=sl * 128, b_off=w2, c_off=sl * 256,
+                     gate=p1, gate_off=sl * 256, ld_gate=S1 * 256)
+            if s > 0:
+                ops.gemm(df1, W, dctx_carry, N, E, 256, S1 * 256, 256, E, a_off=sl * 256, b_off=w1 + M * 256)
+        # ---- hoisted weight gradients
+        ops.gemm(fr, df1, g, M, 256, rows, M, 256, 256, a_mode=1, b_mode=1, c_off=w1, accumulate=2, split_k=sk(rows, M, 256))
+        ops.gemm(hc, df1, g, E, 256, rows - 1, HC, 256, 256, a_mode=1, b_mode=1, a_off=A, b_off=256, c_off=w1 + M * 256,
+                 accumulate=2, split_k=sk(rows, E, 256))
+        ops.colsum(df1, 256, rows, 256, g, out_off=o("decoder/decoder_prenet/dense_1/bias"))
+        ops.gemm(p1, dp2, g, 256, 128, rows, 256, 128, 128, a_mode=1, b_mode=1, c_off=w2, accumulate=2, split_k=sk(rows, 256, 128))
+        ops.colsum(dp2, 128, rows, 128, g, out_off=o("decoder/decoder_prenet/dense_2/bias"))
+        ops.gemm(xa, dzg, g, XA, 2 * A, rows, XA, 2 * A, 2 * A, a_mode=1, b_mode=1, c_off=ag, accumulate=2, split_k=sk(rows, XA, 2 * A))
+        ops.colsum(dzg, 2 * A, rows, 2 * A, g, out_off=o("decoder/attention_gru/gates/bias"))
+        ops.gemm(xc, dzc, g, XA, A, rows, XA, A, A, a_mode=1, b_mode=1, c_off=ac_, accumulate=2, split_k=sk(rows, XA, A))
+        ops.colsum(dzc, A, rows, A, g, out_off=o("decoder/attention_gru/candidate/bias"))
+        ops.gemm(hc, dq, g, A, A, rows, HC, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2, split_k=sk(rows, A, A))
+        # attention: sums over all steps
+        dkeys_t = buf("att_dkeys_t", N * A * Tia, torch.float32)
+        dwcl = buf("att_dwcl", 8 * A, torch.float32); dwcl.zero_()
+        ops.attention_post_bwd(N, S, Ti, Tia, A, self.KW, lengths, keys_t, q, al, de, tsh["wcl"], (self.flat_p, ov), dkeys_t,
+                               (g, ov), dwcl)
+        dkeys = buf("att_dkeys", N * Pi * A, torch.float32); dkeys.zero_()
+        ops.keys_transpose_add(dkeys, dkeys_t, N, Ti, Tia, Pi, self.padl, A)
+        dkeys_T = buf("att_dkeys_T", N * Pi * A, T_)
+        ops.copy3d(dkeys, dkeys_T, 1, N * Pi, A, (0, A), (0, A))
+        om = o("attention_decoder/memory_layer/kernel")
+        ops.gemm(enc.buf, dkeys_T, g, E, A, N * Pi, E, A, A, a_mode=1, b_mode=1, c_off=om, accumulate=2, split_k=sk(N * Pi, E, A))
+        ops.gemm(dkeys_T, W, enc.grad, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
+        for n in range(N):     # dvalues[n] += align[n]^T . dctx[n]
+            ops.gemm(al_t, dctx_t, enc.grad, Ti, E, S1, Tia, E, E, a_mode=1, b_mode=1, a_off=n * S1 * Tia,
+                     b_off=n * S1 * E, c_off=(n * Pi + self.padl) * E, accumulate=1)
+

@@ -33,6 +33,9 @@ def _round_up(x, m):
 
 
 class Tacotron2(object):
+    padl, padr = PADL, PADR
+    LAYOUT = staticmethod(P_.taco2_layout)
+
     def __init__(self, hparams, device="cuda:0", dtype="bf16", seed=0, world_size=1):
         self._hparams = hparams
         self.device = torch.device(device)
@@ -49,7 +52,7 @@ class Tacotron2(object):
         self.passes_fwd = {"bf16": 0, "fp32": 0, "bf16x3": 3, "mixed": 3}[dtype]
         self.passes_bwd = {"bf16": 0, "fp32": 0, "bf16x3": 3, "mixed": 1}[dtype]
         self.vocab = len(symbols)
-        self.layout, self.stat_layout = P_.taco2_layout(hparams, self.vocab)
+        self.layout, self.stat_layout = self.LAYOUT(hparams, self.vocab)
         n = self.layout.size
         dev = self.device
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -254,7 +257,7 @@ class Tacotron2(object):
         """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198)."""
         kl = (k - 1) // 2
         rows = N * Pp
-        a_rows = PADL - kl
+        a_rows = self.padl - kl
         Mg = rows - (k - 1) - a_rows
         D = D or self.T
         z = self._buf(tag + "_z", rows * cout, D)
@@ -262,12 +265,12 @@ class Tacotron2(object):
         st = self._buf(tag + "_st", 4 * cout, torch.float32)
         st[:2 * cout].zero_()
         ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
-                 a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=PADL * cout,
+                 a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=self.padl * cout,
                  bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
-                 row_mask=(Pp, PADL, PADL + T, PADL),
+                 row_mask=(Pp, self.padl, self.padl + T, self.padl),
                  col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
         ops.bn_fwd(z, y, rows, cout, st, st[cout:], N * T, self.flat_p, self.flat_p, self.flat_stats,
-                   self.flat_stats, st[2 * cout:], st[3 * cout:], training, row_mask=(Pp, PADL, PADL + T),
+                   self.flat_stats, st[2 * cout:], st[3 * cout:], training, row_mask=(Pp, self.padl, self.padl + T),
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    beta_off=self._o(scope + "/batch_normalization/beta"),
                    mm_off=self.stat_layout.off(scope + "/batch_normalization/moving_mean"),
@@ -287,24 +290,24 @@ class Tacotron2(object):
         work = self._buf("bn_work", 2 * 2048, torch.float32)
         g = self.flat_g
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
-                   row_mask=(Pp, PADL, PADL + T),
+                   row_mask=(Pp, self.padl, self.padl + T),
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dgamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dbeta_off=self._o(scope + "/batch_normalization/beta"),
                    dbias_off=self._o(scope + "/conv1d/bias"))
         # weight gradient: dW[(k,ci),co] += sum_rows X[row+k, ci] * dpre[row, co]
-        a_rows = PADL - kl
+        a_rows = self.padl - kl
         Mg = rows - (k - 1) - a_rows
         ops.gemm(xin, dpre, g, k * cin, cout, Mg, cin, cout, cout, a_mode=1, b_mode=1,
-                 a_off=a_rows * cin, b_off=PADL * cout, c_off=self._o(scope + "/conv1d/kernel"),
+                 a_off=a_rows * cin, b_off=self.padl * cout, c_off=self._o(scope + "/conv1d/kernel"),
                  accumulate=2, split_k=self._splitk(Mg, k * cin, cout))
         if need_dx:
-            a2 = PADL - kr
+            a2 = self.padl - kr
             Mg2 = rows - (k - 1) - a2
             ops.gemm(dpre, self._W(D), dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
                      a_off=a2 * cout, b_off=self._o(scope + "/conv1d/kernel") + (k - 1) * cin * cout,
-                     b_seg=(cout, -cin * cout), c_off=PADL * cin, accumulate=1 if dx_accumulate else 0,
-                     row_mask=(Pp, PADL, PADL + T, PADL))
+                     b_seg=(cout, -cin * cout), c_off=self.padl * cin, accumulate=1 if dx_accumulate else 0,
+                     row_mask=(Pp, self.padl, self.padl + T, self.padl))
 
     @staticmethod
     def _splitk(K, M, N):
@@ -325,7 +328,7 @@ class Tacotron2(object):
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
             gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
             wk = "%s_%s_whT" % (key, d)
-            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, xg, 4 * H, self.tsh[wk], None,
+            pair.append(ops.lstm_seq_params(N, T, H, Pp, self.padl, xg, 4 * H, self.tsh[wk], None,
                                             lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H,
                                             whT_hi=self.tsh.get(wk + "_hi") if D == torch.float32 else None,
                                             whT_lo=self.tsh.get(wk + "_lo") if D == torch.float32 else None))
@@ -364,7 +367,7 @@ class Tacotron2(object):
             gt = self._bufs["%s_g_%s" % (tag, d)]
             dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, D)
             work = self._buf("lstm_work_%s" % d, N * H + 64, torch.float32)
-            pair.append(ops.lstm_seq_params(N, T, H, Pp, PADL, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
+            pair.append(ops.lstm_seq_params(N, T, H, Pp, self.padl, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
                                             self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
                                             ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
                                             h_off=di * H, dh_off=di * H,
@@ -403,7 +406,7 @@ class Tacotron2(object):
         M, F = hp.num_mels, hp.num_freq
         Fp = _round_up(F, 16)
         E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
-        Pi, Po = Ti + PADL + PADR, To + PADL + PADR
+        Pi, Po = Ti + self.padl + self.padr, To + self.padl + self.padr
         S1 = S + 1
         self.dims = dict(N=N, Ti=Ti, To=To, S=S, Pi=Pi, Po=Po, Fp=Fp)
         sig = ("train", N, Ti, To)
@@ -417,7 +420,7 @@ class Tacotron2(object):
         # ---- encoder (tacotron2.py:37-60)
         emb = hp.embedding_dim
         x = self._buf("enc_x0", N * Pi * emb, T_)
-        ops.embedding_fwd(self.inputs, self.flat_p, x, N, Ti, Pi, PADL, emb, self.vocab,
+        ops.embedding_fwd(self.inputs, self.flat_p, x, N, Ti, Pi, self.padl, emb, self.vocab,
                           table_off=self._o("embedding/embedding"))
         cin = emb
         self._enc_in = [x]
@@ -453,7 +456,7 @@ class Tacotron2(object):
         q = self._buf("dec_q", N * S1 * A, torch.float32)
         al = self._buf("dec_al", N * S1 * Tia, torch.float32)
         self._attn_args = dict(
-            dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=PADL, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
+            dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=self.padl, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
             lengths=self.input_lengths, keys=keys, values=enc, f1=f1,
             w1cT=self.tsh["w1cT"], w2T=self.tsh["w2T"], wattT=self.tsh["wattT"], wqT=self.tsh["wqT"],
             b2=(self.flat_p, self._o("decoder/decoder_prenet/dense_2/bias")),
@@ -495,8 +498,8 @@ class Tacotron2(object):
         # ---- postnet + residual (tacotron2.py:89-95)
         decp = self._buf("decp", N * Po * M, torch.float32)
         pin = self._buf("post_in", N * Po * M, T_)
-        ops.copy3d(dec, decp, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=PADL * M)
-        ops.copy3d(dec, pin, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=PADL * M)
+        ops.copy3d(dec, decp, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=self.padl * M)
+        ops.copy3d(dec, pin, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=self.padl * M)
         x = pin
         cin = M
         self._post_in = [x]
@@ -510,7 +513,7 @@ class Tacotron2(object):
         mel = self._buf("mel_out", N * Po * M, torch.float32)
         ops.gemm(x, self._W(self.T), mel, N * Po, M, Cp, Cp, M, M, b_mode=1,
                  b_off=self._o("decoder_postnet/dense/kernel"), bias=self.flat_p,
-                 bias_off=self._o("decoder_postnet/dense/bias"), row_mask=(Po, PADL, PADL + To, 0))
+                 bias_off=self._o("decoder_postnet/dense/bias"), row_mask=(Po, self.padl, self.padl + To, 0))
         ops.copy3d(decp, mel, N, Po, M, (Po * M, M), (Po * M, M), accumulate=1)
         self._tick("postnet")
 
@@ -535,8 +538,8 @@ class Tacotron2(object):
         ops.gemm(ex, self.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=self.tsh["bl_pad"])
         self._tick("linear")
 
-        self.mel_outputs = mel[:N * Po * M].view(N, Po, M)[:, PADL:PADL + To]
-        self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, PADL:PADL + To, :F]
+        self.mel_outputs = mel[:N * Po * M].view(N, Po, M)[:, self.padl:self.padl + To]
+        self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
         self.decoder_outputs = dec[:rows * M * r].view(N, S1, M * r)[:, 1:].reshape(N, To, M)
         self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:, :Ti].permute(0, 2, 1)
         return self
@@ -561,9 +564,9 @@ class Tacotron2(object):
         n_prio = int(2000 / (hp.sample_rate * 0.5) * F)
         dmel = self._buf("d_mel", N * Po * M, torch.float32)
         dlin = self._buf("d_lin", N * Po * Fp, Tx)
-        ops.l1_loss(B["mel_out"], M, self.mel_targets, dmel, M, N, To, Po, PADL, M, 0, 1.0 / (N * To * M), 0.0,
+        ops.l1_loss(B["mel_out"], M, self.mel_targets, dmel, M, N, To, Po, self.padl, M, 0, 1.0 / (N * To * M), 0.0,
                     self.scal, acc_off=0)
-        ops.l1_loss(B["lin_out"], Fp, self.linear_targets, dlin, Fp, N, To, Po, PADL, F, n_prio,
+        ops.l1_loss(B["lin_out"], Fp, self.linear_targets, dlin, Fp, N, To, Po, self.padl, F, n_prio,
                     0.5 / (N * To * F), 0.5 / (N * To * n_prio), self.scal, acc_off=2)
         self._n_prio = n_prio
         self._tick("loss")
@@ -623,7 +626,7 @@ class Tacotron2(object):
         # ---- decoder output projection (grad wrt decoder_outputs sits in dmel, padded layout)
         rows = N * S1
         ddec = self._buf("d_dec", rows * M * r, T_)      # slot 0 rows stay zero
-        ops.copy3d(dmel, ddec, N, To, M, (Po * M, M), (S1 * M * r, M), src_off=PADL * M, dst_off=M * r)
+        ops.copy3d(dmel, ddec, N, To, M, (Po * M, M), (S1 * M * r, M), src_off=self.padl * M, dst_off=M * r)
         h2, h1, hc = B["dec_h2"], B["dec_h1"], B["dec_hc"]
         kp = self._o("decoder/output_projection/kernel")
         ops.gemm(h2, ddec, g, D, M * r, rows, D, M * r, M * r, a_mode=1, b_mode=1, c_off=kp, accumulate=2,
@@ -721,7 +724,7 @@ class Tacotron2(object):
             self._conv_bwd("encoder/conv_%d" % i, self._enc_in[i], cur, cin, Ce, hp.encoder_conv_width, act, N, Ti, Pi,
                            "enc%d" % i, nxt)
             cur, nxt = nxt, cur
-        ops.embedding_bwd(self.inputs, cur, g, N, Ti, Pi, PADL, hp.embedding_dim, self.vocab,
+        ops.embedding_bwd(self.inputs, cur, g, N, Ti, Pi, self.padl, hp.embedding_dim, self.vocab,
                           dtable_off=self._o("embedding/embedding"))
         self._tick("encoder_bwd")
 

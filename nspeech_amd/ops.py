@@ -37,7 +37,8 @@ def ptr(t, off=0):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0, c_off=0,
          bias=None, bias_off=0, act=0, alpha=1.0, accumulate=0, row_mask=None, col_sum=None,
-         col_sumsq=None, split_k=1, b_seg=None, addend=None, addend_off=0, ld_add=0, f32_passes=None):
+         col_sumsq=None, split_k=1, b_seg=None, addend=None, addend_off=0, ld_add=0, f32_passes=None,
+         gate=None, gate_off=0, ld_gate=0):
     """C = act(alpha * A.B + bias); see ns_gemm in include/nspeech_hip.h."""
     assert A.dtype == B.dtype
     p = L.GemmParams()
@@ -59,6 +60,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     p.split_k = split_k
     if addend is not None:
         p.addend, p.ld_add = ptr(addend, addend_off), ld_add
+    if gate is not None:
+        p.gate, p.ld_gate = ptr(gate, gate_off), ld_gate
     p.f32_passes = F32_PASSES if f32_passes is None else f32_passes
     L.call("ns_gemm", p, stream())
 
@@ -206,3 +209,77 @@ def split_hi_lo(src, hi, lo, n):
     p = L.struct("ns_split_params")
     _fill(p, src=ptr(src), hi=ptr(hi), lo=ptr(lo), n=n)
     L.call("ns_split_hi_lo", p, stream())
+
+
+def act_bwd(dy, y, dpre, rows, Cc, act, row_mask=None):
+    p = L.struct("ns_act_bwd_params")
+    _fill(p, dy=ptr(dy), y=ptr(y), dpre=ptr(dpre), dtype=dt(y), rows=rows, C=Cc, act=act)
+    if row_mask is not None:
+        p.row_period, p.row_lo, p.row_hi = row_mask
+    L.call("ns_act_bwd", p, stream())
+
+
+def highway(h, t, x, n, y=None, dy=None, dhpre=None, dtpre=None, dx=None):
+    p = L.struct("ns_highway_params")
+    _fill(p, backward=int(dy is not None), dtype=dt(h), n=n, h=ptr(h), t=ptr(t), x=ptr(x), y=ptr(y), dy=ptr(dy),
+          dhpre=ptr(dhpre), dtpre=ptr(dtpre), dx=ptr(dx))
+    L.call("ns_highway", p, stream())
+
+
+def gru_pointwise(mode, like, N, H, t, lengths, ru=None, ru_sn=0, c=None, c_sn=0, h_prev=None, hp_sn=0, out=None,
+                  out_sn=0, out2=None, out2_sn=0, dzg=None, dzg_sn=0, dh=None, dh_sn=0, carry=None, carry_sn=0):
+    """Pointers are (tensor, element offset) pairs or None."""
+    def P(x):
+        return None if x is None else ptr(x[0], x[1])
+    p = L.struct("ns_gru_pointwise_params")
+    _fill(p, mode=mode, dtype=dt(like), N=N, H=H, t=t, lengths=ptr(lengths), ru=P(ru), ru_sn=ru_sn, c=P(c), c_sn=c_sn,
+          h_prev=P(h_prev), hp_sn=hp_sn, out=P(out), out_sn=out_sn, out2=P(out2), out2_sn=out2_sn, dzg=P(dzg),
+          dzg_sn=dzg_sn, dh=P(dh), dh_sn=dh_sn, carry=P(carry), carry_sn=carry_sn)
+    L.call("ns_gru_pointwise", p, stream())
+
+
+def _pp(x):
+    """(tensor, offset) pair, tensor or None -> device address."""
+    if x is None:
+        return None
+    if isinstance(x, tuple):
+        return ptr(x[0], x[1])
+    return ptr(x)
+
+
+def keys_transpose(keys, keys_t, N, Ti, Tia, Pi, padl, A):
+    L.check(L.lib().ns_taco2_keys_transpose(C.c_void_p(ptr(keys)), C.c_void_p(ptr(keys_t)), N, Ti, Tia, Pi, padl, A,
+                                            C.c_void_p(stream())), "ns_taco2_keys_transpose")
+
+
+def keys_transpose_add(keys, keys_t, N, Ti, Tia, Pi, padl, A):
+    L.check(L.lib().ns_taco2_keys_transpose_add(C.c_void_p(ptr(keys)), C.c_void_p(ptr(keys_t)), N, Ti, Tia, Pi, padl, A,
+                                                C.c_void_p(stream())), "ns_taco2_keys_transpose_add")
+
+
+def attention_step(like, N, Ti, Pi, padl, Tia, A, E, kw, lengths, keys_t, values, q, q_sn, aprev, aout, al_sn, ctx_out,
+                   ctx_sn, ctx_out2, ctx2_sn, wcl, v, e_raw):
+    p = L.struct("ns_attention_step_params")
+    _fill(p, dtype=dt(like), N=N, Ti=Ti, Pi=Pi, padl_i=padl, Tia=Tia, A=A, E=E, kw=kw, lengths=ptr(lengths),
+          keys_t=ptr(keys_t), values=ptr(values), q=_pp(q), q_sn=q_sn, aprev=_pp(aprev), aout=_pp(aout), al_sn=al_sn,
+          ctx_out=_pp(ctx_out), ctx_sn=ctx_sn, ctx_out2=_pp(ctx_out2), ctx2_sn=ctx2_sn, wcl=_pp(wcl), v=_pp(v),
+          e_raw=ptr(e_raw))
+    L.call("ns_attention_step", p, stream())
+
+
+def attention_step_bwd(like, N, Ti, Pi, padl, Tia, A, E, kw, lengths, keys, keys_t, values, q, q_sn, acur, aprev, al_sn,
+                       dctx_ext, dce_sn, dctx_carry, gk, da, has_carry, dq_out, dq_sn, de_out, dctx_out, dco_sn, wcl, v):
+    p = L.struct("ns_attention_step_bwd_params")
+    _fill(p, dtype=dt(like), N=N, Ti=Ti, Pi=Pi, padl_i=padl, Tia=Tia, A=A, E=E, kw=kw, lengths=ptr(lengths),
+          keys=ptr(keys), keys_t=ptr(keys_t), values=ptr(values), q=_pp(q), q_sn=q_sn, acur=_pp(acur), aprev=_pp(aprev),
+          al_sn=al_sn, dctx_ext=_pp(dctx_ext), dce_sn=dce_sn, dctx_carry=_pp(dctx_carry), gk=ptr(gk), da=ptr(da),
+          has_carry=has_carry, dq_out=_pp(dq_out), dq_sn=dq_sn, de_out=_pp(de_out), dctx_out=_pp(dctx_out), dco_sn=dco_sn,
+          wcl=_pp(wcl), v=_pp(v))
+    L.call("ns_attention_step_bwd", p, stream())
+
+
+def attention_post_bwd(N, S, Ti, Tia, A, kw, lengths, keys_t, q, align, de, wcl, v, dkeys_t, dv, dwcl):
+    p = L.struct("ns_attention_post_bwd_params")
+    _fill(p, N=N, S=S, Ti=Ti, Tia=Tia, A=A, kw=kw, lengths=ptr(lengths), keys_t=ptr(keys_t), q=ptr(q), align=ptr(align),
+          de=ptr(de), wcl=_pp(wcl), v=_pp(v), dkeys_t=ptr(dkeys_t), dv=_pp(dv), dwcl=ptr(dwcl))
+    L.call("ns_attention_post_bwd", p, stream())

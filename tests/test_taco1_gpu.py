@@ -1,0 +1,98 @@
+"""Tacotron-1 (CBHG encoder / Bahdanau attention with a GRU cell / residual GRU decoder / post
+CBHG) on the GPU against the float64 oracle: outputs, losses, every gradient, Noam schedule."""
+import numpy as np
+import pytest
+import torch
+
+from nspeech_amd import hparams as hparams_mod
+from util import make_batch
+
+pytestmark = pytest.mark.gpu
+
+
+def _hp():
+    hp = hparams_mod.load("taco1")
+    for k, v in dict(num_mels=16, num_freq=65, embedding_dim=32, encoder_prenet=[32, 128], encoder_cbhg_banks=4,
+                     attention_dim=64, decoder_dim=64, post_cbhg_banks=3, post_cbhg_bank_sizes=[64], max_iters=50,
+                     batch_size=2).items():
+        setattr(hp, k, v)
+    return hp
+
+
+def _oracle(hp, params, stats, inputs, lengths, mel, lin):
+    from oracle import taco1_oracle as O
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in stats.items()})
+    hpd = hp.values()
+    out = O.taco1_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel, dtype=torch.float64),
+                          torch.tensor(lin, dtype=torch.float64))
+    loss, ml, ll = O.taco1_loss(hpd, out, torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+    loss.backward()
+    grads = {k: (p[k].grad.numpy() if p[k].grad is not None else np.zeros_like(params[k])) for k in params}
+    return out, (float(loss.detach()), float(ml.detach()), float(ll.detach())), grads
+
+
+def _stabilise(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3):
+    from oracle import taco1_oracle as O
+    mel, lin = mel.copy(), lin.copy()
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in list(params.items()) + list(stats.items())}
+    for _ in range(4):
+        with torch.no_grad():
+            out = O.taco1_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
+                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+        bm = np.abs(out["mel_outputs"].numpy() - mel) < margin
+        bl = np.abs(out["linear_outputs"].numpy() - lin) < margin
+        if not bm.any() and not bl.any():
+            break
+        mel[bm] -= 10 * margin
+        lin[bl] -= 10 * margin
+    return mel.astype(np.float32), lin.astype(np.float32)
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 15), (3, 14, 25)])
+def test_taco1_fp32_matches_oracle(dev, shape):
+    from nspeech_amd.models import create_model
+    N, Ti, To = shape
+    hp = _hp()
+    m = create_model("taco1", hp, device="cuda:0", dtype="fp32", seed=4)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N)
+    params, stats = m.numpy_params(), m.numpy_stats()
+    mel, lin = _stabilise(hp, params, stats, inputs, lengths, mel, lin)
+    out, (loss, ml, ll), grads = _oracle(hp, params, stats, inputs, lengths, mel, lin)
+    m.initialize(inputs, lengths, None, mel, lin)
+    m.backward()
+    m.read_losses()
+
+    def rel(a, b):
+        return np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-12)
+    assert rel(m.alignments.cpu().numpy(), out["alignments"].detach().numpy()) < 2e-4
+    assert rel(m.mel_outputs.cpu().numpy(), out["mel_outputs"].detach().numpy()) < 5e-4
+    assert rel(m.linear_outputs.cpu().numpy(), out["linear_outputs"].detach().numpy()) < 5e-4
+    assert abs(m.loss - loss) < 1e-5 * max(1.0, abs(loss))
+    assert abs(m.mel_loss - ml) < 1e-5 and abs(m.linear_loss - ll) < 1e-5
+    got = m.numpy_grads()
+    bad = []
+    for k in grads:
+        scale = np.abs(grads[k]).max()
+        err = np.abs(got[k] - grads[k]).max()
+        if err > 2e-3 * scale + 2e-6:
+            bad.append((k, float(err), float(scale)))
+    assert not bad, bad[:8]
+    st = m.numpy_stats()
+    for k, v in out["bn_updates"].items():
+        assert np.abs(st[k] - v.numpy()).max() < 1e-4, k
+
+
+def test_taco1_train_steps_bf16_and_noam_schedule(dev):
+    """BASELINE configs[0]: taco1, batch_size=2, outputs_per_step=5 - a few optimiser steps run and the
+    loss is finite; learning rate follows the Noam schedule (tacotron.py:186-190)."""
+    from nspeech_amd.models import create_model
+    from oracle import taco1_oracle as O
+    hp = _hp()
+    m = create_model("taco1", hp, device="cuda:0", dtype="bf16", seed=1)
+    inputs, lengths, mel, lin = make_batch(hp, 2, 10, 20, seed=3)
+    m.add_optimizer(0)
+    losses = [m.step(inputs, lengths, mel, lin) for _ in range(3)]
+    assert all(np.isfinite(l) for l in losses) and m.global_step == 3
+    assert abs(m.learning_rate - O.learning_rate(hp.values(), 2)) < 1e-12
+    assert abs(O.learning_rate(hp.values(), 3999) - hp.initial_learning_rate) < 1e-9
