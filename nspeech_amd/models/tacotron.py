@@ -280,9 +280,130 @@ class Tacotron(Tacotron2):
         return out
 
     def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
-        if linear_targets is None:
-            raise NotImplementedError("Tacotron-1 free-running synthesis is not built yet (training path only)")
-        return Tacotron2.initialize(self, text_inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
+        if linear_targets is not None:
+            return Tacotron2.initialize(self, text_inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
+        dev = self.device
+        self.inputs = torch.as_tensor(np.asarray(text_inputs)).to(dev, torch.int32).contiguous()
+        self.input_lengths = torch.as_tensor(np.asarray(input_lengths)).to(dev, torch.int32).contiguous()
+        self.is_training = False
+        self.mel_targets = self.linear_targets = None
+        return self.forward_infer()
+
+    # ------------------------------------------------------------------ free-running synthesis
+    def _gru_step_infer(self, x, x_off, x_sn, K, gT, cT, bg, bc, xc, H, hprev_off, out, out_off, out_sn, out2, out2_off,
+                        out2_sn, ru, cc, N):
+        """One GRUCell step on an explicit [input | h_prev] row (x) with whole-kernel transposes."""
+        xin = K - H
+        ops.gemm(x, gT, ru, N, 2 * H, K, x_sn, K, 2 * H, a_off=x_off, bias=self.flat_p, bias_off=bg, act=ACT_SIGMOID)
+        ops.copy3d(x, xc, N, 1, xin, (x_sn, 0), (K, 0), src_off=x_off)
+        ops.gru_pointwise(0, x, N, H, 0, None, ru=(ru, 0), ru_sn=2 * H, h_prev=(x, x_off + xin), hp_sn=x_sn,
+                          out=(xc, xin), out_sn=K)
+        ops.gemm(xc, cT, cc, N, H, K, K, K, H, bias=self.flat_p, bias_off=bc, act=ACT_TANH)
+        ops.gru_pointwise(1, x, N, H, 0, None, ru=(ru, 0), ru_sn=2 * H, c=(cc, 0), c_sn=H, h_prev=(x, x_off + xin),
+                          hp_sn=x_sn, out=(out, out_off), out_sn=out_sn, out2=(out2, out2_off) if out2 is not None else None,
+                          out2_sn=out2_sn)
+
+    def forward_infer(self):
+        """tacotron.py with linear_targets=None: TacoTestHelper feedback for max_iters steps (Q7),
+        BatchNorm on moving statistics; sets mel_outputs, linear_outputs, alignments and audio."""
+        hp = self._hparams
+        T_ = self.T
+        N, Ti = self.inputs.shape
+        r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
+        S = int(hp.max_iters)
+        To = S * r
+        Fp = _round_up(F, 16)
+        A, D, E = hp.attention_dim, hp.decoder_dim, 256
+        Pi, Po, S1 = Ti + self.padl + self.padr, To + self.padl + self.padr, S + 2
+        sig = ("infer1", N, Ti, S)
+        if sig != self._sig:
+            self._bufs.clear()
+            self._sig = sig
+        self._tape = []
+        ops.F32_PASSES = self.passes_fwd
+        W, o, tsh, buf = self._W(T_), self._o, self.tsh, self._buf
+        # whole-kernel transposes for the [input | h] steps of the two decoder GRUs
+        for key, scope in (("gru_1", "decoder/gru_1"), ("gru_2", "decoder/gru_2")):
+            for suf, nm, cols in (("_gTf", "/gates/kernel", 2 * D), ("_cTf", "/candidate/kernel", D)):
+                if key + suf not in tsh:
+                    tsh[key + suf] = torch.zeros(cols * 2 * D, dtype=T_, device=self.device)
+                ops.cast2d(self.flat_p, 2 * D, cols, cols, tsh[key + suf], 2 * D, True, src_off=o(scope + nm))
+        for key, nm, rows, cols in (("w1T_full", "decoder/decoder_prenet/dense_1/kernel", M + E, 256),
+                                    ("wprojT", "decoder/attention_projection/kernel", A + E, D),
+                                    ("woutT", "decoder/output_projection/kernel", D, M * r)):
+            if key not in tsh:
+                tsh[key] = torch.zeros(rows * cols, dtype=T_, device=self.device)
+            ops.cast2d(self.flat_p, rows, cols, cols, tsh[key], rows, True, src_off=o(nm))
+        lengths = self.input_lengths
+        emb = Act(self, "emb", N, Pi, self.padl, Ti, hp.embedding_dim)
+        ops.embedding_fwd(self.inputs, self.flat_p, emb.buf, N, Ti, Pi, self.padl, hp.embedding_dim, self.vocab,
+                          table_off=o("embedding/embedding"))
+        pn = list(hp.encoder_prenet)
+        x = self._dense("pre1", emb, "prenet/dense_1", pn[0], ACT_RELU)
+        x = self._dense("pre2", x, "prenet/dense_2", pn[1], ACT_RELU)
+        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), False)
+        keys = buf("keys", N * Pi * A, torch.float32)
+        ops.gemm(enc.buf, W, keys, N * Pi, A, E, E, A, A, b_mode=1, b_off=o("attention_decoder/memory_layer/kernel"))
+        Tia = _round_up(Ti, 8)
+        keys_t = buf("keys_t", N * A * Tia, torch.float32)
+        ops.keys_transpose(keys, keys_t, N, Ti, Tia, Pi, self.padl, A)
+        XP, XA, HC, X1 = M + E, 128 + A, A + E, 2 * D
+        xp = buf("i_xp", N * S1 * XP, T_); p1 = buf("i_p1", N * 256, T_)
+        xa = buf("i_xa", N * S1 * XA, T_); xc = buf("i_xc", N * max(XA, X1), T_)
+        hc = buf("i_hc", N * S1 * HC, T_)
+        g1 = buf("i_g1", N * S1 * X1, T_); g2 = buf("i_g2", N * S1 * X1, T_)     # [input | h_prev] rows of the GRUs
+        y1 = buf("i_y1", N * D, T_); y2 = buf("i_y2", N * D, T_); hh = buf("i_hh", N * D, T_)
+        ru = buf("i_ru", N * 2 * max(A, D), torch.float32); cc = buf("i_cc", N * max(A, D), torch.float32)
+        q = buf("i_q", N * A, torch.float32); al = buf("i_al", N * S1 * Tia, torch.float32)
+        er = buf("i_er", N * Tia, torch.float32); dec = buf("i_dec", N * S1 * M * r, torch.float32)
+        for b in (xp, xa, hc, g1, g2, al):
+            b.zero_()
+        ov = o("decoder/attention/attention_v")
+        for s in range(S):
+            sl, nx = s + 1, s + 2
+            ops.gemm(xp, tsh["w1T_full"], p1, N, 256, XP, S1 * XP, XP, 256, a_off=sl * XP, bias=self.flat_p,
+                     bias_off=o("decoder/decoder_prenet/dense_1/bias"), act=ACT_RELU)
+            ops.gemm(p1, tsh["w2T"], xa, N, 128, 256, 256, 256, S1 * XA, c_off=sl * XA, bias=self.flat_p,
+                     bias_off=o("decoder/decoder_prenet/dense_2/bias"), act=ACT_RELU)
+            self._gru_step_infer(xa, sl * XA, S1 * XA, XA, tsh["att_gT"], tsh["att_cT"], o("decoder/attention_gru/gates/bias"),
+                                 o("decoder/attention_gru/candidate/bias"), xc, A, 0, hc, sl * HC, S1 * HC, xa,
+                                 nx * XA + 128, S1 * XA, ru, cc, N)
+            ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, A, a_off=sl * HC)
+            ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, 0), A,
+                               (al, s * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, (xp, nx * XP + M),
+                               S1 * XP, tsh["wcl"], (self.flat_p, ov), er)
+            # x1 = Dense([h_att | ctx]) -> residual GRU 1 -> residual GRU 2 -> r frames
+            ops.gemm(hc, tsh["wprojT"], g1, N, D, HC, S1 * HC, HC, S1 * X1, a_off=sl * HC, c_off=sl * X1, bias=self.flat_p,
+                     bias_off=o("decoder/attention_projection/bias"))
+            self._gru_step_infer(g1, sl * X1, S1 * X1, X1, tsh["gru_1_gTf"], tsh["gru_1_cTf"], o("decoder/gru_1/gates/bias"),
+                                 o("decoder/gru_1/candidate/bias"), xc, D, 0, hh, 0, D, g1, nx * X1 + D, S1 * X1, ru, cc, N)
+            ops.copy3d(g1, y1, N, 1, D, (S1 * X1, 0), (D, 0), src_off=sl * X1)
+            ops.copy3d(hh, y1, N, 1, D, (D, 0), (D, 0), accumulate=1)
+            ops.copy3d(y1, g2, N, 1, D, (D, 0), (S1 * X1, 0), dst_off=sl * X1)
+            self._gru_step_infer(g2, sl * X1, S1 * X1, X1, tsh["gru_2_gTf"], tsh["gru_2_cTf"], o("decoder/gru_2/gates/bias"),
+                                 o("decoder/gru_2/candidate/bias"), xc, D, 0, hh, 0, D, g2, nx * X1 + D, S1 * X1, ru, cc, N)
+            ops.copy3d(y1, y2, N, 1, D, (D, 0), (D, 0))
+            ops.copy3d(hh, y2, N, 1, D, (D, 0), (D, 0), accumulate=1)
+            ops.gemm(y2, tsh["woutT"], dec, N, M * r, D, D, D, S1 * M * r, c_off=sl * M * r, bias=self.flat_p,
+                     bias_off=o("decoder/output_projection/bias"))
+            ops.copy3d(dec, xp, N, 1, M, (S1 * M * r, 0), (S1 * XP, 0), src_off=sl * M * r + (r - 1) * M, dst_off=nx * XP)
+        melp = Act(self, "mel_pad", N, Po, self.padl, To, M)
+        ops.copy3d(dec, melp.buf, N, To, M, (S1 * M * r, M), (Po * M, M), src_off=M * r, dst_off=self.padl * M)
+        post = self._cbhg("post", melp, None, "post_cbhg", hp.post_cbhg_banks, list(hp.post_cbhg_bank_sizes) + [M], False)
+        lin = buf("lin_out", N * Po * Fp, torch.float32)
+        ops.gemm(post.buf, tsh["wl_pad"], lin, N * Po, Fp, 256, 256, Fp, Fp, b_mode=1, bias=tsh["bl_pad"])
+        self._tape = []
+        self.dims = dict(N=N, Ti=Ti, To=To, S=S, Pi=Pi, Po=Po, Fp=Fp)
+        self.mel_outputs = dec[:N * S1 * M * r].view(N, S1, M * r)[:, 1:S + 1].reshape(N, To, M)
+        self.decoder_outputs = self.mel_outputs
+        self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
+        self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:S + 1, :Ti].permute(0, 2, 1)
+        if F == 1025 and M == 80:       # tacotron.py:107: self.audio = Griffin-Lim of the whole batch
+            from ..utils import audio
+            from .. import hparams as hparams_mod
+            if hparams_mod.get_hparams() is not None:
+                self.audio = audio.griffin_lim_gpu(self.linear_outputs.contiguous())
+        return self
 
     # ------------------------------------------------------------------ forward (training)
     def forward_train(self):

@@ -50,3 +50,25 @@ def test_train_checkpoint_resume_eval(tmp_path):
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert os.path.exists(os.path.join(run, "eval-2-0.wav"))
+
+
+def test_taco1_config1_plumbing(tmp_path):
+    """BASELINE configs[0]: --model taco1, 4 utterances, batch_size=2, outputs_per_step=5 (run on the GPU
+    here: the product path has no CPU fallback): 3 steps, a checkpoint, one eval synthesis."""
+    data = str(tmp_path / "lj")
+    os.makedirs(data)
+    _corpus(data)
+    logs = str(tmp_path / "logs")
+    small = ("embedding_dim=32,encoder_prenet=[32,128],encoder_cbhg_banks=4,attention_dim=64,decoder_dim=64,"
+             "post_cbhg_banks=3,post_cbhg_bank_sizes=[64],batch_size=2,batch_group_size=2,outputs_per_step=5,max_iters=40")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--ljspeech", data, "--model", "taco1",
+                        "--log_dir", logs, "--hparams", small, "--checkpoint_interval", "3", "--max_steps", "3",
+                        "--precision", "bf16"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    run = os.path.join(logs, "logs-taco1")
+    assert os.path.exists(os.path.join(run, "model.ckpt-3")) and "Step 3 " in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "--checkpoint", os.path.join(run, "model.ckpt-3"),
+                        "--model", "taco1", "--hparams", small, "--precision", "bf16"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(os.path.join(run, "eval-3-0.wav"))

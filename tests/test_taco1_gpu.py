@@ -96,3 +96,24 @@ def test_taco1_train_steps_bf16_and_noam_schedule(dev):
     assert all(np.isfinite(l) for l in losses) and m.global_step == 3
     assert abs(m.learning_rate - O.learning_rate(hp.values(), 2)) < 1e-12
     assert abs(O.learning_rate(hp.values(), 3999) - hp.initial_learning_rate) < 1e-9
+
+
+def test_taco1_inference_matches_oracle(dev):
+    from nspeech_amd.models import create_model
+    from oracle import taco1_oracle as O
+    hp = _hp()
+    hp.max_iters = 5
+    m = create_model("taco1", hp, device="cuda:0", dtype="fp32", seed=6)
+    inputs, lengths, mel, lin = make_batch(hp, 2, 10, 20, seed=3)
+    m.add_optimizer(0)
+    m.step(inputs, lengths, mel, lin)         # non-trivial BN moving statistics
+    inputs, lengths, _, _ = make_batch(hp, 2, 12, 10, seed=8)
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in list(m.numpy_params().items()) + list(m.numpy_stats().items())}
+    with torch.no_grad():
+        out = O.taco1_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths))
+    m.initialize(inputs, lengths)
+    assert tuple(m.mel_outputs.shape) == (2, 25, hp.num_mels) and tuple(m.alignments.shape) == (2, 12, 5)
+    for name in ("mel_outputs", "linear_outputs", "alignments"):
+        got = getattr(m, name).float().cpu().numpy()
+        ref = out[name].numpy()
+        assert np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), name
