@@ -213,6 +213,8 @@ typedef struct {
   /* optional pre-split bf16 copies of fp32 weights (dtype NS_F32 only): whT = whT_hi + whT_lo
    * spares the in-kernel split for f32_passes = 3; wh_bf16 serves f32_passes = 1 at half the bytes */
   const void* whT_hi; const void* whT_lo; const void* wh_bf16;
+  void* dgates_bf16;                    /* optional [N*P, 4H] bf16 copy of dgates written and re-read by the
+                                           backward recurrence (with wh_bf16: pure bf16 operand loads) */
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -381,6 +383,7 @@ typedef struct {
   float* work;                     /* fp32 scratch, ns_taco2_attn_work_bytes() */
   int f32_passes;                  /* as in ns_gemm_params, for the in-loop products */
   const void* wattT_hi; const void* wattT_lo; const void* watt_bf16;   /* optional, as in ns_lstm_seq_params */
+  void* dga_bf16;                  /* optional [N,S+1,4A] bf16 copy of dga for the backward recurrence */
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

@@ -430,7 +430,7 @@ __global__ __launch_bounds__(ATHREADS) void attn_bwd_dq_kernel(AttnBwdStep<T> a)
 //   dWcl[k,u]  = sum_{s,t} align_{s-1}[t+k-half] dpre_s[t,u]
 // One wave = 64 memory positions x PU units, looping over the S steps with everything in
 // registers (th is recomputed; nothing is read-modify-written in memory).
-constexpr int PU = 16;
+constexpr int PU = 8;
 struct AttnPost {
   int S, Ti, A, kw, Tia;
   const int* lengths;
@@ -693,6 +693,10 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     c.dgates = (T*)p.dga + slot * 4 * A; c.dg_sn = S1 * 4 * A;
     c.passes = p.f32_passes;
     c.w_bf16 = p.watt_bf16 ? (const bf16_t*)p.watt_bf16 + D2 * 4 * A : nullptr;
+    if (p.dga_bf16 && sizeof(T) == 4) {
+      c.dgates_b = (bf16_t*)p.dga_bf16 + slot * 4 * A;
+      c.dg_next_b = last ? nullptr : (const bf16_t*)p.dga_bf16 + (slot + 1) * 4 * A;
+    }
     rc = lstm_bwd_step_launch<T>(c, s);
     if (rc) return rc;
     for (int nb = 0; nb < p.N; nb += 32) {

@@ -209,19 +209,23 @@ extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
 }
 
 // ------------------------------------------------------------------ column sums
+constexpr int CS_ROWS = 32;
 __global__ void colsum_kernel(ns_colsum_params p) {
-  const int r0 = blockIdx.x * 64;
-  const int r1 = min(p.rows, r0 + 64);
+  const int r0 = blockIdx.x * CS_ROWS;
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float v[CS_ROWS];
+#pragma unroll
+    for (int j = 0; j < CS_ROWS; ++j) v[j] = (r0 + j < p.rows) ? ld_dyn(p.x, p.dtype, (long)(r0 + j) * p.ld + c) : 0.f;
     float s = 0.f;
-    for (int row = r0; row < r1; ++row) s += ld_dyn(p.x, p.dtype, (long)row * p.ld + c);
+#pragma unroll
+    for (int j = 0; j < CS_ROWS; ++j) s += v[j];
     atomicAdd(p.out + c, s);
   }
 }
 extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_colsum: null");
   if (p->rows <= 0 || p->C <= 0) return NS_OK;
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(p->rows, 64)), dim3(256), 0, (hipStream_t)s, *p);
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(p->rows, CS_ROWS)), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("colsum");
   return NS_OK;
 }

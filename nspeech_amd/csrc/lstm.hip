@@ -286,15 +286,22 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
       const float* brow = (const float*)a.w + (long)(u0 + r16) * a.K;
       if (a.w_bf16 && !three) {
         const bf16_t* wrow = a.w_bf16 + (long)(u0 + r16) * a.K;
+        const bf16_t* brow0 = a.dg_next_b ? a.dg_next_b + (long)(nb + r16) * a.dgn_sn : nullptr;
+        const bf16_t* brow1 = a.dg_next_b ? a.dg_next_b + (long)(nb + 16 + r16) * a.dgn_sn : nullptr;
         for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
           bf16x8 af[GROUP][2], bfr[GROUP];
 #pragma unroll
           for (int q = 0; q < GROUP; ++q) {
             const int k = (kc0 + q * LW) * 32 + g * 8;
             const bool okk = k < a.K;
-            bf16x8 dummy;
-            ldsplit8(arow0 + k, ok0 && okk, af[q][0], dummy);
-            ldsplit8(arow1 + k, ok1 && okk, af[q][1], dummy);
+            if (brow0) {
+              af[q][0] = (ok0 && okk) ? *(const bf16x8*)(brow0 + k) : zero8();
+              af[q][1] = (ok1 && okk) ? *(const bf16x8*)(brow1 + k) : zero8();
+            } else {
+              bf16x8 dummy;
+              ldsplit8(arow0 + k, ok0 && okk, af[q][0], dummy);
+              ldsplit8(arow1 + k, ok1 && okk, af[q][1], dummy);
+            }
             bfr[q] = (oku && okk) ? *(const bf16x8*)(wrow + k) : zero8();
           }
 #pragma unroll
@@ -350,8 +357,10 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
   const int r = er, uu = euu, n = en, u = eu;
   T* dg = a.dgates + (long)n * a.dg_sn;
   const long ci = (long)n * H + u;
+  bf16_t* dgb = a.dgates_b ? a.dgates_b + (long)n * a.dg_sn : nullptr;
   if (pmask) {
     stf(dg + u, 0.f); stf(dg + H + u, 0.f); stf(dg + 2 * H + u, 0.f); stf(dg + 3 * H + u, 0.f);
+    if (dgb) { dgb[u] = (bf16_t)0.f; dgb[H + u] = (bf16_t)0.f; dgb[2 * H + u] = (bf16_t)0.f; dgb[3 * H + u] = (bf16_t)0.f; }
     a.dc_carry[ci] = 0.f;
     return;
   }
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
   const float d_f = dc * cp * gf * (1.f - gf);
   a.dc_carry[ci] = dc * gf;
   stf(dg + u, d_i); stf(dg + H + u, d_j); stf(dg + 2 * H + u, d_f); stf(dg + 3 * H + u, d_o);
+  if (dgb) { dgb[u] = (bf16_t)d_i; dgb[H + u] = (bf16_t)d_j; dgb[2 * H + u] = (bf16_t)d_f; dgb[3 * H + u] = (bf16_t)d_o; }
 }
 
 template <typename T>
@@ -437,6 +447,10 @@ static void fill_bwd(LstmBwdStep<T>& a, const ns_lstm_seq_params& p, int step, f
   a.dgates = (T*)p.dgates + row * 4 * H; a.dg_sn = P * 4 * H;
   a.passes = p.f32_passes;
   a.w_bf16 = (const bf16_t*)p.wh_bf16;
+  if (p.dgates_bf16 && sizeof(T) == 4) {
+    a.dgates_b = (bf16_t*)p.dgates_bf16 + row * 4 * H;
+    a.dg_next_b = has_next ? (const bf16_t*)p.dgates_bf16 + rown * 4 * H : nullptr;
+  }
 }
 
 static int check_fwd(const ns_lstm_seq_params* p, const char* who) {

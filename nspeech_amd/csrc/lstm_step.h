@@ -41,6 +41,7 @@ struct LstmBwdStep {
   T* dgates; long dg_sn;                   // out [N, 4H]
   int passes;
   const bf16_t* w_bf16;                    // optional bf16 copy of an fp32 w (passes == 1)
+  const bf16_t* dg_next_b; bf16_t* dgates_b;   // optional bf16 copies of dg_next / dgates (same strides)
 };
 template <typename T>
 struct LstmBwdStepPair { LstmBwdStep<T> s[2]; int n; };

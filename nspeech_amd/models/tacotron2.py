@@ -133,6 +133,12 @@ class Tacotron2(object):
             return self.flat_s
         return None
 
+    def _dgb(self, name, numel, D):
+        """bf16 side copy of a gate-gradient history for single-pass backward recurrences on fp32 storage."""
+        if self._bf16_w(D) is None:
+            return None
+        return self._buf(name, numel, torch.bfloat16)
+
     def _W(self, D):
         """Flat weight buffer to use as a GEMM operand of dtype D."""
         return self.flat_p if D == torch.float32 else self.flat_s
@@ -371,7 +377,8 @@ class Tacotron2(object):
                                             self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
                                             ld_dh=2 * H, dgates=dg, work=work, wh_off=ko + cin * 4 * H,
                                             h_off=di * H, dh_off=di * H,
-                                            wh_bf16=self._bf16_w(D), wh_bf16_off=ko + cin * 4 * H))
+                                            wh_bf16=self._bf16_w(D), wh_bf16_off=ko + cin * 4 * H,
+                                            dgates_bf16=self._dgb("%s_dgb_%s" % (tag, d), rows * 4 * H, D)))
         self._run_bilstm("bwd", pair, tag)
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
@@ -640,14 +647,15 @@ class Tacotron2(object):
         dg2 = self._buf("d_g2", rows * 4 * D, T_)
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D, B["dec_c2"],
                      B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
-                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D)
+                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D, dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_))
         self._lstm_wgrads(h1, D, h2, D, dg2, rows, k2, "decoder/lstm_2/bias")
         dh1 = self._buf("d_h1", rows * D, torch.float32)
         ops.gemm(dg2, self._W(self.T), dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
         dg1 = self._buf("d_g1", rows * 4 * D, T_)
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D, B["dec_c1"],
                      B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
-                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D)
+                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D,
+                     dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
         self._lstm_wgrads(hc, A + E, h1, D, dg1, rows, k1, "decoder/lstm_1/bias")
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
         ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
@@ -674,6 +682,7 @@ class Tacotron2(object):
                     wq=(self._W(self.T), wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
                     dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork,
                     watt_bf16=(self._bf16_w(T_), wa) if self._bf16_w(T_) is not None else None,
+                    dga_bf16=self._dgb("d_gab", rows * 4 * A, T_),
                     de=self._buf("d_energy", rows * Tia, torch.float32),
                     dctx_t=self._buf("d_ctx_t", rows * E, T_))
         ops.taco2_attn("bwd", **args)

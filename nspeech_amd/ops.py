@@ -152,13 +152,13 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
 
 def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
                     dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
-                    forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0):
+                    forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0, dgates_bf16=None):
     p = L.struct("ns_lstm_seq_params")
     _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
           dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES,
-          whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off))
+          whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off), dgates_bf16=ptr(dgates_bf16))
     return p
 
 
