@@ -14,6 +14,7 @@
 // Every spin is bounded; on timeout the kernel sets *status and every workgroup leaves.
 #include "common.h"
 #include <stdlib.h>
+#include <stdint.h>
 
 typedef unsigned long long u64;
 constexpr int CW = 8;            // waves per workgroup
@@ -36,11 +37,14 @@ struct LstmClusterArgs {
   u64* xbuf;                      // [chains][2][16][granules per row]
   int* status;
   int dbg;                        // timing experiments only (NS_CLUSTER_DBG), 0 in production
+  unsigned* flags;                // role-split backward: [chains][8] published-step counters (zeroed per launch)
+  long long* trace;               // dbg bit 4: [step][8] timestamps of workgroup 0 (100 MHz clock)
 };
 
 __device__ __forceinline__ int swz_off(int row, int k, int H) {   // bf16 element offset in the LDS h image
   const int chunk = k >> 3;
-  return row * H + (((chunk ^ (row & 15)) << 3) | (k & 7));
+  const int m = ((H >> 3) & 15) ? 7 : 15;   // the XOR must stay inside an aligned group of chunks of the row
+  return row * H + (((chunk ^ (row & m)) << 3) | (k & 7));
 }
 
 // ------------------------------------------------------------------ forward
@@ -351,6 +355,480 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_bwd_kernel(LstmClusterA
   }
 }
 
+// ==================================================================== role-split kernels (H <= 256)
+// Same clustering and exchange protocol as above, with two changes that take the exchange latency
+// (~2 us publish -> gathered, most of a step) off the critical path:
+//
+//  * ROLES.  No wave mixes global loads and global stores (gfx9 has one vmcnt for both, so a polling
+//    load issued behind a store waits for the store's acknowledgement):
+//      - XW compute waves (16 units each): MFMA from LDS, cell update, publish + saves.  Stores only.
+//      - poller wave(s): spin on the exchange granules and drop them into the LDS operand image
+//        (double-buffered).  Loads only.
+//      - one prefetcher wave: streams the per-step operands (xg rows / saved gates, dh, c) one slot
+//        ahead into an LDS stage.  Loads only.
+//    One workgroup barrier per slot hands the LDS images over.
+//  * INTERLEAVED CHAINS.  A workgroup serves R row groups of the same direction with the same resident
+//    weights, round-robin: while row group A's new h is in flight to the peers, the compute waves work
+//    on row group B.  Slot q = step * R + rg.
+//
+// Exchange layout (per chain and parity): a publishing lane's granules are contiguous, so one base
+// register + immediates address them; the poller decodes granule index -> (row, k) when it fills LDS.
+constexpr int XW = 4;
+constexpr int FW_WAVES = XW + 2;
+constexpr int BW_POLL = 2;
+constexpr int BW_WAVES = XW + 1 + BW_POLL + 1;   // compute, publisher, pollers, prefetcher
+constexpr int XG_LD = 256 + 4;          // floats per row of the xg stage (pad: rows 4 apart hit different banks)
+
+__device__ __forceinline__ void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
+  const bf16_t b0 = (bf16_t)lo, b1 = (bf16_t)hi;
+  return (unsigned)(*(const unsigned short*)&b0) | ((unsigned)(*(const unsigned short*)&b1) << 16);
+}
+
+template <int HB, int R>
+__global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = HB * 64, FW_PG = 8 * HB, GPR = H / 2, KS = H / 32;
+  const int CS = HB;
+  bf16_t* hs = (bf16_t*)smem;                                   // [2][16][H] swizzled
+  float* xgs = (float*)(smem + (size_t)2 * 16 * H * 2);         // [2][16][XG_LD]: row, gate * 64 + unit
+  int* abortf = (int*)(xgs + 2 * 16 * XG_LD);                   // [2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsets = ((a.N + 15) / 16 + R - 1) / R;
+  const int set = blockIdx.x / CS, wgc = blockIdx.x % CS;
+  const int d = set / nsets, rg0 = (set % nsets) * R;           // this workgroup serves row groups rg0 .. rg0+R-1
+  const int r16 = lane & 15, g = lane >> 4;
+  u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * 16 * GPR;   // + rg * 2*16*GPR + parity * 16*GPR
+  const int u0 = wgc * 64;
+  const int T = a.T, Q = a.T * R;
+  if (tid < 2) abortf[tid] = 0;
+
+  if (wave < XW) {
+    // ================================================================ compute role
+    const int unit = u0 + wave * 16 + r16;
+    const int pub0 = (((wgc * XW + wave) * 32) + g * 8 + (r16 >> 1)) * 4;    // this lane's 4 granules (rows g*4 .. g*4+3)
+    bf16x8 bw[4][KS];
+    {
+      const bf16_t* W = a.whT[d];
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) {
+        const bf16_t* row = W + ((long)gate * H + unit) * H;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) bw[gate][ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
+      }
+    }
+    float cst[R][4];
+    int len[R][4];
+#pragma unroll
+    for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (rg0 + rg) * 16 + g * 4 + r;
+        cst[rg][r] = 0.f;
+        len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
+      }
+    for (int step = 0; step < T; ++step) {
+      const int t = d ? T - 1 - step : step;
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) {
+        const int q = step * R + rg, buf = q & 1;
+        const int n0 = (rg0 + rg) * 16;
+        wg_barrier();
+        if (abortf[buf]) return;
+        const bool tr = (a.dbg & 16) && blockIdx.x == 0 && tid == 0 && q < 512;
+        if (tr) a.trace[q * 8 + 0] = wall_clock64();
+        const float* xr = xgs + (size_t)buf * 16 * XG_LD + (wave * 16 + r16);
+        f32x4 acc[4];
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[gate][r] = xr[(g * 4 + r) * XG_LD + gate * 64];
+        if (step > 0) {
+          const bf16_t* hb = hs + (size_t)buf * 16 * H;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 af = *(const bf16x8*)(hb + swz_off(r16, ks * 32 + g * 8, H));
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate)
+              acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bw[gate][ks], acc[gate], 0, 0, 0);
+          }
+        }
+        float hv[4], sg[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool masked = t >= len[rg][r];
+          const float gi = sigmoidf_(acc[0][r]), gj = tanhf_(acc[1][r]);
+          const float gf = sigmoidf_(acc[2][r] + a.forget_bias), go = sigmoidf_(acc[3][r]);
+          float cn = gf * cst[rg][r] + gi * gj;
+          float hn = go * tanhf_(cn);
+          if (masked) { cn = 0.f; hn = 0.f; }
+          cst[rg][r] = cn;
+          hv[r] = hn;
+          sg[r][0] = masked ? 0.f : gi; sg[r][1] = masked ? 0.f : gj; sg[r][2] = masked ? 0.f : gf; sg[r][3] = masked ? 0.f : go;
+        }
+        if (tr) a.trace[q * 8 + 1] = wall_clock64();
+        // publish first (tag = step + 1): even-unit lanes pack (h[u], h[u+1])
+        if (step + 1 < T) {
+          u64* nxt = xb0 + ((size_t)rg * 2 + ((step + 1) & 1)) * 16 * GPR + pub0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned pay = pack_bf16(hv[r], __shfl_down(hv[r], 1, 64));
+            if (!(r16 & 1))
+              __hip_atomic_store(nxt + r, ((u64)(unsigned)(step + 1) << 32) | pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (tr) a.trace[q * 8 + 2] = wall_clock64();
+        // saves for the backward pass / the consumers of h
+        {
+          bf16_t* __restrict__ hp_ = a.h[d];
+          float* __restrict__ cp_ = a.c[d];
+          bf16_t* __restrict__ gp_ = a.gates[d];
+          const unsigned row0 = (unsigned)((n0 + g * 4) * a.P + a.padl + t);   // 32-bit element offsets (host-checked)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (n0 + g * 4 + r < a.N) {
+              const unsigned rowi = row0 + (unsigned)(r * a.P);
+              hp_[rowi * (unsigned)a.ld_h + (unsigned)unit] = (bf16_t)hv[r];
+              cp_[rowi * (unsigned)H + (unsigned)unit] = cst[rg][r];
+              const unsigned go = rowi * (unsigned)(4 * H) + (unsigned)unit;
+#pragma unroll
+              for (int gate = 0; gate < 4; ++gate) gp_[go + (unsigned)(gate * H)] = (bf16_t)sg[r][gate];
+            }
+          }
+        }
+      }
+    }
+  } else if (wave == XW) {
+    // ================================================================ poller role
+    static_assert(16 * GPR == FW_PG * 64, "poller coverage");
+    // granule lane + 64*jj: r = lane & 3, unit pair = (lane >> 2) & 7, g = ((jj & 1) << 1) | (lane >> 5), wave slot = jj >> 1
+    const int pr_ = lane & 3, pp = (lane >> 2) & 7, pgl = lane >> 5;
+    for (int q = 0; q < Q; ++q) {
+      const int step = q / R, rg = q % R, buf = q & 1;
+      const bool tr = (a.dbg & 16) && blockIdx.x == 0 && lane == 0 && q < 512;
+      if (tr) a.trace[q * 8 + 4] = wall_clock64();
+      if (step > 0) {
+        const u64* cur = xb0 + ((size_t)rg * 2 + (step & 1)) * 16 * GPR;   // published by the peers with tag = step
+        u64 v[FW_PG];
+        unsigned spins = 0;
+        bool ok;
+        do {
+          ok = true;
+#pragma unroll
+          for (int j = 0; j < FW_PG; ++j) v[j] = __hip_atomic_load(cur + lane + j * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int j = 0; j < FW_PG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)step);
+          if (!ok) {
+            ++spins;
+            if (spins > SPIN_LIMIT) { atomicExch(a.status, 1); abortf[buf] = 1; ok = true; }
+            else if ((spins & 1023) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              abortf[buf] = 1; ok = true;
+            }
+          }
+        } while (!ok);
+        if (tr) { a.trace[q * 8 + 5] = wall_clock64(); a.trace[q * 8 + 6] = spins; }
+        bf16_t* dst = hs + (size_t)buf * 16 * H;
+#pragma unroll
+        for (int jj = 0; jj < FW_PG; ++jj) {
+          const int row = (((jj & 1) << 1) | pgl) * 4 + pr_;
+          const int k = (jj >> 1) * 16 + pp * 2;
+          *(unsigned*)(dst + swz_off(row, k, H)) = (unsigned)v[jj];
+        }
+      }
+      wg_barrier();
+      if (abortf[buf]) return;
+    }
+  } else {
+    // ================================================================ prefetcher role
+    // stage row j, gate = lane / 16, 4 floats at (lane % 16) * 4
+    f32x4 pf[16];
+    const float* xg = a.xg[d];
+    const int pgate = lane >> 4, pf4 = (lane & 15) * 4;
+    auto pf_load = [&](int q) {
+      const int step = q / R, rg = q % R;
+      const int t = d ? T - 1 - step : step;
+      const int n0 = (rg0 + rg) * 16;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int n = n0 + j;
+        pf[j] = n < a.N ? *(const f32x4*)(xg + ((unsigned)(n * a.P + a.padl + t) * (unsigned)a.ld_xg + (unsigned)(pgate * H + u0 + pf4)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto pf_store = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) *(f32x4*)(xgs + ((size_t)buf * 16 + j) * XG_LD + pgate * 64 + pf4) = pf[j];
+    };
+    pf_load(0);
+    pf_store(0);
+    if (Q > 1) pf_load(1);
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q + 1 < Q) {
+        pf_store((q + 1) & 1);
+        if (q + 2 < Q) pf_load(q + 2);
+      }
+    }
+  }
+}
+
+// Backward.  Compute wave w owns 16 units and the full K = 4H contraction for them (W_h rows as B
+// fragments, K/32 k-steps), so no cross-wave reduction is needed.
+//
+// The backward exchange is 4x the forward one (every workgroup needs all 4H gate gradients of the
+// step after), and a granule sweep of that size is bound by the CU's outstanding-miss budget
+// (~12 GB/s).  So the payload travels dense instead: the gate gradients are saved to the dgates
+// array anyway (the weight-gradient GEMMs read them later), so a PUBLISHER wave writes this
+// workgroup's slice there with 16-byte write-through (sc1) stores, drains them, and raises one flag
+// per (chain, workgroup); the pollers wait for the cluster's flags and read the rows back with
+// 16-byte sc1 loads straight into the LDS operand image.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int HB, int R>
+__global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = HB * 64, K = 4 * H, KS = K / 32;
+  constexpr int CPL = K / 64;                                         // 16-byte chunks per poller lane: 16 * (K/8) / 128
+  const int CS = HB;
+  bf16_t* dgs = (bf16_t*)smem;                                        // [2][16][K] swizzled
+  char* ops = smem + (size_t)2 * 16 * K * 2;                          // [2] stages of {gates, dh, cprev}
+  constexpr int OPS_STAGE = 16 * 4 * 64 * 2 + 2 * 16 * 64 * 4;        // 16 KB
+  bf16_t* outs = (bf16_t*)(ops + 2 * OPS_STAGE);                      // [2][16][4][64] this slot's gate gradients
+  float* c0 = (float*)(outs + 2 * 16 * 4 * 64);                       // [R][16][64] cell state at the first processed step
+  int* abortf = (int*)(c0 + R * 16 * 64);                             // [2] + [2] = compute waves done with their slot (counter)
+  int* ready = abortf + 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsets = ((a.N + 15) / 16 + R - 1) / R;
+  const int set = blockIdx.x / CS, wgc = blockIdx.x % CS;
+  const int d = set / nsets, rg0 = (set % nsets) * R;
+  const int r16 = lane & 15, g = lane >> 4;
+  unsigned* flags0 = a.flags + (size_t)(d * nsets * R + rg0) * 8;     // [chain][8]: published backward steps per workgroup
+  const int u0 = wgc * 64;
+  const int T = a.T, Q = a.T * R;
+  if (tid < 3) abortf[tid] = 0;                                        // abortf[0..1], ready
+  auto t_of = [&](int step) { return d ? T - 1 - step : step; };
+
+  if (wave < XW) {
+    // ================================================================ compute role (LDS only)
+    const int wu = wave * 16 + r16;                    // unit inside the workgroup's 64
+    bf16x8 bw[KS];
+    {
+      const bf16_t* row = a.wh[d] + (long)(u0 + wu) * K;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bw[ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
+    }
+    int asw[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) asw[m] = r16 * K + (((m * 4 + g) ^ r16) << 3);
+    float dcc[R][4], pc[R][4];
+    int len[R][4];
+#pragma unroll
+    for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (rg0 + rg) * 16 + g * 4 + r;
+        dcc[rg][r] = 0.f; pc[rg][r] = 0.f;
+        len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
+      }
+    for (int bs = 0; bs < T; ++bs) {                 // backward step index; forward step = T-1-bs
+      const int t = t_of(T - 1 - bs);
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) {
+        const int q = bs * R + rg, buf = q & 1;
+        const int n0 = (rg0 + rg) * 16;
+        wg_barrier();
+        if (abortf[buf]) return;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (bs > 0) {
+          const bf16_t* db = dgs + (size_t)buf * 16 * K;
+          f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ks += 2) {
+            // swz_off(r16, ks*32 + g*8): the XOR only touches the low 4 chunk bits -> 4 lane bases + immediates
+            const bf16x8 a0 = *(const bf16x8*)(db + asw[ks & 3] + (ks >> 2) * 128);
+            const bf16x8 a1 = *(const bf16x8*)(db + asw[(ks + 1) & 3] + ((ks + 1) >> 2) * 128);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bw[ks], acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bw[ks + 1], acc2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+        }
+        const char* st = ops + (size_t)buf * OPS_STAGE;
+        const bf16_t* sgt = (const bf16_t*)st;
+        const float* sdh = (const float*)(st + 8192);
+        const float* scp = (const float*)(st + 12288);
+        bf16_t* so = outs + (size_t)buf * 16 * 4 * 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = g * 4 + r;
+          const int n = n0 + row;
+          const float gi = (float)sgt[(row * 4 + 0) * 64 + wu], gj = (float)sgt[(row * 4 + 1) * 64 + wu];
+          const float gf = (float)sgt[(row * 4 + 2) * 64 + wu], go = (float)sgt[(row * 4 + 3) * 64 + wu];
+          const float cprev = scp[row * 64 + wu];
+          const float ccur = bs == 0 ? c0[(rg * 16 + row) * 64 + wu] : pc[rg][r];
+          const float dh = sdh[row * 64 + wu] + acc[r];
+          const float tc = tanhf_(ccur);
+          const float d_o = dh * tc * go * (1.f - go);
+          const float dc = dh * go * (1.f - tc * tc) + dcc[rg][r];
+          float dgv[4] = {dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj), dc * cprev * gf * (1.f - gf), d_o};
+          dcc[rg][r] = dc * gf;
+          if (t >= len[rg][r] || n >= a.N) {
+            dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f;
+            dcc[rg][r] = 0.f;
+          }
+          pc[rg][r] = cprev;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) so[(row * 4 + j) * 64 + wu] = (bf16_t)dgv[j];
+        }
+        // tell the publisher this wave's part of the slot is in LDS (release: the writes above are ordered before it)
+        if (lane == 0) __hip_atomic_fetch_add(ready, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    wg_barrier();
+  } else if (wave == XW) {
+    // ================================================================ publisher role (stores only)
+    // slot q's tile: 64 (row, gate) lines of 128 B = 512 chunks of 16 B, 8 per lane; LDS offset = chunk * 16
+    const long dg_bytes = (long)a.N * a.P * K * 2;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgates[d], 0, (int)dg_bytes, 0x00020000);
+    wg_barrier();
+    for (int q = 0; q < Q; ++q) {
+      const int bs = q / R, rg = q % R;
+      const int t = t_of(T - 1 - bs);
+      const int n0 = (rg0 + rg) * 16;
+      // wait for the XW compute waves of slot q (LDS counter)
+      unsigned spins = 0;
+      while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < XW * (q + 1)) {
+        __builtin_amdgcn_s_sleep(1);
+        if (((++spins) & 255) == 0 && (abortf[0] | abortf[1])) return;
+        if (spins > SPIN_LIMIT) { atomicExch(a.status, 3); return; }
+      }
+      const char* so = (const char*)(outs + (size_t)(q & 1) * 16 * 4 * 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
+        const u32x4 v = *(const u32x4*)(so + idx * 16);
+        if (n0 + row < a.N) {
+          const unsigned off = ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)K + (unsigned)(gate * H + u0 + c8 * 8)) * 2u;
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, off, 0, 16);           // aux 16 = sc1 (write-through)
+        }
+      }
+      // R >= 2: join the slot barrier first (the compute waves are waiting there; the flag is not needed before the
+      // slot after next).  R == 1: the pollers need this flag to reach the barrier at all.
+      if (R > 1) wg_barrier();
+      if (bs + 1 < T) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // drain before the flag
+        if (lane == 0) __hip_atomic_store(flags0 + rg * 8 + wgc, (unsigned)(bs + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (R == 1) wg_barrier();
+    }
+  } else if (wave < XW + 1 + BW_POLL) {
+    // ================================================================ poller role (loads only)
+    const int pl = (wave - XW - 1) * 64 + lane;
+    const long dg_bytes = (long)a.N * a.P * K * 2;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.dgates[d], 0, (int)dg_bytes, 0x00020000);
+    for (int q = 0; q < Q; ++q) {
+      const int bs = q / R, rg = q % R, buf = q & 1;
+      if (bs > 0) {
+        // every workgroup of the chain must have published backward step bs-1 (flag >= bs)
+        const unsigned* fl = flags0 + rg * 8;
+        unsigned spins = 0;
+        for (;;) {
+          const unsigned v = lane < CS ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+          if (__all(v >= (unsigned)bs)) break;
+          ++spins;
+          if (spins > SPIN_LIMIT) { atomicExch(a.status, 2); abortf[buf] = 1; break; }
+          if ((spins & 1023) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; break; }
+        }
+        const int tn = t_of(T - bs);                   // time index of the step processed just before
+        const int n0 = (rg0 + rg) * 16;
+        bf16_t* dst = dgs + (size_t)buf * 16 * K;
+        u32x4 v[CPL];
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const int idx = pl + 128 * j, row = idx / (K / 8), ch = idx % (K / 8);
+          v[j] = (u32x4){0u, 0u, 0u, 0u};
+          if (n0 + row < a.N) {
+            const unsigned off = ((unsigned)((n0 + row) * a.P + a.padl + tn) * (unsigned)K + (unsigned)(ch * 8)) * 2u;
+            v[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);       // sc1: bypasses this CU's L1
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CPL; ++j) {
+          const int idx = pl + 128 * j, row = idx / (K / 8), ch = idx % (K / 8);
+          *(u32x4*)(dst + swz_off(row, ch * 8, K)) = v[j];
+        }
+      }
+      wg_barrier();
+      if (abortf[buf]) return;
+    }
+    wg_barrier();
+  } else {
+    // ================================================================ prefetcher role (loads only)
+    // gates 8 x 16 B per lane, dh 4 x 16 B, cprev 4 x 16 B per slot
+    f32x4 pg[8], pd[4], pcp[4];
+    auto pf_load = [&](int q) {
+      const int bs = q / R, rg = q % R, step = T - 1 - bs;
+      const int t = t_of(step), tp = d ? t + 1 : t - 1;
+      const bool has_prev = step > 0;
+      const int n0 = (rg0 + rg) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
+        const int n = n0 + row;
+        pg[j] = n < a.N ? *(const f32x4*)(a.gates[d] + ((unsigned)(n * a.P + a.padl + t) * (unsigned)(4 * H) + (unsigned)(gate * H + u0 + c8 * 8)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
+        const int n = n0 + row;
+        pd[j] = n < a.N ? *(const f32x4*)(a.dh[d] + ((unsigned)(n * a.P + a.padl + t) * (unsigned)a.ld_dh + (unsigned)(u0 + c16 * 4)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        pcp[j] = (n < a.N && has_prev) ? *(const f32x4*)(a.c[d] + ((unsigned)(n * a.P + a.padl + tp) * (unsigned)H + (unsigned)(u0 + c16 * 4)))
+                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto pf_store = [&](int buf) {
+      char* st = ops + (size_t)buf * OPS_STAGE;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *(f32x4*)(st + (size_t)(lane + 64 * j) * 16) = pg[j];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *(f32x4*)(st + 8192 + (size_t)(lane + 64 * j) * 16) = pd[j];
+        *(f32x4*)(st + 12288 + (size_t)(lane + 64 * j) * 16) = pcp[j];
+      }
+    };
+    {
+      const int t0 = t_of(T - 1);
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
+          const int n = (rg0 + rg) * 16 + row;
+          const f32x4 v = n < a.N ? *(const f32x4*)(a.c[d] + ((unsigned)(n * a.P + a.padl + t0) * (unsigned)H + (unsigned)(u0 + c16 * 4)))
+                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+          *(f32x4*)(c0 + (rg * 16 * 64) + idx * 4) = v;
+        }
+      pf_load(0);
+      pf_store(0);
+      if (Q > 1) pf_load(1);
+    }
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q + 1 < Q) {
+        pf_store((q + 1) & 1);
+        if (q + 2 < Q) pf_load(q + 2);
+      }
+    }
+    wg_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 static int cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1) {
   return p0->dtype == NS_BF16 && p1->dtype == NS_BF16 && p0->H % 64 == 0 && p0->H <= 512 && p0->T >= 2;
@@ -358,11 +836,12 @@ static int cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_par
 
 extern "C" size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
-  const size_t chains = 2 * (size_t)((p->N + 15) / 16);
-  // exchange buffers for the larger (backward) payload + status word
-  return chains * 2 * 16 * (size_t)(4 * p->H / 2) * sizeof(u64) + 256;
+  const size_t chains = 2 * (size_t)((p->N + 15) / 16 + 1);   // one spare row group per direction (pairs of interleaved chains)
+  // exchange buffers for the larger (backward) payload + status word + debug trace
+  return chains * 2 * 16 * (size_t)(4 * p->H / 2) * sizeof(u64) + 256 + 4096 + 512 * 8 * sizeof(long long);
 }
 
+constexpr size_t FLAG_BYTES = 4096;   // 128 chains x 8 counters
 static void fill(LstmClusterArgs& a, const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, void* work) {
   const ns_lstm_seq_params* pp[2] = {p0, p1};
   a.N = p0->N; a.T = p0->T; a.H = p0->H; a.P = p0->P; a.padl = p0->padl; a.CS = p0->H / 64;
@@ -374,9 +853,28 @@ static void fill(LstmClusterArgs& a, const ns_lstm_seq_params* p0, const ns_lstm
     a.dh[d] = pp[d]->dh; a.dgates[d] = (bf16_t*)pp[d]->dgates;
   }
   a.status = (int*)work;
-  a.xbuf = (u64*)((char*)work + 256);
+  a.flags = (unsigned*)((char*)work + 256);               // FLAG_BYTES, zeroed together with the status word
+  a.xbuf = (u64*)((char*)work + 256 + FLAG_BYTES);
   const char* dbg = getenv("NS_CLUSTER_DBG");
   a.dbg = dbg ? atoi(dbg) : 0;
+  const size_t chains = 2 * (size_t)((a.N + 15) / 16 + 1);
+  a.trace = (long long*)((char*)work + 256 + FLAG_BYTES + chains * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64));
+}
+
+// The role-split kernels cover H <= 256 with 16-byte aligned operand rows; NS_CLUSTER_DBG bit 3 forces
+// the single-role kernels (A/B timing).
+static bool role_split_ok(const LstmClusterArgs& a, bool bwd) {
+  if (a.dbg & 8) return false;
+  if (a.H > 256 || a.H % 64) return false;
+  if (2 * ((a.N + 15) / 16 + 1) * 8 * sizeof(unsigned) > FLAG_BYTES) return false;
+  const long widest = a.ld_xg > 4L * a.H ? a.ld_xg : 4L * a.H;
+  if ((long)a.N * a.P * (widest > a.ld_dh ? widest : a.ld_dh) >= (1L << 31)) return false;   // 32-bit element offsets
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  for (int d = 0; d < 2; ++d) {
+    if (!bwd && !(al16(a.xg[d]) && a.ld_xg % 4 == 0)) return false;
+    if (bwd && !(al16(a.dh[d]) && a.ld_dh % 4 == 0 && al16(a.c[d]) && al16(a.gates[d]) && al16(a.dgates[d]))) return false;
+  }
+  return true;
 }
 
 // Both directions of a BiLSTM, whole sequence, one launch.  p0 must be the forward-in-time direction
@@ -392,8 +890,25 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   LstmClusterArgs a = {};
   fill(a, p0, p1, work);
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);
-  const size_t xbytes = chains * 2 * 16 * (size_t)(a.H / 2) * sizeof(u64);
-  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
+  const size_t xbytes = (chains + 2) * 2 * 16 * (size_t)(a.H / 2) * sizeof(u64);
+  if (hipMemsetAsync(work, 0, 256 + FLAG_BYTES + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
+  if (role_split_ok(a, false)) {
+    const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 16;
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && !(a.dbg & 32)) ? 2 : 1;
+    const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * a.CS)), block(FW_WAVES * 64);
+#define NS_LAUNCH_F(HB_) \
+    if (R == 2) hipLaunchKernelGGL((lstm_cluster2_fwd_kernel<HB_, 2>), grid, block, lds2, s, a); \
+    else hipLaunchKernelGGL((lstm_cluster2_fwd_kernel<HB_, 1>), grid, block, lds2, s, a)
+    switch (a.H / 64) {
+      case 1: NS_LAUNCH_F(1); break;
+      case 2: NS_LAUNCH_F(2); break;
+      case 3: NS_LAUNCH_F(3); break;
+      default: NS_LAUNCH_F(4); break;
+    }
+#undef NS_LAUNCH_F
+    NS_CHECK_LAUNCH("lstm_cluster2_fwd");
+    return NS_OK;
+  }
   const size_t lds = (size_t)16 * a.H * 2;
   hipLaunchKernelGGL(lstm_cluster_fwd_kernel, dim3((unsigned)(chains * a.CS)), dim3(CTHREADS), lds, s, a);
   NS_CHECK_LAUNCH("lstm_cluster_fwd");
@@ -410,14 +925,37 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   LstmClusterArgs a = {};
   fill(a, p0, p1, work);
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);
-  const size_t xbytes = chains * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64);
-  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
-  const size_t lds = (size_t)16 * 4 * a.H * 2 + sizeof(float) * CW * 16 * 65;
+  // the role-split kernel exchanges through the dgates array + flags; only the single-role kernel needs the granule buffers
+  const size_t xbytes = role_split_ok(a, true) ? 0 : (chains + 2) * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64);
+  if (hipMemsetAsync(work, 0, 256 + FLAG_BYTES + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)lstm_cluster_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
+  if (role_split_ok(a, true)) {
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && !(a.dbg & 32)) ? 2 : 1;
+    const size_t lds2 = (size_t)2 * 16 * 4 * a.H * 2 + 2 * 16384 + 2 * 8192 + (size_t)R * 4096 + 32;
+    const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * a.CS)), block(BW_WAVES * 64);
+#define NS_LAUNCH_B(HB_) \
+    if (R == 2) hipLaunchKernelGGL((lstm_cluster2_bwd_kernel<HB_, 2>), grid, block, lds2, s, a); \
+    else hipLaunchKernelGGL((lstm_cluster2_bwd_kernel<HB_, 1>), grid, block, lds2, s, a)
+    switch (a.H / 64) {
+      case 1: NS_LAUNCH_B(1); break;
+      case 2: NS_LAUNCH_B(2); break;
+      case 3: NS_LAUNCH_B(3); break;
+      default: NS_LAUNCH_B(4); break;
+    }
+#undef NS_LAUNCH_B
+    NS_CHECK_LAUNCH("lstm_cluster2_bwd");
+    return NS_OK;
+  }
+  const size_t lds = (size_t)16 * 4 * a.H * 2 + sizeof(float) * CW * 16 * 65;
   hipLaunchKernelGGL(lstm_cluster_bwd_kernel, dim3((unsigned)(chains * a.CS)), dim3(CTHREADS), lds, s, a);
   NS_CHECK_LAUNCH("lstm_cluster_bwd");
   return NS_OK;

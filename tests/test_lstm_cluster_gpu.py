@@ -64,7 +64,8 @@ def _run(dev, data, cluster):
     return out
 
 
-@pytest.mark.parametrize("N,T,H,masked", [(16, 9, 64, False), (20, 33, 256, True), (32, 61, 256, False), (5, 12, 128, True)])
+@pytest.mark.parametrize("N,T,H,masked", [(16, 9, 64, False), (20, 33, 256, True), (32, 61, 256, False), (5, 12, 128, True),
+                                              (40, 21, 256, True), (48, 17, 192, False)])
 def test_cluster_matches_per_step_kernels(dev, N, T, H, masked):
     data = _setup(dev, N, T, H, seed=N + T, masked=masked)
     ref = _run(dev, data, cluster=False)
