@@ -234,6 +234,20 @@ size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p);
 int ns_lstm_cluster_fwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
 int ns_lstm_cluster_bwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
 
+/* Persistent variant of ns_lstm_seq_* for WIDE cells (the decoder LSTMs of tacotron2.py:67-73, 1024 units):
+ * ONE launch for the whole sequence.  Every workgroup keeps its slice of W_h in registers; the state
+ * (h[t-1] forward, the bf16 gate gradients of step t+1 backward) travels through the history arrays
+ * themselves with write-through stores + one flag per (row group, workgroup).
+ * Forward: dtype NS_BF16 (whT), or NS_F32 with whT_hi (+ whT_lo when f32_passes == 3).
+ * Backward: dtype NS_BF16 (wh), or NS_F32 with wh_bf16 + dgates_bf16 and f32_passes == 1.
+ * H %% 128 == 0, 128 <= H <= 1024, 16-byte aligned rows, the grid must fit the device (one workgroup per CU).
+ * ns_lstm_wide_supported() says whether a parameter block qualifies.  work[0] (int) is a status word:
+ * non-zero after the call completes = an exchange timed out and the outputs are invalid. */
+int ns_lstm_wide_supported(const ns_lstm_seq_params* p, int backward);
+size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p);
+int ns_lstm_wide_fwd(const ns_lstm_seq_params* p, void* work, ns_stream_t stream);
+int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stream_t stream);
+
 /* One LSTMBlockCell step on an explicit input row: gates = [a].W^T + xg + bias with a = the
  * concatenated [input | h_prev] rows (the free-running decoder of tacotron2.py:67-83 with
  * TacoTestHelper feedback, helpers.py:32-38, where nothing can be hoisted).

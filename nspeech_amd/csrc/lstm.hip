@@ -16,19 +16,22 @@ constexpr int GROUP = 4;       // K chunks whose loads are in flight together, p
 __device__ __forceinline__ bf16x8 zero8() { return (bf16x8){0, 0, 0, 0, 0, 0, 0, 0}; }
 
 // ------------------------------------------------------------------ fused forward step
-template <typename T>
+// HALF = false: 16 units x 32 rows per workgroup; HALF = true: 8 units x 16 rows (4x the workgroups, half the
+// operand bytes each: wide cells at small batch, where the big tiling fills only a quarter of the CUs).
+template <typename T, bool HALF>
 __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp) {
-  __shared__ float red[LW][32][65];
+  constexpr int UPW = HALF ? 8 : 16, RPW = HALF ? 16 : 32, MT = RPW / 16, NTL = UPW / 4;
+  __shared__ float red[LW][RPW][NTL * 16 + 1];
   const LstmStep<T>& a = pp.s[blockIdx.z];
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * 16;
-  const int nb = blockIdx.y * 32;
+  const int u0 = blockIdx.x * UPW;
+  const int nb = blockIdx.y * RPW;
   const int H = a.H;
   // epilogue operands of this thread's (row, unit): issued now so that their memory latency
   // overlaps the weight / state fragment loads instead of following the LDS reduction
-  const int er = tid >> 4, euu = tid & 15;
+  const int er = tid / UPW, euu = tid % UPW;
   const int en = nb + er, eu = u0 + euu;
-  const bool eok = en < a.N && eu < H;
+  const bool eok = tid < RPW * UPW && en < a.N && eu < H;
   float pz[4] = {0.f, 0.f, 0.f, 0.f};
   float pcp = 0.f;
   bool pmask = false;
@@ -45,43 +48,45 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
   if constexpr (sizeof(T) == 2) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    f32x4 acc[2][4];
+    f32x4 acc[MT][NTL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.a) {
       const int nkc = (a.K + 31) / 32;
       const bf16_t* arow0 = a.a + (long)(nb + r16) * a.a_sn;
       const bf16_t* arow1 = a.a + (long)(nb + 16 + r16) * a.a_sn;
-      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
-      const bool oku = u0 + r16 < H;
-      const bf16_t* brow = a.wT + (long)(u0 + r16) * a.K;
-      const long gstride = (long)H * a.K;
+      const bool ok0 = nb + r16 < a.N, ok1 = MT > 1 && nb + 16 + r16 < a.N;
+      // tile j, column r16 -> (gate, unit): 16 units: gate j; 8 units: gates 2j, 2j+1
+      const int bu = u0 + (HALF ? (r16 & 7) : r16), bg0 = HALF ? (r16 >> 3) : 0;
+      const bool oku = bu < H;
+      const long gstride = (long)H * a.K * (HALF ? 2 : 1);
+      const bf16_t* brow = a.wT + ((long)bg0 * H + bu) * a.K;
       for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
-        bf16x8 af[GROUP][2], bfr[GROUP][4];
+        bf16x8 af[GROUP][MT], bfr[GROUP][NTL];
 #pragma unroll
         for (int q = 0; q < GROUP; ++q) {
           const int k = (kc0 + q * LW) * 32 + g * 8;
           const bool okk = k < a.K;
           af[q][0] = (ok0 && okk) ? *(const bf16x8*)(arow0 + k) : zero8();
-          af[q][1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
+          if (MT > 1) af[q][MT - 1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bfr[q][j] = (oku && okk) ? *(const bf16x8*)(brow + j * gstride + k) : zero8();
+          for (int j = 0; j < NTL; ++j) bfr[q][j] = (oku && okk) ? *(const bf16x8*)(brow + j * gstride + k) : zero8();
         }
 #pragma unroll
         for (int q = 0; q < GROUP; ++q)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NTL; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q][j], acc[i][j], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   } else if (a.passes > 0) {
@@ -89,76 +94,82 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const bool three = a.passes >= 3;
-    f32x4 acc[2][4];
+    constexpr int QG = HALF ? 4 : 2;       // K chunks in flight per wave
+    f32x4 acc[MT][NTL];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.a) {
       const int nkc = (a.K + 31) / 32;
       const float* arow0 = (const float*)a.a + (long)(nb + r16) * a.a_sn;
       const float* arow1 = (const float*)a.a + (long)(nb + 16 + r16) * a.a_sn;
-      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
-      const bool oku = u0 + r16 < H;
-      const float* brow = (const float*)a.wT + (long)(u0 + r16) * a.K;
-      const long gstride = (long)H * a.K;
-      for (int kc0 = wave; kc0 < nkc; kc0 += LW * 2) {
-        bf16x8 ah[2][2], al[2][2], bh[2][4], bl[2][4];
+      const bool ok0 = nb + r16 < a.N, ok1 = MT > 1 && nb + 16 + r16 < a.N;
+      const int bu = u0 + (HALF ? (r16 & 7) : r16), bg0 = HALF ? (r16 >> 3) : 0;
+      const bool oku = bu < H;
+      const long gstride = (long)H * a.K * (HALF ? 2 : 1);
+      const long bo0 = ((long)bg0 * H + bu) * a.K;
+      const float* brow = (const float*)a.wT + bo0;
+      for (int kc0 = wave; kc0 < nkc; kc0 += LW * QG) {
+        bf16x8 ah[QG][MT], al[QG][MT], bh[QG][NTL], bl[QG][NTL];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
+        for (int q = 0; q < QG; ++q) {
           const int k = (kc0 + q * LW) * 32 + g * 8;
           const bool okk = k < a.K;
           ldsplit8(arow0 + k, ok0 && okk, ah[q][0], al[q][0]);
-          ldsplit8(arow1 + k, ok1 && okk, ah[q][1], al[q][1]);
+          if (MT > 1) ldsplit8(arow1 + k, ok1 && okk, ah[q][MT - 1], al[q][MT - 1]);
           if (a.wT_hi) {
-            const long bo = (long)(u0 + r16) * a.K + k;
+            const long bo = bo0 + k;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
+            for (int j = 0; j < NTL; ++j) {
               bh[q][j] = (oku && okk) ? *(const bf16x8*)(a.wT_hi + bo + j * gstride) : zero8();
               bl[q][j] = (oku && okk && three) ? *(const bf16x8*)(a.wT_lo + bo + j * gstride) : zero8();
             }
           } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ldsplit8(brow + j * gstride + k, oku && okk, bh[q][j], bl[q][j]);
+            for (int j = 0; j < NTL; ++j) ldsplit8(brow + j * gstride + k, oku && okk, bh[q][j], bl[q][j]);
           }
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
+        for (int q = 0; q < QG; ++q)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < NTL; ++j)
               acc[i][j] = three ? mfma_split<3>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j])
                                 : mfma_split<1>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < NTL; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][j * 16 + r16] = acc[i][j][r];
   } else {
     // exact fp32 path (parity tests): thread = (row, 4 gate columns)
-    const int r = tid >> 4, cb = (tid & 15) * 4;
+    constexpr int TPR = UPW;                 // threads per row, 4 gate columns each (column = gate * UPW + unit)
+    const int r = tid / TPR, cb = (tid % TPR) * 4;
     const int n = nb + r;
-    float s[4] = {0, 0, 0, 0};
-    if (a.a && n < a.N) {
-      const float* arow = (const float*)a.a + (long)n * a.a_sn;
-      for (int k = 0; k < a.K; ++k) {
-        const float av = arow[k];
+    if (tid < RPW * TPR) {
+      float s[4] = {0, 0, 0, 0};
+      if (a.a && n < a.N) {
+        const float* arow = (const float*)a.a + (long)n * a.a_sn;
+        for (int k = 0; k < a.K; ++k) {
+          const float av = arow[k];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = cb + q, j = col >> 4, u = u0 + (col & 15);
-          if (u < H) s[q] = fmaf(av, ((const float*)a.wT)[((long)j * H + u) * a.K + k], s[q]);
+          for (int q = 0; q < 4; ++q) {
+            const int col = cb + q, j = col / UPW, u = u0 + (col % UPW);
+            if (u < H) s[q] = fmaf(av, ((const float*)a.wT)[((long)j * H + u) * a.K + k], s[q]);
+          }
         }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      red[0][r][cb + q] = s[q];
+      for (int q = 0; q < 4; ++q) {
+        red[0][r][cb + q] = s[q];
 #pragma unroll
-      for (int w = 1; w < LW; ++w) red[w][r][cb + q] = 0.f;
+        for (int w = 1; w < LW; ++w) red[w][r][cb + q] = 0.f;
+      }
     }
   }
   __syncthreads();
@@ -170,7 +181,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     for (int j = 0; j < 4; ++j) {
       float v = pz[j];
 #pragma unroll
-      for (int w = 0; w < LW; ++w) v += red[w][r][j * 16 + uu];
+      for (int w = 0; w < LW; ++w) v += red[w][r][j * UPW + uu];
       z[j] = v;
     }
     const bool masked = pmask;
@@ -194,8 +205,15 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
 
 template <typename T>
 int lstm_step_launch2(const LstmStepPair<T>& a, hipStream_t s) {
-  dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
-  hipLaunchKernelGGL(lstm_step_kernel<T>, grid, dim3(LTHREADS), 0, s, a);
+  // few big tiles leave most CUs idle: switch to the small tiling when it still gives at most ~2 workgroups per CU
+  const int big = ceil_div(a.s[0].H, 16) * ceil_div(a.s[0].N, 32) * a.n;
+  if (a.s[0].H >= 256 && big <= 128) {
+    dim3 grid(ceil_div(a.s[0].H, 8), ceil_div(a.s[0].N, 16), a.n);
+    hipLaunchKernelGGL((lstm_step_kernel<T, true>), grid, dim3(LTHREADS), 0, s, a);
+  } else {
+    dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
+    hipLaunchKernelGGL((lstm_step_kernel<T, false>), grid, dim3(LTHREADS), 0, s, a);
+  }
   NS_CHECK_LAUNCH("lstm_step");
   return NS_OK;
 }
@@ -211,18 +229,19 @@ template int lstm_step_launch2<float>(const LstmStepPair<float>&, hipStream_t);
 template int lstm_step_launch2<bf16_t>(const LstmStepPair<bf16_t>&, hipStream_t);
 
 // ------------------------------------------------------------------ fused backward step
-template <typename T>
+template <typename T, bool HALF>
 __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair<T> pp) {
-  __shared__ float red[LW][32][17];
+  constexpr int UPW = HALF ? 8 : 16, RPW = HALF ? 16 : 32, MT = RPW / 16;
+  __shared__ float red[LW][RPW][17];
   const LstmBwdStep<T>& a = pp.s[blockIdx.z];
   const int tid = threadIdx.x;
-  const int u0 = blockIdx.x * 16;
-  const int nb = blockIdx.y * 32;
+  const int u0 = blockIdx.x * UPW;
+  const int nb = blockIdx.y * RPW;
   const int H = a.H;
   // epilogue operands first (see the forward kernel)
-  const int er = tid >> 4, euu = tid & 15;
+  const int er = tid / UPW, euu = tid % UPW;
   const int en = nb + er, eu = u0 + euu;
-  const bool eok = en < a.N && eu < H;
+  const bool eok = tid < RPW * UPW && en < a.N && eu < H;
   float pdh = 0.f, pgi = 0.f, pgj = 0.f, pgf = 0.f, pgo = 0.f, pc = 0.f, pcp = 0.f, pdc = 0.f;
   bool pmask = false;
   if (eok) {
@@ -239,117 +258,112 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
   if constexpr (sizeof(T) == 2) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.dg_next) {
       const int nkc = (a.K + 31) / 32;
       const bf16_t* arow0 = a.dg_next + (long)(nb + r16) * a.dgn_sn;
       const bf16_t* arow1 = a.dg_next + (long)(nb + 16 + r16) * a.dgn_sn;
-      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
-      const bool oku = u0 + r16 < H;
+      const bool ok0 = nb + r16 < a.N, ok1 = MT > 1 && nb + 16 + r16 < a.N;
+      const bool oku = r16 < UPW && u0 + r16 < H;
       const bf16_t* brow = a.w + (long)(u0 + r16) * a.K;
       for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
-        bf16x8 af[GROUP][2], bfr[GROUP];
+        bf16x8 af[GROUP][MT], bfr[GROUP];
 #pragma unroll
         for (int q = 0; q < GROUP; ++q) {
           const int k = (kc0 + q * LW) * 32 + g * 8;
           const bool okk = k < a.K;
           af[q][0] = (ok0 && okk) ? *(const bf16x8*)(arow0 + k) : zero8();
-          af[q][1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
+          if (MT > 1) af[q][MT - 1] = (ok1 && okk) ? *(const bf16x8*)(arow1 + k) : zero8();
           bfr[q] = (oku && okk) ? *(const bf16x8*)(brow + k) : zero8();
         }
 #pragma unroll
-        for (int q = 0; q < GROUP; ++q) {
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][0], bfr[q], acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][1], bfr[q], acc[1], 0, 0, 0);
-        }
+        for (int q = 0; q < GROUP; ++q)
+#pragma unroll
+          for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q], acc[i], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
   } else if (a.passes > 0) {
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const bool three = a.passes >= 3;
-    f32x4 acc[2];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (a.dg_next) {
       const int nkc = (a.K + 31) / 32;
       const float* arow0 = (const float*)a.dg_next + (long)(nb + r16) * a.dgn_sn;
       const float* arow1 = (const float*)a.dg_next + (long)(nb + 16 + r16) * a.dgn_sn;
-      const bool ok0 = nb + r16 < a.N, ok1 = nb + 16 + r16 < a.N;
-      const bool oku = u0 + r16 < H;
+      const bool ok0 = nb + r16 < a.N, ok1 = MT > 1 && nb + 16 + r16 < a.N;
+      const bool oku = r16 < UPW && u0 + r16 < H;
       const float* brow = (const float*)a.w + (long)(u0 + r16) * a.K;
       if (a.w_bf16 && !three) {
         const bf16_t* wrow = a.w_bf16 + (long)(u0 + r16) * a.K;
         const bf16_t* brow0 = a.dg_next_b ? a.dg_next_b + (long)(nb + r16) * a.dgn_sn : nullptr;
         const bf16_t* brow1 = a.dg_next_b ? a.dg_next_b + (long)(nb + 16 + r16) * a.dgn_sn : nullptr;
         for (int kc0 = wave; kc0 < nkc; kc0 += LW * GROUP) {
-          bf16x8 af[GROUP][2], bfr[GROUP];
+          bf16x8 af[GROUP][MT], bfr[GROUP];
 #pragma unroll
           for (int q = 0; q < GROUP; ++q) {
             const int k = (kc0 + q * LW) * 32 + g * 8;
             const bool okk = k < a.K;
             if (brow0) {
               af[q][0] = (ok0 && okk) ? *(const bf16x8*)(brow0 + k) : zero8();
-              af[q][1] = (ok1 && okk) ? *(const bf16x8*)(brow1 + k) : zero8();
+              if (MT > 1) af[q][MT - 1] = (ok1 && okk) ? *(const bf16x8*)(brow1 + k) : zero8();
             } else {
               bf16x8 dummy;
               ldsplit8(arow0 + k, ok0 && okk, af[q][0], dummy);
-              ldsplit8(arow1 + k, ok1 && okk, af[q][1], dummy);
+              if (MT > 1) ldsplit8(arow1 + k, ok1 && okk, af[q][MT - 1], dummy);
             }
             bfr[q] = (oku && okk) ? *(const bf16x8*)(wrow + k) : zero8();
           }
 #pragma unroll
-          for (int q = 0; q < GROUP; ++q) {
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][0], bfr[q], acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][1], bfr[q], acc[1], 0, 0, 0);
-          }
+          for (int q = 0; q < GROUP; ++q)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[q][i], bfr[q], acc[i], 0, 0, 0);
         }
       } else
       for (int kc0 = wave; kc0 < nkc; kc0 += LW * 2) {
-        bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
+        bf16x8 ah[2][MT], al[2][MT], bh[2], bl[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
           const int k = (kc0 + q * LW) * 32 + g * 8;
           const bool okk = k < a.K;
           ldsplit8(arow0 + k, ok0 && okk, ah[q][0], al[q][0]);
-          ldsplit8(arow1 + k, ok1 && okk, ah[q][1], al[q][1]);
-          if (false) {
-            bh[q] = (oku && okk) ? *(const bf16x8*)(a.w_bf16 + (long)(u0 + r16) * a.K + k) : zero8();
-            bl[q] = zero8();
-          } else {
-            ldsplit8(brow + k, oku && okk, bh[q], bl[q]);
-          }
+          if (MT > 1) ldsplit8(arow1 + k, ok1 && okk, ah[q][MT - 1], al[q][MT - 1]);
+          ldsplit8(brow + k, oku && okk, bh[q], bl[q]);
         }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-          for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < MT; ++i)
             acc[i] = three ? mfma_split<3>(ah[q][i], al[q][i], bh[q], bl[q], acc[i])
                            : mfma_split<1>(ah[q][i], al[q][i], bh[q], bl[q], acc[i]);
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
   } else {
-    const int r = tid >> 4, uu = tid & 15;
+    const int r = er, uu = euu;
     const int n = nb + r, u = u0 + uu;
-    float s = 0.f;
-    if (a.dg_next && n < a.N && u < H) {
-      const float* arow = (const float*)a.dg_next + (long)n * a.dgn_sn;
-      const float* brow = (const float*)a.w + (long)u * a.K;
-      for (int k = 0; k < a.K; ++k) s = fmaf(arow[k], brow[k], s);
-    }
-    red[0][r][uu] = s;
+    if (tid < RPW * UPW) {
+      float s = 0.f;
+      if (a.dg_next && n < a.N && u < H) {
+        const float* arow = (const float*)a.dg_next + (long)n * a.dgn_sn;
+        const float* brow = (const float*)a.w + (long)u * a.K;
+        for (int k = 0; k < a.K; ++k) s = fmaf(arow[k], brow[k], s);
+      }
+      red[0][r][uu] = s;
 #pragma unroll
-    for (int w = 1; w < LW; ++w) red[w][r][uu] = 0.f;
+      for (int w = 1; w < LW; ++w) red[w][r][uu] = 0.f;
+    }
   }
   __syncthreads();
 
@@ -381,8 +395,14 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
 
 template <typename T>
 int lstm_bwd_step_launch2(const LstmBwdStepPair<T>& a, hipStream_t s) {
-  dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
-  hipLaunchKernelGGL(lstm_bwd_step_kernel<T>, grid, dim3(LTHREADS), 0, s, a);
+  const int big = ceil_div(a.s[0].H, 16) * ceil_div(a.s[0].N, 32) * a.n;
+  if (a.s[0].H >= 256 && big <= 128) {
+    dim3 grid(ceil_div(a.s[0].H, 8), ceil_div(a.s[0].N, 16), a.n);
+    hipLaunchKernelGGL((lstm_bwd_step_kernel<T, true>), grid, dim3(LTHREADS), 0, s, a);
+  } else {
+    dim3 grid(ceil_div(a.s[0].H, 16), ceil_div(a.s[0].N, 32), a.n);
+    hipLaunchKernelGGL((lstm_bwd_step_kernel<T, false>), grid, dim3(LTHREADS), 0, s, a);
+  }
   NS_CHECK_LAUNCH("lstm_bwd_step");
   return NS_OK;
 }

@@ -204,6 +204,22 @@ def lstm_cluster(direction, p0, p1, work):
     L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_cluster_" + direction)
 
 
+def lstm_wide_supported(p, backward):
+    return bool(L.lib().ns_lstm_wide_supported(C.byref(p), int(backward)))
+
+
+def lstm_wide_work_floats(p):
+    fn = L.lib().ns_lstm_wide_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(p)) + 3) // 4
+
+
+def lstm_wide(direction, p, work):
+    """Persistent whole-sequence recurrence for wide cells (one launch); work[0] is the status word."""
+    fn = getattr(L.lib(), "ns_lstm_wide_fwd" if direction == "fwd" else "ns_lstm_wide_bwd")
+    L.check(fn(C.byref(p), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_wide_" + direction)
+
+
 def split_hi_lo(src, hi, lo, n):
     """hi = bf16(src), lo = bf16(src - hi)  (pre-split operands of the 3-pass products)."""
     p = L.struct("ns_split_params")
