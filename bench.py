@@ -53,19 +53,24 @@ def cpu_baseline(hp, seed, budget_s=25.0):
     sys.stderr.flush()
     lay, st = P.taco2_layout(hp, len(symbols))
     pv, sv = P.init_values(lay, st, seed)
-    N, Ti, To = 4, 160, 250
+    N, Ti, To = 8, 160, 500
     inputs, lengths, mel, lin = synthetic_batch(hp, N, Ti, To, seed)
     p = {k: torch.tensor(v, requires_grad=True) for k, v in pv.items()}
     p.update({k: torch.tensor(v) for k, v in sv.items()})
     hpd = hp.values()
     t0 = time.time()
-    out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin))
-    loss, _, _ = O.taco2_loss(hpd, out, torch.tensor(mel), torch.tensor(lin))
-    loss.backward()
+    steps = 0
+    while steps < 4 and (steps == 0 or time.time() - t0 < 12.0):     # about 10-30 s of CPU work
+        for v in p.values():
+            v.grad = None
+        out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin))
+        loss, _, _ = O.taco2_loss(hpd, out, torch.tensor(mel), torch.tensor(lin))
+        loss.backward()
+        steps += 1
     dt = time.time() - t0
-    return {"value": N * To / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": "1 train step (fwd+bwd, no Adam) at batch %d, T_in %d, T_out %d, fp32 torch-CPU oracle, %.1f s"
-                      % (N, Ti, To, dt)}
+    return {"value": steps * N * To / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
+            "sample": "%d train steps (fwd+bwd, no Adam) at batch %d, T_in %d, T_out %d, fp32 torch-CPU oracle, %.1f s"
+                      % (steps, N, Ti, To, dt)}
 
 
 def griffin_lim_bench(hp, with_cpu):
@@ -103,10 +108,10 @@ def griffin_lim_bench(hp, with_cpu):
         sys.stderr.write("[bench] griffin-lim cpu sample...\n")
         sys.stderr.flush()
         t0 = time.time()
-        AO.inv_spectrogram_tensorflow(spec[:200], hpd)       # bounded sample: 200 frames, 60 iterations
+        AO.inv_spectrogram_tensorflow(spec, hpd)             # the same 797 frames, 60 iterations
         dt = time.time() - t0
-        res["cpu_rtf"] = dt / ((199 * 250 + 1000) / hp.sample_rate)
-        res["cpu_sample"] = "float64 NumPy oracle, 200 frames (2.5 s of audio), 60 iterations, %.1f s" % dt
+        res["cpu_rtf"] = dt / ((796 * 250 + 1000) / hp.sample_rate)
+        res["cpu_sample"] = "float64 NumPy oracle, the same 797 frames (10 s of audio), 60 iterations, 1 thread, %.1f s" % dt
     return res
 
 
@@ -169,21 +174,31 @@ def main():
     ms = dt / args.steps * 1e3
     frames = args.batch * args.t_out * world
 
-    phases = None
+    # Two more steps outside the timed region, executed by EVERY rank (the step contains collectives):
+    # one with per-phase events, one with an event pair around every large GEMM launch.
+    model.timing = []
+    one_step()
+    torch.cuda.synchronize()
+    tm = model.timing
+    model.timing = None
+    phases = [(tm[i][0], tm[i - 1][1].elapsed_time(tm[i][1])) for i in range(1, len(tm))]
     if args.phases and rank == 0:
-        model.timing = []
-        one_step()
-        torch.cuda.synchronize()
-        tm = model.timing
-        model.timing = None
-        phases = [(tm[i][0], tm[i - 1][1].elapsed_time(tm[i][1])) for i in range(1, len(tm))]
         for name, v in phases:
             sys.stderr.write("%-20s %8.3f ms\n" % (name, v))
         sys.stderr.write("%-20s %8.3f ms\n" % ("total", sum(v for _, v in phases)))
+    from nspeech_amd import profiling
+    roof = profiling.roofline(model, one_step)
 
     if rank == 0:
-        from nspeech_amd import profiling
-        roof = profiling.roofline(model, one_step)
+        pd = dict(phases)
+        # decoder gate GEMMs: 2*N*[(768+1024)+(1024+1024)]*4096 flop per decoder step forward, x3 with
+        # the backward; measured over the two decoder-LSTM phases (hoisted input GEMMs + the recurrent launches)
+        hp_ = hp
+        S = args.t_out // hp_.outputs_per_step
+        D = hp_.decoder_lstm_units
+        gate_flop = 3 * 2.0 * args.batch * ((hp_.attention_dim + 2 * hp_.encoder_lstm_units + D) + (D + D)) * 4 * D * S
+        gate_ms = pd.get("dec_lstm", 0.0) + pd.get("dec_lstm_bwd", 0.0)
+        w_bytes = 2.0 * (2 * D) * 4 * D * 2          # recurrent weights of both cells, bf16
         res = {
             "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -193,6 +208,12 @@ def main():
                                    % (args.batch, args.t_in, args.t_out, hp.outputs_per_step),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss": loss},
             "roofline": roof,
+            "decoder_gates": {"gflop_fwd_bwd": gate_flop / 1e9, "ms": gate_ms,
+                              "achieved_TFLOPs": gate_flop / (gate_ms * 1e-3) / 1e12 if gate_ms else None,
+                              "frac_of_mfma_peak": gate_flop / (gate_ms * 1e-3) / 1e12 / 2500.0 if gate_ms else None,
+                              "bound": "weight stream / dependent-launch latency at M=32",
+                              "hbm_floor_ms": 2 * S * w_bytes / 8e12 * 1e3},
+            "phases_ms": {k: round(v, 3) for k, v in phases},
         }
         if world == 1:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)

@@ -586,45 +586,48 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
   mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
-// skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h)
-template <int PASSES>
+// skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h).
+// MT = 16-row tiles per workgroup (2: all 32 rows; 1: grid.y picks the half), NC = columns per workgroup
+// (16, or 8 = half a tile: 4x the workgroups with half the operand bytes each when N is small - these
+// launches are latency bound and a handful of workgroups leaves the load queues of most CUs idle).
+template <int PASSES, int MT, int NC>
 __global__ __launch_bounds__(SKW * 64) void gemm_skinny_f32_kernel(ns_gemm_params p) {
-  __shared__ float red[SKW][32][17];
+  __shared__ float red[SKW][16 * MT][17];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 16;
+  const int n0 = blockIdx.x * NC;
+  const int m0 = blockIdx.y * 16 * MT;
   const float* A = (const float*)p.A;
   const float* B = (const float*)p.B;
   const int r16 = lane & 15, g = lane >> 4;
-  f32x4 acc[2];
-  acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  acc[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int nkc = (p.K + 31) / 32;
-  const bool ok0 = r16 < p.M, ok1 = 16 + r16 < p.M, okn = n0 + r16 < p.N;
+  const bool ok0 = m0 + r16 < p.M, ok1 = MT > 1 && m0 + 16 + r16 < p.M, okn = r16 < NC && n0 + r16 < p.N;
   for (int kc0 = wave; kc0 < nkc; kc0 += SKW * 2) {
-    bf16x8 ah[2][2], al[2][2], bh[2], bl[2];
+    bf16x8 ah[2][MT], al[2][MT], bh[2], bl[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int k = (kc0 + q * SKW) * 32 + g * 8;
       const bool okk = k < p.K;
-      ldsplit8(A + (long)r16 * p.lda + k, ok0 && okk, ah[q][0], al[q][0]);
-      ldsplit8(A + (long)(16 + r16) * p.lda + k, ok1 && okk, ah[q][1], al[q][1]);
+      ldsplit8(A + (long)(m0 + r16) * p.lda + k, ok0 && okk, ah[q][0], al[q][0]);
+      if (MT > 1) ldsplit8(A + (long)(m0 + 16 + r16) * p.lda + k, ok1 && okk, ah[q][MT - 1], al[q][MT - 1]);
       ldsplit8(B + (long)(n0 + r16) * p.ldb + k, okn && okk, bh[q], bl[q]);
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      acc[0] = mfma_split<PASSES>(ah[q][0], al[q][0], bh[q], bl[q], acc[0]);
-      acc[1] = mfma_split<PASSES>(ah[q][1], al[q][1], bh[q], bl[q], acc[1]);
-    }
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = mfma_split<PASSES>(ah[q][i], al[q][i], bh[q], bl[q], acc[i]);
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 4; ++r) red[wave][i * 16 + g * 4 + r][r16] = acc[i][r];
   __syncthreads();
   Epi e = make_epi(p);
-  for (int idx = tid; idx < 32 * 16; idx += SKW * 64) {
-    const int mm = idx >> 4, nn = idx & 15;
-    const int m = mm, n = n0 + nn;
+  for (int idx = tid; idx < 16 * MT * NC; idx += SKW * 64) {
+    const int mm = idx / NC, nn = idx % NC;
+    const int m = m0 + mm, n = n0 + nn;
     if (m >= p.M || n >= p.N) continue;
     float v = 0.f;
 #pragma unroll
@@ -702,8 +705,14 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     const bool three = p.f32_passes >= 3;
     if (ok && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 && !p.col_sum &&
         p.K % 8 == 0 && p.lda % 4 == 0) {
-      if (three) hipLaunchKernelGGL(gemm_skinny_f32_kernel<3>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
-      else hipLaunchKernelGGL(gemm_skinny_f32_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
+      if (ceil_div(p.N, 16) <= 64) {      // few column tiles: 16 rows x 8 columns per workgroup
+        const dim3 grid(ceil_div(p.N, 8), ceil_div(p.M, 16));
+        if (three) hipLaunchKernelGGL((gemm_skinny_f32_kernel<3, 1, 8>), grid, dim3(SKW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 1, 8>), grid, dim3(SKW * 64), 0, stream, p);
+      } else {
+        if (three) hipLaunchKernelGGL((gemm_skinny_f32_kernel<3, 2, 16>), dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_skinny_f32_kernel<1, 2, 16>), dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
+      }
       NS_CHECK_LAUNCH("gemm_skinny_f32");
       return NS_OK;
     }

@@ -374,7 +374,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_bwd_kernel(LstmClusterA
 // Exchange layout (per chain and parity): a publishing lane's granules are contiguous, so one base
 // register + immediates address them; the poller decodes granule index -> (row, k) when it fills LDS.
 constexpr int XW = 4;
-constexpr int FW_WAVES = XW + 2;
+constexpr int FW_WAVES = XW + 3;         // compute, poller, saver, prefetcher
 constexpr int BW_POLL = 2;
 constexpr int BW_WAVES = XW + 1 + BW_POLL + 1;   // compute, publisher, pollers, prefetcher
 constexpr int XG_LD = 256 + 4;          // floats per row of the xg stage (pad: rows 4 apart hit different banks)
@@ -392,7 +392,10 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
   const int CS = HB;
   bf16_t* hs = (bf16_t*)smem;                                   // [2][16][H] swizzled
   float* xgs = (float*)(smem + (size_t)2 * 16 * H * 2);         // [2][16][XG_LD]: row, gate * 64 + unit
-  int* abortf = (int*)(xgs + 2 * 16 * XG_LD);                   // [2]
+  // this slot's results for the saver wave: h bf16 [16][64], c f32 [16][64], gates bf16 [16][4][64]  (2 + 4 + 8 KB)
+  constexpr int SV_H = 16 * 64 * 2, SV_C = 16 * 64 * 4, SV_G = 16 * 4 * 64 * 2, SV_BYTES = SV_H + SV_C + SV_G;
+  char* svs = (char*)(xgs + 2 * 16 * XG_LD);                    // [2][SV_BYTES]
+  int* abortf = (int*)(svs + 2 * SV_BYTES);                     // [2]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nsets = ((a.N + 15) / 16 + R - 1) / R;
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
   u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * 16 * GPR;   // + rg * 2*16*GPR + parity * 16*GPR
   const int u0 = wgc * 64;
   const int T = a.T, Q = a.T * R;
-  if (tid < 2) abortf[tid] = 0;
+  if (tid < 3) abortf[tid] = 0;
 
   if (wave < XW) {
     // ================================================================ compute role
@@ -479,26 +482,23 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
           }
         }
         if (tr) a.trace[q * 8 + 2] = wall_clock64();
-        // saves for the backward pass / the consumers of h
+        // results for the backward pass / the consumers of h go to LDS; the saver wave writes them out
         {
-          bf16_t* __restrict__ hp_ = a.h[d];
-          float* __restrict__ cp_ = a.c[d];
-          bf16_t* __restrict__ gp_ = a.gates[d];
-          const unsigned row0 = (unsigned)((n0 + g * 4) * a.P + a.padl + t);   // 32-bit element offsets (host-checked)
+          char* sv = svs + (size_t)buf * SV_BYTES;
+          const int wu = wave * 16 + r16;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            if (n0 + g * 4 + r < a.N) {
-              const unsigned rowi = row0 + (unsigned)(r * a.P);
-              hp_[rowi * (unsigned)a.ld_h + (unsigned)unit] = (bf16_t)hv[r];
-              cp_[rowi * (unsigned)H + (unsigned)unit] = cst[rg][r];
-              const unsigned go = rowi * (unsigned)(4 * H) + (unsigned)unit;
+            const int row = g * 4 + r;
+            ((bf16_t*)sv)[row * 64 + wu] = (bf16_t)hv[r];
+            ((float*)(sv + SV_H))[row * 64 + wu] = cst[rg][r];
+            bf16_t* gp = (bf16_t*)(sv + SV_H + SV_C) + row * 4 * 64 + wu;
 #pragma unroll
-              for (int gate = 0; gate < 4; ++gate) gp_[go + (unsigned)(gate * H)] = (bf16_t)sg[r][gate];
-            }
+            for (int gate = 0; gate < 4; ++gate) gp[gate * 64] = (bf16_t)sg[r][gate];
           }
         }
       }
     }
+    wg_barrier();
   } else if (wave == XW) {
     // ================================================================ poller role
     static_assert(16 * GPR == FW_PG * 64, "poller coverage");
@@ -539,6 +539,42 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
       wg_barrier();
       if (abortf[buf]) return;
     }
+    wg_barrier();
+  } else if (wave == XW + 2) {
+    // ================================================================ saver role (stores only)
+    // Runs one slot behind the compute waves (slot q-1 is complete once barrier q has passed), so its store
+    // issue overlaps their next slot.  Per slot: h 128 chunks of 16 B, c 256, gates 512 -> 14 per lane.
+    auto save = [&](int q) {
+      const int step = q / R, rg = q % R;
+      const int t = d ? T - 1 - step : step;
+      const int n0 = (rg0 + rg) * 16;
+      const char* sv = svs + (size_t)(q & 1) * SV_BYTES;
+#pragma unroll
+      for (int j = 0; j < 14; ++j) {
+        const int idx = lane + 64 * j;
+        const f32x4 v = *(const f32x4*)(sv + idx * 16);
+        if (idx < 128) {
+          const int row = idx >> 3, cc = idx & 7;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.h[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)a.ld_h + (unsigned)(u0 + cc * 8))) = v;
+        } else if (idx < 384) {
+          const int jj = idx - 128, row = jj >> 4, cc = jj & 15;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.c[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)H + (unsigned)(u0 + cc * 4))) = v;
+        } else {
+          const int jj = idx - 384, row = jj >> 5, gate = (jj >> 3) & 3, cc = jj & 7;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.gates[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)(4 * H) + (unsigned)(gate * H + u0 + cc * 8))) = v;
+        }
+      }
+    };
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q > 0) save(q - 1);
+    }
+    wg_barrier();
+    save(Q - 1);
   } else {
     // ================================================================ prefetcher role
     // stage row j, gate = lane / 16, 4 floats at (lane % 16) * 4
@@ -571,6 +607,7 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
         if (q + 2 < Q) pf_load(q + 2);
       }
     }
+    wg_barrier();
   }
 }
 
@@ -871,7 +908,7 @@ static bool role_split_ok(const LstmClusterArgs& a, bool bwd) {
   if ((long)a.N * a.P * (widest > a.ld_dh ? widest : a.ld_dh) >= (1L << 31)) return false;   // 32-bit element offsets
   auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
   for (int d = 0; d < 2; ++d) {
-    if (!bwd && !(al16(a.xg[d]) && a.ld_xg % 4 == 0)) return false;
+    if (!bwd && !(al16(a.xg[d]) && a.ld_xg % 4 == 0 && al16(a.h[d]) && a.ld_h % 8 == 0 && al16(a.c[d]) && al16(a.gates[d]))) return false;
     if (bwd && !(al16(a.dh[d]) && a.ld_dh % 4 == 0 && al16(a.c[d]) && al16(a.gates[d]) && al16(a.dgates[d]))) return false;
   }
   return true;
@@ -893,7 +930,7 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   const size_t xbytes = (chains + 2) * 2 * 16 * (size_t)(a.H / 2) * sizeof(u64);
   if (hipMemsetAsync(work, 0, 256 + FLAG_BYTES + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
   if (role_split_ok(a, false)) {
-    const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 16;
+    const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 2 * (2048 + 4096 + 8192) + 32;
     const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && !(a.dbg & 32)) ? 2 : 1;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * a.CS)), block(FW_WAVES * 64);
 #define NS_LAUNCH_F(HB_) \

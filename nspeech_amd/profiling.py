@@ -22,7 +22,8 @@ def roofline(model, one_step):
         e0.record()
         orig(A, B, Cm, M, N, K, *a, **kw)
         e1.record()
-        rec.append((2.0 * M * N * K, e0, e1, passes))
+        esz = A.element_size()
+        rec.append((2.0 * M * N * K, e0, e1, passes, float(M * K + K * N) * esz + float(M * N) * Cm.element_size()))
 
     ops.gemm = timed
     try:
@@ -36,8 +37,21 @@ def roofline(model, one_step):
     issued = sum(r[0] * r[3] for r in rec)         # MFMA work actually issued (x3 for split-bf16)
     ms = sum(r[1].elapsed_time(r[2]) for r in rec)
     ach = flops / (ms * 1e-3) / 1e12
+    # memory-side traffic of the same kernels from the PMC passes kept under profiles/ (collected offline: rocprofv3
+    # refuses --pmc together with the trace domains this bench would need, and a counter pass serialises the step)
+    traffic = None
+    try:
+        import json
+        import os
+        f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
+        traffic = float(json.load(open(f))["traffic_bytes_per_launch"])
+    except Exception:
+        pass
     return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv1d / dense / LSTM input + all weight and data gradients)",
             "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
             "launches": len(rec), "avg_launch_us": ms * 1e3 / len(rec), "gflop_per_step": flops / 1e9,
             "issued_mfma_tflops": issued / (ms * 1e-3) / 1e12,
-            "traffic": None}
+            "algorithmic_bytes_per_launch": sum(r[4] for r in rec) / len(rec),
+            "traffic": traffic,
+            "traffic_note": "bytes per launch at the L2's fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
+                            "included), rocprofv3 --pmc passes summarised in profiles/r01_pmc_traffic.json"}
