@@ -60,7 +60,7 @@ def cpu_baseline(hp, seed, budget_s=25.0):
     hpd = hp.values()
     t0 = time.time()
     steps = 0
-    while steps < 4 and (steps == 0 or time.time() - t0 < 12.0):     # about 10-30 s of CPU work
+    while steps < 16 and (steps == 0 or time.time() - t0 < 12.0):    # about 10-30 s of CPU work
         for v in p.values():
             v.grad = None
         out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin))
@@ -113,6 +113,32 @@ def griffin_lim_bench(hp, with_cpu):
         res["cpu_rtf"] = dt / ((796 * 250 + 1000) / hp.sample_rate)
         res["cpu_sample"] = "float64 NumPy oracle, the same 797 frames (10 s of audio), 60 iterations, 1 thread, %.1f s" % dt
     return res
+
+
+def inference_bench(hp, dtype, seed=1234):
+    """Free-running synthesis (SURVEY 8d, C2 eval / C4): mel frames per second at batch 1 and 32, max_iters 300
+    (the reference default) - the whole pass: encoder, 300 decoder steps, postnet, expand net, linear head."""
+    import copy
+    out = {}
+    for N in (1, 32):
+        hpi = copy.deepcopy(hp)
+        hpi.max_iters = 300
+        m = create_model("taco2", hpi, device="cuda:%d" % torch.cuda.current_device(), dtype=dtype, seed=seed)
+        inputs, lengths, _, _ = synthetic_batch(hpi, N, 160, 10, seed)
+        for _ in range(3):                       # eager pass, graph capture, first replay
+            m.initialize(inputs, lengths)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            m.initialize(inputs, lengths)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        frames = N * 300 * hpi.outputs_per_step
+        out["batch_%d" % N] = {"mel_frames_per_s": frames / dt, "ms": dt * 1e3, "decoder_steps": 300,
+                               "rtf": dt / (300 * hpi.outputs_per_step * hpi.frame_shift_ms * 1e-3)}
+        del m
+    return out
 
 
 def main():
@@ -217,6 +243,7 @@ def main():
         }
         if world == 1:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
+            res["inference"] = inference_bench(hp, args.dtype)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hp, 1234)
         print(json.dumps(res))

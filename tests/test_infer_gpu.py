@@ -37,6 +37,24 @@ def test_inference_matches_oracle(dev, trained):
         assert np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), name
 
 
+def test_inference_graph_replay_matches_eager(dev):
+    """Second call with one signature captures a HIP graph, later calls replay it: new inputs and lengths (same
+    shapes) must give what a fresh eager pass gives, in the mode the bench uses."""
+    from nspeech_amd.models import create_model
+    hp = small_hparams(max_iters=5)
+    m = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=3)
+    e = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=3)
+    e.use_graph = False
+    for seed in (1, 2, 3, 4):           # eager, capture + replay, replay, replay
+        inputs, lengths, _, _ = make_batch(hp, 3, 11, 10, seed=seed)
+        m.initialize(inputs, lengths)
+        e.initialize(inputs, lengths)
+        assert (m._infer_graph["graph"] is not None) == (seed > 1)
+        for name in ("mel_outputs", "linear_outputs", "alignments"):
+            got, ref = getattr(m, name).float(), getattr(e, name).float()
+            assert torch.equal(got, ref), (seed, name, (got - ref).abs().max().item())
+
+
 def test_synthesizer_end_to_end(dev):
     from nspeech_amd import hparams as hparams_mod
     from nspeech_amd.synthesizer import Synthesizer
