@@ -1,16 +1,33 @@
-"""Minimal synchronous feeder for train.py (the reference's threaded DataFeeder is SURVEY row F2,
-scheduled after the hot path): reads an LJSpeech-layout directory (metadata.csv + wavs/,
-corpus/ljspeech.py:4-11), computes both spectrograms with the GPU feature kernels, buckets by
-length like datafeeder.py:139-147 (groups of batch_size*batch_group_size sorted by frame count) and
-pads exactly like datafeeder.py:189-220 (inputs with 0, targets with 0 up to a multiple of r after
-+1 frame of silence)."""
+"""Training data feeder (datasets/datafeeder.py:19-220 of the reference).
+
+Same batching semantics as the reference:
+  * the item list is walked in order and reshuffled at every wrap-around (`_get_next_example`,
+    datafeeder.py:157-181); processed utterances are cached in RAM (`processed_data`);
+  * a group of batch_size * batch_group_size examples is sorted by target length and cut into
+    batches, the batches are shuffled, and every batch is shuffled internally
+    (`_enqueue_next_group` :139-147, `_prepare_batch` :190);
+  * inputs are padded with 0 to the longest, targets with 0 to (longest + 1) rounded up to a
+    multiple of outputs_per_step (`_prepare_targets` :204-206, `_round_up` :218-220);
+  * with a CMUDict (`use_cmudict`, commented out in the reference, :96-108) half of the sentences
+    get each word replaced by its `{ARPAbet}` spelling with probability 0.5 (:178-186);
+  * a background thread keeps up to 8 prepared batches queued (the reference's FIFOQueue(8), :72).
+
+MI355X-side differences: both spectrograms of an utterance come from ONE pass of the fused GPU
+feature kernel (`audio.spectrogram_and_mel`) instead of two librosa STFTs in worker threads, and for
+data-parallel runs the sorted group is dealt round-robin over the ranks so that every
+rank sees the same length mix: rank r takes examples r, r + world, ... of the sorted group."""
 import os
+import queue
 import random
+import threading
 
 import numpy as np
 
 from ..utils import audio
 from ..utils.text import text_to_sequence
+
+_p_cmudict = 0.5      # datafeeder.py:16
+_pad = 0              # datafeeder.py:17
 
 
 def _round_up(x, m):
@@ -19,6 +36,7 @@ def _round_up(x, m):
 
 
 def load_ljspeech_metadata(path):
+    """corpus/ljspeech.py:4-11: `id|raw text|normalised text` -> (wavs/id.wav, normalised text)."""
     items = []
     with open(os.path.join(path, "metadata.csv"), encoding="utf-8") as f:
         for line in f:
@@ -30,45 +48,116 @@ def load_ljspeech_metadata(path):
     return items
 
 
+def prepare_batch(batch, outputs_per_step, rng):
+    """datafeeder.py:189-220.  batch: list of (ids, speaker_id, mel [T,M], linear [T,F])."""
+    batch = list(batch)
+    rng.shuffle(batch)
+    Ti = max(len(e[0]) for e in batch)
+    To = _round_up(max(e[3].shape[0] for e in batch) + 1, outputs_per_step)
+    N = len(batch)
+    inputs = np.full((N, Ti), _pad, np.int32)
+    lengths = np.zeros((N,), np.int32)
+    speakers = np.zeros((N,), np.int32)
+    mel = np.full((N, To, batch[0][2].shape[1]), _pad, np.float32)
+    lin = np.full((N, To, batch[0][3].shape[1]), _pad, np.float32)
+    for i, (ids, spk, m, l) in enumerate(batch):
+        inputs[i, :len(ids)] = ids
+        lengths[i] = len(ids)
+        speakers[i] = spk
+        mel[i, :m.shape[0]] = m
+        lin[i, :l.shape[0]] = l
+    return inputs, lengths, speakers, mel, lin
+
+
 class DataFeeder(object):
-    def __init__(self, hparams, ljspeech=None, seed=0):
+    """next_batch() -> (inputs [N,T_in] int32, input_lengths [N], mel [N,T_out,M], linear [N,T_out,F]);
+    `speaker_ids` of the last batch are kept in .speaker_ids (single-speaker corpora: zeros)."""
+
+    def __init__(self, hparams, ljspeech=None, seed=0, rank=0, world=1, cmudict=None, prefetch=True, features=None,
+                 loader=None):
         self.hp = hparams
         self.items = load_ljspeech_metadata(ljspeech) if ljspeech else []
-        self.cache = {}
-        self.rng = random.Random(seed)
-        self.cleaners = [x.strip() for x in hparams.cleaners.split(",")]
-        self._batches = []
         assert self.items, "no training data found"
+        self.rank, self.world = rank, world
+        self.cleaners = [x.strip() for x in hparams.cleaners.split(",")]
+        self.cache = {}                       # wav path -> (mel, linear), the reference's processed_data
+        # every rank walks the SAME shuffled item order (shared seed) and deals the sorted group; the
+        # CMUDict coin flips and in-batch shuffles use a rank-local generator
+        self._order_rng = random.Random(seed)
+        self._rng = random.Random(seed * 7919 + rank)
+        self._offset = 0
+        self._cmudict = cmudict
+        self._features = features or audio.spectrogram_and_mel
+        self._loader = loader or audio.load_wav
+        self.speaker_ids = None
+        self._queue = queue.Queue(maxsize=8) if prefetch else None
+        self._thread = None
+        self._pending = []
+        self._error = None
 
-    def _example(self, idx):
-        if idx not in self.cache:
-            wav_path, text = self.items[idx]
-            wav = audio.load_wav(wav_path)
-            lin, mel = audio.spectrogram_and_mel(wav)
-            ids = np.asarray(text_to_sequence(text, self.cleaners), dtype=np.int32)
-            self.cache[idx] = (ids, mel.T.astype(np.float32), lin.T.astype(np.float32))
-        return self.cache[idx]
+    # ------------------------------------------------------------------ examples
+    def _maybe_get_arpabet(self, word):
+        arpabet = self._cmudict.lookup(word)
+        return "{%s}" % arpabet[0] if arpabet is not None and self._rng.random() < 0.5 else word
+
+    def _get_next_example(self):
+        if self._offset >= len(self.items):
+            self._offset = 0
+            self._order_rng.shuffle(self.items)
+        wav_path, text = self.items[self._offset]
+        self._offset += 1
+        if wav_path not in self.cache:
+            lin, mel = self._features(self._loader(wav_path))
+            self.cache[wav_path] = (np.ascontiguousarray(mel.T, np.float32), np.ascontiguousarray(lin.T, np.float32))
+        mel, lin = self.cache[wav_path]
+        if self._cmudict and self._rng.random() < _p_cmudict:
+            text = " ".join(self._maybe_get_arpabet(w) for w in text.split(" "))
+        ids = np.asarray(text_to_sequence(text, self.cleaners), dtype=np.int32)
+        return ids, 0, mel, lin
+
+    def _next_group(self):
+        n, r = self.hp.batch_size, self.hp.outputs_per_step
+        per_rank = n * self.hp.batch_group_size
+        if self.world == 1:
+            examples = [self._get_next_example() for _ in range(per_rank)]
+            examples.sort(key=lambda e: e[3].shape[0])
+        else:
+            # every rank walks the same per_rank * world items (cheap for the ones it does not keep: the target
+            # length is all the sort needs, but the features are cached anyway), sorts, and keeps its share
+            group = [self._get_next_example() for _ in range(per_rank * self.world)]
+            group.sort(key=lambda e: e[3].shape[0])
+            examples = group[self.rank::self.world]
+        batches = [examples[i:i + n] for i in range(0, len(examples), n)]
+        self._order_rng.random()              # keeps the shared generator in step across ranks
+        self._rng.shuffle(batches)
+        return [prepare_batch(b, r, self._rng) for b in batches]
+
+    # ------------------------------------------------------------------ queue
+    def _worker(self):
+        try:
+            while True:
+                for b in self._next_group():
+                    self._queue.put(b)
+        except Exception as e:              # surfaced by next_batch()
+            self._error = e
+            self._queue.put(None)
+
+    def start(self):
+        if self._queue is not None and self._thread is None:
+            self._thread = threading.Thread(target=self._worker, name="datafeeder", daemon=True)
+            self._thread.start()
+        return self
 
     def next_batch(self):
-        hp = self.hp
-        if not self._batches:
-            n, r = hp.batch_size, hp.outputs_per_step
-            group = [self._example(self.rng.randrange(len(self.items))) for _ in range(n * hp.batch_group_size)]
-            group.sort(key=lambda e: e[1].shape[0])
-            self._batches = [group[i:i + n] for i in range(0, len(group), n)]
-            self.rng.shuffle(self._batches)
-        batch = self._batches.pop()
-        r = hp.outputs_per_step
-        Ti = max(len(e[0]) for e in batch)
-        To = _round_up(max(e[1].shape[0] for e in batch) + 1, r)
-        N = len(batch)
-        inputs = np.zeros((N, Ti), np.int32)
-        lengths = np.zeros((N,), np.int32)
-        mel = np.zeros((N, To, hp.num_mels), np.float32)
-        lin = np.zeros((N, To, hp.num_freq), np.float32)
-        for i, (ids, m, l) in enumerate(batch):
-            inputs[i, :len(ids)] = ids
-            lengths[i] = len(ids)
-            mel[i, :m.shape[0]] = m
-            lin[i, :l.shape[0]] = l
+        if self._queue is not None:
+            self.start()
+            b = self._queue.get()
+            if b is None:
+                raise self._error
+        else:
+            if not self._pending:
+                self._pending = self._next_group()
+            b = self._pending.pop(0)
+        inputs, lengths, speakers, mel, lin = b
+        self.speaker_ids = speakers
         return inputs, lengths, mel, lin

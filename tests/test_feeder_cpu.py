@@ -1,0 +1,116 @@
+"""Batching semantics of the training feeder against the reference's rules (datafeeder.py:139-220): epoch walk,
+length bucketing, padding (+1 frame, multiple of r), in-RAM cache, CMUDict substitution, the prefetch thread and
+the round-robin dealing over data-parallel ranks.  Feature extraction is stubbed (it needs the GPU)."""
+import os
+
+import numpy as np
+
+from nspeech_amd import hparams as hparams_mod
+from nspeech_amd.datasets.datafeeder import DataFeeder, prepare_batch, _round_up
+from nspeech_amd.utils.text import cmudict, sequence_to_text
+
+
+def _corpus(tmp_path, n):
+    os.makedirs(tmp_path / "wavs", exist_ok=True)
+    words = ["hello", "world", "speech", "street", "turn", "left", "right", "now"]
+    with open(tmp_path / "metadata.csv", "w") as f:
+        for i in range(n):
+            text = " ".join(words[(i * 3 + j) % len(words)] for j in range(2 + i % 5))
+            f.write("utt%03d|raw|%s\n" % (i, text))
+    return str(tmp_path)
+
+
+def _stubs(hp):
+    calls = []
+
+    def loader(path):
+        i = int(os.path.basename(path)[3:6])
+        return np.zeros(250 * (20 + (i * 7) % 31), np.float32)          # 20..50 frames
+
+    def features(wav):
+        calls.append(len(wav))
+        T = 1 + len(wav) // 250
+        return np.full((hp.num_freq, T), 0.5, np.float32), np.full((hp.num_mels, T), 0.25, np.float32)
+    return loader, features, calls
+
+
+def _hp(**kw):
+    hp = hparams_mod.load("taco2")
+    hp.batch_size, hp.batch_group_size, hp.outputs_per_step = 4, 3, 5
+    for k, v in kw.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def test_padding_rule_and_lengths():
+    rng = __import__("random").Random(0)
+    batch = [(np.arange(2, 2 + L, dtype=np.int32), 0, np.ones((T, 80), np.float32), np.ones((T, 1025), np.float32))
+             for L, T in ((5, 17), (9, 24), (3, 20))]
+    inputs, lengths, speakers, mel, lin = prepare_batch(batch, 5, rng)
+    assert inputs.shape == (3, 9) and mel.shape == (3, 25, 80) and lin.shape == (3, 25, 1025)   # round_up(24 + 1, 5)
+    assert sorted(lengths.tolist()) == [3, 5, 9]
+    for i in range(3):
+        assert (inputs[i, lengths[i]:] == 0).all() and (inputs[i, :lengths[i]] != 0).all()
+        T = int(mel[i, :, 0].sum())
+        assert (mel[i, T:] == 0).all() and (lin[i, T:] == 0).all()
+    assert _round_up(25, 5) == 25 and _round_up(26, 5) == 30
+    batch2 = [(np.arange(2, 6, dtype=np.int32), 0, np.ones((20, 80), np.float32), np.ones((20, 1025), np.float32))]
+    assert prepare_batch(batch2, 5, rng)[3].shape[1] == 25                                         # 20 + 1 -> 25
+
+
+def test_epoch_walk_bucketing_and_cache(tmp_path):
+    hp = _hp()
+    root = _corpus(tmp_path, 24)
+    loader, features, calls = _stubs(hp)
+    f = DataFeeder(hp, ljspeech=root, seed=3, prefetch=False, features=features, loader=loader)
+    group = [f.next_batch() for _ in range(3)]            # one group = 3 batches of 4
+    assert len(calls) == 12                                # 12 utterances processed, each once
+    lens = [sorted(int(m[:, :, 0].sum(axis=1)[i]) for i in range(4)) for _, _, m, _ in group]
+    flat = sorted(x for b in lens for x in b)
+    runs = sorted(lens, key=lambda b: b[0])
+    assert [x for b in runs for x in b] == flat            # batches are contiguous runs of the sorted group
+    [f.next_batch() for _ in range(3)]                     # second group: the other 12 utterances
+    assert len(calls) == 24
+    [f.next_batch() for _ in range(3)]                     # wrap-around: reshuffled, served from the cache
+    assert len(calls) == 24 and len(f.cache) == 24
+
+
+def test_prefetch_thread_matches_synchronous(tmp_path):
+    hp = _hp()
+    root = _corpus(tmp_path, 30)
+    out = []
+    for prefetch in (False, True):
+        loader, features, _ = _stubs(hp)
+        f = DataFeeder(hp, ljspeech=root, seed=5, prefetch=prefetch, features=features, loader=loader)
+        out.append([f.next_batch() for _ in range(7)])
+    for a, b in zip(*out):
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+
+
+def test_rank_dealing(tmp_path):
+    hp = _hp()
+    root = _corpus(tmp_path, 40)
+    per_rank = []
+    for rank in range(2):
+        loader, features, _ = _stubs(hp)
+        f = DataFeeder(hp, ljspeech=root, seed=9, rank=rank, world=2, prefetch=False, features=features, loader=loader)
+        batches = [f.next_batch() for _ in range(3)]
+        per_rank.append(sorted(int(t) for _, _, m, _ in batches for t in m[:, :, 0].sum(axis=1)))
+    # the two ranks split one sorted group of 24 alternately: their sorted lengths interleave
+    merged = sorted(per_rank[0] + per_rank[1])
+    assert merged[0::2] == per_rank[0] and merged[1::2] == per_rank[1]
+
+
+def test_cmudict_substitution(tmp_path):
+    hp = _hp()
+    root = _corpus(tmp_path, 12)
+    d = cmudict.CMUDict(__import__("io").StringIO("HELLO  HH AH0 L OW1\nWORLD  W ER1 L D\nSTREET  S T R IY1 T\n"))
+    loader, features, _ = _stubs(hp)
+    f = DataFeeder(hp, ljspeech=root, seed=1, prefetch=False, cmudict=d, features=features, loader=loader)
+    texts = []
+    for _ in range(12):
+        inputs, lengths, _, _ = f.next_batch()
+        texts += [sequence_to_text(inputs[i, :lengths[i]]) for i in range(len(lengths))]
+    assert any("{HH AH0 L OW1}" in t for t in texts) and any("hello" in t for t in texts)
+    assert all(t.endswith("~") for t in texts)

@@ -64,7 +64,17 @@ def train(log_dir, args):
     log("Checkpoint path: %s" % os.path.join(log_dir, "model.ckpt"), logf)
     log(hparams_mod.debug_string(hp), logf)
     from nspeech_amd.datasets.datafeeder import DataFeeder
-    feeder = DataFeeder(hp, ljspeech=args.ljspeech, seed=1234 + rank)
+    cmu = None
+    if getattr(hp, "use_cmudict", False):       # datafeeder.py:96-108 (commented out in the reference)
+        from nspeech_amd.utils.text import cmudict
+        cmudict_path = os.path.join(args.ljspeech, "cmudict-0.7b")
+        if not os.path.isfile(cmudict_path):
+            raise Exception("If use_cmudict=True, you must download "
+                            "http://svn.code.sf.net/p/cmusphinx/code/trunk/cmudict/cmudict-0.7b to %s" % cmudict_path)
+        cmu = cmudict.CMUDict(cmudict_path, keep_ambiguous=False)
+        log("Loaded CMUDict with %d unambiguous entries" % len(cmu), logf)
+    # shared seed: every rank walks the same item order and keeps its round-robin share of each sorted group
+    feeder = DataFeeder(hp, ljspeech=args.ljspeech, seed=1234, rank=rank, world=world, cmudict=cmu).start()
     model = create_model(args.model, hp, device="cuda:%d" % local, dtype=args.precision, world_size=world)
     step0 = 0
     if args.restore_step:
