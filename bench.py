@@ -158,11 +158,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # NSPEECH_DIST_BACKEND=gloo lets the multi-rank flow be rehearsed with several ranks on ONE GPU (tests); the
+    # driver's runs use nccl = RCCL, one rank per GPU
+    backend = os.environ.get("NSPEECH_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     hp = hparams_mod.load("taco2")
     model = create_model("taco2", hp, device="cuda:%d" % local, dtype=args.dtype, seed=1234, world_size=world)
     if world > 1:
