@@ -161,8 +161,11 @@ int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t stream);
 /* ------------------------------------------------------------------ optimizer
  * tf.clip_by_global_norm + tf.train.AdamOptimizer (tacotron2.py:150-161).
  * ns_sumsq: out[0] += sum g^2.   ns_adam: scale = clip / max(sqrt(gnorm_sq[0]), clip);
- * m,v,p updated in place with lr_t (bias-corrected on the host); optional bf16 shadow copy. */
-typedef struct { const float* x; int64_t n; float* out; } ns_sumsq_params;
+ * m,v,p updated in place with lr_t (bias-corrected on the host); optional bf16 shadow copy.
+ * With `work` (fp32[1032], zeroed once by the caller) the sum is formed in a FIXED order (per-block partials, then the
+ * last block to arrive adds them up in index order), so identical inputs give bit-identical norms on every
+ * data-parallel rank; without it the block sums meet in one float atomic (order varies from run to run). */
+typedef struct { const float* x; int64_t n; float* out; float* work; } ns_sumsq_params;
 int ns_sumsq(const ns_sumsq_params* p, ns_stream_t stream);
 typedef struct {
   float* p; const float* g; float* m; float* v; int64_t n;

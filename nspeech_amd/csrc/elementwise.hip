@@ -271,6 +271,7 @@ extern "C" int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t s) {
 // ------------------------------------------------------------------ sum of squares / Adam
 __global__ void sumsq_kernel(ns_sumsq_params p) {
   __shared__ float red[32];
+  __shared__ int last;
   float s = 0.f;
   const long n4 = p.n / 4;
   const float4* x4 = (const float4*)p.x;
@@ -281,7 +282,28 @@ __global__ void sumsq_kernel(ns_sumsq_params p) {
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x)
     s += p.x[i] * p.x[i];
   s = block_sum(s, red);
-  if (threadIdx.x == 0) atomicAdd(p.out, s);
+  if (!p.work) {
+    if (threadIdx.x == 0) atomicAdd(p.out, s);
+    return;
+  }
+  // deterministic: partials in work[0..grid), arrival counter in work[1024] (as unsigned); the last block sums in order
+  unsigned* counter = (unsigned*)(p.work + 1024);
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(p.work + blockIdx.x, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last = (atomicAdd(counter, 1u) == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  float t = 0.f;
+  for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+    t += __hip_atomic_load(p.work + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  t = block_sum(t, red);          // fixed tree: same lanes, same order on every run
+  if (threadIdx.x == 0) {
+    *p.out += t;
+    *counter = 0u;                 // ready for the next call on this stream
+  }
 }
 extern "C" int ns_sumsq(const ns_sumsq_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_sumsq: null");

@@ -758,7 +758,8 @@ class Tacotron2(object):
         b1, b2 = hp.adam["beta1"], hp.adam["beta2"]
         lr_t = lr * math.sqrt(1 - b2 ** t) / (1 - b1 ** t)
         n = self.layout.size
-        ops.sumsq(self.flat_g, n, self.scal, out_off=8)
+        # fixed summation order: every data-parallel rank must derive the same clip factor from the same gradient
+        ops.sumsq(self.flat_g, n, self.scal, out_off=8, work=self._buf("sumsq_work", 1032, torch.float32))
         ops.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, n, self.scal[8:], self.gradient_clip,
                  1.0 / self.world_size, lr_t, b1, b2, 1e-8,
                  shadow=self.flat_s if self.flat_s is not self.flat_p else None)

@@ -130,9 +130,9 @@ def l1_loss(pred, ldp, target, dpred, ldd, N, T, P, padl, F, n_prio, w_all, w_pr
     L.call("ns_l1_loss", p, stream())
 
 
-def sumsq(x, n, out, out_off=0):
+def sumsq(x, n, out, out_off=0, work=None):
     p = L.struct("ns_sumsq_params")
-    _fill(p, x=ptr(x), n=n, out=ptr(out, out_off))
+    _fill(p, x=ptr(x), n=n, out=ptr(out, out_off), work=ptr(work))
     L.call("ns_sumsq", p, stream())
 
 

@@ -23,12 +23,26 @@ def main():
     model = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=7, world_size=world)
     parallel.broadcast_parameters(model, 0)
     inputs, lengths, mel, lin = make_batch(hp, 3, 9, 20, seed=100 + rank)
+    # keep every |target - prediction| far from zero: the L1 gradient is sign(), and one flip under the rounding noise
+    # of the fp32 atomic sums moves a bucket's gradient by ~1e-2.  Targets are placed around the GPU's own predictions.
+    model.initialize(inputs, lengths, None, mel, lin)
+    dec, mo, lo_ = (t.float().cpu().numpy() for t in (model.decoder_outputs, model.mel_outputs, model.linear_outputs))
+    import numpy as np
+    sgn = np.where((np.arange(mel.size).reshape(mel.shape) % 2) == 0, 1.0, -1.0).astype(np.float32)
+    mel = (np.where(sgn > 0, np.maximum(dec, mo), np.minimum(dec, mo)) + 0.1 * sgn).astype(np.float32)
+    sgl = np.where((np.arange(lin.size).reshape(lin.shape) % 2) == 0, 1.0, -1.0).astype(np.float32)
+    lin = (lo_ + 0.1 * sgl).astype(np.float32)
     model.add_optimizer(0)
     # local gradient, no reducer
     model.initialize(inputs, lengths, None, mel, lin)
     model.backward()
     torch.cuda.synchronize()
     local = model.flat_g.clone()
+    model.initialize(inputs, lengths, None, mel, lin)      # repeat without reducer: the noise floor in this environment
+    model.backward()
+    torch.cuda.synchronize()
+    floor = {name: ((model.flat_g[lo:hi] - local[lo:hi]).norm() / (local[lo:hi].norm() + 1e-30)).item()
+             for name, lo, hi in parallel.bucket_ranges(model.layout)}
     parts = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(parts, local)
     want = sum(parts)
@@ -39,9 +53,14 @@ def main():
     model.reducer.wait()
     torch.cuda.synchronize()
     got = model.flat_g
-    err = (got - want).abs().max().item()
-    scale = want.abs().max().item()
-    assert err <= 1e-3 * scale + 1e-9, (rank, err, scale)      # run-to-run noise of the fp32 atomic sums is ~1e-5
+    # two passes differ by the order of fp32 atomic sums and by the odd L1 sign() flip that follows from it, so compare
+    # per bucket in the L2 sense: a bucket reduced too early (or twice) would be off by O(1)
+    err = 0.0
+    for name, lo, hi in parallel.bucket_ranges(model.layout):
+        e = ((got[lo:hi] - want[lo:hi]).norm() / (want[lo:hi].norm() + 1e-30)).item()
+        assert e < 2e-3, (rank, name, e, floor)
+        err = max(err, e)
+    scale = 1.0
     # and the optimiser step leaves every rank with identical parameters
     model.apply_gradients()
     torch.cuda.synchronize()

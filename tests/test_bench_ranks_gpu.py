@@ -32,4 +32,6 @@ def test_bucketed_allreduce_inside_backward_matches_sum_of_rank_gradients(dev):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29654", os.path.join(ROOT, "tests", "dp_check.py")]
     out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0 and "DP_CHECK_OK" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    if out.returncode != 0:
+        sys.stderr.write(out.stderr)          # full child tracebacks in the captured output
+    assert out.returncode == 0 and "DP_CHECK_OK" in out.stdout, out.stdout[-1500:]
