@@ -65,3 +65,31 @@ def test_synthesizer_end_to_end(dev):
     T = 8 * hp.outputs_per_step
     assert mel.shape == (T, 80) and lin.shape == (T, 1025)
     assert wav.ndim == 1 and len(wav) <= (T - 1) * 250 + 1000 and np.isfinite(wav).all()
+
+
+def test_config3_cmudict_longform_decode(dev):
+    """BASELINE config 3: Tacotron-2 at the shipped widths on `{ARPAbet}` phoneme input (what CMUDict substitution
+    produces), max_iters=400 -> 2000 mel frames = 25 s of audio through the free-running decoder, the postnet, the
+    expand net and the 60-iteration Griffin-Lim.  No oracle finishes this size in seconds, so: ids are the golden
+    ARPAbet ids, shapes and lengths follow SURVEY Q7, every output is finite, the alignment rows are distributions,
+    and a second call (HIP-graph replay) reproduces the first."""
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.synthesizer import Synthesizer
+    from nspeech_amd.utils.text import text_to_sequence
+    hp = hparams_mod.load("taco2")
+    hp.max_iters = 400
+    hparams_mod.set_hparams(hp)
+    text = "Turn left on {HH AW1 S S T AH0 N} Street, then {R AY1 T} at the {L AY1 T}."
+    ids = text_to_sequence(text, ["english_cleaners"])
+    assert [107, 83, 132, 132, 134, 74, 120] == ids[13:20] and max(ids) < 149 and ids[-1] == 1   # SURVEY 8c golden ids
+    synth = Synthesizer(hp, dtype="mixed").load(None, "taco2")
+    outs = [synth.synthesize(text) for _ in range(3)]          # eager pass, graph capture, replay
+    wav, mel, lin = outs[0]
+    T = 400 * hp.outputs_per_step
+    assert mel.shape == (T, hp.num_mels) and lin.shape == (T, hp.num_freq)
+    assert np.isfinite(mel).all() and np.isfinite(lin).all() and np.isfinite(wav).all()
+    assert wav.ndim == 1 and len(wav) <= (T - 1) * 250 + 1000
+    al = synth.model.alignments[0].float().cpu().numpy()       # [T_in, steps]
+    assert al.shape == (len(ids), 400) and np.abs(al.sum(axis=0) - 1.0).max() < 1e-4 and (al >= 0).all()
+    for w2, m2, l2 in outs[1:]:
+        assert np.array_equal(m2, mel) and np.array_equal(l2, lin)
