@@ -65,10 +65,11 @@ typedef struct {
   int row_period, row_lo, row_hi, row_shift;
   float* col_sum; float* col_sumsq;
   int split_k;
-  const float* addend; int64_t ld_add;   /* optional fp32 [M,N] added before the activation */
+  const void* addend; int64_t ld_add;    /* optional [M,N] (fp32, or bf16 when addend_dtype = NS_BF16) added before the activation */
   const void* gate; int64_t ld_gate;     /* optional (dtype of A) [M,N]: result *= (gate > 0)  (ReLU backward) */
   int f32_passes;   /* fp32 operands only: 0 = exact fp32 FMA kernel; 3 = split-bf16 on MFMA
                        (x = hi + lo, hi*hi + hi*lo + lo*hi, ~2^-17 relative); 1 = hi*hi only */
+  int addend_dtype; /* 0 / NS_F32: addend is fp32; NS_BF16: addend is bf16 */
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
 
@@ -406,6 +407,37 @@ int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 size_t ns_taco2_attn_work_bytes(const ns_taco2_attn_params* p);
 
+
+/* ------------------------------------------------------------------ simple WaveNet (models/wavenet_simple.py)
+ * Row r of every series buffer is (n, t) = (r / T, r %% T) on ONE time grid of T = (clip length - 1) rows per item;
+ * the VALID causal convolutions only shift the first valid row (`start`) to the right.  The convolutions are
+ * ns_gemm launches; these are the pieces around them. */
+/* One-hot causal layer (wavenet_simple.py:246-252, 385-397) as table look-ups: x[n,t,:] = w[0][ids[n,t-1]] +
+ * w[1][ids[n,t]] (t >= 1), w = [2, Q, C] fp32.  With dx != NULL the call is the backward pass instead:
+ * dw[0][ids[t-1]] += dx[t], dw[1][ids[t]] += dx[t] for t >= max(1, start) (dx (dx_dtype) [N*T, C]). */
+typedef struct {
+  const int* ids;            /* [N, T] */
+  const float* w; void* x; int dtype;
+  const void* dx; int dx_dtype; float* dw; int start;
+  int N, T, C, Q;
+} ns_wavenet_input_params;
+int ns_wavenet_input(const ns_wavenet_input_params* p, ns_stream_t stream);
+/* Gated unit (wavenet_simple.py:325): z fp32 [rows, 2C] = [filter | gate]; forward out = tanh * sigmoid into
+ * out[row * ld_out + c] (dtype); with dout != NULL backward: dz (dtype) [rows, 2C].  Rows with t < start give 0. */
+typedef struct {
+  const float* z; int rows, C, T, start;
+  void* out; int64_t ld_out; int dtype;
+  const void* dout; int64_t ld_dout; void* dz;
+} ns_wavenet_gate_params;
+int ns_wavenet_gate(const ns_wavenet_gate_params* p, ns_stream_t stream);
+/* tf.nn.softmax_cross_entropy_with_logits + reduce_mean (wavenet_simple.py:479-502) against integer targets:
+ * loss_acc[0] += scale * sum_rows (logsumexp - logit[target]); dlogits (optional) = scale * (softmax - onehot). */
+typedef struct {
+  const float* logits; int64_t ld; const int* targets; int rows, Q;
+  float scale; float* loss_acc;
+  void* dlogits; int64_t ld_d; int d_dtype;
+} ns_wavenet_ce_params;
+int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t stream);
 
 /* ------------------------------------------------------------------ audio DSP (utils/audio.py)
  * Radix-2 Stockham FFTs of n_fft points run inside LDS, one workgroup per frame; no MFMA,

@@ -14,7 +14,7 @@ struct Epi {
   const float* bias; int act; float alpha;
   int row_period, row_lo, row_hi, row_shift;
   int M, N;
-  const float* addend; long ld_add;
+  const void* addend; long ld_add; int add_bf16;
   const void* gate; long ld_gate; int gate_dtype;
 };
 
@@ -24,7 +24,7 @@ __device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
   e.bias = p.bias; e.act = p.act; e.alpha = p.alpha;
   e.row_period = p.row_period; e.row_lo = p.row_lo; e.row_hi = p.row_hi; e.row_shift = p.row_shift;
   e.M = p.M; e.N = p.N;
-  e.addend = p.addend; e.ld_add = p.ld_add;
+  e.addend = p.addend; e.ld_add = p.ld_add; e.add_bf16 = p.addend_dtype == NS_BF16;
   e.gate = p.gate; e.ld_gate = p.ld_gate; e.gate_dtype = p.dtype;
   return e;
 }
@@ -39,7 +39,10 @@ __device__ __forceinline__ bool row_valid(const Epi& e, int m) {
 __device__ __forceinline__ float epi_value(const Epi& e, int m, int n, float acc, bool add_bias, bool valid) {
   float v = e.alpha * acc;
   if (add_bias && e.bias) v += e.bias[n];
-  if (add_bias && e.addend) v += e.addend[(long)m * e.ld_add + n];
+  if (add_bias && e.addend) {
+    const long ao = (long)m * e.ld_add + n;
+    v += e.add_bf16 ? (float)((const bf16_t*)e.addend)[ao] : ((const float*)e.addend)[ao];
+  }
   v = apply_act(v, e.act);
   if (e.gate) {
     const long go = (long)m * e.ld_gate + n;

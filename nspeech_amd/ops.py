@@ -59,7 +59,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     p.col_sumsq = ptr(col_sumsq)
     p.split_k = split_k
     if addend is not None:
-        p.addend, p.ld_add = ptr(addend, addend_off), ld_add
+        p.addend, p.ld_add, p.addend_dtype = ptr(addend, addend_off), ld_add, dt(addend)
     if gate is not None:
         p.gate, p.ld_gate = ptr(gate, gate_off), ld_gate
     p.f32_passes = F32_PASSES if f32_passes is None else f32_passes
@@ -299,3 +299,25 @@ def attention_post_bwd(N, S, Ti, Tia, A, kw, lengths, keys_t, q, align, de, wcl,
     _fill(p, N=N, S=S, Ti=Ti, Tia=Tia, A=A, kw=kw, lengths=ptr(lengths), keys_t=ptr(keys_t), q=ptr(q), align=ptr(align),
           de=ptr(de), wcl=_pp(wcl), v=_pp(v), dkeys_t=ptr(dkeys_t), dv=_pp(dv), dwcl=ptr(dwcl))
     L.call("ns_attention_post_bwd", p, stream())
+
+
+def wavenet_input(ids, w, x, N, T, C, Q, w_off=0, dx=None, dw=None, dw_off=0, start=0):
+    p = L.struct("ns_wavenet_input_params")
+    _fill(p, ids=ptr(ids), w=ptr(w, w_off), x=ptr(x), dtype=dt(x) if x is not None else 0, dx=ptr(dx),
+          dx_dtype=dt(dx) if dx is not None else 0, dw=ptr(dw, dw_off), start=start, N=N, T=T, C=C, Q=Q)
+    L.call("ns_wavenet_input", p, stream())
+
+
+def wavenet_gate(z, rows, C, T, start, out=None, out_off=0, ld_out=0, dout=None, dout_off=0, ld_dout=0, dz=None):
+    p = L.struct("ns_wavenet_gate_params")
+    ref = out if out is not None else dz
+    _fill(p, z=ptr(z), rows=rows, C=C, T=T, start=start, out=ptr(out, out_off), ld_out=ld_out, dtype=dt(ref),
+          dout=ptr(dout, dout_off), ld_dout=ld_dout, dz=ptr(dz))
+    L.call("ns_wavenet_gate", p, stream())
+
+
+def wavenet_softmax_ce(logits, ld, targets, rows, Q, scale, loss_acc, acc_off=0, dlogits=None, ld_d=0):
+    p = L.struct("ns_wavenet_ce_params")
+    _fill(p, logits=ptr(logits), ld=ld, targets=ptr(targets), rows=rows, Q=Q, scale=scale, loss_acc=ptr(loss_acc, acc_off),
+          dlogits=ptr(dlogits), ld_d=ld_d, d_dtype=dt(dlogits) if dlogits is not None else 0)
+    L.call("ns_wavenet_softmax_ce", p, stream())

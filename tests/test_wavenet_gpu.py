@@ -1,0 +1,112 @@
+"""simple_wavenet (BASELINE config 4) against the float64 oracle: logits, loss, every gradient, one Adam
+step, predict_proba, mu-law round trip; exact-fp32 mode for parity, bf16 mode within its rounding."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _hp(**over):
+    from nspeech_amd import hparams as hparams_mod
+    hp = hparams_mod.load("wavenet")
+    small = dict(dilations_depth=2, dilations_length=3, residual_channels=16, dilation_channels=16, skip_channels=32,
+                 quantization_channels=64)
+    small.update(over)
+    for k, v in small.items():
+        setattr(hp, k, v)
+    return hp
+
+
+def _audio(N, T, seed):
+    rng = np.random.RandomState(seed)
+    t = np.arange(T) / 16000.0
+    return np.stack([0.6 * np.sin(2 * np.pi * rng.uniform(100, 900) * t + rng.uniform(0, 6)) + 0.05 * rng.randn(T)
+                     for _ in range(N)]).astype(np.float32)
+
+
+def _oracle(hp, params, ids):
+    from oracle import wavenet_oracle as O
+    p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
+    loss, logits = O.loss(p, hp.values(), torch.tensor(ids))
+    loss.backward()
+    # the last layer's dense kernel feeds nothing (its residual output is unused): no gradient -> zeros
+    return float(loss), logits.detach().numpy(), {k: (v.grad.numpy() if v.grad is not None else np.zeros(v.shape)) for k, v in p.items()}
+
+
+@pytest.mark.parametrize("shape,over", [((2, 40), {}), ((1, 17), {}), ((3, 75), dict(quantization_channels=256, skip_channels=64)),
+                                        ((2, 60), dict(dilations_depth=1, dilations_length=5, residual_channels=32,
+                                                       dilation_channels=32))])
+def test_wavenet_fp32_matches_oracle(dev, shape, over):
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_encode, receptive_field
+    hp = _hp(**over)
+    N, T = shape
+    assert T > receptive_field(hp)
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="fp32", seed=4)
+    audio = _audio(N, T, seed=N)
+    ids = mu_law_encode(audio, hp.quantization_channels)
+    loss, logits, grads = _oracle(hp, m.numpy_params(), ids)
+    m.initialize(audio)
+    m.backward()
+    got_loss = m.read_losses()
+    assert np.abs(m.raw_output.cpu().numpy() - logits).max() < 2e-5 * max(1.0, np.abs(logits).max())
+    assert abs(got_loss - loss) < 1e-5 * max(1.0, abs(loss))
+    got = m.numpy_grads()
+    for k in grads:
+        scale = np.abs(grads[k]).max()
+        assert np.abs(got[k] - grads[k]).max() < 1e-4 * scale + 1e-8, (k, np.abs(got[k] - grads[k]).max(), scale)
+
+
+def test_wavenet_adam_step_and_predict_proba(dev):
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_encode
+    from oracle import wavenet_oracle as O
+    hp = _hp()
+    hp.decay_learning_rate = True
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="fp32", seed=1)
+    m.add_loss().add_optimizer(0).add_stats()
+    audio = _audio(2, 50, seed=9)
+    ids = mu_law_encode(audio, hp.quantization_channels)
+    p0 = m.numpy_params()
+    _, _, grads = _oracle(hp, p0, ids)
+    loss = m.step(audio)
+    assert np.isfinite(loss) and m.global_step == 1
+    # first Adam step with bias correction = lr * g / (|g| + eps'), lr from the Noam schedule at step 0, after the clip
+    gn = np.sqrt(sum((g ** 2).sum() for g in grads.values()))
+    lr = hp.initial_learning_rate * 4000.0 ** 0.5 * min(1 * 4000.0 ** -1.5, 1.0)
+    new = m.numpy_params()
+    for k, g in grads.items():
+        gc = g * min(1.0, 1.0 / gn)
+        want = -lr * gc / (np.abs(gc) + 1e-8)
+        mask = np.abs(gc) > 1e-5
+        if mask.any():
+            # lr at step 0 of the Noam schedule is 5e-7: the update itself is only ~60 fp32 ulps of a 0.1-sized weight
+            assert np.abs((new[k] - p0[k])[mask] - want[mask]).max() < 6e-2 * lr, k
+    # predict_proba on a waveform longer than the receptive field
+    wav = ids[0, :30]
+    pr = m.predict_proba(wav).cpu().numpy()
+    ref = O.predict_proba({k: torch.tensor(v, dtype=torch.float64) for k, v in new.items()}, hp.values(), torch.tensor(wav)).numpy()
+    assert abs(pr.sum() - 1.0) < 1e-5 and np.abs(pr - ref).max() < 1e-5
+
+
+def test_wavenet_bf16_close_to_oracle_and_mu_law(dev):
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_decode, mu_law_encode
+    from oracle import wavenet_oracle as O
+    hp = _hp(residual_channels=32, dilation_channels=32, skip_channels=64)
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="bf16", seed=2)
+    audio = _audio(4, 120, seed=3)
+    ids = mu_law_encode(audio, hp.quantization_channels)
+    assert np.array_equal(ids, O.mu_law_encode(audio, hp.quantization_channels)) and ids.min() >= 0 and ids.max() < 64
+    back = mu_law_decode(ids, hp.quantization_channels)
+    assert np.abs(back - np.clip(audio, -1, 1)).max() < 0.08          # 64-level mu-law quantisation error
+    loss, logits, grads = _oracle(hp, m.numpy_params(), ids)
+    m.initialize(audio)
+    m.backward()
+    assert abs(m.read_losses() - loss) < 2e-2 * abs(loss)
+    got = m.numpy_grads()
+    for k in grads:
+        a, b = got[k].ravel().astype(np.float64), grads[k].ravel()
+        if np.linalg.norm(b) > 1e-8:
+            assert float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30)) > 0.98, k
