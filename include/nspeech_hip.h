@@ -439,6 +439,22 @@ typedef struct {
 } ns_wavenet_ce_params;
 int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t stream);
 
+/* Sample-by-sample generation (generate_wavenet.py:56-142): B waveforms, one workgroup each.  ids [B, total] holds
+ * n_seed seed codes per waveform (n_seed >= receptive field for results equal to the full network) and receives the
+ * total - n_seed drawn ones; uniform [B, total - n_seed] in [0,1) drives the inverse-CDF draws (float64 softmax as in
+ * predict_proba, wavenet_simple.py:436-453); queues fp32 [B, sum(dilations), R] zeroed by the caller; weights = one
+ * flat buffer (w_dtype fp32 or bf16) with element offsets: causal [2,Q,R]; per layer l at off_layer0 + l*layer_stride
+ * the [2,R,2Dc] filter|gate block and, off_dense_in_layer further, the [Dc,R] dense kernel; skip [L,Dc,S];
+ * post1 [S,S]; post2 [S,Q].  probs (optional) fp32 [B,Q]: distribution of the last drawn sample. */
+typedef struct {
+  const void* weights; int w_dtype;
+  int64_t off_causal, off_layer0, layer_stride, off_dense_in_layer, off_skip, off_post1, off_post2;
+  const int* dilations; int L, R, Dc, S, Q;
+  int B, n_seed, total; int64_t queue_rows;
+  int* ids; const float* uniform; float* queues; float* probs;
+} ns_wavenet_generate_params;
+int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t stream);
+
 /* ------------------------------------------------------------------ audio DSP (utils/audio.py)
  * Radix-2 Stockham FFTs of n_fft points run inside LDS, one workgroup per frame; no MFMA,
  * the kernels are bandwidth / latency bound.  window = periodic Hann(win) and

@@ -126,3 +126,119 @@ extern "C" int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t 
   NS_CHECK_LAUNCH("wavenet_softmax_ce");
   return NS_OK;
 }
+
+// ------------------------------------------------------------------ incremental generation
+// One workgroup per waveform walks the samples one by one (generate_wavenet.py:56-142 with per-layer queues): for
+// sample t the causal layer, the L dilated layers (each reads the value its own input had `dilation` steps ago from
+// a ring in global memory, L2 resident), the skip sum and the two post-processing layers, then - once the seed is
+// used up - a draw from the softmax by inverse CDF on a caller-supplied uniform number.  The state after the seed
+// equals what the full network computes on the same history, so the samples equal a sliding-window predict_proba.
+constexpr int GEN_THREADS = 512;
+template <typename W>
+__global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_generate_params p) {
+  extern __shared__ float gsm[];
+  const int R = p.R, Dc = p.Dc, S = p.S, Q = p.Q;
+  float* xin = gsm;                 // [2R]: x[t-d] | x[t]
+  float* z = xin + 2 * R;           // [2Dc]
+  float* out = z + 2 * Dc;          // [Dc]
+  float* skip = out + Dc;           // [S]
+  float* h1 = skip + S;             // [S]
+  float* lg = h1 + S;               // [Q]
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const W* wb = (const W*)p.weights;
+  int* ids = p.ids + (long)b * p.total;
+  float* queues = p.queues + (long)b * p.queue_rows * R;
+  const float* un = p.uniform + (long)b * (p.total - p.n_seed);
+  for (int t = 1; t < p.total; ++t) {
+    const bool emit = t + 1 >= p.n_seed && t + 1 < p.total;      // sample t+1 must be drawn
+    // causal layer
+    if (tid < R) {
+      const int a = ids[t - 1], c = ids[t];
+      xin[R + tid] = ldf(wb + p.off_causal + (long)a * R + tid) + ldf(wb + p.off_causal + ((long)Q + c) * R + tid);
+    }
+    for (int j = tid; j < S; j += GEN_THREADS) skip[j] = 0.f;
+    long qrow = 0;
+    for (int l = 0; l < p.L; ++l) {
+      const int d = p.dilations[l];
+      float* ring = queues + (qrow + (t % d)) * R;
+      qrow += d;
+      __syncthreads();                                         // xin[R..2R) (this layer's input) is complete
+      if (tid < R) {
+        xin[tid] = ring[tid];                                    // the input of d steps ago
+        ring[tid] = xin[R + tid];                                // and the current one takes its slot
+      }
+      __syncthreads();
+      const W* fg = wb + p.off_layer0 + (long)l * p.layer_stride;     // [2][R][2Dc]
+      if (tid < 2 * Dc) {
+        float acc = 0.f;
+        for (int k = 0; k < 2 * R; ++k) acc = fmaf(xin[k], ldf(fg + (long)k * 2 * Dc + tid), acc);
+        z[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < Dc) out[tid] = tanhf(z[tid]) * (1.f / (1.f + expf(-z[Dc + tid])));
+      __syncthreads();
+      if (emit) {                                                // the skip path only matters when a sample is drawn
+        const W* sk = wb + p.off_skip + (long)l * Dc * S;
+        for (int j = tid; j < S; j += GEN_THREADS) {
+          float acc = skip[j];
+          for (int k = 0; k < Dc; ++k) acc = fmaf(out[k], ldf(sk + (long)k * S + j), acc);
+          skip[j] = acc;
+        }
+      }
+      float xn = 0.f;
+      if (tid < R) {
+        const W* de = fg + p.off_dense_in_layer;                 // [Dc][R]
+        xn = xin[R + tid];
+        for (int k = 0; k < Dc; ++k) xn = fmaf(out[k], ldf(de + (long)k * R + tid), xn);
+      }
+      __syncthreads();                                           // every reader of xin[R..2R) and out is done
+      if (tid < R) xin[R + tid] = xn;                            // input of the next layer
+    }
+    if (!emit) continue;
+    __syncthreads();
+    for (int j = tid; j < S; j += GEN_THREADS) skip[j] = fmaxf(skip[j], 0.f);
+    __syncthreads();
+    for (int j = tid; j < S; j += GEN_THREADS) {
+      float acc = 0.f;
+      for (int k = 0; k < S; ++k) acc = fmaf(skip[k], ldf(wb + p.off_post1 + (long)k * S + j), acc);
+      h1[j] = fmaxf(acc, 0.f);
+    }
+    __syncthreads();
+    for (int j = tid; j < Q; j += GEN_THREADS) {
+      float acc = 0.f;
+      for (int k = 0; k < S; ++k) acc = fmaf(h1[k], ldf(wb + p.off_post2 + (long)k * Q + j), acc);
+      lg[j] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float m = lg[0];
+      for (int j = 1; j < Q; ++j) m = fmaxf(m, lg[j]);
+      double se = 0.0;
+      for (int j = 0; j < Q; ++j) se += exp((double)lg[j] - (double)m);      // float64 softmax as predict_proba
+      const double u = (double)un[t + 1 - p.n_seed] * se;
+      double c = 0.0;
+      int pick = Q - 1;
+      for (int j = 0; j < Q; ++j) {
+        c += exp((double)lg[j] - (double)m);
+        if (u < c) { pick = j; break; }
+      }
+      ids[t + 1] = pick;
+      if (p.probs) {                                             // optional: the distribution of the LAST drawn sample
+        for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(exp((double)lg[j] - (double)m) / se);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->weights && p->ids && p->queues && p->uniform && p->dilations, "ns_wavenet_generate: null");
+  NS_CHECK_ARG(p->B > 0 && p->n_seed >= 2 && p->total > p->n_seed && p->L > 0, "ns_wavenet_generate: bad sizes");
+  NS_CHECK_ARG(p->R <= 256 && 2 * p->Dc <= GEN_THREADS && p->Q <= 1024, "ns_wavenet_generate: layer too wide");
+  const size_t lds = sizeof(float) * (2 * p->R + 3 * p->Dc + 2 * p->S + p->Q);
+  NS_CHECK_ARG(lds <= 60 * 1024, "ns_wavenet_generate: state does not fit in LDS");
+  if (p->w_dtype == NS_BF16) hipLaunchKernelGGL(wn_generate_kernel<bf16_t>, dim3(p->B), dim3(GEN_THREADS), lds, (hipStream_t)s, *p);
+  else hipLaunchKernelGGL(wn_generate_kernel<float>, dim3(p->B), dim3(GEN_THREADS), lds, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("wavenet_generate");
+  return NS_OK;
+}

@@ -363,3 +363,34 @@ class SimpleWaveNet(object):
         logits, ow = self._forward(ids, 1, ids.shape[1], keep=False)
         last = logits[(ow - 1) * self.Q: ow * self.Q].double()
         return torch.softmax(last, dim=0).float()
+
+    def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None):
+        """Incremental generation (generate_wavenet.py:56-142): seed_ids int [B, n_seed] (or [n_seed]) of mu-law codes,
+        n_seed >= receptive field; returns int32 [B, n_seed + n_samples].  uniforms [B, n_samples] in [0,1) drive the
+        categorical draws (default: numpy Generator(seed)).  Weights: the fp32 master copy when exact (default in fp32
+        mode), else the bf16 shadow (half the bytes streamed per sample)."""
+        seed_ids = np.atleast_2d(np.asarray(seed_ids, np.int32))
+        B, n_seed = seed_ids.shape
+        assert n_seed >= self.rf, "seed shorter than the receptive field (%d)" % self.rf
+        total = n_seed + int(n_samples)
+        if uniforms is None:
+            uniforms = np.random.default_rng(seed).random((B, n_samples))
+        uniforms = np.atleast_2d(np.asarray(uniforms, np.float32))
+        dev = self.device
+        ids = torch.zeros(B, total, dtype=torch.int32, device=dev)
+        ids[:, :n_seed] = torch.from_numpy(seed_ids).to(dev)
+        un = torch.from_numpy(np.ascontiguousarray(uniforms)).to(dev)
+        qrows = int(sum(self.dil))
+        queues = torch.zeros(B * qrows * self.R, dtype=torch.float32, device=dev)
+        dil = torch.tensor(self.dil, dtype=torch.int32, device=dev)
+        if exact is None:
+            exact = self.T == torch.float32
+        W = self.flat_p if exact else self.flat_s
+        offs = dict(causal=self._o("causal"), layer0=self._o("fg0"),
+                    layer_stride=(self._o("fg1") - self._o("fg0")) if self.L > 1 else 0,
+                    dense_in_layer=self._o("dense0") - self._o("fg0"), skip=self._o("skip"), post1=self._o("post1"),
+                    post2=self._o("post2"))
+        self.last_probs = torch.zeros(B * self.Q, dtype=torch.float32, device=dev)
+        ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
+                             probs=self.last_probs)
+        return ids

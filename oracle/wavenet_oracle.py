@@ -85,13 +85,15 @@ def predict_proba(p, hp, ids):
     return torch.softmax(logits[0, -1].double(), dim=0)
 
 
-def generate(p, hp, seed_ids, n_samples, rng):
+def generate(p, hp, seed_ids, uniforms):
     """Sample-by-sample generation with the full network on a sliding window of receptive_field samples
-    (generate_wavenet.py:100-140 without fast generation).  rng: numpy Generator for the categorical draws."""
+    (generate_wavenet.py:100-140 without fast generation).  The categorical draw is the inverse CDF of predict_proba
+    at the given uniform numbers (np.random.choice does the same with its own stream)."""
     rf = receptive_field(hp)
     wave = list(int(v) for v in seed_ids)
-    for _ in range(n_samples):
-        window = torch.tensor(wave[-rf:])
-        pr = predict_proba(p, hp, window).numpy()
-        wave.append(int(rng.choice(len(pr), p=pr / pr.sum())))
+    assert len(wave) >= rf, "seed shorter than the receptive field"
+    for u in uniforms:
+        pr = predict_proba(p, hp, torch.tensor(wave[-rf:])).numpy()
+        c = np.cumsum(pr)
+        wave.append(int(min(np.searchsorted(c, u * c[-1], side="right"), len(pr) - 1)))
     return np.asarray(wave, np.int32)
