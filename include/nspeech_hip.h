@@ -445,13 +445,17 @@ int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t stream);
  * predict_proba, wavenet_simple.py:436-453); queues fp32 [B, sum(dilations), R] zeroed by the caller; weights = one
  * flat buffer (w_dtype fp32 or bf16) with element offsets: causal [2,Q,R]; per layer l at off_layer0 + l*layer_stride
  * the [2,R,2Dc] filter|gate block and, off_dense_in_layer further, the [Dc,R] dense kernel; skip [L,Dc,S];
- * post1 [S,S]; post2 [S,Q].  probs (optional) fp32 [B,Q]: distribution of the last drawn sample. */
+ * post1 [S,S]; post2 [S,Q].  probs (optional) fp32 [B,Q]: distribution of the last drawn sample.
+ * fgT / deT (optional, bf16, with w_dtype = NS_BF16 and R == Dc in {16, 32}): column-major shadows [L][2Dc][2R] and
+ * [L][R][Dc] of the layer kernels; with them the residual chain runs inside one wavefront (no barriers, weights
+ * fetched three layers ahead), about 7x faster per sample. */
 typedef struct {
   const void* weights; int w_dtype;
   int64_t off_causal, off_layer0, layer_stride, off_dense_in_layer, off_skip, off_post1, off_post2;
   const int* dilations; int L, R, Dc, S, Q;
   int B, n_seed, total; int64_t queue_rows;
   int* ids; const float* uniform; float* queues; float* probs;
+  const void* fgT; const void* deT;
 } ns_wavenet_generate_params;
 int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t stream);
 

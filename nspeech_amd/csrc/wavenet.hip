@@ -134,73 +134,136 @@ extern "C" int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t 
 // used up - a draw from the softmax by inverse CDF on a caller-supplied uniform number.  The state after the seed
 // equals what the full network computes on the same history, so the samples equal a sliding-window predict_proba.
 constexpr int GEN_THREADS = 512;
+constexpr int GEN_FG = 8, GEN_DE = 2, GEN_SK = 32;     // per-thread weight registers: filter|gate, dense, skip
+
+// this thread's share of one layer's weights; loaded one layer ahead so that the L2 / Infinity-Cache latency of a
+// layer's 10 KB sits under the previous layer's barriers instead of in front of its own products
+template <typename W>
+struct GenLayerW { W fg[GEN_FG]; W de[GEN_DE]; W sk[GEN_SK]; };
+
+template <typename W>
+__device__ __forceinline__ void gen_load(GenLayerW<W>& w, const ns_wavenet_generate_params& p, const W* wb, int l, int tid,
+                                         bool with_skip) {
+  const int R = p.R, Dc = p.Dc, S = p.S;
+  const W* fg = wb + p.off_layer0 + (long)l * p.layer_stride;
+  const W* de = fg + p.off_dense_in_layer;
+  const W* sk = wb + p.off_skip + (long)l * Dc * S;
+  const int nfg = 2 * R * 2 * Dc, nde = Dc * R;
+#pragma unroll
+  for (int q = 0; q < GEN_FG; ++q) {
+    const int e = q * GEN_THREADS + tid;
+    w.fg[q] = e < nfg ? fg[e] : (W)0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < GEN_DE; ++q) {
+    const int e = q * GEN_THREADS + tid;
+    w.de[q] = e < nde ? de[e] : (W)0.f;
+  }
+  if (with_skip) {
+#pragma unroll
+    for (int k = 0; k < GEN_SK; ++k) w.sk[k] = (k < Dc && tid < S) ? sk[(long)k * S + tid] : (W)0.f;
+  }
+}
+
 template <typename W>
 __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_generate_params p) {
   extern __shared__ float gsm[];
   const int R = p.R, Dc = p.Dc, S = p.S, Q = p.Q;
-  float* xin = gsm;                 // [2R]: x[t-d] | x[t]
-  float* z = xin + 2 * R;           // [2Dc]
-  float* out = z + 2 * Dc;          // [Dc]
-  float* skip = out + Dc;           // [S]
-  float* h1 = skip + S;             // [S]
-  float* lg = h1 + S;               // [Q]
+  float* xin = gsm;                       // [2R]: x[t-d] | x[t]
+  float* z = xin + 2 * R;                 // [2Dc]
+  float* out = z + 2 * Dc;                // [Dc]
+  float* part = out + Dc;                 // [GEN_THREADS] partial sums of the layer products
+  float* h0 = part + GEN_THREADS;         // [S] relu(skip sum)
+  float* h1 = h0 + S;                     // [S]
+  float* lg = h1 + S;                     // [Q]
+  double* ex = (double*)(lg + ((Q + 1) & ~1));   // [Q]
   const int tid = threadIdx.x, b = blockIdx.x;
   const W* wb = (const W*)p.weights;
   int* ids = p.ids + (long)b * p.total;
   float* queues = p.queues + (long)b * p.queue_rows * R;
   const float* un = p.uniform + (long)b * (p.total - p.n_seed);
+  const int nfg = 2 * R * 2 * Dc, nde = Dc * R;
+  const int jz = tid % (2 * Dc), kz0 = tid / (2 * Dc), kzs = GEN_THREADS / (2 * Dc);   // fg element q: k = q*kzs + kz0
+  const int jd = tid % R, kd0 = tid / R, kds = GEN_THREADS / R;
+  __shared__ int dil[128];
+  for (int i = tid; i < p.L && i < 128; i += GEN_THREADS) dil[i] = p.dilations[i];
+  __syncthreads();
+  GenLayerW<W> wa, wbuf;
   for (int t = 1; t < p.total; ++t) {
     const bool emit = t + 1 >= p.n_seed && t + 1 < p.total;      // sample t+1 must be drawn
-    // causal layer
-    if (tid < R) {
+    gen_load(wa, p, wb, 0, tid, emit);
+    if (tid < R) {                                               // causal layer
       const int a = ids[t - 1], c = ids[t];
       xin[R + tid] = ldf(wb + p.off_causal + (long)a * R + tid) + ldf(wb + p.off_causal + ((long)Q + c) * R + tid);
     }
-    for (int j = tid; j < S; j += GEN_THREADS) skip[j] = 0.f;
+    float skip = 0.f;                                            // thread j < S owns skip[j]
     long qrow = 0;
-    for (int l = 0; l < p.L; ++l) {
-      const int d = p.dilations[l];
+    // ring slot of layer l at time t: holds that layer's input of d steps ago; read one layer ahead like the weights
+    float rcur = (tid < R) ? queues[(0 + (t % dil[0])) * R + tid] : 0.f, rnext = 0.f;
+    // two layers per trip so that the current / next weight registers are statically known (a run-time choice
+    // between the two structs would push both into scratch memory)
+    auto layer = [&](int l, GenLayerW<W>& wc, GenLayerW<W>& wn) {
+      const int d = dil[l];
       float* ring = queues + (qrow + (t % d)) * R;
       qrow += d;
-      __syncthreads();                                         // xin[R..2R) (this layer's input) is complete
+      if (l + 1 < p.L) {
+        if (tid < R) rnext = queues[(qrow + (t % dil[l + 1])) * R + tid];
+        gen_load(wn, p, wb, l + 1, tid, emit);
+      }
+      __syncthreads();                                           // xin[R..2R) (this layer's input) is complete
       if (tid < R) {
-        xin[tid] = ring[tid];                                    // the input of d steps ago
+        xin[tid] = rcur;                                         // the input of d steps ago
         ring[tid] = xin[R + tid];                                // and the current one takes its slot
       }
+      rcur = rnext;
       __syncthreads();
-      const W* fg = wb + p.off_layer0 + (long)l * p.layer_stride;     // [2][R][2Dc]
-      if (tid < 2 * Dc) {
+      {
         float acc = 0.f;
-        for (int k = 0; k < 2 * R; ++k) acc = fmaf(xin[k], ldf(fg + (long)k * 2 * Dc + tid), acc);
-        z[tid] = acc;
+#pragma unroll
+        for (int q = 0; q < GEN_FG; ++q)
+          if (q * GEN_THREADS + tid < nfg) acc = fmaf(xin[q * kzs + kz0], (float)wc.fg[q], acc);
+        part[tid] = acc;
+      }
+      __syncthreads();
+      if (tid < 2 * Dc) {
+        float v = 0.f;
+        for (int i = 0; i < kzs; ++i) v += part[i * 2 * Dc + tid];
+        z[tid] = v;
       }
       __syncthreads();
       if (tid < Dc) out[tid] = tanhf(z[tid]) * (1.f / (1.f + expf(-z[Dc + tid])));
       __syncthreads();
-      if (emit) {                                                // the skip path only matters when a sample is drawn
-        const W* sk = wb + p.off_skip + (long)l * Dc * S;
-        for (int j = tid; j < S; j += GEN_THREADS) {
-          float acc = skip[j];
-          for (int k = 0; k < Dc; ++k) acc = fmaf(out[k], ldf(sk + (long)k * S + j), acc);
-          skip[j] = acc;
-        }
+      if (emit) {
+#pragma unroll
+        for (int k = 0; k < GEN_SK; ++k)
+          if (k < Dc) skip = fmaf(out[k], (float)wc.sk[k], skip);
       }
+      {
+        float acc = 0.f;
+#pragma unroll
+        for (int q = 0; q < GEN_DE; ++q)
+          if (q * GEN_THREADS + tid < nde) acc = fmaf(out[q * kds + kd0], (float)wc.de[q], acc);
+        part[tid] = acc;
+      }
+      __syncthreads();
       float xn = 0.f;
       if (tid < R) {
-        const W* de = fg + p.off_dense_in_layer;                 // [Dc][R]
         xn = xin[R + tid];
-        for (int k = 0; k < Dc; ++k) xn = fmaf(out[k], ldf(de + (long)k * R + tid), xn);
+        for (int i = 0; i < kds; ++i) xn += part[i * R + tid];
       }
-      __syncthreads();                                           // every reader of xin[R..2R) and out is done
+      __syncthreads();                                           // every reader of xin[R..2R), out and part is done
       if (tid < R) xin[R + tid] = xn;                            // input of the next layer
+    };
+    for (int l = 0; l < p.L; l += 2) {
+      layer(l, wa, wbuf);
+      if (l + 1 < p.L) layer(l + 1, wbuf, wa);
     }
     if (!emit) continue;
-    __syncthreads();
-    for (int j = tid; j < S; j += GEN_THREADS) skip[j] = fmaxf(skip[j], 0.f);
+    if (tid < S) h0[tid] = fmaxf(skip, 0.f);
     __syncthreads();
     for (int j = tid; j < S; j += GEN_THREADS) {
       float acc = 0.f;
-      for (int k = 0; k < S; ++k) acc = fmaf(skip[k], ldf(wb + p.off_post1 + (long)k * S + j), acc);
+      for (int k = 0; k < S; ++k) acc = fmaf(h0[k], ldf(wb + p.off_post1 + (long)k * S + j), acc);
       h1[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
@@ -210,22 +273,190 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_gen
       lg[j] = acc;
     }
     __syncthreads();
+    float m = -3.0e38f;
+    for (int j = tid; j < Q; j += GEN_THREADS) m = fmaxf(m, lg[j]);
+    m = block_max(m, part);
+    for (int j = tid; j < Q; j += GEN_THREADS) ex[j] = exp((double)lg[j] - (double)m);   // float64 softmax as predict_proba
+    __syncthreads();
     if (tid == 0) {
-      float m = lg[0];
-      for (int j = 1; j < Q; ++j) m = fmaxf(m, lg[j]);
       double se = 0.0;
-      for (int j = 0; j < Q; ++j) se += exp((double)lg[j] - (double)m);      // float64 softmax as predict_proba
+      for (int j = 0; j < Q; ++j) se += ex[j];
       const double u = (double)un[t + 1 - p.n_seed] * se;
       double c = 0.0;
       int pick = Q - 1;
       for (int j = 0; j < Q; ++j) {
-        c += exp((double)lg[j] - (double)m);
+        c += ex[j];
         if (u < c) { pick = j; break; }
       }
       ids[t + 1] = pick;
-      if (p.probs) {                                             // optional: the distribution of the LAST drawn sample
-        for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(exp((double)lg[j] - (double)m) / se);
+      if (p.probs)                                               // the distribution of the LAST drawn sample
+        for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(ex[j] / se);
+    }
+    __syncthreads();
+  }
+}
+
+// ---- fast variant (bf16 weights, R == Dc == C): the residual chain of a sample - 50 dependent layers of tiny
+// matrix-vector products - runs inside ONE wavefront with no barrier at all: lane j owns column j, the input vector is
+// broadcast lane by lane (v_readlane), and the layer's weights come from a transposed bf16 shadow ([column][k], so a
+// lane's whole column is 8 + 4 sixteen-byte loads) fetched THREE layers ahead into packed registers, which covers the
+// L2 latency.  The other seven waves only join for the skip / post-processing products of a drawn sample.
+template <int C>
+struct GenPk { unsigned fg[C]; unsigned de[C / 2]; float ring; };   // 2C + C bf16 values, packed in pairs
+
+template <int C>
+__device__ __forceinline__ void genpk_load(GenPk<C>& w, const ns_wavenet_generate_params& p, int l, int lane, const float* queues,
+                                           long qrow, int t, int d) {
+  const uint4* fg = (const uint4*)((const bf16_t*)p.fgT + ((long)l * 2 * C + (lane < 2 * C ? lane : 0)) * 2 * C);
+#pragma unroll
+  for (int i = 0; i < C / 4; ++i) {
+    const uint4 v = fg[i];
+    w.fg[4 * i] = v.x; w.fg[4 * i + 1] = v.y; w.fg[4 * i + 2] = v.z; w.fg[4 * i + 3] = v.w;
+  }
+  const uint4* de = (const uint4*)((const bf16_t*)p.deT + ((long)l * C + (lane < C ? lane : 0)) * C);
+#pragma unroll
+  for (int i = 0; i < C / 8; ++i) {
+    const uint4 v = de[i];
+    w.de[4 * i] = v.x; w.de[4 * i + 1] = v.y; w.de[4 * i + 2] = v.z; w.de[4 * i + 3] = v.w;
+  }
+  w.ring = lane < C ? queues[(qrow + (t % d)) * C + lane] : 0.f;
+}
+__device__ __forceinline__ float pk_lo(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float pk_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ float lane_bcast(float v, int k) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), k));
+}
+
+// y[0..N) = act(sum_k x[k] * Wm[k*N + n]) for a bf16 [K, N] matrix streamed from L2 once: a thread owns 8 adjacent
+// columns (one 16-byte load per row) and the workgroup splits K, 16 rows in flight per thread; the partial sums meet
+// in LDS.  x, y and part are LDS; part needs (GEN_THREADS / (N/8)) * N floats.  N % 8 == 0, N/8 <= GEN_THREADS.
+__device__ __forceinline__ void gen_matvec8(const bf16_t* Wm, int K, int N, const float* x, float* y, float* part, bool relu,
+                                            int tid) {
+  const int ncg = N >> 3, nks = GEN_THREADS / ncg;
+  const int cg = tid % ncg, ks = tid / ncg;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (ks < nks) {
+    const uint4* col = (const uint4*)(Wm + cg * 8);
+    for (int k0 = ks; k0 < K; k0 += nks * 16) {
+      uint4 w[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = k0 + q * nks;
+        w[q] = k < K ? col[(long)k * ncg] : make_uint4(0u, 0u, 0u, 0u);
       }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = k0 + q * nks;
+        const float xv = k < K ? x[k] : 0.f;
+        acc[0] = fmaf(xv, pk_lo(w[q].x), acc[0]); acc[1] = fmaf(xv, pk_hi(w[q].x), acc[1]);
+        acc[2] = fmaf(xv, pk_lo(w[q].y), acc[2]); acc[3] = fmaf(xv, pk_hi(w[q].y), acc[3]);
+        acc[4] = fmaf(xv, pk_lo(w[q].z), acc[4]); acc[5] = fmaf(xv, pk_hi(w[q].z), acc[5]);
+        acc[6] = fmaf(xv, pk_lo(w[q].w), acc[6]); acc[7] = fmaf(xv, pk_hi(w[q].w), acc[7]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[ks * N + cg * 8 + i] = acc[i];
+  }
+  __syncthreads();
+  for (int n = tid; n < N; n += GEN_THREADS) {
+    float v = 0.f;
+    for (int i = 0; i < nks; ++i) v += part[i * N + n];
+    y[n] = relu ? fmaxf(v, 0.f) : v;
+  }
+  __syncthreads();
+}
+
+template <int C>
+__global__ __launch_bounds__(GEN_THREADS) void wn_generate_fast_kernel(ns_wavenet_generate_params p) {
+  extern __shared__ float gsm[];
+  const int S = p.S, Q = p.Q, L = p.L;
+  float* outs = gsm;                       // [L][C] gated outputs of this sample (skip path)
+  float* h0 = outs + L * C;                // [S]
+  float* h1 = h0 + S;                      // [S]
+  float* lg = h1 + S;                      // [Q]
+  float* red = lg + ((Q + 1) & ~1);        // [16]
+  float* part = red + 16;                  // [GEN_THREADS * 8]: K-split partial sums of the big products
+  double* ex = (double*)(part + GEN_THREADS * 8);   // [Q]
+  __shared__ int dil[128];
+  __shared__ long qoff[128];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const bf16_t* wb = (const bf16_t*)p.weights;
+  int* ids = p.ids + (long)b * p.total;
+  float* queues = p.queues + (long)b * p.queue_rows * C;
+  const float* un = p.uniform + (long)b * (p.total - p.n_seed);
+  if (tid == 0) {
+    long q = 0;
+    for (int i = 0; i < L; ++i) { dil[i] = p.dilations[i]; qoff[i] = q; q += p.dilations[i]; }
+  }
+  __syncthreads();
+  for (int t = 1; t < p.total; ++t) {
+    const bool emit = t + 1 >= p.n_seed && t + 1 < p.total;
+    if (wave == 0) {
+      float xcur = 0.f;
+      if (lane < C) {
+        const int a = ids[t - 1], c = ids[t];
+        xcur = (float)wb[p.off_causal + (long)a * C + lane] + (float)wb[p.off_causal + ((long)Q + c) * C + lane];
+      }
+      GenPk<C> w0, w1, w2;
+      genpk_load(w0, p, 0, lane, queues, qoff[0], t, dil[0]);
+      if (L > 1) genpk_load(w1, p, 1, lane, queues, qoff[1], t, dil[1]);
+      if (L > 2) genpk_load(w2, p, 2, lane, queues, qoff[2], t, dil[2]);
+      auto layer = [&](int l, GenPk<C>& w) {
+        const float xold = w.ring;
+        float z = 0.f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const unsigned pw = w.fg[k >> 1];
+          z = fmaf(lane_bcast(xold, k), (k & 1) ? pk_hi(pw) : pk_lo(pw), z);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const unsigned pw = w.fg[(C + k) >> 1];
+          z = fmaf(lane_bcast(xcur, k), (k & 1) ? pk_hi(pw) : pk_lo(pw), z);
+        }
+        const float zg = __shfl(z, (lane + C) & 63, 64);
+        const float o = tanhf(z) * (1.f / (1.f + expf(-zg)));          // meaningful in lanes < C
+        if (emit && lane < C) outs[l * C + lane] = o;
+        float xn = xcur;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+          const unsigned pw = w.de[k >> 1];
+          xn = fmaf(lane_bcast(o, k), (k & 1) ? pk_hi(pw) : pk_lo(pw), xn);
+        }
+        if (lane < C) queues[(qoff[l] + (t % dil[l])) * C + lane] = xcur;   // the current input replaces the one just used
+        xcur = xn;
+        if (l + 3 < L) genpk_load(w, p, l + 3, lane, queues, qoff[l + 3], t, dil[l + 3]);
+      };
+      for (int l = 0; l < L; l += 3) {
+        layer(l, w0);
+        if (l + 1 < L) layer(l + 1, w1);
+        if (l + 2 < L) layer(l + 2, w2);
+      }
+    }
+    __syncthreads();
+    if (!emit) continue;
+    // skip sum over all layers as ONE [L*C, S] product, relu, post1, relu, post2
+    gen_matvec8(wb + p.off_skip, L * C, S, outs, h0, part, true, tid);
+    gen_matvec8(wb + p.off_post1, S, S, h0, h1, part, true, tid);
+    gen_matvec8(wb + p.off_post2, S, Q, h1, lg, part, false, tid);
+    float m = -3.0e38f;
+    for (int j = tid; j < Q; j += GEN_THREADS) m = fmaxf(m, lg[j]);
+    m = block_max(m, red);
+    for (int j = tid; j < Q; j += GEN_THREADS) ex[j] = exp((double)lg[j] - (double)m);
+    __syncthreads();
+    if (tid == 0) {
+      double se = 0.0;
+      for (int j = 0; j < Q; ++j) se += ex[j];
+      const double u = (double)un[t + 1 - p.n_seed] * se;
+      double c = 0.0;
+      int pick = Q - 1;
+      for (int j = 0; j < Q; ++j) {
+        c += ex[j];
+        if (u < c) { pick = j; break; }
+      }
+      ids[t + 1] = pick;
+      if (p.probs)
+        for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(ex[j] / se);
     }
     __syncthreads();
   }
@@ -233,10 +464,23 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_gen
 
 extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->weights && p->ids && p->queues && p->uniform && p->dilations, "ns_wavenet_generate: null");
-  NS_CHECK_ARG(p->B > 0 && p->n_seed >= 2 && p->total > p->n_seed && p->L > 0, "ns_wavenet_generate: bad sizes");
-  NS_CHECK_ARG(p->R <= 256 && 2 * p->Dc <= GEN_THREADS && p->Q <= 1024, "ns_wavenet_generate: layer too wide");
-  const size_t lds = sizeof(float) * (2 * p->R + 3 * p->Dc + 2 * p->S + p->Q);
+  NS_CHECK_ARG(p->B > 0 && p->n_seed >= 2 && p->total > p->n_seed && p->L > 0 && p->L <= 128, "ns_wavenet_generate: bad sizes");
+  NS_CHECK_ARG(GEN_THREADS % (2 * p->Dc) == 0 && GEN_THREADS % p->R == 0 && 2 * p->R * 2 * p->Dc <= GEN_FG * GEN_THREADS &&
+                   p->Dc * p->R <= GEN_DE * GEN_THREADS && p->Dc <= GEN_SK && p->S <= GEN_THREADS && p->Q <= 1024,
+               "ns_wavenet_generate: channel counts outside the kernel's register plan");
+  const size_t lds = sizeof(float) * (2 * p->R + 3 * p->Dc + GEN_THREADS + 2 * p->S + ((p->Q + 1) & ~1)) + sizeof(double) * p->Q;
   NS_CHECK_ARG(lds <= 60 * 1024, "ns_wavenet_generate: state does not fit in LDS");
+  if (p->fgT && p->deT) {
+    NS_CHECK_ARG(p->w_dtype == NS_BF16 && p->R == p->Dc && (p->R == 32 || p->R == 16) && p->S % 8 == 0 && p->Q % 8 == 0 && p->S / 8 <= GEN_THREADS &&
+                     GEN_THREADS % (p->S / 8) == 0 && GEN_THREADS % (p->Q / 8) == 0,
+                 "ns_wavenet_generate: the single-wave chain needs bf16 weights and R == Dc in {16, 32}");
+    const size_t lds2 = sizeof(float) * ((size_t)p->L * p->R + 2 * p->S + ((p->Q + 1) & ~1) + 16 + GEN_THREADS * 8) + sizeof(double) * p->Q;
+    NS_CHECK_ARG(lds2 <= 60 * 1024 && ((size_t)p->L * p->R) % 2 == 0, "ns_wavenet_generate: state does not fit in LDS");
+    if (p->R == 32) hipLaunchKernelGGL(wn_generate_fast_kernel<32>, dim3(p->B), dim3(GEN_THREADS), lds2, (hipStream_t)s, *p);
+    else hipLaunchKernelGGL(wn_generate_fast_kernel<16>, dim3(p->B), dim3(GEN_THREADS), lds2, (hipStream_t)s, *p);
+    NS_CHECK_LAUNCH("wavenet_generate_fast");
+    return NS_OK;
+  }
   if (p->w_dtype == NS_BF16) hipLaunchKernelGGL(wn_generate_kernel<bf16_t>, dim3(p->B), dim3(GEN_THREADS), lds, (hipStream_t)s, *p);
   else hipLaunchKernelGGL(wn_generate_kernel<float>, dim3(p->B), dim3(GEN_THREADS), lds, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("wavenet_generate");

@@ -364,7 +364,7 @@ class SimpleWaveNet(object):
         last = logits[(ow - 1) * self.Q: ow * self.Q].double()
         return torch.softmax(last, dim=0).float()
 
-    def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None):
+    def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None, fast=True):
         """Incremental generation (generate_wavenet.py:56-142): seed_ids int [B, n_seed] (or [n_seed]) of mu-law codes,
         n_seed >= receptive field; returns int32 [B, n_seed + n_samples].  uniforms [B, n_samples] in [0,1) drive the
         categorical draws (default: numpy Generator(seed)).  Weights: the fp32 master copy when exact (default in fp32
@@ -391,6 +391,17 @@ class SimpleWaveNet(object):
                     dense_in_layer=self._o("dense0") - self._o("fg0"), skip=self._o("skip"), post1=self._o("post1"),
                     post2=self._o("post2"))
         self.last_probs = torch.zeros(B * self.Q, dtype=torch.float32, device=dev)
+        fgT = deT = None
+        ok = self.S % 8 == 0 and self.Q % 8 == 0 and 512 % (self.S // 8) == 0 and 512 % (self.Q // 8) == 0
+        if fast and not exact and self.R == self.Dc and self.R in (16, 32) and ok:
+            # column-major bf16 shadows of the layer kernels for the single-wave chain (a lane loads its whole column)
+            R, Dc = self.R, self.Dc
+            fg = torch.stack([self.flat_p[self._o("fg%d" % l):self._o("fg%d" % l) + 2 * R * 2 * Dc].view(2 * R, 2 * Dc).t()
+                              for l in range(self.L)])
+            de = torch.stack([self.flat_p[self._o("dense%d" % l):self._o("dense%d" % l) + Dc * R].view(Dc, R).t()
+                              for l in range(self.L)])
+            fgT, deT = fg.contiguous().to(torch.bfloat16), de.contiguous().to(torch.bfloat16)
         ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
-                             probs=self.last_probs)
+                             probs=self.last_probs, fgT=fgT, deT=deT)
+        self._gen_keep = (fgT, deT, un, queues, dil)        # keep the operands alive until the stream has used them
         return ids
