@@ -141,6 +141,48 @@ def inference_bench(hp, dtype, seed=1234):
     return out
 
 
+def wavenet_bench(seed=1234):
+    """BASELINE config 4 (simple_wavenet, shipped wavenet.yaml: 50 layers, receptive field 5117): one training step on
+    8 clips of receptive field + 8000 samples, and incremental generation of 2000 samples behind a receptive-field
+    seed, batch 1 and 32 (one workgroup per waveform), bf16 weights."""
+    from nspeech_amd.models.wavenet import mu_law_encode, receptive_field
+    hp = hparams_mod.load("wavenet")
+    rf = receptive_field(hp)
+    m = create_model("simple_wavenet", hp, device="cuda:%d" % torch.cuda.current_device(), dtype="bf16", seed=seed)
+    m.add_optimizer(0)
+    rng = np.random.default_rng(seed)
+    N, T = 8, rf + 8000
+    t = np.arange(T) / 16000.0
+    audio = (0.5 * np.sin(2 * np.pi * 220 * t)[None] + 0.02 * rng.standard_normal((N, T))).astype(np.float32)
+    for _ in range(2):
+        m.step(audio)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        m.step(audio)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    out = {"receptive_field": rf, "train": {"ms_per_step": dt * 1e3, "target_samples_per_s": N * (T - rf) / dt,
+                                            "batch": N, "clip_samples": T, "loss": m.loss}}
+    seeds = mu_law_encode((0.01 * rng.standard_normal((1, rf))).astype(np.float32), hp.quantization_channels)
+    for B in (1, 32):
+        sd = np.repeat(seeds, B, 0)
+        m.generate(sd, 64)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.generate(sd, 2000)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        m.generate(sd, 1)
+        torch.cuda.synchronize()
+        warm = time.perf_counter() - t0                      # the seed walk alone
+        gen = max(dt - warm, 1e-9)
+        out["generate_batch_%d" % B] = {"samples_per_s": B * 2000 / gen, "us_per_drawn_sample": gen / 2000 * 1e6,
+                                        "seed_walk_ms": warm * 1e3, "realtime_factor_16k": (B * 2000 / gen) / 16000.0}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -251,6 +293,7 @@ def main():
         if world == 1:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
             res["inference"] = inference_bench(hp, args.dtype)
+            res["wavenet"] = wavenet_bench()
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hp, 1234)
         print(json.dumps(res))
