@@ -266,6 +266,11 @@ class SimpleWaveNet(object):
         return hp.initial_learning_rate * warm ** 0.5 * min(s * warm ** -1.5, s ** -0.5)
 
     # ------------------------------------------------------------------ backward
+    @staticmethod
+    def _sk(K):
+        """split-K factor of a weight-gradient GEMM: its output tile is tiny (<= 64 x 64) and K is the row count."""
+        return max(1, min(256, K // 2048))
+
     def backward(self):
         T_, W, g = self.T, self.flat_s, self.flat_g
         R, Dc, S, Q, L = self.R, self.Dc, self.S, self.Q, self.L
@@ -277,12 +282,12 @@ class SimpleWaveNet(object):
         f32 = torch.float32
         t1, c1, outs, xs, zs = B["t1"], B["c1"], B["outs"], B["xs"], B["zs"]
         # post2 / post1
-        ops.gemm(c1, self.dlogits, g, S, Q, M, S, Q, Q, a_mode=1, b_mode=1, c_off=self._o("post2"), accumulate=1)
+        ops.gemm(c1, self.dlogits, g, S, Q, M, S, Q, Q, a_mode=1, b_mode=1, c_off=self._o("post2"), accumulate=2, split_k=self._sk(M))
         dc1 = self._buf("dc1", M * S, f32)
         ops.gemm(self.dlogits, W, dc1, M, S, Q, Q, Q, S, b_mode=0, b_off=self._o("post2"))
         dp1 = self._buf("dp1", M * S, T_)
         ops.act_bwd(dc1, c1, dp1, M, S, ACT_RELU)
-        ops.gemm(t1, dp1, g, S, S, M, S, S, S, a_mode=1, b_mode=1, c_off=self._o("post1"), accumulate=1)
+        ops.gemm(t1, dp1, g, S, S, M, S, S, S, a_mode=1, b_mode=1, c_off=self._o("post1"), accumulate=2, split_k=self._sk(M))
         dt1 = self._buf("dt1", M * S, f32)
         ops.gemm(dp1, W, dt1, M, S, S, S, S, S, b_mode=0, b_off=self._o("post1"))
         dsk = self._buf("dsk", M * S, T_)
@@ -294,7 +299,7 @@ class SimpleWaveNet(object):
             ao = (n * T0 + self.rf - 1) * L * Dc
             ops.gemm(dsk, W, douts, ow, L * Dc, S, S, S, L * Dc, b_mode=0, a_off=n * ow * S, b_off=self._o("skip"), c_off=ao)
             ops.gemm(outs, dsk, g, L * Dc, S, ow, L * Dc, S, S, a_mode=1, b_mode=1, a_off=ao, b_off=n * ow * S,
-                     c_off=self._o("skip"), accumulate=1)
+                     c_off=self._o("skip"), accumulate=2, split_k=self._sk(ow))
         # dilated stack, last layer first; dx of the last residual output is zero (nothing reads it)
         dx = self._buf("dx", 2 * rows * R, T_)
         dx.zero_()
@@ -311,13 +316,14 @@ class SimpleWaveNet(object):
             dol = self._buf("dout_l", rows * Dc, T_)
             ops.gemm(dx, W, dol, rows, Dc, R, R, R, Dc, b_mode=0, a_off=nxt, b_off=de, addend=douts, addend_off=l * Dc,
                      ld_add=L * Dc)
-            ops.gemm(outs, dx, g, Dc, R, rows, L * Dc, R, R, a_mode=1, b_mode=1, a_off=l * Dc, b_off=nxt, c_off=de, accumulate=1)
+            ops.gemm(outs, dx, g, Dc, R, rows, L * Dc, R, R, a_mode=1, b_mode=1, a_off=l * Dc, b_off=nxt, c_off=de, accumulate=2,
+                     split_k=self._sk(rows))
             ops.wavenet_gate(zs[zo:], rows, Dc, T0, starts[l + 1], dout=dol, ld_dout=Dc, dz=dz)
             # weight gradients of the two taps (contraction over rows m >= d)
             ops.gemm(xs, dz, g, R, 2 * Dc, rows - d, R, 2 * Dc, 2 * Dc, a_mode=1, b_mode=1, a_off=xo, b_off=d * 2 * Dc, c_off=fg,
-                     accumulate=1)
+                     accumulate=2, split_k=self._sk(rows))
             ops.gemm(xs, dz, g, R, 2 * Dc, rows - d, R, 2 * Dc, 2 * Dc, a_mode=1, b_mode=1, a_off=xo + d * R, b_off=d * 2 * Dc,
-                     c_off=fg + R * 2 * Dc, accumulate=1)
+                     c_off=fg + R * 2 * Dc, accumulate=2, split_k=self._sk(rows))
             # dx_l = dx_{l+1} + dz . W[1]^T (same row) + dz[m] . W[0]^T -> row m - d
             # (dz has max(dilation) zero rows behind its end, so the shifted read covers every row; two launches through
             # a scratch buffer, no accumulate= - that needs an fp32 C - and nothing in place)
