@@ -402,6 +402,13 @@ typedef struct {
   int f32_passes;                  /* as in ns_gemm_params, for the in-loop products */
   const void* wattT_hi; const void* wattT_lo; const void* watt_bf16;   /* optional, as in ns_lstm_seq_params */
   void* dga_bf16;                  /* optional [N,S+1,4A] bf16 copy of dga for the backward recurrence */
+  /* Projected-memory form (optional): pv (dtype) [N*Pi, D1] = values . W1c in the row layout of `values`.  Forward:
+   * the context kernel writes the NEXT step's prenet layer relu(align . pv + f1) directly (no per-step p1 product)
+   * and the contexts hc[:, :, A:] are formed after the loop by one product per batch item.  Backward additionally
+   * takes da0 fp32 [N,S+1,Tia] = dhc[:, :, A:] . values^T (hoisted by the caller); the per-step dctx product
+   * disappears and dctx_t is formed after the loop (df1 then needs one extra zero row behind its N*(S+1) rows).
+   * Results equal the plain form up to rounding. */
+  const void* pv; const float* da0;
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

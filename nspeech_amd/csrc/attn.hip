@@ -75,6 +75,7 @@ struct AttnStep {
   T* ctx_out; long ctx_sn;             // [E]
   T* ctx_out2; long ctx2_sn;           // optional second destination
   const float* wcl; const float* v;
+  const float* add; long add_sn; int relu;   // optional: ctx_out = relu?(weighted sum + add[n*add_sn + c])
 };
 
 // x[t,u] = keys[t,u] + q[u] + sum_k align_prev[t+k-half] Wcl[k,u];  lane = t, wave = unit chunk.
@@ -204,7 +205,9 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnStep<T> a) {
   for (int i = tid; i < CCH; i += 256) {
     const int cc = ch * CCH + i;
     if (cc < E) {
-      const float v = cpart[i] + cpart[CCH + i] + cpart[2 * CCH + i] + cpart[3 * CCH + i];
+      float v = cpart[i] + cpart[CCH + i] + cpart[2 * CCH + i] + cpart[3 * CCH + i];
+      if (a.add) v += a.add[(long)n * a.add_sn + cc];
+      if (a.relu) v = fmaxf(v, 0.f);
       stf(a.ctx_out + (long)n * a.ctx_sn + cc, v);
       if (a.ctx_out2) stf(a.ctx_out2 + (long)n * a.ctx2_sn + cc, v);
     }
@@ -228,8 +231,12 @@ struct AttnBwdStep {
   float* da;                               // [N,Tia] scratch
   T* dq_out; long dq_sn;
   float* de_out;                           // [Tia] per row (stride al_sn): energy gradients of this step
-  T* dctx_out; long dco_sn;                // [E] total context gradient of this step (operand dtype)
+  T* dctx_out; long dco_sn;                // [E] total context gradient of this step (operand dtype); null = not stored
   const float* wcl; const float* v;
+  // projected-memory form (values = memory . W1c, E = prenet width): the vector dotted with the memory rows is the
+  // prenet gradient of the step after (dvec, operand dtype, null on the last step) and the part of da that needs no
+  // recurrence arrives precomputed (da0)
+  int pv_mode; const T* dvec; long dv_sn; const float* da0; long da0_sn;
 };
 
 // (1) da[t] = dctx . values[t] + sum_k G_next[t-k+half][k];  grid (t-chunks of 32, N)
@@ -242,10 +249,14 @@ __global__ __launch_bounds__(ATHREADS) void attn_bwd_da_kernel(AttnBwdStep<T> a)
   const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
   const int half = (a.kw - 1) / 2;
   for (int c = tid; c < E; c += ATHREADS) {
-    float d = a.dctx_ext[(long)n * a.dce_sn + c];
-    if (a.dctx_carry) d += a.dctx_carry[(long)n * E + c];
+    float d;
+    if (a.pv_mode) d = a.dvec ? ldf(a.dvec + (long)n * a.dv_sn + c) : 0.f;
+    else {
+      d = a.dctx_ext[(long)n * a.dce_sn + c];
+      if (a.dctx_carry) d += a.dctx_carry[(long)n * E + c];
+    }
     sm[c] = d;
-    if (blockIdx.x == 0) stf(a.dctx_out + (long)n * a.dco_sn + c, d);
+    if (blockIdx.x == 0 && a.dctx_out) stf(a.dctx_out + (long)n * a.dco_sn + c, d);
   }
   __syncthreads();
   const T* values = a.values + (long)n * a.values_sn;
@@ -279,7 +290,8 @@ __global__ __launch_bounds__(ATHREADS) void attn_bwd_da_kernel(AttnBwdStep<T> a)
           if (ts >= 0 && ts < Ti) carry += gk[(long)ts * MAXKW + k];
         }
       }
-      a.da[(long)n * Tia + t] = t < L ? sv + carry : 0.f;
+      const float base = (a.da0 && t < L) ? a.da0[(long)n * a.da0_sn + t] : 0.f;
+      a.da[(long)n * Tia + t] = t < L ? sv + carry + base : 0.f;
     }
   }
 }
@@ -561,6 +573,15 @@ static size_t dq_lds(const ns_taco2_attn_params& p) {
   return sizeof(float) * ((size_t)p.Ti + 2 * PADK + p.Tia + AW * 64);
 }
 
+// projected-memory form, step 0: p1[slot 1] = relu(f1[slot 1]) (the context before the first step is zero)
+template <typename T>
+__global__ void attn_p1_init_kernel(const float* f1, T* p1, int N, long S1, int D1) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * D1) return;
+  const long o = ((long)(i / D1) * S1 + 1) * D1 + i % D1;
+  stf(p1 + o, fmaxf(f1[o], 0.f));
+}
+
 template <typename T>
 static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
@@ -573,16 +594,22 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(p.Tia, 32), ceil_div(p.A, 32), p.N), dim3(256), 0, s,
                      p.keys, p.keys_t, p.Ti, p.Tia, p.Pi, p.padl_i, p.A, 0);
   NS_CHECK_LAUNCH("keys_transpose");
+  const bool pvm = p.pv != nullptr;
+  T* p1_spill = (T*)(e_raw + (size_t)p.N * p.Tia);      // [N, D1]: where the last step's (unused) next-p1 goes
+  if (pvm)
+    hipLaunchKernelGGL(attn_p1_init_kernel<T>, dim3(ceil_div(p.N * (int)D1, 256)), dim3(256), 0, s, p.f1, (T*)p.p1, p.N, S1, (int)D1);
   for (int st = 0; st < p.S; ++st) {
     const long slot = st + 1, prev = st;
     T* hc = (T*)p.hc; T* xa = (T*)p.xa; T* p1 = (T*)p.p1;
     int rc;
     for (int nb = 0; nb < p.N; nb += 32) {
       const int nn = min(32, p.N - nb);
-      // p1 = relu(ctx_prev . W1c + F1)
-      rc = gemm_small(dt, nn, D1, E, hc + (nb * S1 + prev) * HC + A, S1 * HC, p.w1cT, E, p1 + (nb * S1 + slot) * D1,
-                      S1 * D1, dt, nullptr, NS_ACT_RELU, p.f1 + (nb * S1 + slot) * D1, S1 * D1, nullptr, 0, s);
-      if (rc) return rc;
+      // p1 = relu(ctx_prev . W1c + F1)   (projected-memory form: already written by the previous step's context kernel)
+      if (!pvm) {
+        rc = gemm_small(dt, nn, D1, E, hc + (nb * S1 + prev) * HC + A, S1 * HC, p.w1cT, E, p1 + (nb * S1 + slot) * D1,
+                        S1 * D1, dt, nullptr, NS_ACT_RELU, p.f1 + (nb * S1 + slot) * D1, S1 * D1, nullptr, 0, s);
+        if (rc) return rc;
+      }
       // p2 = relu(p1 . W2 + b2) -> xa[:, 0:D2]
       rc = gemm_small(dt, nn, D2, D1, p1 + (nb * S1 + slot) * D1, S1 * D1, p.w2T, D1, xa + (nb * S1 + slot) * XA,
                       S1 * XA, dt, p.b2, NS_ACT_RELU, nullptr, 0, nullptr, 0, s);
@@ -618,8 +645,38 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     a.ctx_out = hc + slot * HC + A; a.ctx_sn = S1 * HC;
     a.wcl = p.wcl; a.v = p.v; a.e_raw = e_raw;
     hipLaunchKernelGGL(attn_energy_kernel<T>, dim3(ceil_div(p.Ti, 64), p.N), dim3(ATHREADS), 0, s, a);
-    hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div(p.E, CCH), p.N), dim3(256), lds, s, a);
+    if (pvm) {
+      // next step's prenet layer straight from the alignments: p1[slot+1] = relu(align . (memory . W1c) + f1[slot+1])
+      AttnStep<T> c = a;
+      c.E = (int)D1;
+      c.values = (const T*)p.pv + (long)p.padl_i * D1; c.values_sn = (long)p.Pi * D1;
+      if (st + 1 < p.S) {
+        c.ctx_out = p1 + (slot + 1) * D1; c.ctx_sn = S1 * D1;
+        c.add = p.f1 + (slot + 1) * D1; c.add_sn = S1 * D1;
+      } else {
+        c.ctx_out = p1_spill; c.ctx_sn = D1;
+      }
+      c.relu = 1;
+      hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div((int)D1, CCH), p.N), dim3(256), lds, s, c);
+    } else {
+      hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div(p.E, CCH), p.N), dim3(256), lds, s, a);
+    }
     NS_CHECK_LAUNCH("attn_fwd");
+  }
+  if (pvm) {
+    // the contexts themselves feed nothing inside the loop any more: one product per batch item over all steps,
+    // hc[n, 1..S, A:] = align[n, 1..S, :] . memory[n]
+    NS_CHECK_ARG(p.align_t != nullptr, "ns_taco2_attn_fwd: the projected-memory form needs align_t");
+    for (int n = 0; n < p.N; ++n) {
+      ns_gemm_params g = {};
+      g.dtype = dt; g.M = p.S; g.N = (int)E; g.K = p.Ti;
+      g.A = (const T*)p.align_t + ((long)n * S1 + 1) * p.Tia; g.lda = p.Tia; g.a_mode = 0;
+      g.B = (const T*)p.values + ((long)n * p.Pi + p.padl_i) * E; g.ldb = E; g.b_mode = 1;
+      g.C = (T*)p.hc + ((long)n * S1 + 1) * HC + A; g.ldc = HC; g.c_dtype = dt;
+      g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
+      int rc = ns_gemm(&g, s);
+      if (rc) return rc;
+    }
   }
   return NS_OK;
 }
@@ -650,6 +707,8 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   NS_CHECK_ARG(lds <= 64 * 1024 && sizeof(float) * p.E <= 64 * 1024,
                "ns_taco2_attn_bwd: T_in / memory depth too large for LDS");
   T* xa = (T*)p.xa; T* p1 = (T*)p.p1;
+  const bool pvm = p.pv != nullptr;
+  NS_CHECK_ARG(!pvm || p.da0 != nullptr, "ns_taco2_attn_bwd: the projected-memory form needs da0");
   for (int st = p.S - 1; st >= 0; --st) {
     const long slot = st + 1, prev = st;
     const bool last = (st == p.S - 1);
@@ -668,6 +727,17 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     a.de_out = p.de + slot * p.Tia;
     a.dctx_out = (T*)p.dctx_t + slot * E; a.dco_sn = S1 * E;
     a.wcl = p.wcl; a.v = p.v;
+    if (pvm) {
+      // da = da0 (hoisted: d(hc context) . memory^T) + dp1[s+1] . (memory . W1c)^T
+      AttnBwdStep<T> c = a;
+      c.pv_mode = 1;
+      c.E = (int)D1;
+      c.values = (const T*)p.pv + (long)p.padl_i * D1; c.values_sn = (long)p.Pi * D1;
+      c.dvec = last ? nullptr : (const T*)p.df1 + (slot + 1) * D1; c.dv_sn = S1 * D1;
+      c.da0 = p.da0 + slot * p.Tia; c.da0_sn = S1 * p.Tia;
+      c.dctx_out = nullptr;
+      hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p.Tia, 32), p.N), dim3(ATHREADS), sizeof(float) * D1, s, c);
+    } else
     hipLaunchKernelGGL(attn_bwd_da_kernel<T>, dim3(ceil_div(p.Tia, 32), p.N), dim3(ATHREADS), sizeof(float) * p.E, s, a);
     hipLaunchKernelGGL(attn_bwd_energy_kernel<T>, dim3(ceil_div(p.Ti, 64), p.N), dim3(ATHREADS), 0, s, a);
     hipLaunchKernelGGL(attn_bwd_dq_kernel<T>, dim3(ceil_div(p.A, 64), p.N), dim3(ATHREADS), lds, s, a);
@@ -711,8 +781,8 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
                       (T*)p.df1 + (nb * S1 + slot) * D1, S1 * D1, dt, nullptr, NS_ACT_NONE, nullptr, 0,
                       p1 + (nb * S1 + slot) * D1, S1 * D1, s);
       if (rc) return rc;
-      // dctx_carry = dp1pre . W1c^T
-      if (st > 0) {
+      // dctx_carry = dp1pre . W1c^T   (projected-memory form: folded into the next da kernel and the hoisted product)
+      if (st > 0 && !pvm) {
         rc = gemm_small(dt, nn, (int)E, (int)D1, (T*)p.df1 + (nb * S1 + slot) * D1, S1 * D1, p.w1c, D1,
                         dctx_carry + (long)nb * E, E, NS_F32, nullptr, NS_ACT_NONE, nullptr, 0, nullptr, 0, s);
         if (rc) return rc;
@@ -728,6 +798,20 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
     hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, s, q);
     NS_CHECK_LAUNCH("attn_post");
+  }
+  if (pvm) {
+    // total context gradients of all steps in one product: dctx[n, slot] = dhc[n, slot, A:] + df1[n, slot+1] . W1c^T
+    // (df1 slot 0 rows are never written, so the row behind an item's last slot contributes zero; the caller keeps
+    // one zero row behind the end of df1 for the very last one)
+    ns_gemm_params g = {};
+    g.dtype = dt; g.M = (int)(p.N * S1); g.N = (int)E; g.K = (int)D1;
+    g.A = (const T*)p.df1 + D1; g.lda = D1; g.a_mode = 0;
+    g.B = p.w1c; g.ldb = D1; g.b_mode = 0;
+    g.C = p.dctx_t; g.ldc = E; g.c_dtype = dt;
+    g.addend = p.dhc + A; g.ld_add = HC; g.addend_dtype = NS_F32;
+    g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
+    int rc = ns_gemm(&g, s);
+    if (rc) return rc;
   }
   // dvalues[n] += align[n]^T . dctx[n]   (contraction over the decoder steps)
   for (int n = 0; n < p.N; ++n) {

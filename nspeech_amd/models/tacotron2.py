@@ -70,6 +70,7 @@ class Tacotron2(object):
         self._sig = None
         self.timing = None
         self.reducer = None       # parallel.GradReducer when data-parallel
+        self.use_pv = True        # projected-memory form of the attention loop (ns_taco2_attn_params.pv)
         self._status_words = {}
         pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
         self.load_numpy(pv, sv)
@@ -462,7 +463,14 @@ class Tacotron2(object):
         ga = self._buf("dec_ga", N * S1 * 4 * A, T_)
         q = self._buf("dec_q", N * S1 * A, torch.float32)
         al = self._buf("dec_al", N * S1 * Tia, torch.float32)
+        # projected memory: values . W1c once per pass, so that inside the loop the context kernel yields the next
+        # step's prenet layer directly and the 512-wide contexts are formed after the loop
+        pv = None
+        if self.use_pv:
+            pv = self._buf("dec_pv", N * Pi * 256, T_)
+            ops.gemm(enc, self._W(self.T), pv, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
         self._attn_args = dict(
+            pv=pv,
             dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=self.padl, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
             lengths=self.input_lengths, keys=keys, values=enc, f1=f1,
             w1cT=self.tsh["w1cT"], w2T=self.tsh["w2T"], wattT=self.tsh["wattT"], wqT=self.tsh["wqT"],
@@ -661,7 +669,7 @@ class Tacotron2(object):
         ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
         self._tick("dec_lstm_bwd")
         # ---- attention RNN through time
-        df1 = self._buf("d_f1", rows * 256, T_)
+        df1 = self._buf("d_f1", (rows + 1) * 256, T_)        # + one zero row read by the hoisted dctx product
         dp2 = self._buf("d_p2", rows * 128, T_)
         dga = self._buf("d_ga", rows * 4 * A, T_)
         dq = self._buf("d_q", rows * A, T_)
@@ -678,6 +686,19 @@ class Tacotron2(object):
         wa = self._o("decoder/attention_lstm/kernel")
         wq = self._o("decoder/attention/query_layer/kernel")
         args = dict(self._attn_args)
+        if args.get("pv") is not None:
+            # the part of d(align) that needs no recurrence, for all steps at once: da0[n] = dhc[n, :, A:] . memory[n]^T
+            da0 = self._buf("d_a0", rows * Tia, torch.float32)
+            enc = args["values"]
+            if T_ == torch.float32:
+                src, lda, a0 = dhc, A + E, A
+            else:
+                src, lda, a0 = self._buf("d_hc_ctx", rows * E, T_), E, 0
+                ops.copy3d(dhc, src, 1, rows, E, (0, A + E), (0, E), src_off=A)
+            for n in range(N):
+                ops.gemm(src, enc, da0, S1, Ti, E, lda, E, Tia, b_mode=0, a_off=n * S1 * lda + a0,
+                         b_off=(n * Pi + self.padl) * E, c_off=n * S1 * Tia)
+            args["da0"] = da0
         args.update(w1c=(self._W(self.T), w1 + M * 256), w2=(self._W(self.T), w2), watt=(self._W(self.T), wa),
                     wq=(self._W(self.T), wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,
                     dv=(g, self._o("decoder/attention/attention_v")), dwcl=dwcl, work=awork,
