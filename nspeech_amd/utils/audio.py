@@ -81,15 +81,68 @@ def _get_tables():
 
 
 # ---------------------------------------------------------------- wav I/O (host)
+_RESAMPLE_FILTER = None
+
+
+def _kaiser_best():
+    """resampy's 'kaiser_best' interpolation table [3P, resampy filters.py]: rolloff * sinc(rolloff * t) for t in
+    [0, num_zeros] at 2^precision points per zero crossing, tapered by the right half of a Kaiser window."""
+    global _RESAMPLE_FILTER
+    if _RESAMPLE_FILTER is None:
+        num_zeros, precision, rolloff, beta = 64, 9, 0.9475937167399596, 14.769656459379492
+        num_bits = 2 ** precision
+        n = num_bits * num_zeros
+        sinc_win = rolloff * np.sinc(rolloff * np.linspace(0, num_zeros, num=n + 1, endpoint=True))
+        taper = np.kaiser(2 * n + 1, beta)[n:]
+        _RESAMPLE_FILTER = (taper * sinc_win, num_bits)
+    return _RESAMPLE_FILTER
+
+
+def resample(x, sr_orig, sr_new):
+    """librosa.core.load's default resampler (librosa 0.6.0 -> resampy.resample(..., filter='kaiser_best'), audio.py:14)
+    restated [3P, parity unpinned]: band-limited sinc interpolation, the table read with linear interpolation between
+    entries, gain and cut-off scaled by the ratio when down-sampling.  Vectorised over the output samples."""
+    # float64 tensor arithmetic: on the GPU when there is one (a 10 s clip takes milliseconds), else on the host
+    dev = torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+    x = torch.as_tensor(np.asarray(x, np.float64), device=dev)
+    ratio = float(sr_new) / float(sr_orig)
+    n_out = int(x.shape[0] * ratio)
+    win_np, num_table = _kaiser_best()
+    win = torch.as_tensor(win_np * (ratio if ratio < 1 else 1.0), device=dev)
+    delta = torch.zeros_like(win)
+    delta[:-1] = win[1:] - win[:-1]
+    scale = min(1.0, ratio)
+    index_step = int(scale * num_table)
+    nwin, n_orig = win.shape[0], x.shape[0]
+    tr = torch.arange(n_out, device=dev, dtype=torch.float64) * (1.0 / ratio)     # time register
+    n = tr.long()
+    y = torch.zeros(n_out, dtype=torch.float64, device=dev)
+    zero = torch.zeros((), dtype=torch.long, device=dev)
+
+    def wing(frac, count, sign, base):
+        nonlocal y
+        idx = frac * num_table
+        off = idx.long()
+        eta = idx - off
+        cmax = torch.minimum(count, (nwin - off) // index_step)
+        for i in range(int(cmax.max().item())):
+            ok = i < cmax
+            k = torch.where(ok, off + i * index_step, zero)
+            w = win[k] + eta * delta[k]
+            y = y + torch.where(ok, w * x[torch.where(ok, base + sign * i, zero)], torch.zeros_like(y))
+    frac = scale * (tr - n)
+    wing(frac, n + 1, -1, n)                          # left wing: x[n], x[n-1], ...
+    wing(scale - frac, n_orig - n - 1, +1, n + 1)     # right wing: x[n+1], x[n+2], ...
+    return y.float().cpu().numpy()
+
+
 def load_wav(path, offset=0.0, duration=None):
-    """PCM16 / float32 RIFF reader.  The reference resamples through librosa (resampy); here the
-    file must already be at hparams.sample_rate (SURVEY F2 keeps resampling out of the hot path)."""
+    """PCM16 / float32 RIFF reader + mono mix-down + resampling to hparams.sample_rate, as librosa.core.load does for
+    the reference (audio.py:13-14; LJSpeech is 22 050 Hz, audio.yaml asks for 20 000 Hz)."""
     with wave.open(path, "rb") as f:
         sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
         raw = f.readframes(n)
     hp = get_hparams()
-    if sr != hp.sample_rate:
-        raise ValueError("%s is %d Hz, expected %d Hz" % (path, sr, hp.sample_rate))
     if width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
     elif width == 4:
@@ -98,9 +151,12 @@ def load_wav(path, offset=0.0, duration=None):
         raise ValueError("unsupported sample width %d" % width)
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1)
-    s = int(offset * sr)
+    s = int(offset * sr)                     # librosa seeks / truncates at the native rate, then resamples
     e = None if duration is None else s + int(duration * sr)
-    return x[s:e]
+    x = x[s:e]
+    if sr != hp.sample_rate:
+        x = resample(x, sr, hp.sample_rate)
+    return x
 
 
 def save_wav(wav, path):

@@ -84,3 +84,35 @@ def test_find_endpoint():
     e = AO.find_endpoint(wav, HP)
     assert 30000 <= e <= 30000 + 2 * 4000
     assert AO.find_endpoint(0.5 * np.ones(50000), HP) == 50000
+
+
+def test_resample_22050_to_20000_against_polyphase_reference(tmp_path):
+    """load_wav resamples like librosa.load (resampy 'kaiser_best', restated, parity unpinned): checked against an
+    independent band-limited resampler (scipy.signal.resample_poly, 800/882) on in-band material, for length, gain
+    and waveform, and through load_wav on a 22 050 Hz PCM16 file."""
+    import wave
+    from scipy.signal import resample_poly
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.utils import audio
+    hp = hparams_mod.load("taco2")
+    hparams_mod.set_hparams(hp)
+    sr0, sr1 = 22050, hp.sample_rate
+    t = np.arange(sr0) / sr0
+    x = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.3 * np.sin(2 * np.pi * 1870 * t + 0.3) + 0.2 * np.sin(2 * np.pi * 6100 * t)).astype(np.float32)
+    y = audio.resample(x, sr0, sr1)
+    assert len(y) == int(len(x) * sr1 / sr0)
+    ref = resample_poly(x.astype(np.float64), 800, 882)[:len(y)]
+    mid = slice(2000, len(y) - 2000)                       # away from the edge effects of the two filters
+    assert np.abs(y[mid] - ref[mid]).max() < 2e-3
+    t1 = np.arange(len(y)) / sr1
+    exact = 0.4 * np.sin(2 * np.pi * 220 * t1) + 0.3 * np.sin(2 * np.pi * 1870 * t1 + 0.3) + 0.2 * np.sin(2 * np.pi * 6100 * t1)
+    assert np.abs(y[mid] - exact[mid]).max() < 2e-3
+    # a tone above the new Nyquist (10 kHz) is removed instead of aliased
+    hi = audio.resample(np.sin(2 * np.pi * 10700 * t).astype(np.float32), sr0, sr1)
+    assert np.abs(hi[mid]).max() < 2e-2
+    path = str(tmp_path / "a.wav")
+    with wave.open(path, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(sr0)
+        f.writeframes((x * 32767).astype("<i2").tobytes())
+    w = audio.load_wav(path)
+    assert len(w) == len(y) and np.abs(w[mid] - y[mid]).max() < 1e-3
