@@ -97,12 +97,12 @@ def test_resample_22050_to_20000_against_polyphase_reference(tmp_path):
     hp = hparams_mod.load("taco2")
     hparams_mod.set_hparams(hp)
     sr0, sr1 = 22050, hp.sample_rate
-    t = np.arange(sr0) / sr0
+    t = np.arange(sr0 // 3) / sr0
     x = (0.4 * np.sin(2 * np.pi * 220 * t) + 0.3 * np.sin(2 * np.pi * 1870 * t + 0.3) + 0.2 * np.sin(2 * np.pi * 6100 * t)).astype(np.float32)
     y = audio.resample(x, sr0, sr1)
     assert len(y) == int(len(x) * sr1 / sr0)
     ref = resample_poly(x.astype(np.float64), 800, 882)[:len(y)]
-    mid = slice(2000, len(y) - 2000)                       # away from the edge effects of the two filters
+    mid = slice(1500, len(y) - 1500)                       # away from the edge effects of the two filters
     assert np.abs(y[mid] - ref[mid]).max() < 2e-3
     t1 = np.arange(len(y)) / sr1
     exact = 0.4 * np.sin(2 * np.pi * 220 * t1) + 0.3 * np.sin(2 * np.pi * 1870 * t1 + 0.3) + 0.2 * np.sin(2 * np.pi * 6100 * t1)
