@@ -463,6 +463,7 @@ typedef struct {
   int B, n_seed, total; int64_t queue_rows;
   int* ids; const float* uniform; float* queues; float* probs;
   const void* fgT; const void* deT;
+  int engine;   /* with fgT / deT: 0 / 1 = single-wave VALU chain, 2 = MFMA chain + concurrent skip waves (R == Dc == 32) */
 } ns_wavenet_generate_params;
 int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t stream);
 

@@ -328,7 +328,7 @@ __device__ __forceinline__ float lane_bcast(float v, int k) {
 }
 
 // y[0..N) = act(sum_k x[k] * Wm[k*N + n]) for a bf16 [K, N] matrix streamed from L2 once: a thread owns 8 adjacent
-// columns (one 16-byte load per row) and the workgroup splits K, 16 rows in flight per thread; the partial sums meet
+// columns (one 16-byte load per row) and the workgroup splits K, 8 rows in flight per thread; the partial sums meet
 // in LDS.  x, y and part are LDS; part needs (GEN_THREADS / (N/8)) * N floats.  N % 8 == 0, N/8 <= GEN_THREADS.
 __device__ __forceinline__ void gen_matvec8(const bf16_t* Wm, int K, int N, const float* x, float* y, float* part, bool relu,
                                             int tid) {
@@ -337,15 +337,15 @@ __device__ __forceinline__ void gen_matvec8(const bf16_t* Wm, int K, int N, cons
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (ks < nks) {
     const uint4* col = (const uint4*)(Wm + cg * 8);
-    for (int k0 = ks; k0 < K; k0 += nks * 16) {
-      uint4 w[16];
+    for (int k0 = ks; k0 < K; k0 += nks * 8) {
+      uint4 w[8];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int k = k0 + q * nks;
         w[q] = k < K ? col[(long)k * ncg] : make_uint4(0u, 0u, 0u, 0u);
       }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
+      for (int q = 0; q < 8; ++q) {
         const int k = k0 + q * nks;
         const float xv = k < K ? x[k] : 0.f;
         acc[0] = fmaf(xv, pk_lo(w[q].x), acc[0]); acc[1] = fmaf(xv, pk_hi(w[q].x), acc[1]);
@@ -462,6 +462,240 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_fast_kernel(ns_wavene
   }
 }
 
+// ---- MFMA variant (R == Dc == 32): the residual chain of a sample on the matrix cores of ONE wavefront, the skip
+// products of the same sample on the other seven waves while the chain is still running.
+//   chain wave : z = [x[t-d] | x[t]] . W (64 x 64) as 2 k-steps x 4 column tiles of v_mfma_f32_16x16x32_bf16 with the
+//                input vector in row 0 of the A fragment (lanes 0, 16, 32, 48 hold 8 values each), gate + 1x1 dense
+//                (2 more MFMAs) per layer; operands are gathered through a 32-float LDS line; weights (transposed bf16
+//                shadows, 10 sixteen-byte loads per lane per layer) and the ring line are fetched THREE layers ahead.
+//   skip waves : wave w owns rows k = w (mod 8) of every layer's [32, S] skip kernel (wave 1 also k = 0 mod 8), a lane
+//                owns 8 adjacent columns; they follow the chain through an LDS progress counter and keep three layers
+//                of weights in flight, so the skip sum is finished when the chain is.
+constexpr int MF_AHEAD = 3;
+struct GenMf { uint4 fg[8]; uint4 de[2]; float4 r0, r1; };
+
+__device__ __forceinline__ bf16x8 mf_pack(float4 a, float4 b) {
+  bf16x8 v;
+  v[0] = (bf16_t)a.x; v[1] = (bf16_t)a.y; v[2] = (bf16_t)a.z; v[3] = (bf16_t)a.w;
+  v[4] = (bf16_t)b.x; v[5] = (bf16_t)b.y; v[6] = (bf16_t)b.z; v[7] = (bf16_t)b.w;
+  return v;
+}
+__device__ __forceinline__ bf16x8 mf_bits(uint4 w) {
+  union { uint4 u; bf16x8 b; } c;
+  c.u = w;
+  return c.b;
+}
+
+__global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavenet_generate_params p) {
+  extern __shared__ float gsm[];
+  constexpr int C = 32;
+  const int S = p.S, Q = p.Q, L = p.L;
+  float* outs = gsm;                       // [L][C] gated outputs of this sample
+  float* xg = outs + L * C;                // [C] operand gather line of the chain wave
+  float* h0 = xg + C;                      // [S]
+  float* h1 = h0 + S;                      // [S]
+  float* lg = h1 + S;                      // [Q]
+  float* red = lg + ((Q + 1) & ~1);        // [16]
+  float* part = red + 16;                  // [GEN_THREADS * 8]
+  double* ex = (double*)(part + GEN_THREADS * 8);   // [Q]
+  __shared__ int dil[128];
+  __shared__ long qoff[128];
+  __shared__ int chain_pos;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = blockIdx.x;
+  const bf16_t* wb = (const bf16_t*)p.weights;
+  const bf16_t* fgT = (const bf16_t*)p.fgT;
+  const bf16_t* deT = (const bf16_t*)p.deT;
+  int* ids = p.ids + (long)b * p.total;
+  float* queues = p.queues + (long)b * p.queue_rows * C;
+  const float* un = p.uniform + (long)b * (p.total - p.n_seed);
+  if (tid == 0) {
+    long q = 0;
+    for (int i = 0; i < L; ++i) { dil[i] = p.dilations[i]; qoff[i] = q; q += p.dilations[i]; }
+  }
+  __syncthreads();
+  const int l15 = lane & 15, kq = lane >> 4;
+  const bool afl = l15 == 0;               // lanes that carry row 0 of an A fragment
+  // the sample loop is written out once per role: the chain wave and the skip waves then get register allocations of
+  // their own (one loop with a role branch inside made the allocator spill ~300 registers, and every scratch access
+  // forces vmcnt(0) behind the prefetches); both loops execute the same sequence of workgroup barriers
+  auto gen_post = [&](int t) {
+        for (int j = tid; j < S; j += GEN_THREADS) {
+          float v = 0.f;
+    #pragma unroll
+          for (int w = 0; w < 7; ++w) v += part[w * S + j];
+          h0[j] = fmaxf(v, 0.f);
+        }
+        __syncthreads();
+        gen_matvec8(wb + p.off_post1, S, S, h0, h1, part, true, tid);
+        gen_matvec8(wb + p.off_post2, S, Q, h1, lg, part, false, tid);
+        float m = -3.0e38f;
+        for (int j = tid; j < Q; j += GEN_THREADS) m = fmaxf(m, lg[j]);
+        m = block_max(m, red);
+        for (int j = tid; j < Q; j += GEN_THREADS) ex[j] = exp((double)lg[j] - (double)m);
+        __syncthreads();
+        if (tid == 0) {
+          double se = 0.0;
+          for (int j = 0; j < Q; ++j) se += ex[j];
+          const double u = (double)un[t + 1 - p.n_seed] * se;
+          double c = 0.0;
+          int pick = Q - 1;
+          for (int j = 0; j < Q; ++j) {
+            c += ex[j];
+            if (u < c) { pick = j; break; }
+          }
+          ids[t + 1] = pick;
+          if (p.probs)
+            for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(ex[j] / se);
+        }
+        __syncthreads();
+
+  };
+  if (wave == 0) {
+    for (int t = 1; t < p.total; ++t) {
+      const bool emit = t + 1 >= p.n_seed && t + 1 < p.total;
+      if (tid == 0) chain_pos = 0;
+      __syncthreads();
+      // ================================================================ chain wave
+      float xa = 0.f, xb = 0.f;            // pair layout: lanes < 16 hold x[lane] and x[16 + lane]
+      if (lane < 16) {
+        const int a = ids[t - 1], c = ids[t];
+        const bf16_t* w0 = wb + p.off_causal + (long)a * C, *w1 = wb + p.off_causal + ((long)Q + c) * C;
+        xa = (float)w0[lane] + (float)w1[lane];
+        xb = (float)w0[16 + lane] + (float)w1[16 + lane];
+      }
+      // (macros, not lambdas over struct references: the four weight sets must stay in named registers - an address
+      // taken struct goes to scratch memory, and every scratch access drags a vmcnt(0) wait behind the prefetches)
+#define MF_LOAD(W_, l_)                                                                                                  \
+  do {                                                                                                                   \
+    const int ll_ = (l_);                                                                                                \
+    _Pragma("unroll") for (int sidx = 0; sidx < 2; ++sidx)                                                                \
+      _Pragma("unroll") for (int tt = 0; tt < 4; ++tt)                                                                    \
+        W_##_fg[sidx * 4 + tt] = *(const uint4*)(fgT + (((long)ll_ * 2 * C + 16 * tt + l15) * 2 * C + 32 * sidx + 8 * kq)); \
+    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                                      \
+      W_##_de[tt] = *(const uint4*)(deT + (((long)ll_ * C + 16 * tt + l15) * C + 8 * kq));                                 \
+    const float* ring_ = queues + (qoff[ll_] + (t % dil[ll_])) * C + 8 * kq;                                              \
+    W_##_r0 = afl ? *(const float4*)ring_ : make_float4(0.f, 0.f, 0.f, 0.f);                                              \
+    W_##_r1 = afl ? *(const float4*)(ring_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+  } while (0)
+#define MF_DECL(W_) uint4 W_##_fg[8], W_##_de[2]; float4 W_##_r0, W_##_r1
+      MF_DECL(w0); MF_DECL(w1); MF_DECL(w2);
+      MF_LOAD(w0, 0);
+      if (L > 1) MF_LOAD(w1, 1);
+      if (L > 2) MF_LOAD(w2, 2);
+      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#define MF_LAYER(l_, W_)                                                                                                 \
+  do {                                                                                                                   \
+    const int l = (l_);                                                                                                  \
+    if (lane < 16) { xg[lane] = xa; xg[16 + lane] = xb; }                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    bf16x8 a_cur = zero8, a_old = zero8;                                                                                  \
+    if (afl) {                                                                                                            \
+      a_cur = mf_pack(*(const float4*)(xg + 8 * kq), *(const float4*)(xg + 8 * kq + 4));                                   \
+      a_old = mf_pack(W_##_r0, W_##_r1);                                                                                  \
+    }                                                                                                                     \
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;                                             \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[0]), acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[1]), acc1, 0, 0, 0);                            \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[2]), acc2, 0, 0, 0);                            \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[3]), acc3, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[4]), acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[5]), acc1, 0, 0, 0);                            \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[6]), acc2, 0, 0, 0);                            \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[7]), acc3, 0, 0, 0);                            \
+    /* row 0 of the result: lanes < 16, register 0 -> columns 16*tile + lane (filter 0..31 | gate 32..63) */              \
+    const float oa = tanhf(acc0[0]) * (1.f / (1.f + expf(-acc2[0])));                                                     \
+    const float ob = tanhf(acc1[0]) * (1.f / (1.f + expf(-acc3[0])));                                                     \
+    float* ol = outs + l * C;                                                                                             \
+    if (lane < 16) { ol[lane] = oa; ol[16 + lane] = ob; }                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    if (emit && lane == 0) *(volatile int*)&chain_pos = l + 1; /* the skip waves may take layer l */                      \
+    bf16x8 a_out = zero8;                                                                                                 \
+    if (afl) a_out = mf_pack(*(const float4*)(ol + 8 * kq), *(const float4*)(ol + 8 * kq + 4));                            \
+    f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;                                                                             \
+    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_out, mf_bits(W_##_de[0]), d0, 0, 0, 0);                                \
+    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_out, mf_bits(W_##_de[1]), d1, 0, 0, 0);                                \
+    if (lane < 16) { /* the current input replaces the one just used */                                                   \
+      float* ringw = queues + (qoff[l] + (t % dil[l])) * C;                                                               \
+      ringw[lane] = xa; ringw[16 + lane] = xb;                                                                            \
+    }                                                                                                                     \
+    xa += d0[0]; xb += d1[0];                                                                                             \
+    if (l + MF_AHEAD < L) MF_LOAD(W_, l + MF_AHEAD);                                                                      \
+  } while (0)
+      for (int l4 = 0; l4 < L; l4 += 3) {
+        MF_LAYER(l4, w0);
+        if (l4 + 1 < L) MF_LAYER(l4 + 1, w1);
+        if (l4 + 2 < L) MF_LAYER(l4 + 2, w2);
+      }
+#undef MF_LAYER
+#undef MF_LOAD
+#undef MF_DECL
+      __syncthreads();
+      if (!emit) continue;
+      gen_post(t);
+    }
+  } else {
+    for (int t = 1; t < p.total; ++t) {
+      const bool emit = t + 1 >= p.n_seed && t + 1 < p.total;
+      __syncthreads();
+      if (emit) {
+      // ================================================================ skip waves
+      // wave w: rows k = w (mod 8); wave 1 also k = 0 (mod 8); a lane owns columns 8*lane .. 8*lane+7
+      const int nr = wave == 1 ? 8 : 4;
+      const bool colok = 8 * lane < S;
+      // row i of this wave: wave 1 takes k = 0, 8, 16, 24, 1, 9, 17, 25; wave w > 1 takes k = w, w + 8, w + 16, w + 24
+#define SK_ROW(i_) (wave == 1 ? ((i_) < 4 ? 8 * (i_) : 8 * ((i_) - 4) + 1) : 8 * (i_) + wave)
+#define SK_LOAD(W_, l_)                                                                                              \
+  do {                                                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                     \
+      W_[i] = (i < nr && colok) ? *(const uint4*)(wb + p.off_skip + ((long)(l_) * C + SK_ROW(i)) * S + 8 * lane)      \
+                                : make_uint4(0u, 0u, 0u, 0u);                                                        \
+  } while (0)
+#define SK_LAYER(l_, W_)                                                                                             \
+  do {                                                                                                               \
+    const int l = (l_);                                                                                              \
+    unsigned spins = 0;                                                                                              \
+    while (*(volatile int*)&chain_pos < l + 1) {                                                                      \
+      __builtin_amdgcn_s_sleep(1);                                                                                    \
+      if (++spins > (1u << 26)) break;                                                                                \
+    }                                                                                                                 \
+    const float* ol = outs + l * C;                                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+      if (i < nr) {                                                                                                   \
+        const float xv = ol[SK_ROW(i)];                                                                               \
+        a0 = fmaf(xv, pk_lo(W_[i].x), a0); a1 = fmaf(xv, pk_hi(W_[i].x), a1);                                         \
+        a2 = fmaf(xv, pk_lo(W_[i].y), a2); a3 = fmaf(xv, pk_hi(W_[i].y), a3);                                         \
+        a4 = fmaf(xv, pk_lo(W_[i].z), a4); a5 = fmaf(xv, pk_hi(W_[i].z), a5);                                         \
+        a6 = fmaf(xv, pk_lo(W_[i].w), a6); a7 = fmaf(xv, pk_hi(W_[i].w), a7);                                         \
+      }                                                                                                               \
+    }                                                                                                                 \
+    if (l + 3 < L) SK_LOAD(W_, l + 3);                                                                                \
+  } while (0)
+      float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
+      uint4 s0[8], s1[8], s2[8];
+      SK_LOAD(s0, 0);
+      if (L > 1) SK_LOAD(s1, 1);
+      if (L > 2) SK_LOAD(s2, 2);
+      for (int l3 = 0; l3 < L; l3 += 3) {
+        SK_LAYER(l3, s0);
+        if (l3 + 1 < L) SK_LAYER(l3 + 1, s1);
+        if (l3 + 2 < L) SK_LAYER(l3 + 2, s2);
+      }
+#undef SK_LAYER
+#undef SK_LOAD
+#undef SK_ROW
+      const float acc[8] = {a0, a1, a2, a3, a4, a5, a6, a7};
+      if (colok) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[(wave - 1) * S + 8 * lane + i] = acc[i];
+      }
+      }
+      __syncthreads();
+      if (!emit) continue;
+      gen_post(t);
+    }
+  }
+}
+
 extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->weights && p->ids && p->queues && p->uniform && p->dilations, "ns_wavenet_generate: null");
   NS_CHECK_ARG(p->B > 0 && p->n_seed >= 2 && p->total > p->n_seed && p->L > 0 && p->L <= 128, "ns_wavenet_generate: bad sizes");
@@ -476,6 +710,13 @@ extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_strea
                  "ns_wavenet_generate: the single-wave chain needs bf16 weights and R == Dc in {16, 32}");
     const size_t lds2 = sizeof(float) * ((size_t)p->L * p->R + 2 * p->S + ((p->Q + 1) & ~1) + 16 + GEN_THREADS * 8) + sizeof(double) * p->Q;
     NS_CHECK_ARG(lds2 <= 60 * 1024 && ((size_t)p->L * p->R) % 2 == 0, "ns_wavenet_generate: state does not fit in LDS");
+    if (p->engine == 2) {
+      NS_CHECK_ARG(p->R == 32 && p->S / 8 <= 64 && p->S * 7 <= GEN_THREADS * 8, "ns_wavenet_generate: the MFMA chain needs R == Dc == 32, S <= 512");
+      const size_t lds3 = lds2 + sizeof(float) * 32;
+      hipLaunchKernelGGL(wn_generate_mfma_kernel, dim3(p->B), dim3(GEN_THREADS), lds3, (hipStream_t)s, *p);
+      NS_CHECK_LAUNCH("wavenet_generate_mfma");
+      return NS_OK;
+    }
     if (p->R == 32) hipLaunchKernelGGL(wn_generate_fast_kernel<32>, dim3(p->B), dim3(GEN_THREADS), lds2, (hipStream_t)s, *p);
     else hipLaunchKernelGGL(wn_generate_fast_kernel<16>, dim3(p->B), dim3(GEN_THREADS), lds2, (hipStream_t)s, *p);
     NS_CHECK_LAUNCH("wavenet_generate_fast");

@@ -370,7 +370,7 @@ class SimpleWaveNet(object):
         last = logits[(ow - 1) * self.Q: ow * self.Q].double()
         return torch.softmax(last, dim=0).float()
 
-    def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None, fast=True):
+    def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None, fast=True, engine=None):
         """Incremental generation (generate_wavenet.py:56-142): seed_ids int [B, n_seed] (or [n_seed]) of mu-law codes,
         n_seed >= receptive field; returns int32 [B, n_seed + n_samples].  uniforms [B, n_samples] in [0,1) drive the
         categorical draws (default: numpy Generator(seed)).  Weights: the fp32 master copy when exact (default in fp32
@@ -407,7 +407,9 @@ class SimpleWaveNet(object):
             de = torch.stack([self.flat_p[self._o("dense%d" % l):self._o("dense%d" % l) + Dc * R].view(Dc, R).t()
                               for l in range(self.L)])
             fgT, deT = fg.contiguous().to(torch.bfloat16), de.contiguous().to(torch.bfloat16)
+        if engine is None:          # MFMA chain + concurrent skip waves at the shipped widths, else the single-wave VALU chain
+            engine = 2 if (fgT is not None and self.R == 32 and self.S <= 512) else 1
         ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
-                             probs=self.last_probs, fgT=fgT, deT=deT)
+                             probs=self.last_probs, fgT=fgT, deT=deT, engine=engine)
         self._gen_keep = (fgT, deT, un, queues, dil)        # keep the operands alive until the stream has used them
         return ids

@@ -324,11 +324,11 @@ def wavenet_softmax_ce(logits, ld, targets, rows, Q, scale, loss_acc, acc_off=0,
 
 
 def wavenet_generate(weights, offs, dilations, L_, R, Dc, S, Q, B, n_seed, total, queue_rows, ids, uniform, queues, probs=None,
-                     fgT=None, deT=None):
+                     fgT=None, deT=None, engine=0):
     p = L.struct("ns_wavenet_generate_params")
     _fill(p, weights=ptr(weights), w_dtype=dt(weights), off_causal=offs["causal"], off_layer0=offs["layer0"],
           layer_stride=offs["layer_stride"], off_dense_in_layer=offs["dense_in_layer"], off_skip=offs["skip"],
           off_post1=offs["post1"], off_post2=offs["post2"], dilations=ptr(dilations), L=L_, R=R, Dc=Dc, S=S, Q=Q, B=B,
           n_seed=n_seed, total=total, queue_rows=queue_rows, ids=ptr(ids), uniform=ptr(uniform), queues=ptr(queues),
-          probs=ptr(probs), fgT=ptr(fgT), deT=ptr(deT))
+          probs=ptr(probs), fgT=ptr(fgT), deT=ptr(deT), engine=engine)
     L.call("ns_wavenet_generate", p, stream())

@@ -154,7 +154,7 @@ def test_wavenet_single_wave_chain_matches_reference_kernel(dev, over):
     m.load_numpy_params(p)
     seeds = mu_law_encode(_audio(3, rf + 5, seed=2), hp.quantization_channels)
     un = np.random.default_rng(1).random((3, 40))
-    fast = m.generate(seeds, 40, uniforms=un).cpu().numpy()
+    fast = m.generate(seeds, 40, uniforms=un, engine=1).cpu().numpy()
     pf = m.last_probs.clone()
     slow = m.generate(seeds, 40, uniforms=un, fast=False).cpu().numpy()      # reference kernel, same bf16 weights
     ps = m.last_probs
@@ -162,3 +162,28 @@ def test_wavenet_single_wave_chain_matches_reference_kernel(dev, over):
     assert (fast != slow).mean() < 0.02, (fast != slow).sum()
     if np.array_equal(fast, slow):
         assert (pf - ps).abs().max().item() < 1e-5
+
+
+def test_wavenet_mfma_chain_close_to_valu_chain(dev):
+    """The MFMA generation kernel rounds the layer inputs to bf16 (the VALU chains keep them fp32 against bf16 weights):
+    same history -> next-sample distribution within bf16 rounding; over a run most draws coincide and all are valid."""
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_encode, receptive_field
+    hp = _hp(residual_channels=32, dilation_channels=32, skip_channels=64, dilations_length=4)
+    rf = receptive_field(hp)
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="bf16", seed=8)
+    p = m.numpy_params()
+    p["wavenet/postprocessing/postprocess2"] = p["wavenet/postprocessing/postprocess2"] * 10.0
+    m.load_numpy_params(p)
+    seeds = mu_law_encode(_audio(3, rf + 9, seed=4), hp.quantization_channels)
+    un = np.random.default_rng(2).random((3, 1))
+    a = m.generate(seeds, 1, uniforms=un, engine=2).cpu().numpy()
+    pa = m.last_probs.clone()
+    b = m.generate(seeds, 1, uniforms=un, engine=1).cpu().numpy()
+    pb = m.last_probs
+    assert (pa - pb).abs().max().item() < 3e-2 and abs(float(pa.sum()) - 3.0) < 1e-4
+    un = np.random.default_rng(5).random((3, 48))
+    a = m.generate(seeds, 48, uniforms=un, engine=2).cpu().numpy()
+    b = m.generate(seeds, 48, uniforms=un, engine=1).cpu().numpy()
+    assert a.min() >= 0 and a.max() < hp.quantization_channels and np.array_equal(a[:, :rf + 9], seeds)
+    assert (a == b).mean() > 0.5          # histories part ways at the first differing draw
