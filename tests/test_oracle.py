@@ -170,3 +170,49 @@ def test_oracle_shapes_and_teacher_forcing():
     # every trainable gets a gradient; a bias right in front of BatchNorm without activation gets ~0
     assert set(grads) == set(pv)
     assert np.abs(grads["encoder/conv_2/conv1d/bias"]).max() < 1e-12
+
+
+def test_wavenet_oracle_blocks_against_independent_formulations():
+    """oracle/wavenet_oracle.py: the VALID dilated causal convolution against torch.nn.functional.conv1d with
+    dilation, the receptive field of the shipped config (SURVEY 8c known answer: 5117), the mu-law companding pair,
+    and the cross-entropy against an explicit log-softmax."""
+    import torch.nn.functional as F
+    from nspeech_amd import hparams as hparams_mod
+    from oracle import wavenet_oracle as O
+    hp = hparams_mod.load("wavenet").values()
+    assert O.receptive_field(hp) == 5117 and len(O.dilations(hp)) == 50 and max(O.dilations(hp)) == 512
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 40, 6, generator=g, dtype=torch.float64)
+    w = torch.randn(2, 6, 5, generator=g, dtype=torch.float64)
+    for d in (1, 2, 8):
+        ref = F.conv1d(x.permute(0, 2, 1), w.permute(2, 1, 0), dilation=d).permute(0, 2, 1)
+        got = O.causal_conv(x, w, d)
+        assert got.shape == (2, 40 - d, 5) and torch.allclose(got, ref, atol=1e-12)
+    a = np.linspace(-1.2, 1.2, 4001).astype(np.float32)
+    ids = O.mu_law_encode(a, 256)
+    assert ids.min() == 0 and ids.max() == 255 and (np.diff(ids) >= 0).all()
+    back = O.mu_law_decode(ids, 256)
+    assert np.abs(back - np.clip(a, -1, 1)).max() < 0.04 and abs(back[2000]) < 1e-3
+    small = dict(hp, dilations_depth=1, dilations_length=3, residual_channels=4, dilation_channels=4, skip_channels=6,
+                 quantization_channels=8)
+    rf = O.receptive_field(small)
+    assert rf == 1 + 2 + 4 + 2
+    rs = np.random.RandomState(1)
+    p = {"wavenet/causal_layer/filter": torch.tensor(rs.randn(2, 8, 4)),
+         "wavenet/postprocessing/postprocess1": torch.tensor(rs.randn(1, 6, 6)),
+         "wavenet/postprocessing/postprocess2": torch.tensor(rs.randn(1, 6, 8))}
+    for i in range(3):
+        pre = "wavenet/dilated_stack/layer%d/" % i
+        p[pre + "filter"], p[pre + "gate"] = torch.tensor(rs.randn(2, 4, 4)), torch.tensor(rs.randn(2, 4, 4))
+        p[pre + "dense"], p[pre + "skip"] = torch.tensor(rs.randn(1, 4, 4)), torch.tensor(rs.randn(1, 4, 6))
+    ids = torch.tensor(rs.randint(0, 8, size=(2, rf + 5)))
+    loss, logits = O.loss(p, small, ids)
+    assert logits.shape == (2, 5, 8)
+    lp = torch.log_softmax(logits, dim=-1)
+    want = -lp.gather(2, ids[:, rf:, None].long()).mean()
+    assert abs(float(loss) - float(want)) < 1e-12
+    # causality: the logits at output position j depend on inputs up to j + rf - 1 only
+    ids2 = ids.clone()
+    ids2[:, -2] = (ids2[:, -2] + 1) % 8
+    _, logits2 = O.loss(p, small, ids2)
+    assert torch.equal(logits[:, :4], logits2[:, :4]) and not torch.equal(logits[:, 4], logits2[:, 4])
