@@ -29,7 +29,8 @@ typedef void* ns_stream_t; /* hipStream_t */
 
 enum { NS_OK = 0, NS_ERR_BAD_ARG = -1, NS_ERR_UNSUPPORTED_SHAPE = -2, NS_ERR_LAUNCH = -3 };
 enum { NS_F32 = 0, NS_BF16 = 1 };
-enum { NS_ACT_NONE = 0, NS_ACT_RELU = 1, NS_ACT_TANH = 2, NS_ACT_SIGMOID = 3 };
+enum { NS_ACT_NONE = 0, NS_ACT_RELU = 1, NS_ACT_TANH = 2, NS_ACT_SIGMOID = 3,
+       NS_ACT_SOFTSIGN = 4 /* x / (1 + |x|): the speaker projections, rnn_wrappers.py:29, modules.py:159,167 */ };
 
 int ns_version(void);
 const char* ns_device_arch(void); /* "gfx950" */
@@ -409,6 +410,11 @@ typedef struct {
    * disappears and dctx_t is formed after the loop (df1 then needs one extra zero row behind its N*(S+1) rows).
    * Results equal the plain form up to rounding. */
   const void* pv; const float* da0;
+  /* Multi-speaker (tacotron2.py:40-49, rnn_wrappers.py:28-30): Dsp > 0 widens the attention LSTM input to
+   * [prenet(D2) | speaker projection(Dsp) | h(A)]; xa is then [N,S+1,D2+Dsp+A] with the per-utterance projection
+   * written into columns D2..D2+Dsp of every slot by the caller, wattT / watt hold all D2+Dsp+A input rows, and the
+   * caller forms the projection's gradient from dga (sum over the slots) after the backward call. */
+  int Dsp;
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

@@ -565,6 +565,7 @@ static int check_attn(const ns_taco2_attn_params* p, const char* who) {
   NS_CHECK_ARG(p->kw >= 1 && p->kw <= MAXKW, "%s: location filter width must be 1..%d", who, MAXKW);
   NS_CHECK_ARG(p->Tia >= p->Ti && p->Tia % 4 == 0, "%s: Tia must be >= Ti and a multiple of 4", who);
   NS_CHECK_ARG(p->keys_t != nullptr, "%s: keys_t scratch missing", who);
+  NS_CHECK_ARG(p->Dsp >= 0 && p->Dsp % 8 == 0, "%s: speaker projection width must be a multiple of 8", who);
   return NS_OK;
 }
 
@@ -585,7 +586,7 @@ __global__ void attn_p1_init_kernel(const float* f1, T* p1, int N, long S1, int 
 template <typename T>
 static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
-  const long XA = D2 + A, HC = A + E;
+  const long Dsp = p.Dsp, XA = D2 + Dsp + A, HC = A + E;
   const int dt = p.dtype;
   const size_t lds = ctx_lds(p);
   NS_CHECK_ARG(lds <= 64 * 1024, "ns_taco2_attn_fwd: T_in too long for LDS (%zu bytes)", lds);
@@ -621,7 +622,7 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     l.a = xa + slot * XA; l.a_sn = S1 * XA; l.wT = (const T*)p.wattT; l.bias = p.batt;
     l.c_prev = st > 0 ? p.ca + prev * A : nullptr; l.c_sn = S1 * A;
     l.h_out = hc + slot * HC; l.h_sn = S1 * HC;
-    if (st + 1 < p.S) { l.h_out2 = xa + (slot + 1) * XA + D2; l.h2_sn = S1 * XA; }
+    if (st + 1 < p.S) { l.h_out2 = xa + (slot + 1) * XA + D2 + Dsp; l.h2_sn = S1 * XA; }
     l.c_out = p.ca + slot * A; l.co_sn = S1 * A;
     l.gates_out = (T*)p.ga + slot * 4 * A; l.g_sn = S1 * 4 * A;
     l.passes = p.f32_passes;
@@ -695,7 +696,7 @@ extern "C" int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t s) {
 template <typename T>
 static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
-  const long XA = D2 + A, HC = A + E;
+  const long Dsp = p.Dsp, XA = D2 + Dsp + A, HC = A + E;
   const int dt = p.dtype;
   float* dctx_carry = p.work;
   float* da = dctx_carry + (size_t)p.N * E;
@@ -754,7 +755,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     c.N = p.N; c.H = p.A; c.t = st; c.lengths = nullptr; c.K = (int)(4 * A);
     c.first = last ? 1 : 0;
     c.dg_next = last ? nullptr : (const T*)p.dga + (slot + 1) * 4 * A; c.dgn_sn = S1 * 4 * A;
-    c.w = (const T*)p.watt + D2 * 4 * A;
+    c.w = (const T*)p.watt + (D2 + Dsp) * 4 * A;
     c.dh_out = p.dhc + slot * HC; c.dho_sn = S1 * HC;
     c.dh_out2 = dhq; c.dho2_sn = A;
     c.gates = (const T*)p.ga + slot * 4 * A; c.g_sn = S1 * 4 * A;
@@ -762,7 +763,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     c.dc_carry = dc_carry;
     c.dgates = (T*)p.dga + slot * 4 * A; c.dg_sn = S1 * 4 * A;
     c.passes = p.f32_passes;
-    c.w_bf16 = p.watt_bf16 ? (const bf16_t*)p.watt_bf16 + D2 * 4 * A : nullptr;
+    c.w_bf16 = p.watt_bf16 ? (const bf16_t*)p.watt_bf16 + (D2 + Dsp) * 4 * A : nullptr;
     if (p.dga_bf16 && sizeof(T) == 4) {
       c.dgates_b = (bf16_t*)p.dga_bf16 + slot * 4 * A;
       c.dg_next_b = last ? nullptr : (const bf16_t*)p.dga_bf16 + (slot + 1) * 4 * A;

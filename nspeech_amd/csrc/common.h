@@ -57,6 +57,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     case NS_ACT_RELU: return v > 0.f ? v : 0.f;
     case NS_ACT_TANH: return tanhf_(v);
     case NS_ACT_SIGMOID: return sigmoidf_(v);
+    case NS_ACT_SOFTSIGN: return v / (1.0f + fabsf(v));
     default: return v;
   }
 }

@@ -177,6 +177,7 @@ __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
         if (p.act == NS_ACT_RELU) d = zv > 0.f ? d : 0.f;
         else if (p.act == NS_ACT_TANH) d *= (1.f - zv * zv);
         else if (p.act == NS_ACT_SIGMOID) d *= zv * (1.f - zv);
+        else if (p.act == NS_ACT_SOFTSIGN) d *= (1.f - fabsf(zv)) * (1.f - fabsf(zv));
       }
       stf(dpre + idx, d);
       // bias gradient is taken on the value the weight-gradient GEMM will read
@@ -478,6 +479,7 @@ __global__ void act_bwd_kernel(ns_act_bwd_params p) {
       if (p.act == NS_ACT_RELU) d = y > 0.f ? d : 0.f;
       else if (p.act == NS_ACT_TANH) d *= (1.f - y * y);
       else if (p.act == NS_ACT_SIGMOID) d *= y * (1.f - y);
+      else if (p.act == NS_ACT_SOFTSIGN) d *= (1.f - fabsf(y)) * (1.f - fabsf(y));   // y = x/(1+|x|): dy/dx = (1-|y|)^2
     }
     stf((T*)p.dpre + i, d);
   }

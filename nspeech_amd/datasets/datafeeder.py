@@ -16,9 +16,11 @@ MI355X-side differences: both spectrograms of an utterance come from ONE pass of
 feature kernel (`audio.spectrogram_and_mel`) instead of two librosa STFTs in worker threads, and for
 data-parallel runs the sorted group is dealt round-robin over the ranks so that every
 rank sees the same length mix: rank r takes examples r, r + world, ... of the sorted group."""
+import glob
 import os
 import queue
 import random
+import re
 import threading
 
 import numpy as np
@@ -36,15 +38,39 @@ def _round_up(x, m):
 
 
 def load_ljspeech_metadata(path):
-    """corpus/ljspeech.py:4-11: `id|raw text|normalised text` -> (wavs/id.wav, normalised text)."""
+    """corpus/ljspeech.py:4-11: `id|raw text|normalised text` -> (wavs/id.wav, normalised text, speaker 0,
+    "ljspeech")."""
     items = []
     with open(os.path.join(path, "metadata.csv"), encoding="utf-8") as f:
         for line in f:
             parts = line.strip().split("|")
             if len(parts) >= 3:
-                items.append((os.path.join(path, "wavs", "%s.wav" % parts[0]), parts[2]))
+                items.append((os.path.join(path, "wavs", "%s.wav" % parts[0]), parts[2], 0, "ljspeech"))
             elif len(parts) == 2:
-                items.append((os.path.join(path, "wavs", "%s.wav" % parts[0]), parts[1]))
+                items.append((os.path.join(path, "wavs", "%s.wav" % parts[0]), parts[1], 0, "ljspeech"))
+    return items
+
+
+def load_vctk_file_names(path):
+    """corpus/vctk.py:11-20: wav48/pNNN/pNNN_MMM.wav with its transcript under txt/; speaker = NNN."""
+    items = []
+    for wav_path in sorted(glob.glob("%s/wav48/p*/*.wav" % path)):
+        text_path = wav_path.replace("wav48", "txt").replace("wav", "txt")
+        if os.path.isfile(text_path):
+            with open(text_path, "r") as f:
+                text = f.read().strip()
+            name = os.path.splitext(os.path.basename(wav_path))[0]
+            items.append((wav_path, text, re.match(r"p([0-9]+)_", name).group(1), "vctk"))
+    return items
+
+
+def load_librispeech_corpus(path):
+    """corpus/ljspeech.py:14-27 (`load_libre_2`): corpus.csv rows `speaker-chapter-utterance,path,text,mode`."""
+    items = []
+    with open(os.path.join(path, "corpus.csv"), encoding="utf-8") as f:
+        for line in f:
+            identifier, rel, text, _mode = line.strip().split(",")
+            items.append((os.path.join(path, rel), text, identifier.split("-")[0], "libre"))
     return items
 
 
@@ -74,10 +100,18 @@ class DataFeeder(object):
     `speaker_ids` of the last batch are kept in .speaker_ids (single-speaker corpora: zeros)."""
 
     def __init__(self, hparams, ljspeech=None, seed=0, rank=0, world=1, cmudict=None, prefetch=True, features=None,
-                 loader=None):
+                 loader=None, vctk=None, librispeech=None):
         self.hp = hparams
+        # datafeeder.py:44-53: every corpus named on the command line contributes its items
         self.items = load_ljspeech_metadata(ljspeech) if ljspeech else []
+        self.items += load_vctk_file_names(vctk) if vctk else []
+        self.items += load_librispeech_corpus(librispeech) if librispeech else []
         assert self.items, "no training data found"
+        # datafeeder.py:58-61 numbers the (corpus, speaker) pairs in set order and pins that order in a joblib cache;
+        # here the pairs are numbered in sorted order, which every data-parallel rank derives identically
+        pairs = sorted({(dataset, str(spk)) for _, _, spk, dataset in self.items})
+        self.id2speaker = dict(enumerate(pairs))
+        self.speaker2id = {v: k for k, v in self.id2speaker.items()}
         self.rank, self.world = rank, world
         self.cleaners = [x.strip() for x in hparams.cleaners.split(",")]
         self.cache = {}                       # wav path -> (mel, linear), the reference's processed_data
@@ -104,7 +138,7 @@ class DataFeeder(object):
         if self._offset >= len(self.items):
             self._offset = 0
             self._order_rng.shuffle(self.items)
-        wav_path, text = self.items[self._offset]
+        wav_path, text, local_speaker, dataset = self.items[self._offset]
         self._offset += 1
         if wav_path not in self.cache:
             lin, mel = self._features(self._loader(wav_path))
@@ -113,7 +147,7 @@ class DataFeeder(object):
         if self._cmudict and self._rng.random() < _p_cmudict:
             text = " ".join(self._maybe_get_arpabet(w) for w in text.split(" "))
         ids = np.asarray(text_to_sequence(text, self.cleaners), dtype=np.int32)
-        return ids, 0, mel, lin
+        return ids, self.speaker2id[dataset, str(local_speaker)], mel, lin
 
     def _next_group(self):
         n, r = self.hp.batch_size, self.hp.outputs_per_step

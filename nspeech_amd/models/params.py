@@ -77,12 +77,22 @@ def _lstm(trainable, scope, nin, units):
     trainable.add(scope + "/bias", (4 * units,))
 
 
+def taco2_speaker_width(hp):
+    """Width of the speaker projection concatenated to the decoder prenet output when num_speakers > 1
+    (rnn_wrappers.py:28-30: as wide as the prenet output, 128); 0 for a single speaker."""
+    return 128 if int(getattr(hp, "num_speakers", 1) or 1) > 1 else 0
+
+
 def taco2_layout(hp, vocab_size):
     """Variables of tacotron2.py:33-107 (names relative to 'model/inference/')."""
     tr, st = Layout(), Layout()
     M = hp.num_mels
     emb = hp.embedding_dim
     tr.add("embedding/embedding", (vocab_size, emb))
+    n_spk = int(getattr(hp, "num_speakers", 1) or 1)
+    dsp = taco2_speaker_width(hp)
+    if dsp:                                       # tacotron2.py:40-47
+        tr.add("speaker/speaker_embed", (n_spk, hp.speaker_embed_dim))
     cin = emb
     for i in range(hp.encoder_conv_layers):
         _conv_bn(tr, st, "encoder/conv_%d" % i, hp.encoder_conv_width, cin, hp.encoder_conv_channels)
@@ -96,7 +106,10 @@ def taco2_layout(hp, vocab_size):
     tr.add("decoder/decoder_prenet/dense_1/bias", (256,))
     tr.add("decoder/decoder_prenet/dense_2/kernel", (256, 128))
     tr.add("decoder/decoder_prenet/dense_2/bias", (128,))
-    tr.add("decoder/attention_lstm/kernel", (128 + A, 4 * A))
+    if dsp:                                       # rnn_wrappers.py:28-30: dense(speaker_embd, 128, softsign)
+        tr.add("decoder/dense/kernel", (hp.speaker_embed_dim, dsp))
+        tr.add("decoder/dense/bias", (dsp,))
+    tr.add("decoder/attention_lstm/kernel", (128 + dsp + A, 4 * A))
     tr.add("decoder/attention_lstm/bias", (4 * A,))
     tr.add("decoder/attention/query_layer/kernel", (A, A))
     tr.add("decoder/attention/location_conv/kernel", (7, 1, 20))

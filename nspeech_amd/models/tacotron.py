@@ -48,6 +48,14 @@ class Tacotron(Tacotron2):
     LAYOUT = staticmethod(P_.taco1_layout)
     KW = 1    # Bahdanau = location-sensitive kernel with a 1-tap zero filter
 
+    @staticmethod
+    def _speaker_width(hp):
+        """The reference's Tacotron-1 threads the speaker embedding through the CBHG highway stack and the BiGRU
+        (modules.py:157-169) as well; only the Tacotron-2 form is built here, so refuse instead of ignoring it."""
+        if int(getattr(hp, "num_speakers", 1) or 1) > 1:
+            raise NotImplementedError("taco1 with num_speakers > 1 is not supported; use --model taco2")
+        return 0
+
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self, full=False):
         if full and self.flat_s is not self.flat_p:

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .._lib import ACT_NONE, ACT_RELU, ACT_TANH
+from .._lib import ACT_NONE, ACT_RELU, ACT_SOFTSIGN, ACT_TANH
 from ..utils.text.symbols import symbols
 from . import params as P_
 
@@ -35,6 +35,7 @@ def _round_up(x, m):
 class Tacotron2(object):
     padl, padr = PADL, PADR
     LAYOUT = staticmethod(P_.taco2_layout)
+    _speaker_width = staticmethod(P_.taco2_speaker_width)
 
     def __init__(self, hparams, device="cuda:0", dtype="bf16", seed=0, world_size=1):
         self._hparams = hparams
@@ -53,6 +54,8 @@ class Tacotron2(object):
         self.passes_bwd = {"bf16": 0, "fp32": 0, "bf16x3": 3, "mixed": 1}[dtype]
         self.vocab = len(symbols)
         self.layout, self.stat_layout = self.LAYOUT(hparams, self.vocab)
+        self.n_speakers = int(getattr(hparams, "num_speakers", 1) or 1)
+        self.Dsp = self._speaker_width(hparams)      # 0: single speaker, no speaker variables at all
         n = self.layout.size
         dev = self.device
         self.flat_p = torch.zeros(n, dtype=torch.float32, device=dev)
@@ -179,7 +182,7 @@ class Tacotron2(object):
         tr("l2_whT", "decoder/lstm_2/kernel", D, D, 4 * D)
         tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
         tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
-        tr("wattT", "decoder/attention_lstm/kernel", 0, 128 + A, 4 * A)
+        tr("wattT", "decoder/attention_lstm/kernel", 0, 128 + self.Dsp + A, 4 * A)
         tr("wqT", "decoder/attention/query_layer/kernel", 0, A, A)
         # folded location filter Wcl[k,u] = sum_j Wc[k,0,j] Wl[j,u]  (fp32)
         if "wcl" not in self.tsh:
@@ -228,6 +231,15 @@ class Tacotron2(object):
         self.input_lengths = torch.as_tensor(
             np.asarray(input_lengths) if not torch.is_tensor(input_lengths) else input_lengths
         ).to(dev, torch.int32).contiguous()
+        self.speaker_ids = None
+        if self.Dsp:
+            if speaker_ids is None:
+                raise ValueError("num_speakers = %d: speaker_ids are required" % self.n_speakers)
+            ids = speaker_ids.cpu().numpy() if torch.is_tensor(speaker_ids) else np.asarray(speaker_ids)
+            ids = ids.reshape(-1).astype(np.int64)
+            if ids.shape[0] != self.inputs.shape[0] or ids.min() < 0 or ids.max() >= self.n_speakers:
+                raise ValueError("speaker_ids must hold one id in [0, %d) per utterance" % self.n_speakers)
+            self.speaker_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
         self.is_training = linear_targets is not None
         if self.is_training:
             self.mel_targets = torch.as_tensor(mel_targets).to(dev, torch.float32).contiguous()
@@ -401,6 +413,47 @@ class Tacotron2(object):
             ops.gemm(dg, self._W(D), dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
                      accumulate=0 if di == 0 else 1)
 
+    # ------------------------------------------------------------------ multi-speaker (num_speakers > 1)
+    def _speaker_fwd(self, N):
+        """tacotron2.py:40-47 + rnn_wrappers.py:28-30: softsign(speaker_embed[ids] . W + b) -> [N, Dsp]."""
+        hp = self._hparams
+        sd, Dsp = hp.speaker_embed_dim, self.Dsp
+        se = self._buf("spk_e", N * sd, self.T)
+        ops.embedding_fwd(self.speaker_ids, self.flat_p, se, N, 1, 1, 0, sd, self.n_speakers,
+                          table_off=self._o("speaker/speaker_embed"))
+        s1 = self._buf("spk_s", N * Dsp, self.T)
+        ops.gemm(se, self._W(self.T), s1, N, Dsp, sd, sd, Dsp, Dsp, b_mode=1, b_off=self._o("decoder/dense/kernel"),
+                 bias=self.flat_p, bias_off=self._o("decoder/dense/bias"), act=ACT_SOFTSIGN)
+        return s1
+
+    def _speaker_bwd(self, dga, N, S1):
+        """The projection enters every step's gate pre-activations through rows 128..128+Dsp of the attention LSTM
+        kernel, so its gradient is (sum over the slots of dgates) . W_s^T; then softsign, dense and table lookup."""
+        hp = self._hparams
+        sd, Dsp, A = hp.speaker_embed_dim, self.Dsp, hp.attention_dim
+        T_, g, rows = self.T, self.flat_g, N * S1
+        sel = self._bufs.get("spk_sel")
+        if sel is None or sel.numel() != N * rows:          # block indicator [N, N*S1]: row n selects item n's slots
+            sel = torch.zeros(N, rows, dtype=T_, device=self.device)
+            for n in range(N):
+                sel[n, n * S1:(n + 1) * S1] = 1
+            sel = self._bufs["spk_sel"] = sel.reshape(-1)
+        dgs = self._buf("spk_dgs", N * 4 * A, T_)
+        ops.gemm(sel, dga, dgs, N, 4 * A, rows, rows, 4 * A, 4 * A, a_mode=0, b_mode=1)
+        ds1 = self._buf("spk_ds", N * Dsp, torch.float32)
+        wa = self._o("decoder/attention_lstm/kernel")
+        ops.gemm(dgs, self._W(T_), ds1, N, Dsp, 4 * A, 4 * A, 4 * A, Dsp, a_mode=0, b_mode=0, b_off=wa + 128 * 4 * A)
+        dpre = self._buf("spk_dpre", N * Dsp, T_)
+        ops.act_bwd(ds1, self._bufs["spk_s"], dpre, N, Dsp, ACT_SOFTSIGN)
+        se = self._bufs["spk_e"]
+        kd = self._o("decoder/dense/kernel")
+        ops.gemm(se, dpre, g, sd, Dsp, N, sd, Dsp, Dsp, a_mode=1, b_mode=1, c_off=kd, accumulate=2)
+        ops.colsum(dpre, Dsp, N, Dsp, g, out_off=self._o("decoder/dense/bias"))
+        dse = self._buf("spk_de", N * sd, torch.float32)
+        ops.gemm(dpre, self._W(T_), dse, N, sd, Dsp, Dsp, Dsp, sd, a_mode=0, b_mode=0, b_off=kd)
+        ops.embedding_bwd(self.speaker_ids, dse, g, N, 1, 1, 0, sd, self.n_speakers,
+                          dtable_off=self._o("speaker/speaker_embed"))
+
     # ------------------------------------------------------------------ training forward
     def forward_train(self):
         hp = self._hparams
@@ -457,7 +510,10 @@ class Tacotron2(object):
                  bias_off=self._o("decoder/decoder_prenet/dense_1/bias"))
         Tia = _round_up(Ti, 8)
         p1 = self._buf("dec_p1", N * S1 * 256, T_)
-        xa = self._buf("dec_xa", N * S1 * (128 + A), T_)
+        Dsp = self.Dsp
+        xa = self._buf("dec_xa", N * S1 * (128 + Dsp + A), T_)
+        if Dsp:     # the per-utterance speaker projection sits between the prenet output and h in every slot
+            ops.copy3d(self._speaker_fwd(N), xa, N, S1, Dsp, (Dsp, 0), (S1 * (128 + Dsp + A), 128 + Dsp + A), dst_off=128)
         hc = self._buf("dec_hc", N * S1 * (A + E), T_)
         ca = self._buf("dec_ca", N * S1 * A, torch.float32)
         ga = self._buf("dec_ga", N * S1 * 4 * A, T_)
@@ -470,7 +526,7 @@ class Tacotron2(object):
             pv = self._buf("dec_pv", N * Pi * 256, T_)
             ops.gemm(enc, self._W(self.T), pv, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
         self._attn_args = dict(
-            pv=pv,
+            pv=pv, Dsp=Dsp,
             dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=self.padl, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
             lengths=self.input_lengths, keys=keys, values=enc, f1=f1,
             w1cT=self.tsh["w1cT"], w2T=self.tsh["w2T"], wattT=self.tsh["wattT"], wqT=self.tsh["wqT"],
@@ -720,9 +776,12 @@ class Tacotron2(object):
         ops.gemm(p1, dp2, g, 256, 128, rows, 256, 128, 128, a_mode=1, b_mode=1, c_off=w2, accumulate=2,
                  split_k=sk(rows, 256, 128))
         ops.colsum(dp2, 128, rows, 128, g, out_off=self._o("decoder/decoder_prenet/dense_2/bias"))
-        ops.gemm(xa, dga, g, 128 + A, 4 * A, rows, 128 + A, 4 * A, 4 * A, a_mode=1, b_mode=1, c_off=wa, accumulate=2,
-                 split_k=sk(rows, 128 + A, 4 * A))
+        XA = 128 + self.Dsp + A
+        ops.gemm(xa, dga, g, XA, 4 * A, rows, XA, 4 * A, 4 * A, a_mode=1, b_mode=1, c_off=wa, accumulate=2,
+                 split_k=sk(rows, XA, 4 * A))
         ops.colsum(dga, 4 * A, rows, 4 * A, g, out_off=self._o("decoder/attention_lstm/bias"))
+        if self.Dsp:
+            self._speaker_bwd(dga, N, S1)
         ops.gemm(hc, dq, g, A, A, rows, A + E, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2,
                  split_k=sk(rows, A, A))
         # unfold dWcl[k,u] into location_conv [7,1,20] and location_layer [20,A]   (fp32, tiny)
@@ -803,10 +862,10 @@ class Tacotron2(object):
         return self.loss
 
     def step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, grad_hook=None,
-             read_loss=True):
+             read_loss=True, speaker_ids=None):
         """One training step = the reference's sess.run([global_step, loss, optimize]) (train.py:80)."""
         if inputs is not None:
-            self.initialize(inputs, input_lengths, None, mel_targets, linear_targets)
+            self.initialize(inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
         else:
             self.forward_train()
         self.backward()

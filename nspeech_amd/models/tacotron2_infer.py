@@ -59,6 +59,9 @@ def forward_infer(m):
         st["inputs"].copy_(m.inputs)
         st["lengths"].copy_(m.input_lengths)
         m.inputs, m.input_lengths = st["inputs"], st["lengths"]
+        if m.speaker_ids is not None:
+            st["speakers"].copy_(m.speaker_ids)
+            m.speaker_ids = st["speakers"]
         if st["graph"] is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -68,7 +71,8 @@ def forward_infer(m):
         st["graph"].replay()
         return m
     _infer_body(m)
-    m._infer_graph = dict(sig=sig, graph=None, inputs=m.inputs.clone(), lengths=m.input_lengths.clone())
+    m._infer_graph = dict(sig=sig, graph=None, inputs=m.inputs.clone(), lengths=m.input_lengths.clone(),
+                          speakers=m.speaker_ids.clone() if m.speaker_ids is not None else None)
     return m
 
 
@@ -112,10 +116,11 @@ def _infer_body(m):
         L.C.c_void_p(ops.stream())), "ns_taco2_keys_transpose")
 
     # ---- decoder loop; step s lives in slot s+1 of every [N, S+2, X] buffer (slot 0 = zeros)
-    XP, XA, X1, X2 = M + E, 128 + A, A + E + D, 2 * D
+    Dsp = m.Dsp
+    XP, XA, X1, X2 = M + E, 128 + Dsp + A, A + E + D, 2 * D
     xp = buf("inf_xp", N * S1 * XP, T_)      # [frame | ctx_prev]
     p1 = buf("inf_p1", N * S1 * 256, T_)
-    xa = buf("inf_xa", N * S1 * XA, T_)      # [p2 | h_att_prev]
+    xa = buf("inf_xa", N * S1 * XA, T_)      # [p2 | speaker projection | h_att_prev]
     x1 = buf("inf_x1", N * S1 * X1, T_)      # [h_att | ctx | h1_prev]
     x2 = buf("inf_x2", N * S1 * X2, T_)      # [h1 | h2_prev]
     h2 = buf("inf_h2", N * S1 * D, T_)
@@ -128,6 +133,8 @@ def _infer_body(m):
     dec = buf("inf_dec", N * S1 * M * r, torch.float32)
     for b in (xp, xa, x1, x2, al):
         b.zero_()
+    if Dsp:
+        ops.copy3d(m._speaker_fwd(N), xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
     tsh = m.tsh
     o = m._o
     for s in range(S):
@@ -139,7 +146,7 @@ def _infer_body(m):
                  bias=m.flat_p, bias_off=o("decoder/decoder_prenet/dense_2/bias"), act=ACT_RELU)
         # attention LSTM on [p2 | h_att_prev]; h_att -> x1[slot] head and xa[next] tail
         _lstm_step(m, xa, sl * XA, S1 * XA, XA, tsh["wattT"], o("decoder/attention_lstm/bias"),
-                   ca if s > 0 else None, s * A, S1 * A, x1, sl * X1, S1 * X1, xa, nx * XA + 128, S1 * XA,
+                   ca if s > 0 else None, s * A, S1 * A, x1, sl * X1, S1 * X1, xa, nx * XA + 128 + Dsp, S1 * XA,
                    ca, sl * A, N, A)
         ops.gemm(x1, tsh["wqT"], q, N, A, A, S1 * X1, A, S1 * A, a_off=sl * X1, c_off=sl * A)
         ap = L.struct("ns_attention_step_params")

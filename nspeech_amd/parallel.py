@@ -32,11 +32,10 @@ def init_distributed(backend=None):
     return rank, local, world
 
 
-def bucket_ranges(layout, order=("expand/", "dense/", "decoder_postnet/", "decoder/", "attention_decoder/",
-                                 "encoder/", "embedding/")):
+def bucket_ranges(layout):
     """Contiguous [lo, hi) slices of the flat buffer in the order the backward pass finishes them."""
     groups = [("head", ("expand/", "dense/")), ("postnet", ("decoder_postnet/",)),
-              ("decoder", ("decoder/", "attention_decoder/")), ("encoder", ("encoder/", "embedding/"))]
+              ("decoder", ("decoder/", "attention_decoder/")), ("encoder", ("encoder/", "embedding/", "speaker/"))]
     out = []
     for gname, prefixes in groups:
         offs = [(o, o + ((int(_numel(s)) + 7) // 8) * 8) for n, (o, s) in layout.entries.items()

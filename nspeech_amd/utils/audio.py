@@ -139,9 +139,12 @@ def resample(x, sr_orig, sr_new):
 def load_wav(path, offset=0.0, duration=None):
     """PCM16 / float32 RIFF reader + mono mix-down + resampling to hparams.sample_rate, as librosa.core.load does for
     the reference (audio.py:13-14; LJSpeech is 22 050 Hz, audio.yaml asks for 20 000 Hz)."""
-    with wave.open(path, "rb") as f:
-        sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
-        raw = f.readframes(n)
+    try:
+        with wave.open(path, "rb") as f:
+            sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
+            raw = f.readframes(n)
+    except wave.Error as e:     # e.g. LibriSpeech FLAC: no decoder in this build
+        raise ValueError("%s: only RIFF/WAV input is supported (%s)" % (path, e))
     hp = get_hparams()
     if width == 2:
         x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0

@@ -134,8 +134,15 @@ def location_sensitive_alignments(query, prev_align, keys, lengths, p, scope):
 
 
 # ------------------------------------------------------------------ the model
+def speaker_projection(p, speaker_ids, scope):
+    """tacotron2.py:40-47 (lookup in speaker/speaker_embed when num_speakers > 1) and rnn_wrappers.py:28-29
+    (tf.layers.dense(speaker_embd, 128, activation=softsign), softsign(x) = x / (1 + |x|))."""
+    e = p["speaker/speaker_embed"][speaker_ids.long()]
+    return F.softsign(e @ p[scope + "/dense/kernel"] + p[scope + "/dense/bias"])
+
+
 def taco2_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets=None,
-                  max_iters=None, collect=False):
+                  max_iters=None, collect=False, speaker_ids=None):
     """tacotron2.py:15-128.  Training mode iff linear_targets is given (line 34).
 
     p: dict name -> torch tensor (TF layouts, names below 'model/inference/').
@@ -174,12 +181,17 @@ def taco2_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets
     else:
         steps = max_iters if max_iters is not None else hp["max_iters"]
 
+    # multi-speaker: attention_decoder() hands speaker_embd to the PrenetWrapper only (modules.py:95-97; the
+    # ConcatOutputAndAttentionWrapper at :104-105 is built without it)
+    spk = speaker_projection(p, speaker_ids, D) if hp.get("num_speakers", 1) > 1 else None
     frame = enc.new_zeros(N, M)                                 # <GO>, helpers.py:80-82
     outs, aligns = [], []
     trace = {"h_att": [], "ctx": [], "h1": [], "h2": []}
     for s in range(steps):
         cell_in = torch.cat([frame, ctx], dim=-1)               # AttentionWrapper cell_input_fn (Q8)
         pre = prenet(cell_in, p, D + "/decoder_prenet")
+        if spk is not None:
+            pre = torch.cat([pre, spk], dim=-1)                 # rnn_wrappers.py:30
         c_att, h_att = lstm_block_cell(pre, c_att, h_att, p[D + "/attention_lstm/kernel"],
                                        p[D + "/attention_lstm/bias"])
         align = location_sensitive_alignments(h_att, align, keys, lengths, p, D + "/attention")

@@ -114,3 +114,65 @@ def test_cmudict_substitution(tmp_path):
         texts += [sequence_to_text(inputs[i, :lengths[i]]) for i in range(len(lengths))]
     assert any("{HH AH0 L OW1}" in t for t in texts) and any("hello" in t for t in texts)
     assert all(t.endswith("~") for t in texts)
+
+
+def test_multi_corpus_speaker_numbering(tmp_path):
+    """datafeeder.py:44-61,166-167: items of every corpus, (corpus, speaker) pairs numbered once, ids travel with
+    their utterances through sorting, dealing and the in-batch shuffle.  corpus/vctk.py:11-20 and
+    corpus/ljspeech.py:14-27 give the directory conventions."""
+    lj = tmp_path / "lj"
+    os.makedirs(lj)
+    _corpus(lj, 6)
+    vctk = tmp_path / "vctk"
+    for spk, n in (("225", 3), ("301", 2)):
+        os.makedirs(vctk / "wav48" / ("p" + spk))
+        os.makedirs(vctk / "txt" / ("p" + spk))
+        for i in range(n):
+            open(vctk / "wav48" / ("p" + spk) / ("p%s_%03d.wav" % (spk, i)), "wb").close()
+            with open(vctk / "txt" / ("p" + spk) / ("p%s_%03d.txt" % (spk, i)), "w") as f:
+                f.write("speaker %s says hello\n" % ("a" if spk == "225" else "b"))
+    open(vctk / "wav48" / "p225" / "p225_099.wav", "wb").close()       # no transcript: skipped
+    libre = tmp_path / "libre"
+    os.makedirs(libre)
+    with open(libre / "corpus.csv", "w") as f:
+        f.write("1272-128104-0012,dev-clean/1272/128104/1272-128104-0012.wav,only his own work,training\n")
+        f.write("84-121123-0001,dev-clean/84/121123/84-121123-0001.wav,go on,training\n")
+    hp = _hp(batch_size=2, batch_group_size=2)
+    seen = {}
+
+    def loader(path):
+        return path
+
+    def features(path):
+        T = 20 + len(os.path.basename(path)) % 7
+        seen[path] = T
+        return np.full((hp.num_freq, T), 0.5, np.float32), np.full((hp.num_mels, T), 0.25, np.float32)
+    fd = DataFeeder(hp, ljspeech=str(lj), vctk=str(vctk), librispeech=str(libre), seed=2, prefetch=False,
+                    features=features, loader=loader)
+    assert len(fd.items) == 6 + 5 + 2
+    assert fd.id2speaker == {0: ("libre", "1272"), 1: ("libre", "84"), 2: ("ljspeech", "0"), 3: ("vctk", "225"),
+                             4: ("vctk", "301")}
+    # the same numbering on another rank (sorted pairs, no dependence on set order)
+    fd1 = DataFeeder(hp, ljspeech=str(lj), vctk=str(vctk), librispeech=str(libre), seed=2, rank=1, world=2,
+                     prefetch=False, features=features, loader=loader)
+    assert fd1.speaker2id == fd.speaker2id
+    # ids follow their utterances: VCTK texts name their speaker, LJSpeech rows are speaker 2
+    count = {}
+    for _ in range(8):
+        inputs, lengths, mel, lin = fd.next_batch()
+        assert fd.speaker_ids.shape == (2,) and fd.speaker_ids.dtype == np.int32
+        for i in range(2):
+            text = sequence_to_text(inputs[i, :lengths[i]])
+            sid = int(fd.speaker_ids[i])
+            count[sid] = count.get(sid, 0) + 1
+            if text.startswith("speaker a"):
+                assert sid == 3
+            elif text.startswith("speaker b"):
+                assert sid == 4
+            elif text.startswith("only his"):
+                assert sid == 0
+            elif text.startswith("go on"):
+                assert sid == 1
+            else:
+                assert sid == 2
+    assert set(count) == {0, 1, 2, 3, 4}

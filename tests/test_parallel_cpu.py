@@ -32,6 +32,16 @@ def test_bucket_ranges_tile_the_flat_buffer():
     # 7.56 M (head) / 5.50 M (postnet) / 16.93 M (decoder) / 4.89 M (encoder) parameters
     assert abs(sizes["head"] - 7556097) < 2000 and abs(sizes["postnet"] - 5496400) < 2000
     assert abs(sizes["decoder"] - 16927900) < 2000 and abs(sizes["encoder"] - 4894464) < 2000
+    # multi-speaker layouts (tacotron2.py:40-47, rnn_wrappers.py:28-30) still tile: the speaker table travels with the
+    # encoder bucket, its projection and the widened attention LSTM kernel with the decoder bucket
+    hp.num_speakers = 109
+    lay2, _ = P.taco2_layout(hp, 149)
+    b2 = parallel.bucket_ranges(lay2)
+    assert sum(hi - lo for _, lo, hi in b2) == lay2.size
+    s2 = {n: hi - lo for n, lo, hi in b2}
+    assert s2["head"] == sizes["head"] and s2["postnet"] == sizes["postnet"]
+    assert s2["encoder"] - sizes["encoder"] == 109 * 16
+    assert s2["decoder"] - sizes["decoder"] == 16 * 128 + 128 + 128 * 4 * hp.attention_dim
 
 
 def _worker(rank, world, port, size, out):

@@ -37,7 +37,7 @@ def make_batch(hp, N, Ti, To, seed=0, vocab=149):
     return inputs, lengths, mel, lin
 
 
-def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64, need_grad=True):
+def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64, need_grad=True, speaker_ids=None):
     """Forward + loss + gradients with the CPU oracle.  Returns (out dict, loss tuple, grads dict)."""
     sys.path.insert(0, os.path.join(ROOT))
     from oracle import taco2_oracle as O
@@ -45,7 +45,8 @@ def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64
     p.update({k: torch.tensor(v, dtype=dtype) for k, v in stats.items()})
     hpd = hp.values()
     out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths),
-                          torch.tensor(mel, dtype=dtype), torch.tensor(lin, dtype=dtype))
+                          torch.tensor(mel, dtype=dtype), torch.tensor(lin, dtype=dtype),
+                          speaker_ids=None if speaker_ids is None else torch.tensor(speaker_ids))
     loss, mel_loss, lin_loss = O.taco2_loss(hpd, out, torch.tensor(mel, dtype=dtype), torch.tensor(lin, dtype=dtype))
     grads = {}
     if need_grad:
@@ -54,7 +55,7 @@ def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64
     return out, (float(loss.detach()), float(mel_loss.detach()), float(lin_loss.detach())), grads
 
 
-def stabilise_targets(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3, rounds=4):
+def stabilise_targets(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3, rounds=4, speaker_ids=None):
     """The L1 losses have a sign() gradient: an element whose prediction sits within rounding
     noise of its target flips sign between fp32-on-GPU and float64-on-CPU and perturbs every
     upstream gradient by a finite amount.  Move such targets away from the oracle's prediction
@@ -66,7 +67,8 @@ def stabilise_targets(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3,
     for _ in range(rounds):
         with torch.no_grad():
             out = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
-                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64),
+                                  speaker_ids=None if speaker_ids is None else torch.tensor(speaker_ids))
         dm = out["mel_outputs"].numpy() - mel
         dl = out["linear_outputs"].numpy() - lin
         bm, bl = np.abs(dm) < margin, np.abs(dl) < margin

@@ -74,7 +74,10 @@ def train(log_dir, args):
         cmu = cmudict.CMUDict(cmudict_path, keep_ambiguous=False)
         log("Loaded CMUDict with %d unambiguous entries" % len(cmu), logf)
     # shared seed: every rank walks the same item order and keeps its round-robin share of each sorted group
-    feeder = DataFeeder(hp, ljspeech=args.ljspeech, seed=1234, rank=rank, world=world, cmudict=cmu).start()
+    feeder = DataFeeder(hp, ljspeech=args.ljspeech, vctk=args.vctk, librispeech=args.librispeech, seed=1234, rank=rank,
+                        world=world, cmudict=cmu).start()
+    hp.num_speakers = len(feeder.speaker2id)        # train.py:45
+    log("Loaded %d different speaker(s)" % hp.num_speakers, logf)
     model = create_model(args.model, hp, device="cuda:%d" % local, dtype=args.precision, world_size=world)
     step0 = 0
     if args.restore_step:
@@ -92,7 +95,7 @@ def train(log_dir, args):
     while args.max_steps is None or model.global_step < args.max_steps:
         t0 = time.time()
         inputs, lengths, mel, lin = feeder.next_batch()
-        loss = model.step(inputs, lengths, mel, lin)
+        loss = model.step(inputs, lengths, mel, lin, speaker_ids=feeder.speaker_ids)
         if world > 1:   # every rank must agree on the abort decision
             t = torch.tensor([loss], device="cuda")
             torch.distributed.all_reduce(t)
