@@ -71,6 +71,14 @@ typedef struct {
   int f32_passes;   /* fp32 operands only: 0 = exact fp32 FMA kernel; 3 = split-bf16 on MFMA
                        (x = hi + lo, hi*hi + hi*lo + lo*hi, ~2^-17 relative); 1 = hi*hi only */
   int addend_dtype; /* 0 / NS_F32: addend is fp32; NS_BF16: addend is bf16 */
+  /* optional pre-split low parts of fp32 values (dtype NS_BF16, a_mode 0, b_mode 0, same strides as A / B): with
+   * A = hi(a), A_lo = lo(a), B = hi(b), B_lo = lo(b) the call computes hi.hi + hi.lo + lo.hi on the matrix cores
+   * (the f32_passes = 3 product without the in-kernel split).  Both or neither. */
+  const void* A_lo; const void* B_lo;
+  /* batch > 1: `batch` independent products in one launch; item z uses A + z*batch_stride_a, B + z*batch_stride_b,
+   * C + z*batch_stride_c (elements).  The per-utterance products of the attention loop (align[n] . memory[n],
+   * attention.py:48 and its gradients).  No bias / addend / gate / statistics in batched calls. */
+  int batch; int64_t batch_stride_a, batch_stride_b, batch_stride_c;
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
 

@@ -668,12 +668,13 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     // the contexts themselves feed nothing inside the loop any more: one product per batch item over all steps,
     // hc[n, 1..S, A:] = align[n, 1..S, :] . memory[n]
     NS_CHECK_ARG(p.align_t != nullptr, "ns_taco2_attn_fwd: the projected-memory form needs align_t");
-    for (int n = 0; n < p.N; ++n) {
+    {
       ns_gemm_params g = {};
       g.dtype = dt; g.M = p.S; g.N = (int)E; g.K = p.Ti;
-      g.A = (const T*)p.align_t + ((long)n * S1 + 1) * p.Tia; g.lda = p.Tia; g.a_mode = 0;
-      g.B = (const T*)p.values + ((long)n * p.Pi + p.padl_i) * E; g.ldb = E; g.b_mode = 1;
-      g.C = (T*)p.hc + ((long)n * S1 + 1) * HC + A; g.ldc = HC; g.c_dtype = dt;
+      g.A = (const T*)p.align_t + p.Tia; g.lda = p.Tia; g.a_mode = 0;
+      g.B = (const T*)p.values + (long)p.padl_i * E; g.ldb = E; g.b_mode = 1;
+      g.C = (T*)p.hc + HC + A; g.ldc = HC; g.c_dtype = dt;
+      g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = (long)p.Pi * E; g.batch_stride_c = S1 * HC;
       g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
       int rc = ns_gemm(&g, s);
       if (rc) return rc;
@@ -815,12 +816,13 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     if (rc) return rc;
   }
   // dvalues[n] += align[n]^T . dctx[n]   (contraction over the decoder steps)
-  for (int n = 0; n < p.N; ++n) {
+  {
     ns_gemm_params g = {};
     g.dtype = dt; g.M = p.Ti; g.N = (int)E; g.K = (int)S1;
-    g.A = (const T*)p.align_t + (long)n * S1 * p.Tia; g.lda = p.Tia; g.a_mode = 1;
-    g.B = (const T*)p.dctx_t + (long)n * S1 * E; g.ldb = E; g.b_mode = 1;
-    g.C = p.dvalues + ((long)n * p.Pi + p.padl_i) * E; g.ldc = E; g.c_dtype = NS_F32;
+    g.A = (const T*)p.align_t; g.lda = p.Tia; g.a_mode = 1;
+    g.B = (const T*)p.dctx_t; g.ldb = E; g.b_mode = 1;
+    g.C = p.dvalues + (long)p.padl_i * E; g.ldc = E; g.c_dtype = NS_F32;
+    g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = S1 * E; g.batch_stride_c = (long)p.Pi * E;
     g.accumulate = 1; g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
     int rc = ns_gemm(&g, s);
     if (rc) return rc;

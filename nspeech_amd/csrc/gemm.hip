@@ -65,6 +65,15 @@ __device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float v) {
   }
 }
 
+// batched call: item z works on A + z*batch_stride_a, B + z*batch_stride_b, C + z*batch_stride_c (elements)
+__device__ __forceinline__ void batch_shift(ns_gemm_params& p, int z) {
+  if (z == 0) return;
+  const long ea = p.dtype == NS_BF16 ? 2 : 4, ec = p.c_dtype == NS_BF16 ? 2 : 4;
+  p.A = (const char*)p.A + (long)z * p.batch_stride_a * ea;
+  p.B = (const char*)p.B + (long)z * p.batch_stride_b * ea;
+  p.C = (char*)p.C + (long)z * p.batch_stride_c * ec;
+}
+
 // ------------------------------------------------------------------ generic kernel
 template <typename T>
 __device__ __forceinline__ float ld_a(const ns_gemm_params& p, int m, int k) {
@@ -93,7 +102,9 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
   // split-K over blockIdx.z
   const int nk = (p.K + BK - 1) / BK;
   const int per = (nk + p.split_k - 1) / p.split_k;
-  const int kt0 = blockIdx.z * per, kt1 = min(nk, kt0 + per);
+  const int ksl = blockIdx.z % p.split_k;
+  batch_shift(p, blockIdx.z / p.split_k);
+  const int kt0 = ksl * per, kt1 = min(nk, kt0 + per);
   float acc[4][4] = {};
   for (int kt = kt0; kt < kt1; ++kt) {
     const int k0 = kt * BK;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
     __syncthreads();
   }
   Epi e = make_epi(p);
-  const bool add_bias = (blockIdx.z == 0);
+  const bool add_bias = (ksl == 0);
   for (int i = 0; i < 4; ++i) {
     int m = m0 + ty * 4 + i;
     if (m >= p.M) continue;
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   const int nk = (p.K + GBK - 1) / GBK;
   const int per = (nk + p.split_k - 1) / p.split_k;
   const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+  batch_shift(p, blockIdx.z);
 
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
@@ -355,6 +367,239 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   }
 
   mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+}
+
+// ------------------------------------------------------------------ 256 x 256 tiles, 8 phases per two K-tiles
+// Both operands k-contiguous bf16 (a_mode 0, b_mode 0), K % 64 == 0.  One workgroup per CU: 8 waves as 2 (M) x 4 (N),
+// 128 x 64 outputs per wave held as acc[A half][4][B half][2].  LDS = 2 buffers x {A0 A1 B0 B1} half-tiles of
+// 128 rows x 64 k (16 KB each, 128-B rows, 16-B chunk index XOR ((row >> 1) & 7) as in the 128^2 kernel), filled by
+// global_load_lds_dwordx4 (LDS image lane-linear per wave -> the swizzle sits on the SOURCE address).
+// Wave (wr, wc) owns rows wr*64.. of BOTH A halves and columns wc*32.. of BOTH B halves, so a phase touches one
+// half-tile per operand for all waves and half-tiles free up one by one:
+//   phase 1: read A0, B0 | A0 x B0      phase 2: read B1 | A0 x B1
+//   phase 3: read A1     | A1 x B1      phase 4: -        | A1 x B0 (B0 fragments kept)
+// and are restaged one phase after their last read: P1 <- A1(t+1), P2 <- A0(t+2), P3 <- B0(t+2), P4 <- B1(t+2).
+// One counted wait per K-tile (phase 4): everything but the three newest half-tiles has landed = tile t+1 complete.
+// Each phase is [ds_read + stage + lgkmcnt(0)] barrier [16 MFMA] barrier; the wr = 1 waves run one barrier behind
+// the wr = 0 waves, so on every SIMD one wave feeds the matrix core while the other one loads.
+// Hazards: a read completes before its phase's first barrier (lgkmcnt(0) in front of it), so the restage one phase
+// later is behind a barrier both groups passed after their reads; the counted vmcnt sits in front of phase 4's first
+// barrier and the data is read from phase 1 of the next tile on, at least two barriers later for either group.
+// NSEG = 3: split-bf16 product of pre-split operands, K-tiles walk (A, B), (A, B_lo), (A_lo, B).
+// Measured on MI355X (random operands): 4096^3 989 TFLOP/s, 8192^3 1010, conv data gradient 32124 x 512 x 2560
+// 838 (128^2 kernel: 662 / - / 610); three-segment product 344 algorithmic = 1032 issued (in-kernel split: 239).
+constexpr int XHALF = 16384, XBUF = 65536;
+
+// C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+__device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&acc)[4][2], int mq, int nq, int lane) {
+  Epi e = make_epi(p);
+  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nq + j * 16 + (lane & 15);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mq + i * 16 + (lane >> 4) * 4 + r;
+        if (m < p.M && n < p.N) {
+          const bool valid = row_valid(e, m);
+          const float v = epi_value(e, m, n, acc[i][j][r], true, valid);
+          epi_store(e, m, n, v);
+          if (valid) {
+            const float vs = round_stats ? (float)(bf16_t)v : v;
+            s1 += vs;
+            s2 += vs * vs;
+          }
+        }
+      }
+    }
+    if (p.col_sum) {
+      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
+      if ((lane >> 4) == 0 && n < p.N) {
+        atomicAdd(p.col_sum + n, s1);
+        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
+      }
+    }
+  }
+}
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int NSEG>
+__global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int tiles_n = (p.N + 255) / 256, tiles_m = (p.M + 255) / 256;
+  const int nwg = tiles_m * tiles_n;
+  int wgid;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  // column tiles fastest: the workgroups of one XCD share their A rows through its L2
+  const int tm = wgid / tiles_n, tn = wgid % tiles_n;
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nk = p.K / 64, NT = nk * NSEG;
+
+  // staging: piece j of a half-tile covers rows (j*8 + wave)*8 + (lane >> 3), slot lane & 7 holds chunk slot ^ swz(row)
+  unsigned offA00, offA01, offA10, offA11, offB00, offB01, offB10, offB11;
+  {
+    const int r0 = wave * 8 + (lane >> 3), r1 = r0 + 64;
+    const int c0 = (lane & 7) ^ ((r0 >> 1) & 7), c1 = (lane & 7) ^ ((r1 >> 1) & 7);
+    auto oa = [&](int h, int r, int c) { return (unsigned)(((long)min(m0 + h * 128 + r, p.M - 1) * p.lda + c * 8) * 2); };
+    auto ob = [&](int h, int r, int c) { return (unsigned)(((long)min(n0 + h * 128 + r, p.N - 1) * p.ldb + c * 8) * 2); };
+    offA00 = oa(0, r0, c0); offA01 = oa(0, r1, c1); offA10 = oa(1, r0, c0); offA11 = oa(1, r1, c1);
+    offB00 = ob(0, r0, c0); offB01 = ob(0, r1, c1); offB10 = ob(1, r0, c0); offB11 = ob(1, r1, c1);
+  }
+  const char* const Ahi = (const char*)p.A;
+  const char* const Bhi = (const char*)p.B;
+  const char* const Alo = (const char*)p.A_lo;
+  const char* const Blo = (const char*)p.B_lo;
+  char* const lstage = smem + wave * 1024;
+
+#define X_ISSUE(T, HALF, O0, O1, ISA)                                                                   \
+  do {                                                                                                   \
+    const int t_ = (T);                                                                                  \
+    if (t_ < NT) {                                                                                       \
+      const int sg_ = NSEG == 1 ? 0 : t_ / nk;                                                           \
+      const int kt_ = NSEG == 1 ? t_ : t_ - sg_ * nk;                                                    \
+      const char* g_ = (ISA) ? (sg_ == 2 ? Alo : Ahi) : (sg_ == 1 ? Blo : Bhi);                          \
+      if (!(ISA) && p.b_seg_len > 0) {      /* segment s of B's K range starts at B + s * b_seg_stride */ \
+        const int bs_ = (kt_ * 64) / p.b_seg_len;                                                        \
+        g_ += ((long)bs_ * p.b_seg_stride + (kt_ * 64 - bs_ * p.b_seg_len)) * 2;                         \
+      } else {                                                                                           \
+        g_ += (long)kt_ * 128;                                                                           \
+      }                                                                                                  \
+      char* l_ = lstage + (t_ & 1) * XBUF + (HALF) * XHALF;                                              \
+      __builtin_amdgcn_global_load_lds((gptr_t)(g_ + (O0)), (lptr_t)l_, 16, 0, 0);                       \
+      __builtin_amdgcn_global_load_lds((gptr_t)(g_ + (O1)), (lptr_t)(l_ + 8192), 16, 0, 0);             \
+    }                                                                                                    \
+  } while (0)
+#define X_ISSUE_A0(T) X_ISSUE(T, 0, offA00, offA01, 1)
+#define X_ISSUE_A1(T) X_ISSUE(T, 1, offA10, offA11, 1)
+#define X_ISSUE_B0(T) X_ISSUE(T, 2, offB00, offB01, 0)
+#define X_ISSUE_B1(T) X_ISSUE(T, 3, offB10, offB11, 0)
+
+  // fragment addresses: row = w*{64,32} + tile*16 + (lane & 15), chunk = kk*4 + (lane >> 4), swizzle from lane only
+  const int li = lane & 15, sw = (li >> 1) & 7, gq = lane >> 4;
+  const int fa0 = (wr * 64 + li) * 128 + ((gq ^ sw) << 4);
+  const int fa1 = (wr * 64 + li) * 128 + (((4 + gq) ^ sw) << 4);
+  const int fb0 = 2 * XHALF + (wc * 32 + li) * 128 + ((gq ^ sw) << 4);
+  const int fb1 = 2 * XHALF + (wc * 32 + li) * 128 + (((4 + gq) ^ sw) << 4);
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[h][g][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 fa[4][2], fb0r[2][2], fb1r[2][2];
+
+#define X_READ_A(BUF, H)                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
+    fa[i][0] = *(const bf16x8*)(smem + (BUF) * XBUF + (H) * XHALF + fa0 + i * 2048);       \
+    fa[i][1] = *(const bf16x8*)(smem + (BUF) * XBUF + (H) * XHALF + fa1 + i * 2048);       \
+  }
+#define X_READ_B(DST, BUF, H)                                                              \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                          \
+    DST[j][0] = *(const bf16x8*)(smem + (BUF) * XBUF + (H) * XHALF + fb0 + j * 2048);      \
+    DST[j][1] = *(const bf16x8*)(smem + (BUF) * XBUF + (H) * XHALF + fb1 + j * 2048);      \
+  }
+#define X_MFMA(H, G, BR)                                                                                   \
+  do {                                                                                                     \
+    __builtin_amdgcn_s_setprio(1);                                                                         \
+    _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                       \
+      _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
+          acc[H][G][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], BR[j][kk], acc[H][G][i][j], 0, 0, 0); \
+    __builtin_amdgcn_s_setprio(0);                                                                         \
+  } while (0)
+#define X_SYNC_LOADS()                              \
+  do {                                              \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+#define X_SYNC_MFMA()                               \
+  do {                                              \
+    __builtin_amdgcn_sched_barrier(0);              \
+    __builtin_amdgcn_s_barrier();                   \
+    __builtin_amdgcn_sched_barrier(0);              \
+  } while (0)
+
+  // prologue: tile 0 whole, tile 1 without its A1 (phase 1 of tile 0 brings it)
+  X_ISSUE_A0(0); X_ISSUE_B0(0); X_ISSUE_B1(0); X_ISSUE_A1(0);
+  X_ISSUE_A0(1); X_ISSUE_B0(1); X_ISSUE_B1(1);
+  if (NT > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger
+  __builtin_amdgcn_sched_barrier(0);
+
+#define X_TILE(BUF)                                                     \
+  do {                                                                  \
+    /* phase 1 */                                                       \
+    X_READ_B(fb0r, BUF, 0) X_READ_A(BUF, 0)                             \
+    X_ISSUE_A1(t + 1);                                                  \
+    X_SYNC_LOADS();                                                     \
+    X_MFMA(0, 0, fb0r);                                                 \
+    X_SYNC_MFMA();                                                      \
+    /* phase 2 */                                                       \
+    X_READ_B(fb1r, BUF, 1)                                              \
+    X_ISSUE_A0(t + 2);                                                  \
+    X_SYNC_LOADS();                                                     \
+    X_MFMA(0, 1, fb1r);                                                 \
+    X_SYNC_MFMA();                                                      \
+    /* phase 3 */                                                       \
+    X_READ_A(BUF, 1)                                                    \
+    X_ISSUE_B0(t + 2);                                                  \
+    X_SYNC_LOADS();                                                     \
+    X_MFMA(1, 1, fb1r);                                                 \
+    X_SYNC_MFMA();                                                      \
+    /* phase 4 */                                                       \
+    X_ISSUE_B1(t + 2);                                                  \
+    if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    \
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+    X_SYNC_LOADS();                                                     \
+    X_MFMA(1, 0, fb0r);                                                 \
+    X_SYNC_MFMA();                                                      \
+  } while (0)
+
+  int t = 0;
+  for (; t + 1 < NT; t += 2) {
+    X_TILE(0);
+    ++t;
+    X_TILE(1);
+    --t;
+  }
+  if (t < NT) X_TILE(0);
+  if (wr == 0) __builtin_amdgcn_s_barrier();          // pairs with the stagger
+#undef X_TILE
+#undef X_SYNC_MFMA
+#undef X_SYNC_LOADS
+#undef X_MFMA
+#undef X_READ_B
+#undef X_READ_A
+#undef X_ISSUE_B1
+#undef X_ISSUE_B0
+#undef X_ISSUE_A1
+#undef X_ISSUE_A0
+#undef X_ISSUE
+
+  // epilogue, one 64 x 32 quadrant at a time
+  x256_quadrant(p, acc[0][0], m0 + wr * 64, n0 + wc * 32, lane);
+  x256_quadrant(p, acc[0][1], m0 + wr * 64, n0 + 128 + wc * 32, lane);
+  x256_quadrant(p, acc[1][0], m0 + 128 + wr * 64, n0 + wc * 32, lane);
+  x256_quadrant(p, acc[1][1], m0 + 128 + wr * 64, n0 + 128 + wc * 32, lane);
 }
 
 // ------------------------------------------------------------------ skinny kernel (M <= 32)
@@ -506,6 +751,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
   const int nk = (p.K + FBK - 1) / FBK;
   const int per = (nk + p.split_k - 1) / p.split_k;
   const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+  batch_shift(p, blockIdx.z);
   const float* A = (const float*)p.A;
   const float* B = (const float*)p.B;
   f32x4 acc[4][4];
@@ -644,6 +890,19 @@ __global__ __launch_bounds__(SKW * 64) void gemm_skinny_f32_kernel(ns_gemm_param
 // ------------------------------------------------------------------ host dispatch
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// the 256-tile kernel: large k-contiguous bf16 products whose tiles fill the chip
+static bool x256_ok(const ns_gemm_params& p) {
+  if (p.dtype != NS_BF16 || p.a_mode != 0 || p.b_mode != 0 || p.split_k != 1) return false;
+  if (p.b_seg_len != 0 && (p.b_seg_len % 64 != 0 || p.b_seg_stride % 8 != 0)) return false;
+  if (p.K % 64 != 0 || p.K < 128 || p.M < 1024 || p.N % 128 != 0) return false;
+  if ((p.A_lo != nullptr) != (p.B_lo != nullptr)) return false;
+  if (p.A_lo && (!aligned16(p.A_lo) || !aligned16(p.B_lo))) return false;
+  if ((double)p.M * (double)p.lda * 2.0 >= 4.0e9 || (double)p.N * (double)p.ldb * 2.0 >= 4.0e9) return false;
+  if (getenv("NS_GEMM_NO256")) return false;
+  // at least ~3/4 of the CUs busy, or the 128-tile kernel's finer grain wins
+  return ceil_div(p.M, 256) * ceil_div(p.N, 256) >= 96;
+}
+
 extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NS_CHECK_ARG(pp != nullptr, "ns_gemm: null params");
@@ -661,9 +920,13 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   NS_CHECK_ARG(p.b_seg_len == 0 || (p.b_seg_len > 0 && p.K % p.b_seg_len == 0),
                "ns_gemm: K must be a multiple of b_seg_len");
   if (p.alpha == 0.f) p.alpha = 1.f;
+  if (p.batch < 1) p.batch = 1;
+  NS_CHECK_ARG(p.batch == 1 || (!p.col_sum && !p.bias && !p.addend && !p.gate && !p.A_lo && p.batch <= 65535),
+               "ns_gemm: batched calls take no bias / addend / gate / statistics / pre-split operands");
 
   bool fast = (p.dtype == NS_BF16) && aligned16(p.A) && aligned16(p.B) && (p.lda % 8 == 0) &&
-              (p.ldb % 8 == 0) && (p.b_seg_stride % 8 == 0);
+              (p.ldb % 8 == 0) && (p.b_seg_stride % 8 == 0) && (p.batch_stride_a % 8 == 0) &&
+              (p.batch_stride_b % 8 == 0);
   if (fast) {
     // contiguous-dim extents must be whole 16-B chunks
     if (p.a_mode == 0) fast = fast && (p.K % 8 == 0); else fast = fast && (p.M % 8 == 0);
@@ -671,16 +934,32 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     if (p.b_seg_len > 0) fast = fast && (p.b_seg_len % GBK == 0);
   }
   if (fast && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 &&
-      !p.col_sum) {
+      !p.col_sum && p.batch == 1) {
     // enough workgroups to spread the weight stream over the chip
     if (p.N >= 32 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(ceil_div(p.N, 32)), dim3(SKW * 64), 0, stream, p);
     else hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
     NS_CHECK_LAUNCH("gemm_skinny");
     return NS_OK;
   }
+  if (fast && p.batch == 1 && x256_ok(p)) {
+    const int tiles = ceil_div(p.M, 256) * ceil_div(p.N, 256);
+    const size_t lds = 2 * XBUF;
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_set = true;
+    }
+    if (p.A_lo) hipLaunchKernelGGL(gemm_x256_kernel<3>, dim3(tiles), dim3(512), lds, stream, p);
+    else hipLaunchKernelGGL(gemm_x256_kernel<1>, dim3(tiles), dim3(512), lds, stream, p);
+    NS_CHECK_LAUNCH("gemm_x256");
+    return NS_OK;
+  }
+  NS_CHECK_ARG(!p.A_lo && !p.B_lo, "ns_gemm: pre-split operands (A_lo / B_lo) need the 256-tile path "
+               "(bf16, a_mode 0, b_mode 0, K %% 64 == 0, M >= 1024, N %% 128 == 0, >= 96 tiles, no split_k)");
   if (fast) {
     const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
-    dim3 grid(tiles, p.split_k);
+    dim3 grid(tiles, p.split_k, p.batch);
     const size_t lds = 65536;
 #define LAUNCH_MFMA(AM, BM_)                                                                      \
   do {                                                                                            \
@@ -701,13 +980,14 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     return NS_OK;
   }
   if (p.dtype == NS_F32 && p.f32_passes > 0) {
-    bool ok = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && (p.b_seg_stride % 4 == 0);
+    bool ok = aligned16(p.A) && aligned16(p.B) && (p.lda % 4 == 0) && (p.ldb % 4 == 0) && (p.b_seg_stride % 4 == 0) &&
+              (p.batch_stride_a % 4 == 0) && (p.batch_stride_b % 4 == 0);
     if (p.a_mode == 0) ok = ok && (p.K % 4 == 0); else ok = ok && (p.M % 4 == 0);
     if (p.b_mode == 0) ok = ok && (p.K % 4 == 0); else ok = ok && (p.N % 4 == 0);
     if (p.b_seg_len > 0) ok = ok && (p.b_seg_len % FBK == 0);
     const bool three = p.f32_passes >= 3;
     if (ok && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 && !p.col_sum &&
-        p.K % 8 == 0 && p.lda % 4 == 0) {
+        p.K % 8 == 0 && p.lda % 4 == 0 && p.batch == 1) {
       if (ceil_div(p.N, 16) <= 64) {      // few column tiles: 16 rows x 8 columns per workgroup
         const dim3 grid(ceil_div(p.N, 8), ceil_div(p.M, 16));
         if (three) hipLaunchKernelGGL((gemm_skinny_f32_kernel<3, 1, 8>), grid, dim3(SKW * 64), 0, stream, p);
@@ -721,7 +1001,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     }
     if (ok) {
       const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
-      dim3 grid(tiles, p.split_k);
+      dim3 grid(tiles, p.split_k, p.batch);
       const size_t lds = 65536;
 #define LAUNCH_F32(AM, BM_, PS)                                                                     \
   do {                                                                                              \
@@ -747,7 +1027,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
       return NS_OK;
     }
   }
-  dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k);
+  dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k * p.batch);
   if (p.dtype == NS_F32) hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(gemm_generic_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
   NS_CHECK_LAUNCH("gemm_generic");

@@ -751,9 +751,8 @@ class Tacotron2(object):
             else:
                 src, lda, a0 = self._buf("d_hc_ctx", rows * E, T_), E, 0
                 ops.copy3d(dhc, src, 1, rows, E, (0, A + E), (0, E), src_off=A)
-            for n in range(N):
-                ops.gemm(src, enc, da0, S1, Ti, E, lda, E, Tia, b_mode=0, a_off=n * S1 * lda + a0,
-                         b_off=(n * Pi + self.padl) * E, c_off=n * S1 * Tia)
+            ops.gemm(src, enc, da0, S1, Ti, E, lda, E, Tia, b_mode=0, a_off=a0, b_off=self.padl * E, batch=N,
+                     batch_strides=(S1 * lda, Pi * E, S1 * Tia))
             args["da0"] = da0
         args.update(w1c=(self._W(self.T), w1 + M * 256), w2=(self._W(self.T), w2), watt=(self._W(self.T), wa),
                     wq=(self._W(self.T), wq), dhc=dhc, df1=df1, dp2=dp2, dga=dga, dq=dq, dkeys=dkeys, dvalues=dvalues,

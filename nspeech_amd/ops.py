@@ -38,7 +38,7 @@ def ptr(t, off=0):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0, c_off=0,
          bias=None, bias_off=0, act=0, alpha=1.0, accumulate=0, row_mask=None, col_sum=None,
          col_sumsq=None, split_k=1, b_seg=None, addend=None, addend_off=0, ld_add=0, f32_passes=None,
-         gate=None, gate_off=0, ld_gate=0):
+         gate=None, gate_off=0, ld_gate=0, a_lo=None, b_lo=None, batch=1, batch_strides=(0, 0, 0)):
     """C = act(alpha * A.B + bias); see ns_gemm in include/nspeech_hip.h."""
     assert A.dtype == B.dtype
     p = L.GemmParams()
@@ -63,6 +63,11 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     if gate is not None:
         p.gate, p.ld_gate = ptr(gate, gate_off), ld_gate
     p.f32_passes = F32_PASSES if f32_passes is None else f32_passes
+    if batch > 1:
+        p.batch = batch
+        p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch_strides
+    if a_lo is not None:        # pre-split fp32 values: A / B hold the high parts (same offsets and strides)
+        p.A_lo, p.B_lo = ptr(a_lo, a_off), ptr(b_lo, b_off)
     L.call("ns_gemm", p, stream())
 
 

@@ -110,3 +110,104 @@ def test_gemm_fp32_split_bf16(dev, passes, tol, a_mode, b_mode, M, N, K):
     assert err <= bound, (err, bound)
     if passes == 3:   # and it is clearly better than single-pass bf16
         assert err <= 1e-4 * ref.abs().max().item()
+
+
+def test_gemm_256_tile_kernel(dev):
+    """Large k-contiguous bf16 products take the 256 x 256 eight-phase kernel (global_load_lds staging, counted
+    vmcnt, staggered wave groups): ragged M, strided (im2col) A, bias + ReLU + row mask + BatchNorm sums + bf16
+    output, the segmented-B data-gradient walk, and the three-segment product of pre-split fp32 values."""
+    import os
+    from nspeech_amd import ops
+    from nspeech_amd import _lib as L
+    bf = torch.bfloat16
+    # im2col view: rows overlap (lda = Cin < K = taps * Cin)
+    taps, Cin, Cout, rows = 5, 128, 256, 12300
+    X = _mk((rows + taps - 1, Cin), bf, dev, 21)
+    Wt = _mk((Cout, taps * Cin), bf, dev, 22)                 # k-contiguous weights [N, K]
+    bias = _mk((Cout,), torch.float32, dev, 23)
+    out = torch.full((rows, Cout), 7.0, dtype=bf, device=dev)
+    st = torch.zeros(2 * Cout, device=dev)
+    ops.gemm(X, Wt, out, rows, Cout, taps * Cin, Cin, taps * Cin, Cout, a_mode=0, b_mode=0, bias=bias, act=1,
+             row_mask=(100, 2, 98, 0), col_sum=st, col_sumsq=st[Cout:])
+    torch.cuda.synchronize()
+    a = torch.as_strided(X.double().cpu(), (rows, taps * Cin), (Cin, 1))
+    ref = torch.relu(a @ Wt.double().cpu().t() + bias.double().cpu())
+    t = torch.arange(rows) % 100
+    ref[(t < 2) | (t >= 98)] = 0
+    got = out.double().cpu()
+    assert (got - ref).abs().max().item() <= 1e-2 * ref.abs().max().item()
+    assert torch.allclose(st[:Cout].double().cpu(), got.sum(0), rtol=1e-4, atol=1e-1)
+    assert torch.allclose(st[Cout:].double().cpu(), (got * got).sum(0), rtol=1e-4, atol=1e-1)
+    # the same call through the 128-tile kernel gives the same values up to summation order
+    os.environ["NS_GEMM_NO256"] = "1"
+    try:
+        out2 = torch.zeros_like(out)
+        ops.gemm(X, Wt, out2, rows, Cout, taps * Cin, Cin, taps * Cin, Cout, a_mode=0, b_mode=0, bias=bias, act=1,
+                 row_mask=(100, 2, 98, 0))
+        torch.cuda.synchronize()
+    finally:
+        del os.environ["NS_GEMM_NO256"]
+    assert (out2.float() - out.float()).abs().max().item() <= 2e-2 * ref.abs().max().item()
+    # data gradient: taps walked backwards through segments of B
+    W = _mk((taps, Cin, Cout), bf, dev, 24)
+    dY = _mk((rows + taps - 1, Cout), bf, dev, 25)
+    dX = torch.zeros((rows, Cin), dtype=torch.float32, device=dev)
+    ops.gemm(dY, W, dX, rows, Cin, taps * Cout, Cout, Cout, Cin, a_mode=0, b_mode=0,
+             b_off=(taps - 1) * Cin * Cout, b_seg=(Cout, -Cin * Cout))
+    torch.cuda.synchronize()
+    dy, w = dY.double().cpu(), W.double().cpu()
+    ref = torch.zeros(rows, Cin, dtype=torch.float64)
+    for j in range(taps):
+        ref += dy[j:j + rows] @ w[taps - 1 - j].t()
+    assert (dX.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+    # odd number of K tiles, one K tile short of the pipeline depth, N not a multiple of 256
+    for M, N, K in ((25000, 384, 192), (33000, 256, 128), (1100, 6144, 320)):
+        A = _mk((M, K), bf, dev, M)
+        B = _mk((N, K), bf, dev, N)
+        Cm = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+        ops.gemm(A, B, Cm, M, N, K, K, K, N, a_mode=0, b_mode=0)
+        torch.cuda.synchronize()
+        ref = A.double().cpu() @ B.double().cpu().t()
+        assert (Cm.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-4, (M, N, K)
+    # three segments: fp32 values pre-split into bf16 hi + lo
+    M, N, K = 13000, 512, 256
+    a32, b32 = _mk((M, K), torch.float32, dev, 31), _mk((N, K), torch.float32, dev, 32)
+    ah, bh = a32.to(bf), b32.to(bf)
+    al, bl = (a32 - ah.float()).to(bf), (b32 - bh.float()).to(bf)
+    Cm = torch.zeros((M, N), dtype=torch.float32, device=dev)
+    ops.gemm(ah, bh, Cm, M, N, K, K, K, N, a_mode=0, b_mode=0, a_lo=al, b_lo=bl)
+    torch.cuda.synchronize()
+    ref = a32.double().cpu() @ b32.double().cpu().t()
+    assert (Cm.double().cpu() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+    # pre-split operands on a shape the 256-tile kernel does not take: refused, not silently dropped
+    with pytest.raises(L.NSError):
+        ops.gemm(ah, bh, Cm, 64, N, K, K, K, N, a_mode=0, b_mode=0, a_lo=al, b_lo=bl)
+
+
+@pytest.mark.parametrize("dtype,passes,tol", [(torch.float32, 0, 2e-5), (torch.float32, 3, 3e-5), (torch.bfloat16, 0, 2e-5)])
+@pytest.mark.parametrize("a_mode,b_mode", [(0, 1), (1, 1), (0, 0)])
+def test_gemm_batched(dev, dtype, passes, tol, a_mode, b_mode):
+    """batch > 1: independent products in one launch (the per-utterance attention products), with padded strides,
+    accumulate = 1 into distinct outputs, and refusal of per-call extras."""
+    from nspeech_amd import ops
+    from nspeech_amd import _lib as L
+    nb, M, N, K = 5, 41, 72, 88
+    sa, sb, sc = (M + 3) * K + 8, (N + 1) * K + 16, M * N + 24
+    A = _mk((nb * sa,), dtype, dev, 41)
+    B = _mk((nb * sb,), dtype, dev, 42)
+    Cm = torch.ones(nb * sc, dtype=torch.float32, device=dev)
+    lda = K if a_mode == 0 else M
+    ldb = K if b_mode == 0 else N
+    ops.gemm(A, B, Cm, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, accumulate=1, batch=nb,
+             batch_strides=(sa, sb, sc), f32_passes=passes)
+    torch.cuda.synchronize()
+    for z in range(nb):
+        a = A[z * sa:z * sa + M * K].double().cpu().view((M, K) if a_mode == 0 else (K, M))
+        b = B[z * sb:z * sb + N * K].double().cpu().view((N, K) if b_mode == 0 else (K, N))
+        ref = 1.0 + _ref(a, b, a_mode, b_mode)
+        got = Cm[z * sc:z * sc + M * N].double().cpu().view(M, N)
+        assert (got - ref).abs().max().item() <= tol * ref.abs().max().item() + 1e-4, z
+        assert (Cm[z * sc + M * N:(z + 1) * sc] == 1.0).all()          # the padding between items is untouched
+    with pytest.raises(L.NSError):
+        ops.gemm(A, B, Cm, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, batch=nb, batch_strides=(sa, sb, sc),
+                 bias=Cm)
