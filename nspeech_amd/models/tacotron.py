@@ -672,7 +672,7 @@ class Tacotron(Tacotron2):
         om = o("attention_decoder/memory_layer/kernel")
         ops.gemm(enc.buf, dkeys_T, g, E, A, N * Pi, E, A, A, a_mode=1, b_mode=1, c_off=om, accumulate=2, split_k=sk(N * Pi, E, A))
         ops.gemm(dkeys_T, W, enc.grad, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
-        for n in range(N):     # dvalues[n] += align[n]^T . dctx[n]
-            ops.gemm(al_t, dctx_t, enc.grad, Ti, E, S1, Tia, E, E, a_mode=1, b_mode=1, a_off=n * S1 * Tia,
-                     b_off=n * S1 * E, c_off=(n * Pi + self.padl) * E, accumulate=1)
+        # dvalues[n] += align[n]^T . dctx[n], all utterances in one batched launch
+        ops.gemm(al_t, dctx_t, enc.grad, Ti, E, S1, Tia, E, E, a_mode=1, b_mode=1, c_off=self.padl * E, accumulate=1,
+                 batch=N, batch_strides=(S1 * Tia, S1 * E, Pi * E))
 
