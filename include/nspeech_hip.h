@@ -81,6 +81,9 @@ typedef struct {
   int batch; int64_t batch_stride_a, batch_stride_b, batch_stride_c;
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
+/* name of the kernel the calling thread's last ns_gemm call launched (e.g. "gemm_mfma_f32_kernel<0, 1, 3>"): lets a
+ * caller attribute its own event timings to the names a profiler reports. */
+const char* ns_gemm_last_kernel(void);
 
 
 /* ------------------------------------------------------------------ element-wise / reductions */
@@ -143,6 +146,8 @@ typedef struct {
   float count;
   int act;
   int row_period, row_lo, row_hi;
+  int dpre_dtype;   /* 0: dpre has `dtype`; NS_BF16 with dtype NS_F32: dpre is written as bf16 (single-pass backward
+                       products read it at half the bytes; the bias gradient is summed on the rounded values) */
 } ns_bn_bwd_params;
 int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t stream);
 

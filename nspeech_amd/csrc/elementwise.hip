@@ -179,9 +179,15 @@ __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
         else if (p.act == NS_ACT_SIGMOID) d *= zv * (1.f - zv);
         else if (p.act == NS_ACT_SOFTSIGN) d *= (1.f - fabsf(zv)) * (1.f - fabsf(zv));
       }
-      stf(dpre + idx, d);
       // bias gradient is taken on the value the weight-gradient GEMM will read
-      sb += (float)(T)d;
+      if (sizeof(T) == 4 && p.dpre_dtype == NS_BF16) {
+        const bf16_t db = (bf16_t)d;
+        ((bf16_t*)p.dpre)[idx] = db;
+        sb += (float)db;
+      } else {
+        stf(dpre + idx, d);
+        sb += (float)(T)d;
+      }
     }
     if (p.dbias) atomicAdd(p.dbias + c, sb);
     if (blockIdx.x == 0) {

@@ -890,6 +890,11 @@ __global__ __launch_bounds__(SKW * 64) void gemm_skinny_f32_kernel(ns_gemm_param
 // ------------------------------------------------------------------ host dispatch
 static bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+// which kernel the last ns_gemm call of this thread launched (bench.py groups its HIP-event timings by it, so that
+// its per-kernel averages can be read against the rocprofv3 kernel statistics)
+static thread_local const char* g_last_kernel = "";
+extern "C" const char* ns_gemm_last_kernel(void) { return g_last_kernel; }
+
 // the 256-tile kernel: large k-contiguous bf16 products whose tiles fill the chip
 static bool x256_ok(const ns_gemm_params& p) {
   if (p.dtype != NS_BF16 || p.a_mode != 0 || p.b_mode != 0 || p.split_k != 1) return false;
@@ -936,6 +941,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   if (fast && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 &&
       !p.col_sum && p.batch == 1) {
     // enough workgroups to spread the weight stream over the chip
+    g_last_kernel = "gemm_skinny_kernel";
     if (p.N >= 32 * 128) hipLaunchKernelGGL(gemm_skinny_kernel<2>, dim3(ceil_div(p.N, 32)), dim3(SKW * 64), 0, stream, p);
     else hipLaunchKernelGGL(gemm_skinny_kernel<1>, dim3(ceil_div(p.N, 16)), dim3(SKW * 64), 0, stream, p);
     NS_CHECK_LAUNCH("gemm_skinny");
@@ -950,6 +956,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
       (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
+    g_last_kernel = p.A_lo ? "gemm_x256_kernel<3>" : "gemm_x256_kernel<1>";
     if (p.A_lo) hipLaunchKernelGGL(gemm_x256_kernel<3>, dim3(tiles), dim3(512), lds, stream, p);
     else hipLaunchKernelGGL(gemm_x256_kernel<1>, dim3(tiles), dim3(512), lds, stream, p);
     NS_CHECK_LAUNCH("gemm_x256");
@@ -969,6 +976,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
       attr_set = true;                                                                            \
     }                                                                                             \
+    g_last_kernel = "gemm_mfma_kernel<" #AM ", " #BM_ ">";                                        \
     hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_>), grid, dim3(256), lds, stream, p);             \
   } while (0)
     if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
@@ -988,6 +996,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     const bool three = p.f32_passes >= 3;
     if (ok && p.M <= 32 && p.a_mode == 0 && p.b_mode == 0 && p.b_seg_len == 0 && p.split_k == 1 && !p.col_sum &&
         p.K % 8 == 0 && p.lda % 4 == 0 && p.batch == 1) {
+      g_last_kernel = "gemm_skinny_f32_kernel";
       if (ceil_div(p.N, 16) <= 64) {      // few column tiles: 16 rows x 8 columns per workgroup
         const dim3 grid(ceil_div(p.N, 8), ceil_div(p.M, 16));
         if (three) hipLaunchKernelGGL((gemm_skinny_f32_kernel<3, 1, 8>), grid, dim3(SKW * 64), 0, stream, p);
@@ -1011,6 +1020,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_set = true;                                                                              \
     }                                                                                               \
+    g_last_kernel = "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ">";                             \
     hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS>), grid, dim3(256), lds, stream, p);       \
   } while (0)
 #define LAUNCH_F32_MODES(PS)                                                   \
@@ -1028,6 +1038,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     }
   }
   dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k * p.batch);
+  g_last_kernel = "gemm_generic_kernel";
   if (p.dtype == NS_F32) hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(gemm_generic_kernel<bf16_t>, grid, dim3(256), 0, stream, p);
   NS_CHECK_LAUNCH("gemm_generic");

@@ -305,7 +305,15 @@ class Tacotron2(object):
         z = self._bufs[tag + "_z"]
         st = self._bufs[tag + "_st"]
         D = D or self.T
-        dpre = self._buf("dpre_%d" % cout, rows * cout, D)
+        # single-pass backward on fp32 storage rounds every operand to bf16 on load: keep the gradient and a copy of the
+        # layer input in bf16 instead (half the bytes, the bf16 kernels, the 256-tile data-gradient kernel)
+        w16 = self._bf16_w(D)
+        Dg = torch.bfloat16 if w16 is not None else D
+        dpre = self._buf("dpre_%d" % cout, rows * cout, Dg)
+        if w16 is not None:
+            x16 = self._buf("xin16_%d" % cin, rows * cin, torch.bfloat16)
+            ops.cast2d(xin, rows, cin, cin, x16, cin, False)
+            xin = x16
         work = self._buf("bn_work", 2 * 2048, torch.float32)
         g = self.flat_g
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
@@ -323,7 +331,7 @@ class Tacotron2(object):
         if need_dx:
             a2 = self.padl - kr
             Mg2 = rows - (k - 1) - a2
-            ops.gemm(dpre, self._W(D), dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
+            ops.gemm(dpre, w16 if w16 is not None else self._W(D), dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
                      a_off=a2 * cout, b_off=self._o(scope + "/conv1d/kernel") + (k - 1) * cin * cout,
                      b_seg=(cout, -cin * cout), c_off=self.padl * cin, accumulate=1 if dx_accumulate else 0,
                      row_mask=(Pp, self.padl, self.padl + T, self.padl))
@@ -712,17 +720,35 @@ class Tacotron2(object):
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D, B["dec_c2"],
                      B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
                      wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D, dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_))
-        self._lstm_wgrads(h1, D, h2, D, dg2, rows, k2, "decoder/lstm_2/bias")
+        w16 = self._bf16_w(T_)
+        dg2b = self._bufs.get("d_g2b") if w16 is not None else None
+
+        def b16(name, src, cols):       # bf16 copy of a forward activation for the single-pass weight gradients
+            if dg2b is None:
+                return src
+            dst = self._buf(name, rows * cols, torch.bfloat16)
+            ops.cast2d(src, rows, cols, cols, dst, cols, False)
+            return dst
+        h1b, h2b = b16("dec_h1_16", h1, D), b16("dec_h2_16", h2, D)
+        self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2, "decoder/lstm_2/bias")
         dh1 = self._buf("d_h1", rows * D, torch.float32)
-        ops.gemm(dg2, self._W(self.T), dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
+        if dg2b is not None:
+            ops.gemm(dg2b, w16, dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
+        else:
+            ops.gemm(dg2, self._W(self.T), dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
         dg1 = self._buf("d_g1", rows * 4 * D, T_)
         ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D, B["dec_c1"],
                      B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
                      wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D,
                      dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
-        self._lstm_wgrads(hc, A + E, h1, D, dg1, rows, k1, "decoder/lstm_1/bias")
+        dg1b = self._bufs.get("d_g1b") if w16 is not None else None
+        self._lstm_wgrads(b16("dec_hc_16", hc, A + E), A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1,
+                          "decoder/lstm_1/bias")
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
-        ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
+        if dg1b is not None:
+            ops.gemm(dg1b, w16, dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
+        else:
+            ops.gemm(dg1, self._W(self.T), dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
         self._tick("dec_lstm_bwd")
         # ---- attention RNN through time
         df1 = self._buf("d_f1", (rows + 1) * 256, T_)        # + one zero row read by the hoisted dctx product

@@ -116,6 +116,8 @@ def bn_bwd(dy, z, dpre, rows, C, mean, istd, gamma, dgamma, dbeta, dbias, work, 
     _fill(p, dy=ptr(dy), z=ptr(z), dpre=ptr(dpre), dtype=dt(z), rows=rows, C=C, mean=ptr(mean), istd=ptr(istd),
           gamma=ptr(gamma, gamma_off), dgamma=ptr(dgamma, dgamma_off), dbeta=ptr(dbeta, dbeta_off),
           dbias=ptr(dbias, dbias_off), work=ptr(work), count=float(count), act=act)
+    if dpre.dtype != z.dtype:
+        p.dpre_dtype = dt(dpre)
     if row_mask is not None:
         p.row_period, p.row_lo, p.row_hi = row_mask
     L.call("ns_bn_bwd", p, stream())

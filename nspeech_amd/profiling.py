@@ -8,6 +8,13 @@ from . import ops
 MFMA_BF16_PEAK_TFLOPS = 2500.0
 
 
+def _last_kernel():
+    from . import _lib as L
+    fn = L.lib().ns_gemm_last_kernel
+    fn.restype = L.C.c_char_p
+    return fn().decode()
+
+
 def roofline(model, one_step):
     rec = []
     orig = ops.gemm
@@ -23,7 +30,9 @@ def roofline(model, one_step):
         orig(A, B, Cm, M, N, K, *a, **kw)
         e1.record()
         esz = A.element_size()
-        rec.append((2.0 * M * N * K, e0, e1, passes, float(M * K + K * N) * esz + float(M * N) * Cm.element_size()))
+        nb = kw.get("batch", 1)
+        rec.append((2.0 * M * N * K * nb, e0, e1, passes,
+                    (float(M * K + K * N) * esz + float(M * N) * Cm.element_size()) * nb, _last_kernel()))
 
     ops.gemm = timed
     try:
@@ -47,7 +56,20 @@ def roofline(model, one_step):
         traffic = float(json.load(open(f))["traffic_bytes_per_launch"])
     except Exception:
         pass
-    return {"bound": "mfma", "kernel": "gemm_mfma_kernel (conv1d / dense / LSTM input + all weight and data gradients)",
+    # the same timings per kernel variant, named as rocprofv3 names them (profiles/r01_v6_kernel_stats.csv)
+    by = {}
+    for r in rec:
+        b = by.setdefault(r[5], [0, 0.0, 0.0, 0.0])
+        b[0] += 1
+        b[1] += r[1].elapsed_time(r[2])
+        b[2] += r[0]
+        b[3] += r[0] * r[3]
+    by_kernel = [{"kernel": k, "launches": v[0], "avg_launch_us": v[1] * 1e3 / v[0], "ms_per_step": v[1],
+                  "achieved_TFLOPs": v[2] / (v[1] * 1e-3) / 1e12, "issued_mfma_TFLOPs": v[3] / (v[1] * 1e-3) / 1e12}
+                 for k, v in sorted(by.items(), key=lambda kv: -kv[1][1])]
+    return {"bound": "mfma", "kernel": "ns_gemm kernels (conv1d / dense / LSTM input + all weight and data gradients); "
+                                       "dominant: %s" % by_kernel[0]["kernel"],
+            "by_kernel": by_kernel,
             "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
             "launches": len(rec), "avg_launch_us": ms * 1e3 / len(rec), "gflop_per_step": flops / 1e9,
             "issued_mfma_tflops": issued / (ms * 1e-3) / 1e12,
