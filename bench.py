@@ -195,6 +195,8 @@ def main():
                     help="mixed (default): split-bf16 x3 on the mel path forward, bf16 elsewhere - meets the 1e-3 mel tolerance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--phases", action="store_true", help="print a per-phase time table to stderr")
+    ap.add_argument("--train-only", action="store_true",
+                    help="skip the Griffin-Lim / synthesis / WaveNet legs (profiling passes of the headline workload)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -290,7 +292,7 @@ def main():
                               "hbm_floor_ms": 2 * S * w_bytes / 8e12 * 1e3},
             "phases_ms": {k: round(v, 3) for k, v in phases},
         }
-        if world == 1:
+        if world == 1 and not args.train_only:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
             res["inference"] = inference_bench(hp, args.dtype)
             res["wavenet"] = wavenet_bench()
