@@ -111,10 +111,9 @@ __device__ __forceinline__ void ldsplit8(const float* p, bool ok, bf16x8& hi, bf
 template <int PASSES>
 __device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, const bf16x8& bh, const bf16x8& bl,
                                             f32x4 acc) {
-  if (PASSES > 1) {
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
-  }
+  // PASSES 3: a.b ~ lo.hi + hi.lo + hi.hi;  2: b rounded to bf16, a exact to ~16 bits (lo.hi + hi.hi);  1: hi.hi
+  if (PASSES > 1) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+  if (PASSES > 2) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
 }
 

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     // fp32 state / weights on the bf16 MFMA via the hi/lo split (common.h)
     const int lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const bool three = a.passes >= 3;
+    const bool three = a.passes >= 3, two = a.passes == 2;
     constexpr int QG = HALF ? 4 : 2;       // K chunks in flight per wave
     f32x4 acc[MT][NTL];
 #pragma unroll
@@ -137,6 +137,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
 #pragma unroll
             for (int j = 0; j < NTL; ++j)
               acc[i][j] = three ? mfma_split<3>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j])
+                          : two ? mfma_split<2>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j])
                                 : mfma_split<1>(ah[q][i], al[q][i], bh[q][j], bl[q][j], acc[i][j]);
       }
     }
