@@ -72,3 +72,48 @@ def test_taco1_config1_plumbing(tmp_path):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert os.path.exists(os.path.join(run, "eval-3-0.wav"))
+
+
+def test_multi_speaker_train_and_eval(tmp_path):
+    """LJSpeech + a VCTK-layout corpus (wav48/pNNN/*.wav + txt/pNNN/*.txt, corpus/vctk.py:11-20) give
+    three speakers; train.py sizes the speaker table from the feeder (train.py:45), eval.py synthesises a chosen one."""
+    lj = str(tmp_path / "lj")
+    os.makedirs(lj)
+    _corpus(lj)
+    vctk = str(tmp_path / "vctk")
+    rng = np.random.default_rng(1)
+    for spk, f0 in (("225", 120.0), ("301", 210.0)):
+        os.makedirs(os.path.join(vctk, "wav48", "p" + spk))
+        os.makedirs(os.path.join(vctk, "txt", "p" + spk))
+        for i in range(2):
+            L = int(20000 * rng.uniform(0.5, 0.8))
+            t = np.arange(L) / 20000.0
+            y = 0.5 * np.sin(2 * np.pi * f0 * t) + rng.normal(0, 0.01, L)
+            name = "p%s_%03d" % (spk, i + 1)
+            with wave.open(os.path.join(vctk, "wav48", "p" + spk, name + ".wav"), "wb") as f:
+                f.setnchannels(1); f.setsampwidth(2); f.setframerate(20000)
+                f.writeframes((np.clip(y, -1, 1) * 32767).astype("<i2").tobytes())
+            with open(os.path.join(vctk, "txt", "p" + spk, name + ".txt"), "w") as f:
+                f.write("Please call Stella.\n")
+    logs = str(tmp_path / "logs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--ljspeech", lj, "--vctk", vctk, "--model", "taco2",
+                        "--log_dir", logs, "--hparams", SMALL, "--checkpoint_interval", "2", "--max_steps", "2",
+                        "--precision", "bf16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "Loaded 3 different speaker(s)" in r.stdout
+    run = os.path.join(logs, "logs-taco2")
+    ck = os.path.join(run, "model.ckpt-2")
+    assert os.path.exists(ck)
+    import torch
+    sd = torch.load(ck, map_location="cpu")
+    assert tuple(sd["model/inference/speaker/speaker_embed"].shape) == (3, 16)
+    assert tuple(sd["model/inference/decoder/attention_lstm/kernel"].shape) == (128 + 128 + 64, 4 * 64)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "--checkpoint", ck, "--model", "taco2",
+                        "--hparams", SMALL + ",num_speakers=3", "--precision", "bf16", "--speaker", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(os.path.join(run, "eval-2-0.wav"))
+    # a single-speaker hparams set cannot load this checkpoint: refused, not silently truncated
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "--checkpoint", ck, "--model", "taco2",
+                        "--hparams", SMALL, "--precision", "bf16"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
