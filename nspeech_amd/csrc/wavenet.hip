@@ -471,7 +471,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_fast_kernel(ns_wavene
 //   skip waves : wave w owns rows k = w (mod 8) of every layer's [32, S] skip kernel (wave 1 also k = 0 mod 8), a lane
 //                owns 8 adjacent columns; they follow the chain through an LDS progress counter and keep three layers
 //                of weights in flight, so the skip sum is finished when the chain is.
-constexpr int MF_AHEAD = 3;
+constexpr int MF_AHEAD = 2;
 struct GenMf { uint4 fg[8]; uint4 de[2]; float4 r0, r1; };
 
 __device__ __forceinline__ bf16x8 mf_pack(float4 a, float4 b) {
@@ -533,7 +533,40 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
         m = block_max(m, red);
         for (int j = tid; j < Q; j += GEN_THREADS) ex[j] = exp((double)lg[j] - (double)m);
         __syncthreads();
-        if (tid == 0) {
+        if (Q <= GEN_THREADS) {
+          // inverse CDF in parallel: inclusive scan of the float64 weights, pick = #{j : cdf[j] <= u} (the first j with
+          // u < cdf[j]); `part` is free again after the post-processing products
+          double* wsum = (double*)part;                      // [8] wave totals
+          int* wcnt = (int*)(wsum + GEN_THREADS / 64);       // [8] per-wave counts
+          const double v = tid < Q ? ex[tid] : 0.0;
+          double sc = v;
+    #pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const double nb = __shfl_up(sc, o, 64);
+            if (lane >= o) sc += nb;
+          }
+          if (lane == 63) wsum[wave] = sc;
+          __syncthreads();
+          double off = 0.0, se = 0.0;
+    #pragma unroll
+          for (int w = 0; w < GEN_THREADS / 64; ++w) {
+            const double tw = wsum[w];
+            if (w < wave) off += tw;
+            se += tw;
+          }
+          const double u = (double)un[t + 1 - p.n_seed] * se;
+          const unsigned long long bal = __ballot(tid < Q && off + sc <= u);
+          if (lane == 0) wcnt[wave] = __popcll(bal);
+          if (p.probs && t + 2 == p.total && tid < Q)        // the distribution of the LAST drawn sample
+            p.probs[(long)b * Q + tid] = (float)(v / se);
+          __syncthreads();
+          if (tid == 0) {
+            int cnt = 0;
+    #pragma unroll
+            for (int w = 0; w < GEN_THREADS / 64; ++w) cnt += wcnt[w];
+            ids[t + 1] = min(cnt, Q - 1);
+          }
+        } else if (tid == 0) {
           double se = 0.0;
           for (int j = 0; j < Q; ++j) se += ex[j];
           const double u = (double)un[t + 1 - p.n_seed] * se;
@@ -578,10 +611,9 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
     W_##_r1 = afl ? *(const float4*)(ring_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f);                                        \
   } while (0)
 #define MF_DECL(W_) uint4 W_##_fg[8], W_##_de[2]; float4 W_##_r0, W_##_r1
-      MF_DECL(w0); MF_DECL(w1); MF_DECL(w2);
+      MF_DECL(w0); MF_DECL(w1);
       MF_LOAD(w0, 0);
       if (L > 1) MF_LOAD(w1, 1);
-      if (L > 2) MF_LOAD(w2, 2);
       const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MF_LAYER(l_, W_)                                                                                                 \
   do {                                                                                                                   \
@@ -603,8 +635,8 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
     acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[6]), acc2, 0, 0, 0);                            \
     acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[7]), acc3, 0, 0, 0);                            \
     /* row 0 of the result: lanes < 16, register 0 -> columns 16*tile + lane (filter 0..31 | gate 32..63) */              \
-    const float oa = tanhf(acc0[0]) * (1.f / (1.f + expf(-acc2[0])));                                                     \
-    const float ob = tanhf(acc1[0]) * (1.f / (1.f + expf(-acc3[0])));                                                     \
+    const float oa = tanhf_(acc0[0]) * sigmoidf_(acc2[0]);                                                                \
+    const float ob = tanhf_(acc1[0]) * sigmoidf_(acc3[0]);                                                                \
     float* ol = outs + l * C;                                                                                             \
     if (lane < 16) { ol[lane] = oa; ol[16 + lane] = ob; }                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
@@ -621,10 +653,9 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
     xa += d0[0]; xb += d1[0];                                                                                             \
     if (l + MF_AHEAD < L) MF_LOAD(W_, l + MF_AHEAD);                                                                      \
   } while (0)
-      for (int l4 = 0; l4 < L; l4 += 3) {
+      for (int l4 = 0; l4 < L; l4 += MF_AHEAD) {
         MF_LAYER(l4, w0);
         if (l4 + 1 < L) MF_LAYER(l4 + 1, w1);
-        if (l4 + 2 < L) MF_LAYER(l4 + 2, w2);
       }
 #undef MF_LAYER
 #undef MF_LOAD
