@@ -184,6 +184,12 @@ class Tacotron2(object):
         tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
         tr("wattT", "decoder/attention_lstm/kernel", 0, 128 + self.Dsp + A, 4 * A)
         tr("wqT", "decoder/attention/query_layer/kernel", 0, A, A)
+        # bf16 expand convolutions: k-contiguous [C_out, k*C_in] weights put the forward products on the 256-tile kernel
+        if self.Tx == torch.bfloat16:
+            kx = hp.expand_conv_width
+            for i in range(1, hp.expand_conv_layers):
+                if (kx * Cx) % 64 == 0 and Cx % 128 == 0:
+                    tr("expT_%d" % i, "expand/conv_%d/conv1d/kernel" % i, 0, kx * Cx, Cx, self.Tx)
         # folded location filter Wcl[k,u] = sum_j Wc[k,0,j] Wl[j,u]  (fp32)
         if "wcl" not in self.tsh:
             self.tsh["wcl"] = torch.zeros(7 * A, dtype=torch.float32, device=dev)
@@ -283,11 +289,19 @@ class Tacotron2(object):
         y = self._buf(tag + "_y", rows * cout, D)
         st = self._buf(tag + "_st", 4 * cout, torch.float32)
         st[:2 * cout].zero_()
-        ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
-                 a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=self.padl * cout,
-                 bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
-                 row_mask=(Pp, self.padl, self.padl + T, self.padl),
-                 col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+        wT = self.tsh.get("expT_" + tag[3:]) if tag.startswith("exp") and D == torch.bfloat16 else None
+        if wT is not None:      # k-contiguous weight shadow (refresh_shadows)
+            ops.gemm(xin, wT, z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0,
+                     a_off=a_rows * cin, c_off=self.padl * cout,
+                     bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
+                     row_mask=(Pp, self.padl, self.padl + T, self.padl),
+                     col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+        else:
+            ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
+                     a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=self.padl * cout,
+                     bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
+                     row_mask=(Pp, self.padl, self.padl + T, self.padl),
+                     col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
         ops.bn_fwd(z, y, rows, cout, st, st[cout:], N * T, self.flat_p, self.flat_p, self.flat_stats,
                    self.flat_stats, st[2 * cout:], st[3 * cout:], training, row_mask=(Pp, self.padl, self.padl + T),
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
