@@ -211,3 +211,30 @@ def test_gemm_batched(dev, dtype, passes, tol, a_mode, b_mode):
     with pytest.raises(L.NSError):
         ops.gemm(A, B, Cm, M, N, K, lda, ldb, N, a_mode=a_mode, b_mode=b_mode, batch=nb, batch_strides=(sa, sb, sc),
                  bias=Cm)
+
+
+def test_gemm_256_tile_kernel_is_bit_identical_to_the_128_tile_kernel(dev):
+    """Both kernels add the same 32-deep MFMA products in the same order, so their fp32 results must be bit-identical.
+    Many shapes and repeats: a mis-ordered LDS-DMA wait in the eight-phase schedule would show up as rare wrong tiles
+    that a tolerance-based check against a reference can miss."""
+    import os
+    from nspeech_amd import ops
+    bf = torch.bfloat16
+    rs = __import__("random").Random(5)
+    shapes = [(rs.randrange(12300, 40000), 128 * rs.randrange(2, 9), 64 * rs.randrange(2, 24)) for _ in range(10)]
+    shapes += [(rs.randrange(1024, 3000), 128 * rs.randrange(24, 64), 64 * rs.randrange(2, 12)) for _ in range(6)]
+    for M, N, K in shapes:
+        A = _mk((M, K), bf, dev, M)
+        B = _mk((N, K), bf, dev, N + 1)
+        c128 = torch.zeros((M, N), dtype=torch.float32, device=dev)
+        os.environ["NS_GEMM_NO256"] = "1"
+        try:
+            ops.gemm(A, B, c128, M, N, K, K, K, N, a_mode=0, b_mode=0)
+            torch.cuda.synchronize()
+        finally:
+            del os.environ["NS_GEMM_NO256"]
+        for rep in range(3):
+            c256 = torch.full((M, N), float("nan"), dtype=torch.float32, device=dev)
+            ops.gemm(A, B, c256, M, N, K, K, K, N, a_mode=0, b_mode=0)
+            torch.cuda.synchronize()
+            assert torch.equal(c256, c128), (M, N, K, rep, (c256 - c128).abs().max().item())
