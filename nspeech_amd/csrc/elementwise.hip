@@ -196,12 +196,188 @@ __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
     }
   }
 }
+// Vector forms of the two passes for C % 4 == 0.  Float atomics execute at the memory side and collapse (14x) when
+// hundreds of workgroups add into the same few rows (MI355X_MICROARCH.md, Global float atomics): a block therefore
+// owns rows/32 rows x 64 channels, so an address sees at most 32 adders, and reduces through LDS first.  A thread owns
+// 4 adjacent channels (16-byte loads) of every 16th row of the block and keeps four rows in flight.
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+  const bf16x4 v = *(const bf16x4*)p;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+  bf16x4 o;
+  o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+  *(bf16x4*)p = o;
+}
+constexpr int BN4_QUADS = 16;      // channel quads per block (64 channels)
+constexpr int BN4_LANES = 16;      // row lanes per block: 16 x 16 = 256 threads
+constexpr int BN4_UNROLL = 4;
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p) {
+  __shared__ float red[256][8];
+  const T* z = (const T*)p.z;
+  const int tid = threadIdx.x, ql = tid % BN4_QUADS, rl = tid / BN4_QUADS;
+  const int q = blockIdx.y * BN4_QUADS + ql;
+  const bool active = 4 * q < p.C;
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;      // rows per block: the host keeps ~32 adders per address
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float4 mean = *(const float4*)(p.mean + 4 * q), istd = *(const float4*)(p.istd + 4 * q);
+    for (int base = r0 + rl; base < r1; base += BN4_UNROLL * BN4_LANES) {
+      float4 d[BN4_UNROLL], zz[BN4_UNROLL];
+      bool ok[BN4_UNROLL];
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) {
+        const int row = base + u * BN4_LANES;
+        ok[u] = row < r1;
+        if (ok[u] && p.row_period > 0) {
+          const int t = row % p.row_period;
+          ok[u] = t >= p.row_lo && t < p.row_hi;
+        }
+        if (ok[u]) {
+          const long idx = (long)row * p.C + 4 * q;
+          d[u] = *(const float4*)(p.dy + idx);
+          zz[u] = ld4(z + idx);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) {
+        if (ok[u]) {
+          s1[0] += d[u].x; s2[0] = fmaf(d[u].x, (zz[u].x - mean.x) * istd.x, s2[0]);
+          s1[1] += d[u].y; s2[1] = fmaf(d[u].y, (zz[u].y - mean.y) * istd.y, s2[1]);
+          s1[2] += d[u].z; s2[2] = fmaf(d[u].z, (zz[u].z - mean.z) * istd.z, s2[2]);
+          s1[3] += d[u].w; s2[3] = fmaf(d[u].w, (zz[u].w - mean.w) * istd.w, s2[3]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { red[tid][i] = s1[i]; red[tid][4 + i] = s2[i]; }
+  __syncthreads();
+  if (rl == 0 && active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < BN4_LANES; ++r) { a += red[r * BN4_QUADS + ql][i]; b += red[r * BN4_QUADS + ql][4 + i]; }
+      atomicAdd(p.work + 4 * q + i, a);
+      atomicAdd(p.work + p.C + 4 * q + i, b);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) {
+  __shared__ float red[256][4];
+  const T* z = (const T*)p.z;
+  const int tid = threadIdx.x, ql = tid % BN4_QUADS, rl = tid / BN4_QUADS;
+  const int q = blockIdx.y * BN4_QUADS + ql;
+  const bool active = 4 * q < p.C;
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;      // rows per block: the host keeps ~32 adders per address
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
+  const bool d16 = sizeof(T) == 4 && p.dpre_dtype == NS_BF16;
+  const float invM = 1.f / p.count;
+  float sb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const float4 mean = *(const float4*)(p.mean + 4 * q), istd = *(const float4*)(p.istd + 4 * q);
+    const float4 g = *(const float4*)(p.gamma + 4 * q);
+    const float4 w1 = *(const float4*)(p.work + 4 * q), w2 = *(const float4*)(p.work + p.C + 4 * q);
+    const float mu[4] = {mean.x, mean.y, mean.z, mean.w}, is[4] = {istd.x, istd.y, istd.z, istd.w};
+    const float gi[4] = {g.x * istd.x, g.y * istd.y, g.z * istd.z, g.w * istd.w};
+    const float m1[4] = {w1.x * invM, w1.y * invM, w1.z * invM, w1.w * invM};
+    const float m2[4] = {w2.x * invM, w2.y * invM, w2.z * invM, w2.w * invM};
+    for (int base = r0 + rl; base < r1; base += BN4_UNROLL * BN4_LANES) {
+      float4 d[BN4_UNROLL], zz[BN4_UNROLL];
+      bool inr[BN4_UNROLL], ok[BN4_UNROLL];
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) {
+        const int row = base + u * BN4_LANES;
+        inr[u] = row < r1;
+        ok[u] = inr[u];
+        if (ok[u] && p.row_period > 0) {
+          const int t = row % p.row_period;
+          ok[u] = t >= p.row_lo && t < p.row_hi;
+        }
+        if (ok[u]) {
+          const long idx = (long)row * p.C + 4 * q;
+          d[u] = *(const float4*)(p.dy + idx);
+          zz[u] = ld4(z + idx);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) {
+        if (!inr[u]) continue;
+        const long idx = (long)(base + u * BN4_LANES) * p.C + 4 * q;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (ok[u]) {
+          const float dv[4] = {d[u].x, d[u].y, d[u].z, d[u].w}, zv[4] = {zz[u].x, zz[u].y, zz[u].z, zz[u].w};
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float xh = (zv[i] - mu[i]) * is[i];
+            float v = gi[i] * (dv[i] - m1[i] - xh * m2[i]);
+            if (p.act == NS_ACT_RELU) v = zv[i] > 0.f ? v : 0.f;
+            else if (p.act == NS_ACT_TANH) v *= (1.f - zv[i] * zv[i]);
+            else if (p.act == NS_ACT_SIGMOID) v *= zv[i] * (1.f - zv[i]);
+            else if (p.act == NS_ACT_SOFTSIGN) v *= (1.f - fabsf(zv[i])) * (1.f - fabsf(zv[i]));
+            o[i] = v;
+          }
+        }
+        const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
+        // the bias gradient is taken on the values the weight-gradient GEMM will read
+        if (d16) {
+          st4((bf16_t*)p.dpre + idx, ov);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sb[i] += (float)(bf16_t)o[i];
+        } else {
+          st4((T*)p.dpre + idx, ov);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) sb[i] += (float)(T)o[i];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[tid][i] = sb[i];
+  __syncthreads();
+  if (rl == 0 && active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = 0.f;
+      for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
+      if (p.dbias) atomicAdd(p.dbias + 4 * q + i, a);
+      if (blockIdx.x == 0) {
+        if (p.dgamma) p.dgamma[4 * q + i] += p.work[p.C + 4 * q + i];
+        if (p.dbeta) p.dbeta[4 * q + i] += p.work[4 * q + i];
+      }
+    }
+  }
+}
+
 extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   NS_CHECK_ARG(p && p->dy && p->z && p->dpre && p->mean && p->istd && p->gamma && p->work, "ns_bn_bwd: null");
   if (hipMemsetAsync(p->work, 0, sizeof(float) * 2 * p->C, s) != hipSuccess) {
     ns_set_error("ns_bn_bwd: memset failed");
     return NS_ERR_LAUNCH;
+  }
+  const bool al16 = ((uintptr_t)p->dy % 16 == 0) && ((uintptr_t)p->z % 8 == 0) && ((uintptr_t)p->dpre % 8 == 0) &&
+                    ((uintptr_t)p->mean % 16 == 0) && ((uintptr_t)p->istd % 16 == 0) && ((uintptr_t)p->gamma % 16 == 0) &&
+                    ((uintptr_t)p->work % 16 == 0) && (p->dtype == NS_BF16 || ((uintptr_t)p->z % 16 == 0 &&
+                    (uintptr_t)p->dpre % (p->dpre_dtype == NS_BF16 ? 8 : 16) == 0));
+  if (p->C % 4 == 0 && al16) {
+    const dim3 grid4(max(1, min(32, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
+    if (p->dtype == NS_BF16) {
+      hipLaunchKernelGGL(bn_bwd_reduce4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
+      hipLaunchKernelGGL(bn_bwd_apply4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
+    } else {
+      hipLaunchKernelGGL(bn_bwd_reduce4_kernel<float>, grid4, dim3(256), 0, s, *p);
+      hipLaunchKernelGGL(bn_bwd_apply4_kernel<float>, grid4, dim3(256), 0, s, *p);
+    }
+    NS_CHECK_LAUNCH("bn_bwd");
+    return NS_OK;
   }
   const int grid = ceil_div(p->rows, BN_ROWS_PER_BLOCK);
   if (p->dtype == NS_BF16) {
@@ -229,9 +405,53 @@ __global__ void colsum_kernel(ns_colsum_params p) {
     atomicAdd(p.out + c, s);
   }
 }
+// vector form: block = 16 channel quads x 16 row lanes over rows/32 rows, LDS reduction, then at most 32 adders per
+// address (contended float atomics collapse, see the BatchNorm backward kernels)
+template <typename T>
+__global__ __launch_bounds__(256) void colsum4_kernel(ns_colsum_params p) {
+  __shared__ float red[256][4];
+  const T* x = (const T*)p.x;
+  const int tid = threadIdx.x, ql = tid % BN4_QUADS, rl = tid / BN4_QUADS;
+  const int q = blockIdx.y * BN4_QUADS + ql;
+  const bool active = 4 * q < p.C;
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    for (int base = r0 + rl; base < r1; base += BN4_UNROLL * BN4_LANES) {
+      float4 v[BN4_UNROLL];
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) {
+        const int row = base + u * BN4_LANES;
+        v[u] = row < r1 ? ld4(x + (long)row * p.ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < BN4_UNROLL; ++u) { s4[0] += v[u].x; s4[1] += v[u].y; s4[2] += v[u].z; s4[3] += v[u].w; }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) red[tid][i] = s4[i];
+  __syncthreads();
+  if (rl == 0 && active) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float a = 0.f;
+      for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
+      atomicAdd(p.out + 4 * q + i, a);
+    }
+  }
+}
 extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_colsum: null");
   if (p->rows <= 0 || p->C <= 0) return NS_OK;
+  const int esz = p->dtype == NS_BF16 ? 2 : 4;
+  if (p->C % 4 == 0 && p->ld % 4 == 0 && ((uintptr_t)p->x % (4 * esz)) == 0) {
+    const dim3 grid(max(1, min(32, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
+    if (p->dtype == NS_BF16) hipLaunchKernelGGL(colsum4_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, *p);
+    else hipLaunchKernelGGL(colsum4_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, *p);
+    NS_CHECK_LAUNCH("colsum");
+    return NS_OK;
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(p->rows, CS_ROWS)), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("colsum");
   return NS_OK;
