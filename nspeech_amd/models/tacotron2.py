@@ -278,6 +278,24 @@ class Tacotron2(object):
         return self
 
     # ------------------------------------------------------------------ layer helpers
+    def _stats_buf(self, tag, cout):
+        """[sum | sum of squares | mean | 1/std] of one conv layer, carved out of one arena that is cleared with a
+        single fill when a pass revisits a layer (instead of one fill per layer)."""
+        m = self._bufs.setdefault("st_map", {})
+        clean = self._bufs.setdefault("st_clean", set())
+        arena = self._buf("st_arena", 1 << 16, torch.float32)
+        if tag not in m:
+            off = self._bufs.get("st_used", 0)
+            assert off + 4 * cout <= arena.numel(), "BatchNorm statistics arena too small"
+            m[tag] = arena[off:off + 4 * cout]
+            self._bufs["st_used"] = off + ((4 * cout + 63) // 64) * 64
+            clean.add(tag)              # fresh arena memory is zero
+        if tag not in clean:            # second visit: a new pass has begun, every layer's sums are stale
+            arena.zero_()
+            clean.update(m.keys())
+        clean.discard(tag)
+        return m[tag]
+
     def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None):
         """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198)."""
         kl = (k - 1) // 2
@@ -287,8 +305,7 @@ class Tacotron2(object):
         D = D or self.T
         z = self._buf(tag + "_z", rows * cout, D)
         y = self._buf(tag + "_y", rows * cout, D)
-        st = self._buf(tag + "_st", 4 * cout, torch.float32)
-        st[:2 * cout].zero_()
+        st = self._stats_buf(tag, cout)
         wT = self.tsh.get("expT_" + tag[3:]) if tag.startswith("exp") and D == torch.bfloat16 else None
         if wT is not None:      # k-contiguous weight shadow (refresh_shadows)
             ops.gemm(xin, wT, z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0,
@@ -317,7 +334,7 @@ class Tacotron2(object):
         kr = k - 1 - kl
         rows = N * Pp
         z = self._bufs[tag + "_z"]
-        st = self._bufs[tag + "_st"]
+        st = self._bufs["st_map"][tag]
         D = D or self.T
         # single-pass backward on fp32 storage rounds every operand to bf16 on load: keep the gradient and a copy of the
         # layer input in bf16 instead (half the bytes, the bf16 kernels, the 256-tile data-gradient kernel)
