@@ -24,7 +24,11 @@ class Synthesizer(object):
         self.model = create_model(model_name, self.hparams, device=self.device, dtype=self.dtype)
         if checkpoint_path is not None:
             print("Loading checkpoint: %s" % checkpoint_path)
-            self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
+            from .utils import tf_bundle
+            if tf_bundle.is_bundle(checkpoint_path):       # a TensorFlow checkpoint prefix (model.ckpt-N.index + data)
+                tf_bundle.load_into_model(self.model, checkpoint_path)
+            else:
+                self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
         return self
 
     def synthesize(self, text, speaker_id=0):

@@ -1,0 +1,98 @@
+"""TensorFlow checkpoint container: CRC-32C and varint known answers, table / bundle round trips over
+several blocks, corruption detection, and the mapping of TF-style variable names onto the Tacotron-2 layout.
+(Unverified against files written by TensorFlow itself: none is available here.)"""
+import os
+
+import numpy as np
+import pytest
+
+from nspeech_amd.utils import tf_bundle as B
+
+
+def test_crc32c_and_varint_known_answers():
+    assert B.crc32c(b"123456789") == 0xE3069283                       # the CRC-32C check value
+    assert B.crc32c(b"") == 0 and B.crc32c(b"\x00" * 32) == 0x8A9136AA  # RFC 3720 B.4: 32 zero bytes
+    assert B.crc32c(bytes(range(32))) == 0x46DD794E                   # RFC 3720 B.4: 0x00..0x1f
+    for c in (0, 1, 0xE3069283, 0xFFFFFFFF):
+        assert B.unmask_crc(B.mask_crc(c)) == c and (c == 0 or B.mask_crc(c) != c)
+    for v in (0, 1, 127, 128, 300, 2 ** 32 + 5, 2 ** 63 - 1):
+        enc = B._put_varint(v)
+        assert B._get_varint(enc, 0) == (v, len(enc))
+    assert B._put_varint(300) == b"\xac\x02"
+
+
+def test_table_round_trip_prefix_compression_and_blocks(tmp_path):
+    items = [(("model/inference/layer_%03d/kernel" % i).encode(), os.urandom(5 + i % 7)) for i in range(150)]
+    items.append((b"", b"header"))
+    path = str(tmp_path / "t.index")
+    B.write_table(path, items, entries_per_block=16)
+    got = B.read_table(path)
+    assert got == sorted(items)
+    raw = bytearray(open(path, "rb").read())
+    assert int.from_bytes(raw[-8:], "little") == B.MAGIC and len(raw) > 48
+    raw[20] ^= 0x40                                                    # flip a bit inside the first data block
+    open(path, "wb").write(bytes(raw))
+    with pytest.raises(ValueError):
+        B.read_table(path)
+
+
+def test_bundle_round_trip_dtypes_shapes_and_checksums(tmp_path):
+    rs = np.random.RandomState(0)
+    t = {"model/inference/embedding/embedding": rs.randn(149, 8).astype(np.float32),
+         "model/inference/decoder/x/bias": rs.randn(7).astype(np.float32),
+         "global_step": np.asarray(1234, np.int64),
+         "beta1_power": np.asarray(0.5, np.float32),
+         "model/inference/enc/kernel": rs.randn(5, 3, 4).astype(np.float32),
+         "ints": np.arange(6, dtype=np.int32).reshape(2, 3)}
+    prefix = str(tmp_path / "model.ckpt-1234")
+    B.save_tf_checkpoint(prefix, t, entries_per_block=2)
+    assert B.is_bundle(prefix) and os.path.exists(prefix + ".data-00000-of-00001")
+    got = B.load_tf_checkpoint(prefix)
+    assert set(got) == set(t)
+    for k in t:
+        assert got[k].dtype == t[k].dtype and got[k].shape == t[k].shape and np.array_equal(got[k], t[k]), k
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[10] ^= 1
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(ValueError):
+        B.load_tf_checkpoint(prefix)
+    B.load_tf_checkpoint(prefix, check_crc=False)                       # the flipped bit is then accepted
+
+
+def test_name_mapping_onto_the_tacotron2_layout(tmp_path):
+    from nspeech_amd import hparams as H
+    from nspeech_amd.models import params as P
+    hp = H.load("taco2")
+    for k, v in dict(num_mels=8, num_freq=17, embedding_dim=8, encoder_conv_channels=8, encoder_lstm_units=4,
+                     attention_dim=8, decoder_lstm_units=8, postnet_conv_channels=8, expand_conv_channels=8,
+                     expand_lstm_units=4).items():
+        setattr(hp, k, v)
+    lay, st = P.taco2_layout(hp, 149)
+    pv, sv = P.init_values(lay, st, 3)
+    # a checkpoint spelt the way TF 1.x wrappers scope the decoder-loop variables, with optimizer slots beside them
+    tf_names = {}
+    for name in list(pv) + list(sv):
+        tf_names[name] = B.name_candidates(name)[1] if len(B.name_candidates(name)) > 2 and name.startswith("decoder/") \
+            else "model/inference/" + name
+    assert tf_names["decoder/lstm_1/kernel"].endswith("multi_rnn_cell/cell_1/lstm_cell/kernel")
+    tensors = {tf_names[k]: v for k, v in {**pv, **sv}.items()}
+    tensors["global_step"] = np.asarray(77, np.int64)
+    tensors["model/inference/embedding/embedding/Adam"] = np.zeros_like(pv["embedding/embedding"])
+    tensors["beta2_power"] = np.asarray(0.9, np.float32)
+    tensors["model/inference/something/else"] = np.zeros(3, np.float32)
+    prefix = str(tmp_path / "model.ckpt-77")
+    B.save_tf_checkpoint(prefix, tensors)
+    params, stats, rep = B.map_checkpoint(B.load_tf_checkpoint(prefix), lay, st)
+    assert rep["missing"] == [] and rep["global_step"] == 77 and rep["unused"] == ["model/inference/something/else"]
+    assert all(np.array_equal(params[k], pv[k]) for k in pv) and all(np.array_equal(stats[k], sv[k]) for k in sv)
+    # an explicit name map wins; a wrong shape is refused; a missing variable is reported
+    alt = dict(tensors)
+    alt["custom/emb"] = alt.pop("model/inference/embedding/embedding")
+    p2, _, rep2 = B.map_checkpoint(alt, lay, st, name_map={"embedding/embedding": "custom/emb"})
+    assert rep2["missing"] == [] and np.array_equal(p2["embedding/embedding"], pv["embedding/embedding"])
+    _, _, rep3 = B.map_checkpoint(alt, lay, st)
+    assert rep3["missing"] == ["embedding/embedding"]
+    bad = dict(tensors)
+    bad["model/inference/embedding/embedding"] = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError):
+        B.map_checkpoint(bad, lay, st)

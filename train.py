@@ -82,7 +82,11 @@ def train(log_dir, args):
     step0 = 0
     if args.restore_step:
         path = "%s-%d" % (os.path.join(log_dir, "model.ckpt"), args.restore_step)
-        model.load_state_dict(torch.load(path, map_location="cpu"))
+        from nspeech_amd.utils import tf_bundle
+        if tf_bundle.is_bundle(path):          # a TensorFlow checkpoint of the reference (Adam slots start afresh)
+            tf_bundle.load_into_model(model, path)
+        else:
+            model.load_state_dict(torch.load(path, map_location="cpu"))
         step0 = model.global_step
         log("Resuming from checkpoint: %s" % path, logf)
     if world > 1:
