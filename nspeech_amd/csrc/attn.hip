@@ -455,7 +455,7 @@ struct AttnPost {
   float* dv; float* dwcl;  // +=
 };
 __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
-  __shared__ float wl[4][(1 + MAXKW) * PU];
+  __shared__ __attribute__((aligned(8))) float wl[4][(1 + MAXKW) * PU];
   const int n = blockIdx.z, tc = blockIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int u0 = (blockIdx.y * 4 + wave) * PU;
@@ -477,17 +477,22 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
   __syncthreads();
   if (u0 >= A) return;
   const bool act = t < L;
-  float kv[PU], dk[PU], dvp[PU], dwp[MAXKW][PU];
+  // units in pairs: the multiply-adds of the location filter and of its gradient run as v_pk_fma_f32
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int PP = PU / 2;
+  f2 kv[PP], dk[PP], dvp[PP], dwp[MAXKW][PP];
 #pragma unroll
-  for (int j = 0; j < PU; ++j) {
-    kv[j] = (act && u0 + j < A) ? a.keys_t[((long)n * A + u0 + j) * Tia + t] : 0.f;
-    dk[j] = 0.f; dvp[j] = 0.f;
+  for (int j = 0; j < PP; ++j) {
+    kv[j].x = (act && u0 + 2 * j < A) ? a.keys_t[((long)n * A + u0 + 2 * j) * Tia + t] : 0.f;
+    kv[j].y = (act && u0 + 2 * j + 1 < A) ? a.keys_t[((long)n * A + u0 + 2 * j + 1) * Tia + t] : 0.f;
+    dk[j] = (f2){0.f, 0.f}; dvp[j] = (f2){0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < MAXKW; ++k) dwp[k][j] = 0.f;
+    for (int k = 0; k < MAXKW; ++k) dwp[k][j] = (f2){0.f, 0.f};
   }
   const float* alb = a.align + (long)n * S1 * Tia;
   const float* deb = a.de + (long)n * S1 * Tia;
   const float* qb = a.q + (long)n * S1 * A + u0;
+  const f2* wl2 = (const f2*)wl[wave];            // [(1 + MAXKW)][PP] pairs: row 0 = v, row 1 + k = wcl[k]
   // one-step-ahead register prefetch of the per-step operands
   float apn[MAXKW], den;
   auto fetch = [&](int slot, float* apo, float& deo) {
@@ -504,32 +509,37 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
 #pragma unroll
     for (int k = 0; k < MAXKW; ++k) apv[k] = apn[k];
     if (slot < a.S) fetch(slot + 1, apn, den);
-    const float* qs = qb + (long)slot * A;
+    const f2* qs = (const f2*)(qb + (long)slot * A);
+    const f2 de2 = (f2){de, de};
 #pragma unroll
-    for (int j = 0; j < PU; ++j) {
-      float x = kv[j] + qs[j];
+    for (int j = 0; j < PP; ++j) {
+      f2 x = kv[j] + qs[j];
 #pragma unroll
       for (int k = 0; k < MAXKW; ++k)
-        if (k < a.kw) x = fmaf(apv[k], wl[wave][(1 + k) * PU + j], x);
-      const float th = tanhf_(x);
-      const float dpre = de * wl[wave][j] * (1.f - th * th);
+        if (k < a.kw) x = (f2){apv[k], apv[k]} * wl2[(1 + k) * PP + j] + x;
+      f2 th;
+      th.x = tanhf_(x.x);
+      th.y = tanhf_(x.y);
+      const f2 dpre = de2 * wl2[j] * ((f2){1.f, 1.f} - th * th);
       dk[j] += dpre;
-      dvp[j] = fmaf(de, th, dvp[j]);
+      dvp[j] = de2 * th + dvp[j];
 #pragma unroll
       for (int k = 0; k < MAXKW; ++k)
-        if (k < a.kw) dwp[k][j] = fmaf(apv[k], dpre, dwp[k][j]);
+        if (k < a.kw) dwp[k][j] = (f2){apv[k], apv[k]} * dpre + dwp[k][j];
     }
   }
 #pragma unroll
   for (int j = 0; j < PU; ++j) {
     if (u0 + j < A) {
-      if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = dk[j];
-      const float sv = wave_sum(dvp[j]);
+      const float dkj = (j & 1) ? dk[j >> 1].y : dk[j >> 1].x;
+      const float dvj = (j & 1) ? dvp[j >> 1].y : dvp[j >> 1].x;
+      if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = dkj;
+      const float sv = wave_sum(dvj);
       if (lane == 0) atomicAdd(a.dv + u0 + j, sv);
 #pragma unroll
       for (int k = 0; k < MAXKW; ++k)
         if (k < a.kw) {
-          const float sw = wave_sum(dwp[k][j]);
+          const float sw = wave_sum((j & 1) ? dwp[k][j >> 1].y : dwp[k][j >> 1].x);
           if (lane == 0) atomicAdd(a.dwcl + k * A + u0 + j, sw);
         }
     }
