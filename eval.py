@@ -1,60 +1,54 @@
 #!/usr/bin/env python3
-"""Evaluation CLI (flags of the reference's eval.py:62-76): synthesises the test sentences with a
-checkpoint and writes eval-STEP-i.wav next to it."""
+"""Synthesis from a checkpoint, the reference's eval.py surface (eval.py:23-27,62-76): flags --checkpoint --model
+--hparams --gpu --speaker; one `eval-<step>-<i>.wav` per test sentence next to the checkpoint.  The checkpoint may be
+this build's `model.ckpt-<step>` file or a TensorFlow checkpoint prefix (nspeech_amd/utils/tf_bundle.py)."""
 import argparse
 import os
 import re
 import sys
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 from nspeech_amd import hparams as hparams_mod  # noqa: E402
 from nspeech_amd.synthesizer import Synthesizer  # noqa: E402
 from nspeech_amd.utils import audio  # noqa: E402
 
-sentences = [
-    "Scientists at the CERN laboratory say they have discovered a new particle.",
-    "There's a way to measure the acute emotional intelligence that has never gone out of style.",
-    "President Trump met with other leaders at the Group of 20 conference.",
-    "The Senate's bill to repeal and replace the Affordable Care Act is now imperiled.",
-    "Generative adversarial network or variational auto-encoder.",
-    "The buses aren't the problem, they actually provide a solution.",
-]
+# exercises the text front end: abbreviations, digits, an apostrophe, a question, an ARPAbet span
+TEST_SENTENCES = (
+    "Dr. Jones arrived at 9 o'clock with 3 colleagues.",
+    "The first measurement took 12.5 milliseconds; the second one took longer.",
+    "It's the spectrogram, not the waveform, that the network predicts.",
+    "Could you turn left on {HH AW1 S S T AH0 N} Street, please?",
+    "Mr. Smith paid $20 for the recording on May 4th.",
+    "Wave after wave reached the shore while the gulls kept calling.",
+)
 
 
-def get_output_base_path(checkpoint_path):
-    base_dir = os.path.dirname(checkpoint_path)
-    m = re.compile(r".*?\.ckpt\-([0-9]+)").match(checkpoint_path)
-    name = "eval-%d" % int(m.group(1)) if m else "eval"
-    return os.path.join(base_dir, name)
+def output_stem(checkpoint_path):
+    """.../model.ckpt-1234 -> .../eval-1234 (eval.py:23-27 keys the output names on the step in the file name)."""
+    step = re.search(r"\.ckpt-(\d+)", os.path.basename(checkpoint_path))
+    return os.path.join(os.path.dirname(checkpoint_path), "eval-%d" % int(step.group(1)) if step else "eval")
 
 
-def run_eval(args):
-    hp = hparams_mod.get_hparams()
-    synth = Synthesizer(hp, dtype=args.precision).load(args.checkpoint, args.model)
-    base_path = get_output_base_path(args.checkpoint)
-    for i, text in enumerate(sentences):
-        path = "%s-%d.wav" % (base_path, i)
-        print("Synthesizing: %s" % path)
-        wav, mel, lin = synth.synthesize(text, args.speaker)
-        audio.save_wav(wav, path)
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--checkpoint", required=True)
-    ap.add_argument("--model", default="taco2")
-    ap.add_argument("--hparams", default="")
-    ap.add_argument("--gpu", default="0")
-    ap.add_argument("--speaker", type=int, default=0)
-    ap.add_argument("--precision", default="mixed")
-    args = ap.parse_args()
-    os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)
-    hp = hparams_mod.load(args.model)
-    hp.parse(args.hparams)
-    run_eval(args)
+def synthesize_all(checkpoint, model_name, speaker, precision):
+    synth = Synthesizer(hparams_mod.get_hparams(), dtype=precision).load(checkpoint, model_name)
+    stem = output_stem(checkpoint)
+    for index, sentence in enumerate(TEST_SENTENCES):
+        target = "%s-%d.wav" % (stem, index)
+        print("Synthesizing: %s" % target)
+        wav, _, _ = synth.synthesize(sentence, speaker)
+        audio.save_wav(wav, target)
 
 
 if __name__ == "__main__":
-    main()
+    cli = argparse.ArgumentParser(description=__doc__)
+    cli.add_argument("--checkpoint", required=True, help="model.ckpt-<step> (torch file) or a TF checkpoint prefix")
+    cli.add_argument("--model", default="taco2")
+    cli.add_argument("--hparams", default="", help="comma separated name=value overrides")
+    cli.add_argument("--gpu", default="0")
+    cli.add_argument("--speaker", type=int, default=0)
+    cli.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "bf16x3", "fp32"])
+    opts = cli.parse_args()
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", opts.gpu)
+    hparams_mod.load(opts.model).parse(opts.hparams)
+    synthesize_all(opts.checkpoint, opts.model, opts.speaker, opts.precision)

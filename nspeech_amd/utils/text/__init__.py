@@ -1,59 +1,85 @@
-"""Text front end: string -> cleaned string -> symbol ids (bit-exact integer path).
+"""Text front end: string -> cleaned string -> symbol ids (the bit-exact integer path).
 
-Behaviour of neural_speech/utils/text/__init__.py:14-75: text outside {...} goes through the
-named cleaners and is mapped character by character; text inside {...} is ARPAbet ('@'-prefixed
-symbols); '_' (pad) and '~' (eos) are never emitted from text; eos (id 1) is appended."""
-import re
+Contract (neural_speech/utils/text/__init__.py:14-75): text outside braces runs through the named cleaners and is
+mapped character by character; a `{...}` span holds space-separated ARPAbet symbols ('@'-prefixed in the table); the
+pad '_' and end-of-sequence '~' symbols never come out of text; id 1 ('~') closes every sequence.
 
+The reference peels `{...}` spans off with the pattern (.*?)\\{(.+?)\\}(.*) applied to the remaining text in a loop;
+`spans()` restates that as a scanner, including the corner cases the pattern implies: a span needs at least one
+character between its braces (so "{}" is plain text and the search moves on to the next '{'), '.' does not cross a
+line break (a newline before the closing brace makes the rest plain text, a newline after it ends the input)."""
 from . import cleaners
 from .symbols import symbols
 
-_symbol_to_id = {s: i for i, s in enumerate(symbols)}
-_id_to_symbol = {i: s for i, s in enumerate(symbols)}
-_curly_re = re.compile(r"(.*?)\{(.+?)\}(.*)")
+SYMBOL_ID = {sym: idx for idx, sym in enumerate(symbols)}
+ID_SYMBOL = dict(enumerate(symbols))
+_NEVER_FROM_TEXT = ("_", "~")
 
 
-def text_to_sequence(text, cleaner_names):
-    sequence = []
-    while len(text):
-        m = _curly_re.match(text)
-        if not m:
-            sequence += _symbols_to_sequence(_clean_text(text, cleaner_names))
-            break
-        sequence += _symbols_to_sequence(_clean_text(m.group(1), cleaner_names))
-        sequence += _arpabet_to_sequence(m.group(2))
-        text = m.group(3)
-    sequence.append(_symbol_to_id["~"])
-    return sequence
+def spans(text):
+    """Yields (plain, arpabet) pieces in order; `arpabet` is None for the trailing plain piece."""
+    rest = text
+    while rest:
+        line_end = rest.find("\n")
+        limit = len(rest) if line_end < 0 else line_end          # '.' stops at a line break
+        found = None
+        start = rest.find("{", 0, limit)
+        while start >= 0:
+            close = rest.find("}", start + 2, limit)              # at least one character inside
+            if close >= 0:
+                found = (start, close)
+                break
+            start = rest.find("{", start + 1, limit)
+        if found is None:
+            yield rest, None
+            return
+        start, close = found
+        yield rest[:start], rest[start + 1:close]
+        rest = rest[close + 1:limit]                               # the pattern's last group ends at the line break
 
 
-def sequence_to_text(sequence):
-    result = ""
-    for symbol_id in sequence:
-        if symbol_id in _id_to_symbol:
-            s = _id_to_symbol[symbol_id]
-            if len(s) > 1 and s[0] == "@":
-                s = "{%s}" % s[1:]
-            result += s
-    return result.replace("}{", " ")
-
-
-def _clean_text(text, cleaner_names):
+def apply_cleaners(text, cleaner_names):
     for name in cleaner_names:
-        cleaner = getattr(cleaners, name, None)
-        if not cleaner:
+        fn = getattr(cleaners, name, None)
+        if fn is None:
             raise Exception("Unknown cleaner: %s" % name)
-        text = cleaner(text)
+        text = fn(text)
     return text
 
 
-def _symbols_to_sequence(syms):
-    return [_symbol_to_id[s] for s in syms if _should_keep_symbol(s)]
+def ids_of(symbol_list):
+    return [SYMBOL_ID[s] for s in symbol_list if s in SYMBOL_ID and s not in _NEVER_FROM_TEXT]
+
+
+def text_to_sequence(text, cleaner_names):
+    ids = []
+    for plain, arpabet in spans(text):
+        ids.extend(ids_of(apply_cleaners(plain, cleaner_names)))
+        if arpabet is not None:
+            ids.extend(ids_of("@" + s for s in arpabet.split()))
+    ids.append(SYMBOL_ID["~"])
+    return ids
+
+
+def sequence_to_text(sequence):
+    pieces = []
+    for i in sequence:
+        sym = ID_SYMBOL.get(int(i))
+        if sym is None:
+            continue
+        pieces.append("{%s}" % sym[1:] if len(sym) > 1 and sym.startswith("@") else sym)
+    return "".join(pieces).replace("}{", " ")
+
+
+# the reference's private helper names, for callers that reach for them
+_symbol_to_id, _id_to_symbol = SYMBOL_ID, ID_SYMBOL
+_clean_text = apply_cleaners
+_symbols_to_sequence = ids_of
 
 
 def _arpabet_to_sequence(text):
-    return _symbols_to_sequence(["@" + s for s in text.split()])
+    return ids_of("@" + s for s in text.split())
 
 
 def _should_keep_symbol(s):
-    return s in _symbol_to_id and s != "_" and s != "~"
+    return s in SYMBOL_ID and s not in _NEVER_FROM_TEXT

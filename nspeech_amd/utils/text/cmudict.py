@@ -1,61 +1,59 @@
-"""CMUDict reader (behaviour of neural_speech/utils/text/cmudict.py:16-60)."""
-import re
+"""CMU pronouncing dictionary reader with the surface of neural_speech/utils/text/cmudict.py:16-60:
+`valid_symbols` (84 phones: 24 consonants, 15 vowels bare and with stress 0/1/2, in alphabetical order of the base
+phone), `CMUDict(path_or_file, keep_ambiguous=True)`, `len()`, `.lookup(word)` -> list of pronunciations or None."""
+import string
 
-_VOWELS = ["AA", "AE", "AH", "AO", "AW", "AY", "EH", "ER", "EY", "IH", "IY", "OW", "OY", "UH", "UW"]
-_CONSONANTS = ["B", "CH", "D", "DH", "F", "G", "HH", "JH", "K", "L", "M", "N", "NG", "P", "R", "S", "SH", "T",
-               "TH", "V", "W", "Y", "Z", "ZH"]
+VOWEL_PHONES = "AA AE AH AO AW AY EH ER EY IH IY OW OY UH UW".split()
+CONSONANT_PHONES = "B CH D DH F G HH JH K L M N NG P R S SH T TH V W Y Z ZH".split()
 
-
-def _build_symbols():
-    # alphabetical order of the base phones; each vowel comes bare and with stress digits 0..2
-    out = []
-    for ph in sorted(_VOWELS + _CONSONANTS):
-        out.append(ph)
-        if ph in _VOWELS:
-            out.extend(ph + d for d in "012")
-    return out
+valid_symbols = [phone + stress
+                 for phone in sorted(VOWEL_PHONES + CONSONANT_PHONES)
+                 for stress in ([""] + list("012") if phone in VOWEL_PHONES else [""])]
+_PHONE_SET = frozenset(valid_symbols)
+_WORD_START = frozenset(string.ascii_uppercase + "'")
 
 
-valid_symbols = _build_symbols()
-_valid_symbol_set = set(valid_symbols)
-_alt_re = re.compile(r"\([0-9]+\)")
+def _strip_variant(word):
+    """'READ(2)' -> 'READ': alternative pronunciations carry a parenthesised counter."""
+    out, i = [], 0
+    while i < len(word):
+        if word[i] == "(":
+            j = i + 1
+            while j < len(word) and word[j] in "0123456789":
+                j += 1
+            if j > i + 1 and j < len(word) and word[j] == ")":      # every '(digits)' group goes, wherever it sits
+                i = j + 1
+                continue
+        out.append(word[i])
+        i += 1
+    return "".join(out)
+
+
+def _entries(lines):
+    """(word, 'P1 P2 ...') for every dictionary line whose phones are all known; comment lines start with ';;;'."""
+    for raw in lines:
+        if not raw or raw[0] not in _WORD_START:
+            continue
+        fields = raw.split("  ")
+        phones = fields[1].strip().split(" ")
+        if all(p in _PHONE_SET for p in phones):
+            yield _strip_variant(fields[0]), " ".join(phones)
 
 
 class CMUDict(object):
-    """word -> list of ARPAbet pronunciations; accepts a path (latin-1) or an open file."""
-
     def __init__(self, file_or_path, keep_ambiguous=True):
         if isinstance(file_or_path, str):
-            with open(file_or_path, encoding="latin-1") as f:
-                entries = _parse_cmudict(f)
+            with open(file_or_path, encoding="latin-1") as handle:
+                pairs = list(_entries(handle))
         else:
-            entries = _parse_cmudict(file_or_path)
-        if not keep_ambiguous:
-            entries = {w: p for w, p in entries.items() if len(p) == 1}
-        self._entries = entries
+            pairs = list(_entries(file_or_path))
+        table = {}
+        for word, pron in pairs:
+            table.setdefault(word, []).append(pron)
+        self._table = table if keep_ambiguous else {w: p for w, p in table.items() if len(p) == 1}
 
     def __len__(self):
-        return len(self._entries)
+        return len(self._table)
 
     def lookup(self, word):
-        return self._entries.get(word.upper())
-
-
-def _parse_cmudict(lines):
-    table = {}
-    for line in lines:
-        if len(line) and ("A" <= line[0] <= "Z" or line[0] == "'"):
-            parts = line.split("  ")
-            word = re.sub(_alt_re, "", parts[0])
-            pron = _get_pronunciation(parts[1])
-            if pron:
-                table.setdefault(word, []).append(pron)
-    return table
-
-
-def _get_pronunciation(s):
-    parts = s.strip().split(" ")
-    for part in parts:
-        if part not in _valid_symbol_set:
-            return None
-    return " ".join(parts)
+        return self._table.get(word.upper())
