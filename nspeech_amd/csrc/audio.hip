@@ -1,8 +1,9 @@
 // Audio DSP of neural_speech/utils/audio.py on the GPU: STFT -> linear + mel spectrograms, and the
-// TF-style Griffin-Lim vocoder.  Every transform is an n_fft-point radix-2 Stockham FFT that lives
-// entirely in LDS (one 256-thread workgroup per frame, two 16 KB ping-pong buffers + the twiddle
-// table); a Griffin-Lim iteration is ONE kernel: overlap-add gather of the previous iteration's
-// windowed frames -> window -> FFT -> phase normalise x magnitude -> inverse FFT -> window.
+// TF-style Griffin-Lim vocoder.  Transforms are Stockham FFTs that live entirely in LDS (one 256-thread
+// workgroup per frame, two ping-pong buffers + the twiddle table): radix-2 over n_fft points for the
+// feature kernel, radix-4 over n_fft/2 points (real-input split / merge) for Griffin-Lim, where an
+// iteration is ONE kernel: overlap-add gather of the previous iteration's windowed frames -> window ->
+// FFT -> phase normalise x magnitude -> inverse FFT -> window.
 #include "common.h"
 
 constexpr int FT = 256;  // threads per frame
@@ -21,6 +22,56 @@ __device__ __forceinline__ float2* fft_lds(float2* a, float2* b, const float2* t
       const int k = j & (Ns - 1);
       const float2 v0 = a[j];
       const float2 v1 = cmul(a[j + half], tw[k * tstride]);
+      const int j0 = ((j - k) << 1) + k;
+      b[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
+      b[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
+    }
+    __syncthreads();
+    float2* t = a; a = b; b = t;
+  }
+  return a;
+}
+
+// Radix-4 Stockham FFT of M points (M a power of two; a last radix-2 stage when log2 M is odd), same conventions as
+// fft_lds.  twN[m] = exp(-2*pi*i*m/N) for m < N/2 with N = 2M, so exp(-2*pi*i*m/M) = twN[2m] (negated past M/2).
+// One radix-4 stage does the work of two radix-2 stages behind ONE barrier and half the LDS traffic.
+__device__ __forceinline__ float2 tw_m(const float2* twN, int idx, int M) {
+  if (idx < (M >> 1)) return twN[2 * idx];
+  const float2 t = twN[2 * idx - M];
+  return make_float2(-t.x, -t.y);
+}
+__device__ __forceinline__ float2* fft_r4_lds(float2* a, float2* b, const float2* twN, int M, int tid) {
+  const int q4 = M >> 2;
+  int Ns = 1;
+  for (; Ns * 4 <= M; Ns <<= 2) {
+    const int ts = q4 / Ns;                   // twiddle stride in units of 2*pi/M
+    for (int j = tid; j < q4; j += FT) {
+      const int k = j & (Ns - 1);
+      const float2 v0 = a[j];
+      float2 v1 = a[j + q4], v2 = a[j + 2 * q4], v3 = a[j + 3 * q4];
+      if (Ns > 1) {
+        v1 = cmul(v1, tw_m(twN, k * ts, M));
+        v2 = cmul(v2, tw_m(twN, 2 * k * ts, M));
+        v3 = cmul(v3, tw_m(twN, 3 * k * ts, M));
+      }
+      const float2 a0 = make_float2(v0.x + v2.x, v0.y + v2.y), a1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 a2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      const float2 a3 = make_float2(v1.y - v3.y, -(v1.x - v3.x));            // (v1 - v3) * (-i)
+      const int j0 = ((j - k) << 2) + k;
+      b[j0] = make_float2(a0.x + a2.x, a0.y + a2.y);
+      b[j0 + Ns] = make_float2(a1.x + a3.x, a1.y + a3.y);
+      b[j0 + 2 * Ns] = make_float2(a0.x - a2.x, a0.y - a2.y);
+      b[j0 + 3 * Ns] = make_float2(a1.x - a3.x, a1.y - a3.y);
+    }
+    __syncthreads();
+    float2* t = a; a = b; b = t;
+  }
+  if (Ns < M) {                               // Ns * 2 == M: one radix-2 stage
+    const int half = M >> 1;
+    for (int j = tid; j < half; j += FT) {
+      const int k = j & (Ns - 1);
+      const float2 v0 = a[j];
+      const float2 v1 = cmul(a[j + half], tw_m(twN, k * (half / Ns), M));
       const int j0 = ((j - k) << 1) + k;
       b[j0] = make_float2(v0.x + v1.x, v0.y + v1.y);
       b[j0 + Ns] = make_float2(v0.x - v1.x, v0.y - v1.y);
@@ -123,61 +174,90 @@ __device__ __forceinline__ float ola_gather(const float* fr, int T, int hop, int
   return s;
 }
 
+// One Griffin-Lim iteration for one frame.  Both transforms are REAL: the 2M-point real FFT runs as an M-point complex
+// FFT of z[m] = x[2m] + i x[2m+1] followed by the split X[k] = ((Z[k] + conj Z[M-k]) - i W^k (Z[k] - conj Z[M-k])) / 2,
+// and the inverse as the mirrored merge Zt[k] = (X[k] + conj X[M-k]) + i conj(W^k) (X[k] - conj X[M-k]) followed by an
+// M-point FFT of conj(Zt): y[2m] = Re / N, y[2m+1] = -Im / N.  Split, phase normalisation and merge are one pass over
+// the bin pairs (k, M-k).  Half-size radix-4 transforms: 5 + 5 barriers per iteration instead of 11 + 11.
+__device__ __forceinline__ float2 gl_unit(float2 e, float m) {      // m * e / max(1e-8, |e|)
+  const float sc = m / fmaxf(1e-8f, sqrtf(e.x * e.x + e.y * e.y));
+  return make_float2(e.x * sc, e.y * sc);
+}
 __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const ns_griffin_lim_params& p = g.p;
-  const int N = p.n_fft, F = N / 2 + 1;
+  const int N = p.n_fft, M = N >> 1, F = M + 1;
   float2* bufa = (float2*)sm;
-  float2* bufb = bufa + N;
-  float2* tw = bufb + N;
+  float2* bufb = bufa + M;
+  float2* tw = bufb + M;                      // [M] = exp(-2 pi i m / N)
   const int t = blockIdx.x, n = blockIdx.y, tid = threadIdx.x;
-  for (int m = tid; m < N / 2; m += FT) tw[m] = ((const float2*)p.twiddle)[m];
+  for (int m = tid; m < M; m += FT) tw[m] = ((const float2*)p.twiddle)[m];
   float* mag = g.mag + ((long)n * p.T + t) * F;
-  float2* spec;   // spectrum to invert, bins 0..N/2 valid
+  const float2* Z = nullptr;
+  float2* dst = bufa;
   if (g.init) {
     // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
     const float* sp = p.spec + ((long)n * p.T + t) * F;
     for (int k = tid; k < F; k += FT) {
       const float x = fminf(1.f, fmaxf(0.f, sp[k]));
       const float db = x * -p.min_level_db + p.min_level_db + p.ref_level_db;
-      const float m = __powf(__powf(10.f, db * 0.05f), p.power);
-      mag[k] = m;
-      bufa[k] = make_float2(m, 0.f);
+      mag[k] = __powf(__powf(10.f, db * 0.05f), p.power);
     }
-    __syncthreads();
-    spec = bufa;
+    __syncthreads();                          // mag[] of this frame is re-read below by other threads
   } else {
     const float* fr = g.fprev + (long)n * p.T * p.win;
-    for (int j = tid; j < N; j += FT) {
-      float v = 0.f;
-      if (j < p.win) v = ola_gather(fr, p.T, p.hop, p.win, t * p.hop + j) * p.window[j];
-      bufa[j] = make_float2(v, 0.f);
+    for (int m = tid; m < M; m += FT) {
+      float v0 = 0.f, v1 = 0.f;
+      if (2 * m < p.win) v0 = ola_gather(fr, p.T, p.hop, p.win, t * p.hop + 2 * m) * p.window[2 * m];
+      if (2 * m + 1 < p.win) v1 = ola_gather(fr, p.T, p.hop, p.win, t * p.hop + 2 * m + 1) * p.window[2 * m + 1];
+      bufa[m] = make_float2(v0, v1);
     }
     __syncthreads();
-    float2* E = fft_lds(bufa, bufb, tw, N, tid);
-    // angles = E / max(1e-8, |E|);  Z = S * angles   (in place, bins 0..N/2)
-    for (int k = tid; k < F; k += FT) {
-      const float2 e = E[k];
-      const float a = fmaxf(1e-8f, sqrtf(e.x * e.x + e.y * e.y));
-      const float sc = mag[k] / a;
-      E[k] = make_float2(e.x * sc, e.y * sc);
-    }
-    __syncthreads();
-    spec = E;
+    Z = fft_r4_lds(bufa, bufb, tw, M, tid);
+    dst = (Z == bufa) ? bufb : bufa;
   }
-  // inverse real FFT through a forward FFT of the conjugate Hermitian extension
-  float2* other = (spec == bufa) ? bufb : bufa;
-  for (int k = tid; k < N; k += FT) {
-    float2 v;
-    if (k < F) v = make_float2(spec[k].x, -spec[k].y);
-    else v = make_float2(spec[N - k].x, spec[N - k].y);   // conj(conj(X[N-k]))
-    other[k] = v;
+  // bins k and M-k together: split -> unit phase x magnitude -> merge, conj(Zt) goes to dst
+  for (int k = tid; k <= M / 2; k += FT) {
+    const int kk = (k == 0) ? 0 : M - k;      // partner bin inside Z (Z[M] = Z[0])
+    float2 xa, xb;                            // Xn[k], Xn[M-k]
+    const float2 w = (k == 0) ? make_float2(1.f, 0.f) : tw[k];
+    if (g.init) {
+      xa = make_float2(mag[k], 0.f);
+      xb = make_float2(mag[M - k], 0.f);
+    } else {
+      const float2 A = Z[k], B = Z[kk];
+      // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
+      const float2 s1 = make_float2(A.x + B.x, A.y - B.y), d1 = make_float2(A.x - B.x, A.y + B.y);
+      const float2 wd = cmul(w, d1);
+      const float2 ea = make_float2(0.5f * (s1.x + wd.y), 0.5f * (s1.y - wd.x));
+      const float2 s2 = make_float2(s1.x, -s1.y), d2 = make_float2(-d1.x, d1.y);
+      const float2 wc = cmul(make_float2(w.x, -w.y), d2);
+      const float2 eb = make_float2(0.5f * (s2.x - wc.y), 0.5f * (s2.y + wc.x));
+      xa = gl_unit(ea, mag[k]);
+      xb = gl_unit(eb, mag[M - k]);
+    }
+    // Zt[k] = (xa + conj xb) + i conj(w) (xa - conj xb) ;  Zt[M-k] = (xb + conj xa) - i w (xb - conj xa)
+    const float2 s1 = make_float2(xa.x + xb.x, xa.y - xb.y), d1 = make_float2(xa.x - xb.x, xa.y + xb.y);
+    const float2 c1 = cmul(make_float2(w.x, -w.y), d1);
+    const float2 zk = make_float2(s1.x - c1.y, s1.y + c1.x);
+    dst[k] = make_float2(zk.x, -zk.y);
+    if (k != 0 && k != M - k) {
+      const float2 s2 = make_float2(s1.x, -s1.y), d2 = make_float2(-d1.x, d1.y);
+      const float2 c2 = cmul(w, d2);
+      const float2 zm = make_float2(s2.x + c2.y, s2.y - c2.x);
+      dst[M - k] = make_float2(zm.x, -zm.y);
+    }
   }
   __syncthreads();
-  float2* Y = fft_lds(other, spec, tw, N, tid);
+  float2* other = (dst == bufa) ? bufb : bufa;
+  const float2* Y = fft_r4_lds(dst, other, tw, M, tid);
   const float invN = 1.f / N;
   float* fo = g.fnext + ((long)n * p.T + t) * p.win;
-  for (int j = tid; j < p.win; j += FT) fo[j] = Y[j].x * invN * p.window[j];
+  for (int m = tid; 2 * m < p.win; m += FT) {
+    const float2 y = Y[m];
+    fo[2 * m] = y.x * invN * p.window[2 * m];
+    if (2 * m + 1 < p.win) fo[2 * m + 1] = -y.y * invN * p.window[2 * m + 1];
+  }
 }
 
 __global__ void gl_ola_kernel(GlArgs g, int Lout) {
@@ -207,7 +287,7 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
   g.mag = p->work;
   float* fa = p->work + (size_t)p->N * p->T * F;
   float* fb = fa + (size_t)p->N * p->T * p->win;
-  const size_t lds = sizeof(float2) * (2 * p->n_fft + p->n_fft / 2);
+  const size_t lds = sizeof(float2) * (p->n_fft + p->n_fft / 2);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gl_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
