@@ -161,7 +161,15 @@ struct GlArgs {
   int init;
 };
 
-// y[pos] for pos in frame t = sum over the (<= win/hop) frames that cover it
+// overlap-add sum over the (<= win/hop) frames that cover a sample, given the last covering frame f1 and the sample's
+// offset inside it
+__device__ __forceinline__ float ola_frames(const float* fr, int T, int hop, int win, int f1, int off) {
+  if (f1 > T - 1) { off += (f1 - (T - 1)) * hop; f1 = T - 1; }
+  float s = 0.f;
+  for (int f = f1; f >= 0 && off < win; --f, off += hop) s += fr[(long)f * win + off];
+  return s;
+}
+// y[pos]: the same sum from the absolute sample position
 __device__ __forceinline__ float ola_gather(const float* fr, int T, int hop, int win, int pos) {
   int f1 = pos / hop;
   if (f1 > T - 1) f1 = T - 1;
@@ -206,10 +214,17 @@ __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
     __syncthreads();                          // mag[] of this frame is re-read below by other threads
   } else {
     const float* fr = g.fprev + (long)n * p.T * p.win;
+    const float inv_hop = 1.f / p.hop;
     for (int m = tid; m < M; m += FT) {
       float v0 = 0.f, v1 = 0.f;
-      if (2 * m < p.win) v0 = ola_gather(fr, p.T, p.hop, p.win, t * p.hop + 2 * m) * p.window[2 * m];
-      if (2 * m + 1 < p.win) v1 = ola_gather(fr, p.T, p.hop, p.win, t * p.hop + 2 * m + 1) * p.window[2 * m + 1];
+      // sample j of frame t lies in frames f = t + j / hop, t + j / hop - 1, ... while the offset stays below win
+      // (the quotient of two small integers through a float reciprocal: exact, no integer division in the loop)
+      if (2 * m < p.win) {
+        const int j0 = 2 * m, j1 = j0 + 1;
+        const int q0 = (int)((j0 + 0.5f) * inv_hop), q1 = (int)((j1 + 0.5f) * inv_hop);
+        v0 = ola_frames(fr, p.T, p.hop, p.win, t + q0, j0 - q0 * p.hop) * p.window[j0];
+        if (j1 < p.win) v1 = ola_frames(fr, p.T, p.hop, p.win, t + q1, j1 - q1 * p.hop) * p.window[j1];
+      }
       bufa[m] = make_float2(v0, v1);
     }
     __syncthreads();
