@@ -44,10 +44,12 @@ def main():
     floor = {name: ((model.flat_g[lo:hi] - local[lo:hi]).norm() / (local[lo:hi].norm() + 1e-30)).item()
              for name, lo, hi in parallel.bucket_ranges(model.layout)}
     # a ReLU pre-activation within rounding noise of zero changes side between two passes of the same inputs now and
-    # then (the BatchNorm sums are fp32 atomics) and moves a bucket by ~1e-2: the bound follows the measured floor
+    # then (the BatchNorm sums are fp32 atomics) and moves a bucket by 4e-3..1e-2 (seen in one run out of ~5, in the
+    # reducer pass as well as between the two floor passes); a bucket handed over early or reduced twice is off by
+    # O(1), so the bound sits between the two
     fl = torch.tensor([floor[name] for name, _, _ in parallel.bucket_ranges(model.layout)], dtype=torch.float64)
     dist.all_reduce(fl, op=dist.ReduceOp.MAX)
-    tol = {name: max(2e-3, 3.0 * float(fl[i])) for i, (name, _, _) in enumerate(parallel.bucket_ranges(model.layout))}
+    tol = {name: max(3e-2, 3.0 * float(fl[i])) for i, (name, _, _) in enumerate(parallel.bucket_ranges(model.layout))}
     parts = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(parts, local)
     want = sum(parts)
