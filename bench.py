@@ -104,6 +104,17 @@ def griffin_lim_bench(hp, with_cpu):
     alg = 60 * (T * F * 4 + 2 * wav.numel() * 4) + (T * F * 4 + wav.numel() * 4)
     res = {"rtf": ms * 1e-3 / audio_s, "ms": ms, "audio_s": audio_s, "iters": int(hp.griffin_lim_iters),
            "algorithmic_GBps": alg / (ms * 1e-3) / 1e9, "hbm_peak_GBps": HBM_PEAK_GBS}
+    # batched as in the reference's training graph (tacotron.py:107): 32 clips in one call
+    sb = st.unsqueeze(0).repeat(32, 1, 1).contiguous()
+    A.griffin_lim_gpu(sb)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(3):
+        A.griffin_lim_gpu(sb)
+    e1.record()
+    torch.cuda.synchronize()
+    msb = e0.elapsed_time(e1) / 3
+    res["batch_32"] = {"ms": msb, "rtf": msb * 1e-3 / (32 * audio_s), "algorithmic_GBps": 32 * alg / (msb * 1e-3) / 1e9}
     if with_cpu:
         sys.stderr.write("[bench] griffin-lim cpu sample...\n")
         sys.stderr.flush()
