@@ -230,7 +230,7 @@ def main():
     if world > 1:
         from nspeech_amd import parallel
         parallel.broadcast_parameters(model, 0)
-        model.reducer = parallel.GradReducer(model.flat_g, parallel.bucket_ranges(model.layout))
+        model.reducer = parallel.make_reducer(model)
     inputs, lengths, mel, lin = synthetic_batch(hp, args.batch, args.t_in, args.t_out, 1234 + rank)
     model.add_optimizer(global_step=0)
     model.initialize(inputs, lengths, None, mel, lin)
@@ -291,7 +291,7 @@ def main():
             "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "precision_mode": args.dtype, "data": "synthetic",
+            "dtype": {"mixed": "bf16", "bf16": "bf16", "bf16x3": "bf16", "fp32": "f32"}[args.dtype], "precision_mode": args.dtype, "data": "synthetic",
             "config": {"workload": "Tacotron-2 train step (fwd+bwd+clip+Adam), batch %d/GPU, T_in %d, T_out %d, r=%d"
                                    % (args.batch, args.t_in, args.t_out, hp.outputs_per_step),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss": loss},

@@ -48,8 +48,12 @@ const char* ns_last_error(void);
  * conv1d 'same' over the padded layout is a_mode 0 with lda = C_in, K = k*C_in.
  *   row mask: if row_period>0, output row m is written as 0 unless
  *             lo <= (m + row_shift) % row_period < hi.
- *   col_sum/col_sumsq: optional fp32[N]; += sum / sum of squares of the stored values
- *             over unmasked rows (BatchNorm batch statistics, modules.py:198).
+ *   col_sum/col_sumsq: optional fp32[N]; = sum / sum of squares of the stored values
+ *             over unmasked rows (BatchNorm batch statistics, modules.py:198).  Deterministic:
+ *             every 64-row slot of the output writes its own partial sums into `stat_part`
+ *             (caller-owned scratch, ns_gemm_stat_part_floats(M, N) floats, no need to clear it),
+ *             and a fixed-order second stage adds the slots up, so two calls on the same operands
+ *             give the same bits (no float atomics).
  *   accumulate 0: store   1: C += (fp32 C, split_k must be 1)   2: atomic C += (fp32)
  */
 typedef struct {
@@ -79,8 +83,11 @@ typedef struct {
    * C + z*batch_stride_c (elements).  The per-utterance products of the attention loop (align[n] . memory[n],
    * attention.py:48 and its gradients).  No bias / addend / gate / statistics in batched calls. */
   int batch; int64_t batch_stride_a, batch_stride_b, batch_stride_c;
+  float* stat_part;  /* scratch for col_sum / col_sumsq (required with them), ns_gemm_stat_part_floats(M, N) floats */
+  int stat_slots;    /* set by the library */
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
+size_t ns_gemm_stat_part_floats(int M, int N);
 /* name of the kernel the calling thread's last ns_gemm call launched (e.g. "gemm_mfma_f32_kernel<0, 1, 3>"): lets a
  * caller attribute its own event timings to the names a profiler reports. */
 const char* ns_gemm_last_kernel(void);
@@ -136,7 +143,8 @@ int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t stream);
 /* BatchNorm + activation + bias backward of modules.py:194-198.
  * dy fp32 [rows,C] (grad wrt BN output), z = activated pre-BN value saved by forward.
  * Outputs: dpre (grad wrt conv output before the activation, operand dtype, pad rows 0),
- * dgamma/dbeta/dbias += .  work = fp32[2*C] scratch, zeroed by the call. */
+ * dgamma/dbeta/dbias += .  work = fp32[64*C] scratch (per-row-block partial sums of dy and dy*xhat, added up in a
+ * fixed order: the gradient that flows on is bitwise repeatable; no need to clear it). */
 typedef struct {
   const float* dy; const void* z; void* dpre; int dtype;
   int rows, C;
@@ -251,20 +259,6 @@ int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1,
 size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p);
 int ns_lstm_cluster_fwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
 int ns_lstm_cluster_bwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
-
-/* Persistent variant of ns_lstm_seq_* for WIDE cells (the decoder LSTMs of tacotron2.py:67-73, 1024 units):
- * ONE launch for the whole sequence.  Every workgroup keeps its slice of W_h in registers; the state
- * (h[t-1] forward, the bf16 gate gradients of step t+1 backward) travels through the history arrays
- * themselves with write-through stores + one flag per (row group, workgroup).
- * Forward: dtype NS_BF16 (whT), or NS_F32 with whT_hi (+ whT_lo when f32_passes == 3).
- * Backward: dtype NS_BF16 (wh), or NS_F32 with wh_bf16 + dgates_bf16 and f32_passes == 1.
- * H %% 128 == 0, 128 <= H <= 1024, 16-byte aligned rows, the grid must fit the device (one workgroup per CU).
- * ns_lstm_wide_supported() says whether a parameter block qualifies.  work[0] (int) is a status word:
- * non-zero after the call completes = an exchange timed out and the outputs are invalid. */
-int ns_lstm_wide_supported(const ns_lstm_seq_params* p, int backward);
-size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p);
-int ns_lstm_wide_fwd(const ns_lstm_seq_params* p, void* work, ns_stream_t stream);
-int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stream_t stream);
 
 /* One LSTMBlockCell step on an explicit input row: gates = [a].W^T + xg + bias with a = the
  * concatenated [input | h_prev] rows (the free-running decoder of tacotron2.py:67-83 with

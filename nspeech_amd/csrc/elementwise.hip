@@ -122,15 +122,16 @@ extern "C" int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t s) {
 }
 
 // ------------------------------------------------------------------ BatchNorm backward
-// pass 1: work[c] = sum dy, work[C+c] = sum dy*xhat  over valid rows.  Block = 256 threads,
-// each block covers ROWS_PER_BLOCK rows; threads stride over channels (coalesced).
+// pass 1: per row block b (gridDim.x <= 32 blocks): work[(2b)*C + c] = sum dy, work[(2b+1)*C + c] = sum dy*xhat over the
+// block's valid rows - plain stores, added up in block order by pass 2, so the result does not depend on timing.
+constexpr int BN_MAX_BLOCKS = 32;
 constexpr int BN_ROWS_PER_BLOCK = 64;
 
 template <typename T>
 __global__ void bn_bwd_reduce_kernel(ns_bn_bwd_params p) {
   const T* z = (const T*)p.z;
-  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-  const int r1 = min(p.rows, r0 + BN_ROWS_PER_BLOCK);
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
     const float mean = p.mean[c], istd = p.istd[c];
     float s1 = 0.f, s2 = 0.f;
@@ -145,8 +146,8 @@ __global__ void bn_bwd_reduce_kernel(ns_bn_bwd_params p) {
       s1 += dy;
       s2 += dy * xh;
     }
-    atomicAdd(p.work + c, s1);
-    atomicAdd(p.work + p.C + c, s2);
+    p.work[(long)(2 * blockIdx.x) * p.C + c] = s1;
+    p.work[(long)(2 * blockIdx.x + 1) * p.C + c] = s2;
   }
 }
 
@@ -155,12 +156,14 @@ template <typename T>
 __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
   const T* z = (const T*)p.z;
   T* dpre = (T*)p.dpre;
-  const int r0 = blockIdx.x * BN_ROWS_PER_BLOCK;
-  const int r1 = min(p.rows, r0 + BN_ROWS_PER_BLOCK);
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
   const float invM = 1.f / p.count;
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
     const float mean = p.mean[c], istd = p.istd[c], g = p.gamma[c];
-    const float m1 = p.work[c] * invM, m2 = p.work[p.C + c] * invM;
+    float t1 = 0.f, t2 = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) { t1 += p.work[(long)(2 * b) * p.C + c]; t2 += p.work[(long)(2 * b + 1) * p.C + c]; }
+    const float m1 = t1 * invM, m2 = t2 * invM;
     float sb = 0.f;
     for (int row = r0; row < r1; ++row) {
       const long idx = (long)row * p.C + c;
@@ -191,15 +194,15 @@ __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
     }
     if (p.dbias) atomicAdd(p.dbias + c, sb);
     if (blockIdx.x == 0) {
-      if (p.dgamma) p.dgamma[c] += p.work[p.C + c];
-      if (p.dbeta) p.dbeta[c] += p.work[c];
+      if (p.dgamma) p.dgamma[c] += t2;
+      if (p.dbeta) p.dbeta[c] += t1;
     }
   }
 }
-// Vector forms of the two passes for C % 4 == 0.  Float atomics execute at the memory side and collapse (14x) when
-// hundreds of workgroups add into the same few rows (MI355X_MICROARCH.md, Global float atomics): a block therefore
-// owns rows/32 rows x 64 channels, so an address sees at most 32 adders, and reduces through LDS first.  A thread owns
-// 4 adjacent channels (16-byte loads) of every 16th row of the block and keeps four rows in flight.
+// Vector forms of the two passes for C % 4 == 0.  A block owns rows/32 rows x 64 channels and reduces through LDS; its
+// sums go to its own slot of `work` (no float atomics: they are slow when contended - MI355X_MICROARCH.md, Global
+// float atomics - and their arrival order would make the gradient differ from run to run).  A thread owns 4 adjacent
+// channels (16-byte loads) of every 16th row of the block and keeps four rows in flight.
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
   const bf16x4 v = *(const bf16x4*)p;
@@ -263,8 +266,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p)
     for (int i = 0; i < 4; ++i) {
       float a = 0.f, b = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) { a += red[r * BN4_QUADS + ql][i]; b += red[r * BN4_QUADS + ql][4 + i]; }
-      atomicAdd(p.work + 4 * q + i, a);
-      atomicAdd(p.work + p.C + 4 * q + i, b);
+      p.work[(long)(2 * blockIdx.x) * p.C + 4 * q + i] = a;
+      p.work[(long)(2 * blockIdx.x + 1) * p.C + 4 * q + i] = b;
     }
   }
 }
@@ -281,10 +284,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) 
   const bool d16 = sizeof(T) == 4 && p.dpre_dtype == NS_BF16;
   const float invM = 1.f / p.count;
   float sb[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 tot1 = make_float4(0.f, 0.f, 0.f, 0.f), tot2 = tot1;
   if (active) {
     const float4 mean = *(const float4*)(p.mean + 4 * q), istd = *(const float4*)(p.istd + 4 * q);
     const float4 g = *(const float4*)(p.gamma + 4 * q);
-    const float4 w1 = *(const float4*)(p.work + 4 * q), w2 = *(const float4*)(p.work + p.C + 4 * q);
+    float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f), w2 = w1;      // the row blocks' partial sums, in block order
+    for (int b = 0; b < (int)gridDim.x; ++b) {
+      const float4 a1 = *(const float4*)(p.work + (long)(2 * b) * p.C + 4 * q);
+      const float4 a2 = *(const float4*)(p.work + (long)(2 * b + 1) * p.C + 4 * q);
+      w1.x += a1.x; w1.y += a1.y; w1.z += a1.z; w1.w += a1.w;
+      w2.x += a2.x; w2.y += a2.y; w2.z += a2.z; w2.w += a2.w;
+    }
+    tot1 = w1; tot2 = w2;
     const float mu[4] = {mean.x, mean.y, mean.z, mean.w}, is[4] = {istd.x, istd.y, istd.z, istd.w};
     const float gi[4] = {g.x * istd.x, g.y * istd.y, g.z * istd.z, g.w * istd.w};
     const float m1[4] = {w1.x * invM, w1.y * invM, w1.z * invM, w1.w * invM};
@@ -349,8 +360,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) 
       for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
       if (p.dbias) atomicAdd(p.dbias + 4 * q + i, a);
       if (blockIdx.x == 0) {
-        if (p.dgamma) p.dgamma[4 * q + i] += p.work[p.C + 4 * q + i];
-        if (p.dbeta) p.dbeta[4 * q + i] += p.work[4 * q + i];
+        const float t1[4] = {tot1.x, tot1.y, tot1.z, tot1.w}, t2[4] = {tot2.x, tot2.y, tot2.z, tot2.w};
+        if (p.dgamma) p.dgamma[4 * q + i] += t2[i];
+        if (p.dbeta) p.dbeta[4 * q + i] += t1[i];
       }
     }
   }
@@ -359,16 +371,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) 
 extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   NS_CHECK_ARG(p && p->dy && p->z && p->dpre && p->mean && p->istd && p->gamma && p->work, "ns_bn_bwd: null");
-  if (hipMemsetAsync(p->work, 0, sizeof(float) * 2 * p->C, s) != hipSuccess) {
-    ns_set_error("ns_bn_bwd: memset failed");
-    return NS_ERR_LAUNCH;
-  }
   const bool al16 = ((uintptr_t)p->dy % 16 == 0) && ((uintptr_t)p->z % 8 == 0) && ((uintptr_t)p->dpre % 8 == 0) &&
                     ((uintptr_t)p->mean % 16 == 0) && ((uintptr_t)p->istd % 16 == 0) && ((uintptr_t)p->gamma % 16 == 0) &&
                     ((uintptr_t)p->work % 16 == 0) && (p->dtype == NS_BF16 || ((uintptr_t)p->z % 16 == 0 &&
                     (uintptr_t)p->dpre % (p->dpre_dtype == NS_BF16 ? 8 : 16) == 0));
   if (p->C % 4 == 0 && al16) {
-    const dim3 grid4(max(1, min(32, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
+    const dim3 grid4(max(1, min(BN_MAX_BLOCKS, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
     if (p->dtype == NS_BF16) {
       hipLaunchKernelGGL(bn_bwd_reduce4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
       hipLaunchKernelGGL(bn_bwd_apply4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
@@ -379,7 +387,7 @@ extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
     NS_CHECK_LAUNCH("bn_bwd");
     return NS_OK;
   }
-  const int grid = ceil_div(p->rows, BN_ROWS_PER_BLOCK);
+  const int grid = max(1, min(BN_MAX_BLOCKS, ceil_div(p->rows, BN_ROWS_PER_BLOCK)));
   if (p->dtype == NS_BF16) {
     hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *p);
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, s, *p);

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
   }
   Epi e = make_epi(p);
   const bool add_bias = (ksl == 0);
+  float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < 4; ++i) {
     int m = m0 + ty * 4 + i;
     if (m >= p.M) continue;
@@ -146,13 +147,45 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
       if (n >= p.N) continue;
       float v = epi_value(e, m, n, acc[i][j], add_bias, valid);
       epi_store(e, m, n, v);
-      if (valid && p.col_sum) {
+      if (valid) {
         // stats are taken on the value as the consumer will read it back
         float vs = (p.c_dtype == NS_BF16 && p.accumulate == 0) ? (float)(bf16_t)v : v;
-        atomicAdd(p.col_sum + n, vs);
-        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, vs * vs);
+        s1[j] += vs;
+        s2[j] += vs * vs;
       }
     }
+  }
+  if (p.stat_part) {   // this block's 64 rows = one statistics slot; fixed summation order (no atomics)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { As[ty][tx * 4 + j] = s1[j]; Bs[ty][tx * 4 + j] = s2[j]; }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float a = 0.f, b = 0.f;
+      for (int r = 0; r < 16; ++r) { a += As[r][tid]; b += Bs[r][tid]; }
+      p.stat_part[(long)blockIdx.y * p.N + n0 + tid] = a;
+      p.stat_part[((long)p.stat_slots + blockIdx.y) * p.N + n0 + tid] = b;
+    }
+  }
+}
+
+// second stage of the BatchNorm statistics: adds the 64-row slots up in a fixed order
+__global__ __launch_bounds__(256) void gemm_stats_finalize_kernel(const float* part, int slots, int N, float* col_sum,
+                                                                  float* col_sumsq) {
+  __shared__ float red[4][64][2];
+  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + c;
+  float a = 0.f, b = 0.f;
+  if (n < N) {
+    for (int s = q; s < slots; s += 4) {
+      a += part[(long)s * N + n];
+      b += part[((long)slots + s) * N + n];
+    }
+  }
+  red[q][c][0] = a; red[q][c][1] = b;
+  __syncthreads();
+  if (q == 0 && n < N) {
+    col_sum[n] = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
+    if (col_sumsq) col_sumsq[n] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
   }
 }
 
@@ -263,12 +296,13 @@ __device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&a
         }
       }
     }
-    if (p.col_sum) {
+    if (p.stat_part) {     // this wave's 64 rows = one statistics slot
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       if ((lane >> 4) == 0 && n < p.N) {
-        atomicAdd(p.col_sum + n, s1);
-        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
+        const long slot = (m0 >> 6) + wm;
+        p.stat_part[slot * p.N + n] = s1;
+        p.stat_part[(p.stat_slots + slot) * p.N + n] = s2;
       }
     }
   }
@@ -415,12 +449,13 @@ __device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&a
         }
       }
     }
-    if (p.col_sum) {
+    if (p.stat_part) {     // this quadrant's 64 rows = one statistics slot
       s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
       s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
       if ((lane >> 4) == 0 && n < p.N) {
-        atomicAdd(p.col_sum + n, s1);
-        if (p.col_sumsq) atomicAdd(p.col_sumsq + n, s2);
+        const long slot = mq >> 6;
+        p.stat_part[slot * p.N + n] = s1;
+        p.stat_part[(p.stat_slots + slot) * p.N + n] = s2;
       }
     }
   }
@@ -908,10 +943,30 @@ static bool x256_ok(const ns_gemm_params& p) {
   return ceil_div(p.M, 256) * ceil_div(p.N, 256) >= 96;
 }
 
+extern "C" size_t ns_gemm_stat_part_floats(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)2 * 4 * ceil_div(M, 256) * (size_t)N;     // the 256-tile kernel has the most slots per row
+}
+
+static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream);
+
 extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NS_CHECK_ARG(pp != nullptr, "ns_gemm: null params");
   ns_gemm_params p = *pp;
+  NS_CHECK_ARG(!p.col_sumsq || p.col_sum, "ns_gemm: col_sumsq needs col_sum");
+  NS_CHECK_ARG(!p.col_sum || p.stat_part, "ns_gemm: col_sum needs the stat_part scratch (ns_gemm_stat_part_floats)");
+  if (!p.col_sum) p.stat_part = nullptr;
+  p.stat_slots = 0;
+  int rc = gemm_dispatch(p, stream);
+  if (rc || !p.stat_part || p.M == 0 || p.N == 0) return rc;
+  hipLaunchKernelGGL(gemm_stats_finalize_kernel, dim3(ceil_div(p.N, 64)), dim3(256), 0, stream, p.stat_part, p.stat_slots,
+                     p.N, p.col_sum, p.col_sumsq);
+  NS_CHECK_LAUNCH("gemm_stats_finalize");
+  return NS_OK;
+}
+
+static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
   NS_CHECK_ARG(p.M >= 0 && p.N >= 0 && p.K >= 0, "ns_gemm: negative dims");
   if (p.M == 0 || p.N == 0) return NS_OK;
   NS_CHECK_ARG(p.A && p.B && p.C, "ns_gemm: null operand");
@@ -956,6 +1011,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
       (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
+    p.stat_slots = 4 * ceil_div(p.M, 256);
     g_last_kernel = p.A_lo ? "gemm_x256_kernel<3>" : "gemm_x256_kernel<1>";
     if (p.A_lo) hipLaunchKernelGGL(gemm_x256_kernel<3>, dim3(tiles), dim3(512), lds, stream, p);
     else hipLaunchKernelGGL(gemm_x256_kernel<1>, dim3(tiles), dim3(512), lds, stream, p);
@@ -968,6 +1024,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
     dim3 grid(tiles, p.split_k, p.batch);
     const size_t lds = 65536;
+    p.stat_slots = 2 * ceil_div(p.M, GBM);
 #define LAUNCH_MFMA(AM, BM_)                                                                      \
   do {                                                                                            \
     static bool attr_set = false;                                                                 \
@@ -1012,6 +1069,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
       const int tiles = ceil_div(p.M, GBM) * ceil_div(p.N, GBN);
       dim3 grid(tiles, p.split_k, p.batch);
       const size_t lds = 65536;
+      p.stat_slots = 2 * ceil_div(p.M, GBM);
 #define LAUNCH_F32(AM, BM_, PS)                                                                     \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \
@@ -1038,6 +1096,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
     }
   }
   dim3 grid(ceil_div(p.N, 64), ceil_div(p.M, 64), p.split_k * p.batch);
+  p.stat_slots = ceil_div(p.M, 64);
   g_last_kernel = "gemm_generic_kernel";
   if (p.dtype == NS_F32) hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(gemm_generic_kernel<bf16_t>, grid, dim3(256), 0, stream, p);

@@ -74,12 +74,14 @@ def load_librispeech_corpus(path):
     return items
 
 
-def prepare_batch(batch, outputs_per_step, rng):
-    """datafeeder.py:189-220.  batch: list of (ids, speaker_id, mel [T,M], linear [T,F])."""
+def prepare_batch(batch, outputs_per_step, rng, longest=0):
+    """datafeeder.py:189-220.  batch: list of (ids, speaker_id, mel [T,M], linear [T,F]).
+    `longest`: data-parallel runs pass the longest target of the GLOBAL batch (all ranks), so that every rank pads to
+    the same T_out and the mean of the ranks' unmasked mean losses is the global mean."""
     batch = list(batch)
     rng.shuffle(batch)
     Ti = max(len(e[0]) for e in batch)
-    To = _round_up(max(e[3].shape[0] for e in batch) + 1, outputs_per_step)
+    To = _round_up(max(max(e[3].shape[0] for e in batch), longest) + 1, outputs_per_step)
     N = len(batch)
     inputs = np.full((N, Ti), _pad, np.int32)
     lengths = np.zeros((N,), np.int32)
@@ -100,8 +102,18 @@ class DataFeeder(object):
     `speaker_ids` of the last batch are kept in .speaker_ids (single-speaker corpora: zeros)."""
 
     def __init__(self, hparams, ljspeech=None, seed=0, rank=0, world=1, cmudict=None, prefetch=True, features=None,
-                 loader=None, vctk=None, librispeech=None):
+                 loader=None, vctk=None, librispeech=None, device=None):
         self.hp = hparams
+        # the GPU the feature kernels of the prefetch thread must run on: torch's current device is per host thread,
+        # so the worker binds it itself (a rank that called set_device(local) only in its main thread would otherwise
+        # extract features on GPU 0)
+        if device is None:
+            try:
+                import torch
+                device = torch.cuda.current_device() if torch.cuda.is_available() else None
+            except Exception:
+                device = None
+        self.device = device
         # datafeeder.py:44-53: every corpus named on the command line contributes its items
         self.items = load_ljspeech_metadata(ljspeech) if ljspeech else []
         self.items += load_vctk_file_names(vctk) if vctk else []
@@ -162,13 +174,25 @@ class DataFeeder(object):
             group.sort(key=lambda e: e[3].shape[0])
             examples = group[self.rank::self.world]
         batches = [examples[i:i + n] for i in range(0, len(examples), n)]
-        self._order_rng.random()              # keeps the shared generator in step across ranks
-        self._rng.shuffle(batches)
-        return [prepare_batch(b, r, self._rng) for b in batches]
+        if self.world == 1:
+            self._order_rng.random()              # keeps the shared generator in step with the multi-rank walk
+            self._rng.shuffle(batches)
+            return [prepare_batch(b, r, self._rng) for b in batches]
+        # global batch j = group[j*n*world : (j+1)*n*world]; every rank shuffles the batch order with the SHARED
+        # generator (global step k is the same batch j on all ranks) and pads to the longest target of the whole
+        # global batch, so T_out is equal across ranks and averaging the rank gradients is the global mean loss
+        longest = [max(e[3].shape[0] for e in group[j * n * self.world:(j + 1) * n * self.world])
+                   for j in range(len(batches))]
+        order = list(range(len(batches)))
+        self._order_rng.shuffle(order)
+        return [prepare_batch(batches[j], r, self._rng, longest[j]) for j in order]
 
     # ------------------------------------------------------------------ queue
     def _worker(self):
         try:
+            if self.device is not None:
+                import torch
+                torch.cuda.set_device(self.device)
             while True:
                 for b in self._next_group():
                     self._queue.put(b)

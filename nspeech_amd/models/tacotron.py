@@ -19,7 +19,7 @@ import torch
 from .. import ops
 from .._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
 from . import params as P_
-from .tacotron2 import Tacotron2, _round_up
+from .tacotron2 import Tacotron2, _LazyAudio, _round_up
 
 
 class Act(object):
@@ -44,6 +44,9 @@ class Act(object):
 
 
 class Tacotron(Tacotron2):
+    # data parallel: one whole-buffer all-reduce once backward() has been enqueued (parallel.whole_buffer_range)
+    _BUCKET_AFTER = {"backward": "all"}
+
     padl, padr = 8, 8     # bank widths up to 16: 'same' needs 7 left / 8 right; the data gradient the mirror
     LAYOUT = staticmethod(P_.taco1_layout)
     KW = 1    # Bahdanau = location-sensitive kernel with a 1-tap zero filter
@@ -406,11 +409,7 @@ class Tacotron(Tacotron2):
         self.decoder_outputs = self.mel_outputs
         self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
         self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:S + 1, :Ti].permute(0, 2, 1)
-        if F == 1025 and M == 80:       # tacotron.py:107: self.audio = Griffin-Lim of the whole batch
-            from ..utils import audio
-            from .. import hparams as hparams_mod
-            if hparams_mod.get_hparams() is not None:
-                self.audio = audio.griffin_lim_gpu(self.linear_outputs.contiguous())
+        self.audio = _LazyAudio(self)           # tacotron.py:107, vocoded when read
         return self
 
     # ------------------------------------------------------------------ forward (training)
@@ -542,6 +541,7 @@ class Tacotron(Tacotron2):
         self.decoder_outputs = self.mel_outputs
         self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
         self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:, :Ti].permute(0, 2, 1)
+        self.audio = _LazyAudio(self)           # tacotron.py:107, vocoded when read
         return self
 
     # ------------------------------------------------------------------ loss + backward

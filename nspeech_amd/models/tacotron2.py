@@ -32,6 +32,26 @@ def _round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class _LazyAudio(object):
+    """`model.audio` of the reference's training graph (tacotron.py:107: Griffin-Lim of the whole batch of linear
+    outputs, fetched as model.audio[0] by train.py:100-102).  Evaluated on demand: item i runs Griffin-Lim on that
+    utterance only, on the GPU; `all()` vocodes the batch in one call."""
+
+    def __init__(self, model):
+        self._m = model
+
+    def __len__(self):
+        return int(self._m.linear_outputs.shape[0])
+
+    def __getitem__(self, i):
+        from ..utils import audio
+        return audio.inv_spectrogram_tensorflow(self._m.linear_outputs[i].float().contiguous())
+
+    def all(self):
+        from ..utils import audio
+        return audio.inv_spectrogram_tensorflow(self._m.linear_outputs.float().contiguous())
+
+
 class Tacotron2(object):
     padl, padr = PADL, PADR
     LAYOUT = staticmethod(P_.taco2_layout)
@@ -279,21 +299,15 @@ class Tacotron2(object):
 
     # ------------------------------------------------------------------ layer helpers
     def _stats_buf(self, tag, cout):
-        """[sum | sum of squares | mean | 1/std] of one conv layer, carved out of one arena that is cleared with a
-        single fill when a pass revisits a layer (instead of one fill per layer)."""
+        """[sum | sum of squares | mean | 1/std] of one conv layer, carved out of one arena.  Every pass overwrites
+        them (ns_gemm's deterministic two-stage statistics store, they do not accumulate)."""
         m = self._bufs.setdefault("st_map", {})
-        clean = self._bufs.setdefault("st_clean", set())
         arena = self._buf("st_arena", 1 << 16, torch.float32)
         if tag not in m:
             off = self._bufs.get("st_used", 0)
             assert off + 4 * cout <= arena.numel(), "BatchNorm statistics arena too small"
             m[tag] = arena[off:off + 4 * cout]
             self._bufs["st_used"] = off + ((4 * cout + 63) // 64) * 64
-            clean.add(tag)              # fresh arena memory is zero
-        if tag not in clean:            # second visit: a new pass has begun, every layer's sums are stale
-            arena.zero_()
-            clean.update(m.keys())
-        clean.discard(tag)
         return m[tag]
 
     def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None):
@@ -345,7 +359,7 @@ class Tacotron2(object):
             x16 = self._buf("xin16_%d" % cin, rows * cin, torch.bfloat16)
             ops.cast2d(xin, rows, cin, cin, x16, cin, False)
             xin = x16
-        work = self._buf("bn_work", 2 * 2048, torch.float32)
+        work = self._buf("bn_work", 64 * max(2048, cout), torch.float32)
         g = self.flat_g
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
                    row_mask=(Pp, self.padl, self.padl + T),
@@ -652,6 +666,7 @@ class Tacotron2(object):
         self.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, self.padl:self.padl + To, :F]
         self.decoder_outputs = dec[:rows * M * r].view(N, S1, M * r)[:, 1:].reshape(N, To, M)
         self.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:, :Ti].permute(0, 2, 1)
+        self.audio = _LazyAudio(self)
         return self
 
     # ------------------------------------------------------------------ loss + backward

@@ -9,7 +9,7 @@ import torch
 from .. import ops
 from .. import _lib as L
 from .._lib import ACT_NONE, ACT_RELU, ACT_TANH
-from .tacotron2 import PADL, PADR, _round_up
+from .tacotron2 import PADL, PADR, _LazyAudio, _round_up
 
 
 def _infer_shadows(m):
@@ -205,4 +205,5 @@ def _infer_body(m):
     m.linear_outputs = lin[:N * Po * Fp].view(N, Po, Fp)[:, PADL:PADL + To, :F]
     m.decoder_outputs = dec[:N * S1 * M * r].view(N, S1, M * r)[:, 1:S + 1].reshape(N, To, M)
     m.alignments = al[:N * S1 * Tia].view(N, S1, Tia)[:, 1:S + 1, :Ti].permute(0, 2, 1)
+    m.audio = _LazyAudio(m)
     return m

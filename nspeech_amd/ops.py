@@ -57,6 +57,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
         p.row_period, p.row_lo, p.row_hi, p.row_shift = row_mask
     p.col_sum = ptr(col_sum)
     p.col_sumsq = ptr(col_sumsq)
+    if col_sum is not None:      # scratch of the deterministic two-stage statistics (one per device, grown on demand)
+        p.stat_part = ptr(_stat_part(col_sum.device, M, N))
     p.split_k = split_k
     if addend is not None:
         p.addend, p.ld_add, p.addend_dtype = ptr(addend, addend_off), ld_add, dt(addend)
@@ -69,6 +71,19 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     if a_lo is not None:        # pre-split fp32 values: A / B hold the high parts (same offsets and strides)
         p.A_lo, p.B_lo = ptr(a_lo, a_off), ptr(b_lo, b_off)
     L.call("ns_gemm", p, stream())
+
+
+_STAT_PART = {}
+
+
+def _stat_part(device, M, N):
+    fn = L.lib().ns_gemm_stat_part_floats
+    fn.restype = L.C.c_size_t
+    need = int(fn(int(M), int(N)))
+    buf = _STAT_PART.get(device)
+    if buf is None or buf.numel() < need:
+        buf = _STAT_PART[device] = torch.empty(need, dtype=torch.float32, device=device)
+    return buf
 
 
 def _fill(_st, **kw):
@@ -209,22 +224,6 @@ def lstm_cluster(direction, p0, p1, work):
     """Persistent whole-sequence BiLSTM (one launch); work[0] is the status word."""
     fn = getattr(L.lib(), "ns_lstm_cluster_fwd" if direction == "fwd" else "ns_lstm_cluster_bwd")
     L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_cluster_" + direction)
-
-
-def lstm_wide_supported(p, backward):
-    return bool(L.lib().ns_lstm_wide_supported(C.byref(p), int(backward)))
-
-
-def lstm_wide_work_floats(p):
-    fn = L.lib().ns_lstm_wide_work_bytes
-    fn.restype = C.c_size_t
-    return (fn(C.byref(p)) + 3) // 4
-
-
-def lstm_wide(direction, p, work):
-    """Persistent whole-sequence recurrence for wide cells (one launch); work[0] is the status word."""
-    fn = getattr(L.lib(), "ns_lstm_wide_fwd" if direction == "fwd" else "ns_lstm_wide_bwd")
-    L.check(fn(C.byref(p), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_lstm_wide_" + direction)
 
 
 def split_hi_lo(src, hi, lo, n):

@@ -28,7 +28,7 @@ class Synthesizer(object):
             if tf_bundle.is_bundle(checkpoint_path):       # a TensorFlow checkpoint prefix (model.ckpt-N.index + data)
                 tf_bundle.load_into_model(self.model, checkpoint_path)
             else:
-                self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"))
+                self.model.load_state_dict(torch.load(checkpoint_path, map_location="cpu", weights_only=True))
         return self
 
     def synthesize(self, text, speaker_id=0):
@@ -41,6 +41,8 @@ class Synthesizer(object):
         wav = audio.inv_spectrogram_tensorflow(m.linear_outputs[0].contiguous())
         mel = m.mel_outputs[0].float().cpu().numpy()
         lin = m.linear_outputs[0].float().cpu().numpy()
+        m.check_status()        # after the host copies (stream synchronised): a persistent BiLSTM kernel that gave up
+                                # on an exchange leaves invalid outputs behind - never vocode those silently
         wav = audio.inv_preemphasis(wav.cpu().numpy())
         wav = wav[:audio.find_endpoint(wav)]
         return wav, mel, lin

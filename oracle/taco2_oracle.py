@@ -22,6 +22,20 @@ import torch.nn.functional as F
 BN_EPS = 1e-3          # tf.layers.batch_normalization default epsilon
 BN_MOMENTUM = 0.99     # tf.layers.batch_normalization default momentum
 
+# Test aid: when set to a list, every ReLU appends the smallest non-zero |pre-activation| it saw.  A float32
+# implementation can only be held to a tight gradient bound on inputs whose ReLU kinks are not within rounding noise
+# of zero (an element on the other side of the kink changes every gradient upstream of it by a finite amount).
+KINK_LOG = None
+
+
+def _relu(x):
+    if KINK_LOG is not None:
+        a = x.detach().abs()
+        nz = a[a > 0]
+        if nz.numel():
+            KINK_LOG.append(float(nz.min()))
+    return torch.relu(x)
+
 
 # ------------------------------------------------------------------ building blocks
 def conv1d_bn(x, p, scope, activation, training, bn_updates=None):
@@ -38,7 +52,7 @@ def conv1d_bn(x, p, scope, activation, training, bn_updates=None):
     y = F.conv1d(xp, W.permute(2, 1, 0)) + b[None, :, None]
     y = y.transpose(1, 2)
     if activation is not None:
-        y = activation(y)
+        y = _relu(y) if activation is torch.relu else activation(y)
     g = p[scope + "/batch_normalization/gamma"]
     be = p[scope + "/batch_normalization/beta"]
     if training:
@@ -111,8 +125,8 @@ def postnet(x, p, scope, layers, training, bn_updates):
 def prenet(x, p, scope):
     """modules.py:21-27 via rnn_wrappers.py:25-27.  tf.layers.dropout is called without
     training=True, so it is the identity."""
-    x = torch.relu(x @ p[scope + "/dense_1/kernel"] + p[scope + "/dense_1/bias"])
-    x = torch.relu(x @ p[scope + "/dense_2/kernel"] + p[scope + "/dense_2/bias"])
+    x = _relu(x @ p[scope + "/dense_1/kernel"] + p[scope + "/dense_1/bias"])
+    x = _relu(x @ p[scope + "/dense_2/kernel"] + p[scope + "/dense_2/bias"])
     return x
 
 

@@ -84,3 +84,25 @@ def test_griffin_lim_batched_and_roundtrip_gain(audio):
     # saturated input (all ones) -> constant magnitude, zero phase -> impulse at n=0 where Hann is 0
     z = A.griffin_lim_gpu(np.ones((21, 1025), np.float32), iters=2).cpu().numpy()
     assert np.abs(z).max() < 1e-3
+
+
+def test_griffin_lim_at_the_benchmarked_size(audio):
+    """bench.py times 60 iterations on 797 frames (10 s of audio): the same call against the oracle, on the waveform
+    after 0, 1 and 60 iterations and on what Griffin-Lim optimises, the magnitude of the TF-convention STFT of the
+    result."""
+    A, hp = audio
+    y = _speechlike(200000, 1234)
+    spec = AO.spectrogram(y, dict(HP, min_level_db=-100)).T[:797].copy()
+    for iters in (0, 1):
+        got = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
+        ref = AO.inv_spectrogram_tensorflow(spec, HP, iters=iters)
+        assert got.shape == ref.shape == (796 * 250 + 1000,)
+        assert np.abs(got - ref).max() < 2e-4 * np.abs(ref).max(), (iters, np.abs(got - ref).max(), np.abs(ref).max())
+    got = A.griffin_lim_gpu(spec).cpu().numpy().astype(np.float64)        # hparams: 60 iterations
+    ref = AO.inv_spectrogram_tensorflow(spec, HP)
+    # this signal is well conditioned: rounding the oracle's state to float32 at every iteration moves its 60-iteration
+    # waveform by 8e-7 of the peak, so the fp32 kernel chain is held to a sample-wise bound as well
+    assert np.abs(got - ref).max() < 5e-3 * np.abs(ref).max(), (np.abs(got - ref).max(), np.abs(ref).max())
+    Sg, Sr = np.abs(AO.tf_stft(got, 2048, 250, 1000)), np.abs(AO.tf_stft(ref, 2048, 250, 1000))
+    rel = np.linalg.norm(Sg - Sr) / np.linalg.norm(Sr)
+    assert rel < 1e-3, rel

@@ -35,3 +35,13 @@ def test_bucketed_allreduce_inside_backward_matches_sum_of_rank_gradients(dev):
     if out.returncode != 0:
         sys.stderr.write(out.stderr)          # full child tracebacks in the captured output
     assert out.returncode == 0 and "DP_CHECK_OK" in out.stdout, out.stdout[-1500:]
+
+
+def test_nccl_backend_one_rank_full_step(dev):
+    """RCCL itself (backend 'nccl'), one rank on the one GPU: bucket hand-off, RCCL's stream, wait(), check_status()."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_check.py")], cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:
+        sys.stderr.write(out.stderr)
+    assert out.returncode == 0 and "NCCL_CHECK_OK" in out.stdout, out.stdout[-1500:]

@@ -102,6 +102,40 @@ def test_rank_dealing(tmp_path):
     assert merged[0::2] == per_rank[0] and merged[1::2] == per_rank[1]
 
 
+def test_ranks_pad_to_the_global_batch(tmp_path):
+    """the loss is an unmasked mean, so the mean of the ranks' losses is the global loss only if the ranks
+    pad to the same T_out.  Global step k is the same slice of the sorted group on every rank, padded to ITS longest
+    target."""
+    hp = _hp()
+    root = _corpus(tmp_path, 40)
+    per_rank = []
+    for rank in range(2):
+        loader, features, _ = _stubs(hp)
+        f = DataFeeder(hp, ljspeech=root, seed=9, rank=rank, world=2, prefetch=False, features=features, loader=loader)
+        per_rank.append([f.next_batch() for _ in range(6)])           # two groups
+    for (_, _, m0, l0), (_, _, m1, l1) in zip(*per_rank):
+        assert m0.shape[1] == m1.shape[1] == l0.shape[1] == l1.shape[1]
+        longest = max(int(round(m[:, :, 0].sum(axis=1).max() / 0.25)) for m in (m0, m1))     # the stub's mel is 0.25
+        r = hp.outputs_per_step
+        assert m0.shape[1] == (longest + 1 + r - 1) // r * r
+
+
+def test_prefetch_thread_binds_its_device(tmp_path, monkeypatch):
+    """torch's current device is per host thread: the worker must select the rank's GPU itself before the feature
+    kernels run (train.py calls set_device only in the main thread)."""
+    import threading
+
+    import torch
+    seen = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: seen.append((threading.current_thread().name, d)))
+    hp = _hp()
+    root = _corpus(tmp_path, 12)
+    loader, features, _ = _stubs(hp)
+    f = DataFeeder(hp, ljspeech=root, seed=1, prefetch=True, features=features, loader=loader, device=1)
+    f.next_batch()
+    assert ("datafeeder", 1) in seen
+
+
 def test_cmudict_substitution(tmp_path):
     hp = _hp()
     root = _corpus(tmp_path, 12)

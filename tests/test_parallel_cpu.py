@@ -72,3 +72,47 @@ def test_bucketed_allreduce_world2_gloo():
     out = mgr.dict()
     mp.spawn(_worker, args=(world, port, size, out), nprocs=world, join=True)
     assert dict(out) == {0: True, 1: True}
+
+
+def test_reducer_refuses_a_step_that_skipped_a_bucket():
+    g = torch.zeros(100)
+    red = parallel.GradReducer(g, [("head", 50, 100), ("encoder", 0, 50)])
+    red.bucket_ready("head")
+    with __import__("pytest").raises(RuntimeError, match="exactly once"):
+        red.wait()                       # 'encoder' never released
+    red.bucket_ready("head")
+    red.bucket_ready("encoder")
+    red.wait()                           # a complete step passes, and the counts start afresh
+    red.bucket_ready("head")
+    red.bucket_ready("head")
+    red.bucket_ready("encoder")
+    with __import__("pytest").raises(RuntimeError, match="exactly once"):
+        red.wait()                       # released twice
+    with __import__("pytest").raises(KeyError):
+        red.bucket_ready("postnet")
+
+
+def test_bucket_layout_matches_the_model_family():
+    """train.py applies data parallelism to any --model: Tacotron-1 has none of the Tacotron-2 scopes, so it gets one
+    whole-buffer bucket released after backward(); asking for the Tacotron-2 buckets on its layout is a clear error."""
+    hp1 = hparams_mod.load("taco1")
+    lay1, _ = P.taco1_layout(hp1, 149)
+    with __import__("pytest").raises(ValueError, match="not a Tacotron-2 layout|outside every bucket"):
+        parallel.bucket_ranges(lay1)
+    assert parallel.whole_buffer_range(lay1) == [("all", 0, lay1.size)]
+
+    class M1:          # what make_reducer reads off a model
+        _BUCKET_AFTER = {"backward": "all"}
+        layout = lay1
+        flat_g = torch.zeros(lay1.size)
+    red = parallel.make_reducer(M1())
+    assert list(red.buckets) == ["all"]
+    hp2 = hparams_mod.load("taco2")
+    lay2, _ = P.taco2_layout(hp2, 149)
+
+    class M2:
+        _BUCKET_AFTER = {"expand_conv_bwd": "head", "postnet_bwd": "postnet", "attn_wgrad": "decoder",
+                         "encoder_bwd": "encoder"}
+        layout = lay2
+        flat_g = torch.zeros(lay2.size)
+    assert sorted(parallel.make_reducer(M2()).buckets) == ["decoder", "encoder", "head", "postnet"]

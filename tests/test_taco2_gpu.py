@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import make_batch, oracle_run, small_hparams, stabilise_targets
+from util import make_batch, oracle_run, small_hparams, stabilise_targets, well_posed_batch
 
 pytestmark = pytest.mark.gpu
 
@@ -28,9 +28,11 @@ def test_taco2_fp32_forward_backward_matches_oracle(dev, shape):
     N, Ti, To = shape
     hp = small_hparams()
     m = _model(hp, "fp32")
-    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N)
     params, stats = m.numpy_params(), m.numpy_stats()
-    mel, lin = stabilise_targets(hp, params, stats, inputs, lengths, mel, lin)
+    # inputs on which no ReLU pre-activation of the oracle sits within rounding noise of the kink (and no L1 term within
+    # noise of its sign change): float32 and float64 then take the same branch everywhere and EVERY gradient can be held
+    # to the max-norm bound.  The BatchNorm sums are deterministic (ns_gemm stat_part), so this is repeatable.
+    inputs, lengths, mel, lin = well_posed_batch(hp, params, stats, N, Ti, To, seed=N, margin=1e-6)
     out, (loss, mel_loss, lin_loss), grads = oracle_run(hp, params, stats, inputs, lengths, mel, lin)
     m.initialize(inputs, lengths, None, mel, lin)
     m.backward()
@@ -46,23 +48,13 @@ def test_taco2_fp32_forward_backward_matches_oracle(dev, shape):
     assert abs(m.mel_loss - mel_loss) < ltol and abs(m.linear_loss - lin_loss) < ltol
     got = m.numpy_grads()
     bad = []
-    # The larger edge shapes have ~1e4 ReLU pre-activations per expand / encoder conv; with fp32-vs-float64 differences
-    # of ~1e-6 one of them changes side of the kink in about one run out of ten, and that single element moves the
-    # gradients upstream of it by up to a few per cent (measured: 2-8e-2, no L1 sign flips, different from run to run
-    # on identical inputs).  Those shapes are therefore held to an L2 bound; the small ones to the max-norm bound.
-    strict = N * To <= 200
     for k in grads:
         scale = np.abs(grads[k]).max()
         err = np.abs(got[k] - grads[k]).max()
         # fp32 on the GPU vs float64 on the CPU through ~10 BatchNorms over a few hundred samples;
         # typical error is 1e-4 of the tensor's scale, the bound leaves room for the worst tensor
-        if strict:
-            if err > 2e-3 * scale + 5e-6:      # the floor covers conv biases in front of BatchNorm (true gradient 0)
-                bad.append((k, float(err), float(scale)))
-        elif not k.endswith("conv1d/bias"):
-            l2 = np.linalg.norm(got[k] - grads[k]) / (np.linalg.norm(grads[k]) + 1e-12)
-            if l2 > 5e-2:
-                bad.append((k, float(l2)))
+        if err > 2e-3 * scale + 5e-6:      # the floor covers conv biases in front of BatchNorm (true gradient 0)
+            bad.append((k, float(err), float(scale)))
     assert not bad, bad
     # BatchNorm moving statistics (UPDATE_OPS)
     st = m.numpy_stats()
@@ -281,3 +273,44 @@ def test_taco2_full_size_mixed_gradients_follow_split_bf16(dev):
         if cos < 0.7:
             bad.append((k, cos))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("mode", ["fp32", "mixed"])
+def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
+    """BatchNorm batch statistics and the BatchNorm-backward sums are added up in a fixed order (no float atomics), so
+    two passes over the same inputs give the same bits for every output and for the gradient that flows through the
+    network; only the final weight-gradient sums (split-K atomics, bias / table scatter sums) may differ, by rounding."""
+    N, Ti, To = 6, 30, 60
+    hp = small_hparams()
+    m = _model(hp, mode)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=21)
+    runs = []
+    for _ in range(2):
+        m.initialize(inputs, lengths, None, mel, lin)
+        m.backward()
+        torch.cuda.synchronize()
+        runs.append(dict(mel=m.mel_outputs.clone(), lin=m.linear_outputs.clone(), al=m.alignments.clone(),
+                         dmel=m._bufs["d_mel"].clone(), dvalues=m._bufs["d_values"].clone(), g=m.flat_g.clone()))
+    a, b = runs
+    for k in ("mel", "lin", "al", "dmel", "dvalues"):
+        assert torch.equal(a[k], b[k]), k
+    g0, g1 = a["g"].double(), b["g"].double()
+    for name, (off, shape) in m.layout.entries.items():
+        n = int(np.prod(shape))
+        d = (g0[off:off + n] - g1[off:off + n]).abs().max().item()
+        sc = g0[off:off + n].abs().max().item()
+        assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
+
+
+def test_model_audio_is_griffin_lim_of_the_linear_outputs(dev):
+    """tacotron.py:107 / train.py:100-102: model.audio[0] is the in-graph Griffin-Lim of linear_outputs[0]."""
+    from nspeech_amd.utils import audio as A
+    hp = small_hparams(frame_length_ms=5.0, frame_shift_ms=1.25)      # n_fft 128, window 100, hop 25 at num_freq 65
+    m = _model(hp, "fp32")
+    inputs, lengths, mel, lin = make_batch(hp, 2, 9, 20, seed=1)
+    m.initialize(inputs, lengths, None, mel, lin)
+    assert len(m.audio) == 2
+    w0 = m.audio[0]
+    want = A.griffin_lim_gpu(m.linear_outputs[0].float().contiguous())
+    assert w0.shape == ((20 - 1) * 25 + 100,) and torch.equal(w0, want)
+    assert torch.equal(m.audio.all()[1], m.audio[1])

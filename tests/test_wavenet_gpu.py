@@ -187,3 +187,64 @@ def test_wavenet_mfma_chain_close_to_valu_chain(dev):
     b = m.generate(seeds, 48, uniforms=un, engine=1).cpu().numpy()
     assert a.min() >= 0 and a.max() < hp.quantization_channels and np.array_equal(a[:, :rf + 9], seeds)
     assert (a == b).mean() > 0.5          # histories part ways at the first differing draw
+
+
+def _shipped():
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models.wavenet import receptive_field
+    hp = hparams_mod.load("wavenet")          # wavenet.yaml as shipped: 5 x 10 layers, R = Dc = 32, S = 512, Q = 256
+    assert receptive_field(hp) == 5117
+    return hp, 5117
+
+
+def test_wavenet_shipped_config_matches_oracle(dev):
+    """The configuration bench.py times (50 layers, receptive field 5117): logits, loss and every gradient of one clip
+    of receptive field + 16 samples against the float64 oracle, in exact-fp32 mode."""
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_encode
+    hp, rf = _shipped()
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="fp32", seed=4)
+    audio = _audio(1, rf + 16, seed=12)
+    ids = mu_law_encode(audio, hp.quantization_channels)
+    loss, logits, grads = _oracle(hp, m.numpy_params(), ids)
+    assert logits.shape == (1, 16, 256)
+    m.initialize(audio)
+    m.backward()
+    got_loss = m.read_losses()
+    assert np.abs(m.raw_output.cpu().numpy() - logits).max() < 5e-5 * max(1.0, np.abs(logits).max())
+    assert abs(got_loss - loss) < 1e-5 * max(1.0, abs(loss))
+    got = m.numpy_grads()
+    for k in grads:
+        scale = np.abs(grads[k]).max()
+        assert np.abs(got[k] - grads[k]).max() < 2e-4 * scale + 1e-8, (k, np.abs(got[k] - grads[k]).max(), scale)
+
+
+def test_wavenet_mfma_generator_matches_oracle_distribution_at_shipped_config(dev):
+    """The engine bench.py times (MFMA chain, bf16 weights and bf16-rounded layer inputs) against the float64 oracle on
+    the same history: the next-sample distribution behind the first drawn sample.  Stated bf16 bound: 50 layers, each
+    rounding its 32-wide input to 8 significant bits (2^-9 relative), accumulate ~sqrt(50) * 2^-9 ~ 1.4e-2 relative on
+    the skip sums; with the last layer sharpened 10x that is a few 1e-2 on the largest logits, so total variation
+    distance < 5e-2 and every probability within 15 % of the largest one."""
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.wavenet import mu_law_encode
+    from oracle import wavenet_oracle as O
+    hp, rf = _shipped()
+    m = create_model("simple_wavenet", hp, device="cuda:0", dtype="bf16", seed=8)
+    p = m.numpy_params()
+    p["wavenet/postprocessing/postprocess2"] = p["wavenet/postprocessing/postprocess2"] * 10.0
+    m.load_numpy_params(p)
+    seeds = mu_law_encode(_audio(2, rf + 8, seed=4), hp.quantization_channels)
+    un = np.random.default_rng(2).random((2, 1))
+    out = m.generate(seeds, 1, uniforms=un, engine=2).cpu().numpy()
+    pa = m.last_probs.view(2, -1).cpu().numpy().astype(np.float64)
+    pt = {k: torch.tensor(v, dtype=torch.float64) for k, v in m.numpy_params().items()}
+    for b in range(2):
+        ref = O.predict_proba(pt, hp.values(), torch.tensor(seeds[b])).numpy()
+        assert ref.max() > 4.0 / 256, ref.max()            # a distribution with structure, not the uniform one
+        tv = 0.5 * np.abs(pa[b] - ref).sum()
+        worst = np.abs(pa[b] - ref).max() / ref.max()
+        print("wavenet MFMA generator vs oracle: TV %.3e, worst |dp| / max p %.3e" % (tv, worst))
+        assert abs(pa[b].sum() - 1.0) < 1e-4 and tv < 5e-2 and worst < 0.15, (b, tv, worst)
+        # the draw is the inverse CDF of the kernel's own distribution at the given uniform number
+        c = np.cumsum(pa[b])
+        assert abs(int(out[b, -1]) - int(min(np.searchsorted(c, un[b, 0] * c[-1], side="right"), 255))) <= 1

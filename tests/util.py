@@ -77,3 +77,31 @@ def stabilise_targets(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3,
         mel[bm] -= 10 * margin
         lin[bl] -= 10 * margin
     return mel.astype(np.float32), lin.astype(np.float32)
+
+
+def kink_margin(hp, params, stats, inputs, lengths, mel, lin, speaker_ids=None):
+    """Smallest non-zero |ReLU pre-activation| of the oracle's forward pass on these inputs."""
+    from oracle import taco2_oracle as O
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in params.items()}
+    p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in stats.items()})
+    O.KINK_LOG = []
+    try:
+        with torch.no_grad():
+            O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
+                            torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64),
+                            speaker_ids=None if speaker_ids is None else torch.tensor(speaker_ids))
+        return min(O.KINK_LOG)
+    finally:
+        O.KINK_LOG = None
+
+
+def well_posed_batch(hp, params, stats, N, Ti, To, seed, margin=2e-5, tries=12):
+    """A synthetic batch (targets stabilised) none of whose ReLU pre-activations lies within `margin` of the kink, so
+    that a float32 run and the float64 oracle take the same side everywhere and the gradients can be compared in the
+    max norm.  Walks the data seeds from `seed`; deterministic."""
+    for s in range(seed, seed + tries):
+        inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=s)
+        mel, lin = stabilise_targets(hp, params, stats, inputs, lengths, mel, lin)
+        if kink_margin(hp, params, stats, inputs, lengths, mel, lin) > margin:
+            return inputs, lengths, mel, lin
+    raise AssertionError("no well-posed batch within %d seeds" % tries)

@@ -45,15 +45,31 @@ def log(msg, path=None):
             f.write("[%s]  %s\n" % (time.strftime("%Y-%m-%d %H:%M:%S"), msg))
 
 
-def save_checkpoint(model, log_dir, step, keep=5):
-    path = os.path.join(log_dir, "model.ckpt-%d" % step)
-    torch.save(model.state_dict(), path)
-    with open(os.path.join(log_dir, "checkpoint"), "w") as f:
-        f.write('model_checkpoint_path: "model.ckpt-%d"\n' % step)
-    ck = sorted((int(n.split("-")[-1]), n) for n in os.listdir(log_dir) if n.startswith("model.ckpt-"))
-    for _, n in ck[:-keep]:            # tf.train.Saver(max_to_keep=5), train.py:60
-        os.remove(os.path.join(log_dir, n))
-    return path
+class CheckpointSaver(object):
+    """tf.train.Saver(max_to_keep=5, keep_checkpoint_every_n_hours=2) of the reference (train.py:60): the newest
+    `max_to_keep` files stay; when an older one falls out of that window it is deleted - unless it was written later
+    than the next keep-forever mark, in which case it stays for good and the mark moves on by `keep_every_n_hours`
+    (the mark starts that far after the saver was created)."""
+
+    def __init__(self, log_dir, max_to_keep=5, keep_every_n_hours=2.0, clock=time.time):
+        self.log_dir, self.max_to_keep, self.every = log_dir, max_to_keep, keep_every_n_hours * 3600.0
+        self.clock = clock
+        self.recent = []                                   # [(path, time written)], oldest first
+        self.next_keep_time = clock() + self.every
+
+    def save(self, model, step):
+        path = os.path.join(self.log_dir, "model.ckpt-%d" % step)
+        torch.save(model.state_dict(), path)
+        with open(os.path.join(self.log_dir, "checkpoint"), "w") as f:
+            f.write('model_checkpoint_path: "model.ckpt-%d"\n' % step)
+        self.recent = [r for r in self.recent if r[0] != path] + [(path, self.clock())]
+        while len(self.recent) > self.max_to_keep:
+            old, written = self.recent.pop(0)
+            if written > self.next_keep_time:
+                self.next_keep_time += self.every         # kept for good
+            elif os.path.exists(old):
+                os.remove(old)
+        return path
 
 
 def train(log_dir, args):
@@ -86,16 +102,17 @@ def train(log_dir, args):
         if tf_bundle.is_bundle(path):          # a TensorFlow checkpoint of the reference (Adam slots start afresh)
             tf_bundle.load_into_model(model, path)
         else:
-            model.load_state_dict(torch.load(path, map_location="cpu"))
+            model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
         step0 = model.global_step
         log("Resuming from checkpoint: %s" % path, logf)
     if world > 1:
         parallel.broadcast_parameters(model, 0)
-        model.reducer = parallel.GradReducer(model.flat_g, parallel.bucket_ranges(model.layout))
+        model.reducer = parallel.make_reducer(model)
     model.add_loss()
     model.add_optimizer(step0)
     model.add_stats()
     time_window, loss_window = ValueWindow(100), ValueWindow(100)
+    saver = CheckpointSaver(log_dir)
     while args.max_steps is None or model.global_step < args.max_steps:
         t0 = time.time()
         inputs, lengths, mel, lin = feeder.next_batch()
@@ -114,10 +131,9 @@ def train(log_dir, args):
             log("Loss exploded to %.05f at step %d!" % (loss, step), logf)
             raise Exception("Loss Exploded")
         if rank == 0 and step % args.checkpoint_interval == 0:
-            path = save_checkpoint(model, log_dir, step)
+            path = saver.save(model, step)
             log("Saved checkpoint %s" % path, logf)
-            wav = audio.inv_spectrogram_tensorflow(model.linear_outputs[0].float().contiguous())
-            wav = audio.inv_preemphasis(wav.cpu().numpy())
+            wav = audio.inv_preemphasis(model.audio[0].cpu().numpy())      # train.py:100-107 fetches model.audio[0]
             audio.save_wav(wav[:audio.find_endpoint(wav)], os.path.join(log_dir, "step-%06d-audio.wav" % step))
     return model
 
