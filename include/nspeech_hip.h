@@ -427,6 +427,17 @@ int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 size_t ns_taco2_attn_work_bytes(const ns_taco2_attn_params* p);
 
+/* The same recurrence as ONE persistent launch (per 32 utterances) instead of ~12 dependent launches per step pair:
+ * an utterance runs on a cluster of 8 workgroups that keep the prenet-2 / attention-LSTM / query weights in registers
+ * (exact fp32 products), the utterance's keys and memory.W1c rows in LDS, and exchange two small vectors per step
+ * through `work` with tagged 8-byte granules.  Needs the projected-memory form (pv), D1 = 256, D2 = 128, A in
+ * {64, 256}, T_in <= 256; reads the natural-layout weights w2 / watt / wq.  Same history outputs as
+ * ns_taco2_attn_fwd / _bwd.  work: ns_taco2_attn_cluster_work_bytes(); work[0] (int) is a status word, non-zero
+ * after the call completes = an exchange timed out and the outputs are invalid. */
+int ns_taco2_attn_cluster_supported(const ns_taco2_attn_params* p);
+size_t ns_taco2_attn_cluster_work_bytes(const ns_taco2_attn_params* p);
+int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* work, ns_stream_t stream);
+
 
 /* ------------------------------------------------------------------ simple WaveNet (models/wavenet_simple.py)
  * Row r of every series buffer is (n, t) = (r / T, r %% T) on ONE time grid of T = (clip length - 1) rows per item;

@@ -593,6 +593,22 @@ __global__ void attn_p1_init_kernel(const float* f1, T* p1, int N, long S1, int 
   stf(p1 + o, fmaxf(f1[o], 0.f));
 }
 
+// Projected-memory form: the contexts feed nothing inside the loop, so they are one product per batch item over all
+// steps afterwards, hc[n, 1..S, A:] = align[n, 1..S, :] . memory[n]  (also the tail of the persistent forward kernel)
+int ns_attn_contexts_after_loop(const ns_taco2_attn_params& p, hipStream_t s) {
+  const long S1 = p.S + 1, A = p.A, E = p.E, HC = A + E;
+  const long esz = p.dtype == NS_BF16 ? 2 : 4;
+  NS_CHECK_ARG(p.align_t != nullptr, "ns_taco2_attn_fwd: the projected-memory form needs align_t");
+  ns_gemm_params g = {};
+  g.dtype = p.dtype; g.M = p.S; g.N = (int)E; g.K = p.Ti;
+  g.A = (const char*)p.align_t + p.Tia * esz; g.lda = p.Tia; g.a_mode = 0;
+  g.B = (const char*)p.values + (long)p.padl_i * E * esz; g.ldb = E; g.b_mode = 1;
+  g.C = (char*)p.hc + (HC + A) * esz; g.ldc = HC; g.c_dtype = p.dtype;
+  g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = (long)p.Pi * E; g.batch_stride_c = S1 * HC;
+  g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
+  return ns_gemm(&g, s);
+}
+
 template <typename T>
 static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
@@ -674,22 +690,7 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     }
     NS_CHECK_LAUNCH("attn_fwd");
   }
-  if (pvm) {
-    // the contexts themselves feed nothing inside the loop any more: one product per batch item over all steps,
-    // hc[n, 1..S, A:] = align[n, 1..S, :] . memory[n]
-    NS_CHECK_ARG(p.align_t != nullptr, "ns_taco2_attn_fwd: the projected-memory form needs align_t");
-    {
-      ns_gemm_params g = {};
-      g.dtype = dt; g.M = p.S; g.N = (int)E; g.K = p.Ti;
-      g.A = (const T*)p.align_t + p.Tia; g.lda = p.Tia; g.a_mode = 0;
-      g.B = (const T*)p.values + (long)p.padl_i * E; g.ldb = E; g.b_mode = 1;
-      g.C = (T*)p.hc + HC + A; g.ldc = HC; g.c_dtype = dt;
-      g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = (long)p.Pi * E; g.batch_stride_c = S1 * HC;
-      g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
-      int rc = ns_gemm(&g, s);
-      if (rc) return rc;
-    }
-  }
+  if (pvm) return ns_attn_contexts_after_loop(p, s);
   return NS_OK;
 }
 

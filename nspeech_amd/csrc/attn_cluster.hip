@@ -1,0 +1,481 @@
+// Tacotron-2 attention RNN (prenet-2 -> attention LSTM -> query -> location-sensitive energies -> softmax ->
+// next step's prenet layer) as ONE persistent launch per direction instead of ~12 dependent launches per step pair
+// (rnn_wrappers.py:25-31, modules.py:83-102, attention.py:30-60 under the teacher-forced decoder of tacotron2.py:63-83).
+//
+// Every operation of this chain is independent per utterance and its weights are stationary (0.98 M values), so an
+// utterance gets a CLUSTER of G = 8 workgroups (one per CU, 512 threads) that keeps everything it needs on chip for
+// the whole sequence - the weights in REGISTERS as fp32 (the products are matrix-VECTOR at one utterance per
+// cluster, so they run as exact fp32 FMAs from registers; an MFMA would spend 15/16 of its rows on nothing), the
+// utterance's keys and projected memory in LDS:
+//   workgroup g owns  * LSTM units [g*A/8, (g+1)*A/8): the 4 gate columns of each, all K = D2 + A input rows
+//                     * the rows of W_query that belong to those units (all A query columns)
+//                     * all of W_prenet2 (every workgroup computes the whole p2: cheaper than a third exchange)
+//                     * memory positions [g*ts, (g+1)*ts), ts = ceil(length / 8): keys and memory.W1c rows
+// and a step needs only TWO exchanges inside the cluster (8-byte {step tag, fp32} granules, written and polled with
+// relaxed agent-scope atomics = sc1; the data is its own flag, cdna guide G16 / R2):
+//   X2: partial queries h_slice . Wq[slice, :]  (A values) + the new h slice          -> every workgroup sums q, has h
+//   X3: partial next-prenet sums  sum_t w[t] pv[t, :]  (D1 values) + the local softmax max / sum + the local
+//       unnormalised weights w[t]                          -> every workgroup forms p1[s+1] and the whole alignment
+// (the softmax is combined flash-attention style: local max m_g, w = exp(e - m_g), global rescale exp(m_g - m) / L).
+// One buffer per exchange suffices: X2 of step s+1 is published only after X3 of step s has been gathered from every
+// peer, and a peer publishes that only after it has gathered X2 of step s - nobody can still be reading it.
+// Every spin is bounded; on timeout the kernel raises *status and every workgroup of the cluster leaves.
+// All history the backward pass and the hoisted products read (p1, xa, hc, ca, ga, q, align, align_t) is written in
+// the layouts of ns_taco2_attn_fwd, which stays as the fallback for shapes this kernel does not cover.
+#include "common.h"
+
+int ns_attn_contexts_after_loop(const ns_taco2_attn_params& p, hipStream_t s);     // attn.hip
+
+typedef unsigned long long u64;
+namespace {
+constexpr int CG = 8;              // workgroups per utterance
+constexpr int CT = 512;            // threads per workgroup
+constexpr int TSMAX = 32;          // memory positions per workgroup (T_in <= 256)
+constexpr int KWMAX = 8;
+constexpr int APAD = 8;            // zero margin around the alignment vector in LDS
+constexpr unsigned SPIN_LIMIT = 2000000u;
+
+template <int A_, int D1_, int D2_>
+struct Cfg {
+  static constexpr int A = A_, D1 = D1_, D2 = D2_;
+  static constexpr int UPW = A / CG;           // LSTM units per workgroup
+  static constexpr int GC = 4 * UPW;           // gate columns per workgroup
+  static constexpr int K = D2 + A;             // in-loop input rows of the attention LSTM (speaker rows fold into the bias)
+  static constexpr int GG = CT / GC, GK = K / GG;        // gates: k groups, k per thread
+  static constexpr int P2G = CT / D2, P2K = D1 / P2G;    // prenet-2
+  static constexpr int QG = CT / A, QK = UPW / QG;       // query partials / energy t-groups
+  static constexpr int CXG = CT / D1;                    // context t-groups
+  static constexpr int X2N = A + UPW;                    // granules per workgroup, exchange 2
+  static constexpr int X3N = D1 + 2 + TSMAX;             // exchange 3
+  static constexpr int XMAX = X2N > X3N ? X2N : X3N;
+  static_assert(A % CG == 0 && CT % GC == 0 && K % GG == 0 && CT % D2 == 0 && D1 % P2G == 0, "shape");
+  static_assert(CT % A == 0 && UPW % QG == 0 && CT % D1 == 0, "shape");
+};
+
+struct ACArgs {
+  ns_taco2_attn_params p;
+  u64* x2; u64* x3;          // [N][CG][X2N], [N][CG][X3N]
+  int* status;
+};
+
+__device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
+  __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every thread waits for its own granules (PER per thread, stride CT) and drops the values into LDS.
+template <int PER>
+__device__ __forceinline__ void gather_granules(const u64* src, int total, unsigned tag, float* dst, int tid,
+                                                int* status, int code) {
+  u64 v[PER];
+  unsigned spins = 0;
+  bool ok;
+  do {
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int i = tid + j * CT;
+      v[j] = i < total ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)tag << 32);
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
+    if (!ok) {
+      ++spins;
+      if (spins > SPIN_LIMIT) { atomicExch(status, code); ok = true; }
+      else if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = true;
+    }
+  } while (!ok);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + j * CT;
+    if (i < total) dst[i] = __uint_as_float((unsigned)v[j]);
+  }
+}
+
+template <typename T> __device__ __forceinline__ float ldw(const T* p, long i) { return ldf(p + i); }
+
+// sum_i w[i] * x[i] with the weights in registers and x in LDS (wave-uniform addresses: broadcast reads).  The chunks
+// are fenced so that the compiler keeps at most two chunks of x in flight instead of hoisting every LDS read of the
+// product to its top (the weights already take most of the register file).
+template <int NK>
+__device__ __forceinline__ float dot_regs(const float (&w)[NK], const float* x) {
+  static_assert(NK % 4 == 0 || NK < 4, "chunking");
+  float s0 = 0.f, s1 = 0.f;
+  if constexpr (NK < 4) {
+#pragma unroll
+    for (int i = 0; i < NK; ++i) s0 = fmaf(w[i], x[i], s0);
+    return s0;
+  } else {
+    float4 cur = *(const float4*)x;
+#pragma unroll
+    for (int i = 0; i < NK; i += 4) {
+      float4 nxt = cur;
+      if (i + 4 < NK) nxt = *(const float4*)(x + i + 4);
+      s0 = fmaf(w[i], cur.x, s0); s1 = fmaf(w[i + 1], cur.y, s1);
+      s0 = fmaf(w[i + 2], cur.z, s0); s1 = fmaf(w[i + 3], cur.w, s1);
+      // the sums pass through the fence: this chunk's FMAs cannot sink below it, later reads cannot rise above it
+      asm volatile("" : "+v"(s0), "+v"(s1) :: "memory");
+      cur = nxt;
+    }
+    return s0 + s1;
+  }
+}
+
+// ===================================================================================== forward
+template <typename T, typename C>
+__global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
+  constexpr int A = C::A, D1 = C::D1, D2 = C::D2, UPW = C::UPW, GC = C::GC, K = C::K;
+  constexpr int GG = C::GG, GK = C::GK, P2G = C::P2G, P2K = C::P2K, QG = C::QG, QK = C::QK, CXG = C::CXG;
+  constexpr int X2N = C::X2N, X3N = C::X3N;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const ns_taco2_attn_params& p = a.p;
+  float* xs = sm;                          // [K]      LSTM input: p2 | h(s-1)
+  float* p1s = xs + K;                     // [D1]     prenet layer 1 of the current step
+  float* red = p1s + D1;                   // [CT]     partial sums across the k / t groups of a product
+  float* qs = red + CT;                    // [A]      query
+  float* al = qs + A;                      // [APAD + 256 + APAD] alignment of the previous step, zero margins
+  float* es = al + 256 + 2 * APAD;         // [TSMAX]  local unnormalised softmax weights
+  float* ered = es + TSMAX;                // [CT/64][TSMAX/QG + 1] per-wave energy sums
+  float* hloc = ered + (CT / 64) * (TSMAX / QG + 1);    // [UPW] new h of this workgroup's units
+  float* sc = hloc + UPW;                  // [16]     [0] local max, [1] local sum, [2] abort flag
+  float* gath = sc + 16;                   // [CG][XMAX]
+  float* keys_s = gath + CG * C::XMAX;     // [TSMAX][A]
+  float* pv_s = keys_s + TSMAX * A;        // [TSMAX][D1]
+  float* wq_s = pv_s + TSMAX * D1;         // [UPW][A]  W_query rows of the own units
+  float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]  folded location filter, attention_v
+
+  const int tid_ = threadIdx.x;
+  const int n = blockIdx.x / CG, g = blockIdx.x % CG;
+  const long S1 = p.S + 1;
+  const int Dsp = p.Dsp, XA = D2 + Dsp + A, HC = A + p.E;
+  const int L = min(p.lengths ? p.lengths[n] : p.Ti, p.Ti);
+  const int ts = (L + CG - 1) / CG;                       // positions per workgroup
+  const int t0 = g * ts, tn = max(0, min(L, t0 + ts) - t0);      // own slice [t0, t0 + tn)
+  const int half = (p.kw - 1) / 2;
+  u64* x2 = a.x2 + (size_t)n * CG * X2N;
+  u64* x3 = a.x3 + (size_t)n * CG * X3N;
+
+  // ---------------------------------------------------------------- resident weights (registers)
+  const T* W2 = (const T*)p.w2;            // [D1][D2]
+  const T* Watt = (const T*)p.watt;        // [D2 + Dsp + A][4A]
+  const T* Wq = (const T*)p.wq;            // [A][A]
+  const int tid = tid_;
+  const int p2c = tid % D2, p2q0 = tid / D2;
+  float w2r[P2K];
+  {
+    const T* b = W2 + (long)(p2q0 * P2K) * D2 + p2c;          // one base pointer, constant strides
+#pragma unroll
+    for (int i = 0; i < P2K; ++i) w2r[i] = ldf(b + i * D2);
+  }
+  const int gc = tid % GC, gq0 = tid / GC;
+  const int gcol = (gc / UPW) * A + g * UPW + (gc % UPW);          // column of the [.., 4A] kernel
+  float wgr[GK];
+  {
+    // rows behind the prenet part skip the speaker rows (their product is folded into the bias)
+    const int k0 = gq0 * GK;
+    const T* blo = Watt + (long)k0 * 4 * A + gcol;
+    const T* bhi = blo + (long)Dsp * 4 * A;
+#pragma unroll
+    for (int i = 0; i < GK; ++i) wgr[i] = ldf((k0 + i < D2 ? blo : bhi) + i * 4 * A);
+  }
+  // W_query rows of this workgroup's units and the per-unit constants of the energy pass live in LDS (the register
+  // file is taken by the two big weight slices): wq_s[UPW][A], cst_s[KWMAX + 1][A] = folded location filter | v
+  for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
+  for (int i = tid; i < (KWMAX + 1) * A; i += CT) {
+    const int k = i / A, u = i % A;
+    cst_s[i] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
+  }
+  // cell owner threads: tid < UPW
+  float cstate = 0.f;
+  float gbias[4] = {0.f, 0.f, 0.f, 0.f};
+  if (tid < UPW) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int col = j * A + g * UPW + tid;
+      float b = p.batt[col];
+      // the speaker projection is the same in every step: its product joins the bias
+      const T* spk = (const T*)p.xa + ((long)n * S1 + 1) * XA + D2;
+      for (int k = 0; k < Dsp; ++k) b = fmaf(ldf(spk + k), ldw(Watt, (long)(D2 + k) * 4 * A + col), b);
+      gbias[j] = b;
+    }
+  }
+  const float b2c = tid < D2 ? p.b2[tid] : 0.f;
+
+  // ---------------------------------------------------------------- per-utterance LDS images
+  {
+    const float* kn = p.keys + ((long)n * p.Pi + p.padl_i + t0) * A;
+    for (int i = tid; i < TSMAX * A; i += CT) keys_s[i] = (i / A) < tn ? kn[i] : 0.f;
+    const T* pvn = (const T*)p.pv + ((long)n * p.Pi + p.padl_i + t0) * D1;
+    for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
+    for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
+    for (int i = tid; i < K; i += CT) xs[i] = 0.f;
+    if (tid < D1) p1s[tid] = fmaxf(p.f1[((long)n * S1 + 1) * D1 + tid], 0.f);     // context before the first step is 0
+  }
+  // slot 1 of p1 (history): the share of this workgroup
+  if (tid < D1 && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + 1) * D1 + tid, fmaxf(p.f1[((long)n * S1 + 1) * D1 + tid], 0.f));
+  __syncthreads();
+
+  for (int st = 0; st < p.S; ++st) {
+    const long slot = st + 1;
+    const unsigned tag = (unsigned)(st + 1);
+    // The thread index is made opaque once per step: every address below is then recomputed inside the iteration
+    // (a few VALU instructions) instead of being hoisted out of the loop as ~40 loop-invariant 64-bit pointers,
+    // which the register file has no room for beside the resident weights.
+    int tid = tid_;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p2q = tid / D2, gq = tid / GC, qu = tid % A, qq = tid / A;
+    // next step's hoisted frame term, needed at the very end of this step
+    float f1n = 0.f;
+    if (tid < D1 && st + 1 < p.S) f1n = p.f1[((long)n * S1 + slot + 1) * D1 + tid];
+
+    // ---- (1) p2 = relu(p1 . W2 + b2): every workgroup computes all of it
+    red[tid] = dot_regs<P2K>(w2r, p1s + p2q * P2K);
+    __syncthreads();
+    if (tid < D2) {
+      float s = b2c;
+#pragma unroll
+      for (int q = 0; q < P2G; ++q) s += red[q * D2 + tid];
+      s = fmaxf(s, 0.f);
+      xs[tid] = s;
+      if (tid / (D2 / CG) == g) stf((T*)p.xa + ((long)n * S1 + slot) * XA + tid, s);
+    }
+    __syncthreads();
+    // ---- (2) gates of this workgroup's units, cell update
+    red[tid] = dot_regs<GK>(wgr, xs + gq * GK);
+    __syncthreads();
+    if (tid < UPW) {
+      float z[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float s = gbias[j];
+#pragma unroll
+        for (int q = 0; q < GG; ++q) s += red[q * GC + j * UPW + tid];
+        z[j] = s;
+      }
+      const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + 1.0f), go = sigmoidf_(z[3]);
+      cstate = gf * cstate + gi * gj;
+      const float h = go * tanhf_(cstate);
+      hloc[tid] = h;
+      const int u = g * UPW + tid;
+      put_granule(x2 + (size_t)g * X2N + A + tid, tag, h);                 // the peers wait for this first
+      p.ca[((long)n * S1 + slot) * A + u] = cstate;
+      T* gp = (T*)p.ga + ((long)n * S1 + slot) * 4 * A;
+      stf(gp + u, gi); stf(gp + A + u, gj); stf(gp + 2 * A + u, gf); stf(gp + 3 * A + u, go);
+      stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, h);
+      if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, h);
+    }
+    __syncthreads();
+    // ---- (3) partial query of this workgroup's h rows, published
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < QK; ++i) s = fmaf(wq_s[(qq * QK + i) * A + qu], hloc[qq * QK + i], s);
+      red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < A) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < QG; ++q) s += red[q * A + tid];
+      put_granule(x2 + (size_t)g * X2N + tid, tag, s);
+    }
+    // ---- (4) gather X2: q = sum of the partials (fixed order), h of every unit
+    gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1);
+    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    __syncthreads();
+    if (sc[2] != 0.f) return;                 // uniform: every thread reads the same LDS word
+    if (tid < A) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s += gath[q * X2N + tid];
+      qs[tid] = s;
+      if (tid / UPW == g) p.q[((long)n * S1 + slot) * A + tid] = s;
+      xs[D2 + tid] = gath[(tid / UPW) * X2N + A + (tid % UPW)];          // h(s) for the next step's gates
+    }
+    __syncthreads();
+    // ---- (5) energies of the own positions: thread = (unit qu, t group qq)
+    {
+      const float qv = qs[qu];
+      float wcl[KWMAX];
+#pragma unroll
+      for (int k = 0; k < KWMAX; ++k) wcl[k] = cst_s[k * A + qu];
+      const float vu = cst_s[KWMAX * A + qu];
+      constexpr int TPT = (TSMAX + QG - 1) / QG;
+#pragma unroll 2
+      for (int ti = 0; ti < TPT; ++ti) {
+        const int tl = qq + ti * QG;                 // local position
+        float e = 0.f;
+        if (tl < tn) {
+          const float* ap = al + APAD + t0 + tl - half;
+          float x = keys_s[tl * A + qu] + qv;
+#pragma unroll
+          for (int k = 0; k < KWMAX; ++k) x = fmaf(ap[k], wcl[k], x);      // taps past kw carry a zero weight
+          e = vu * tanhf_(x);
+        }
+        e = wave_sum(e);
+        if (lane == 0) ered[wave * (TPT + 1) + ti] = e;
+      }
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // local softmax: lane = local position
+      constexpr int TPT = (TSMAX + QG - 1) / QG;
+      constexpr int WPG = A / 64 > 0 ? A / 64 : 1;          // waves per t group (A >= 64)
+      float e = -INFINITY;
+      if (lane < tn) {
+        const int qg_ = lane % QG, ti = lane / QG;
+        e = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPG; ++w) e += ered[(qg_ * WPG + w) * (TPT + 1) + ti];
+      }
+      const float m = wave_max(e);
+      const float w = lane < tn ? __expf(e - m) : 0.f;
+      const float l = wave_sum(w);
+      if (lane < TSMAX) es[lane] = w;
+      if (lane == 0) { sc[0] = m; sc[1] = l; }
+    }
+    __syncthreads();
+    // ---- (6) partial next-prenet sums over the own positions, published with the softmax pieces
+    {
+      const int c = tid % D1, th = tid / D1;
+      float s = 0.f;
+      for (int tl = th; tl < tn; tl += CXG) s = fmaf(es[tl], pv_s[tl * D1 + c], s);
+      red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < D1) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CXG; ++q) s += red[q * D1 + tid];
+      put_granule(x3 + (size_t)g * X3N + tid, tag, s);
+    } else if (tid < D1 + 2) {
+      put_granule(x3 + (size_t)g * X3N + tid, tag, sc[tid - D1]);
+    } else if (tid < D1 + 2 + TSMAX) {
+      put_granule(x3 + (size_t)g * X3N + tid, tag, es[tid - D1 - 2]);
+    }
+    // ---- (7) gather X3, combine
+    gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2);
+    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    __syncthreads();
+    if (sc[2] != 0.f) return;
+    float mall = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < CG; ++q) mall = fmaxf(mall, gath[q * X3N + D1]);
+    float scl[CG], lsum = 0.f;
+#pragma unroll
+    for (int q = 0; q < CG; ++q) {
+      const float lq = gath[q * X3N + D1 + 1];
+      scl[q] = lq > 0.f ? __expf(gath[q * X3N + D1] - mall) : 0.f;
+      lsum = fmaf(lq, scl[q], lsum);
+    }
+    const float inv = 1.f / lsum;
+    __syncthreads();                                   // al / p1s are rewritten below: everyone is done with step s
+    if (tid < D1) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s = fmaf(scl[q], gath[q * X3N + tid], s);
+      const float v = fmaxf(fmaf(s, inv, f1n), 0.f);
+      p1s[tid] = v;
+      if (st + 1 < p.S && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
+    }
+    // the whole alignment (every workgroup needs its neighbours' positions for the location filter)
+    for (int t = tid; t < p.Tia; t += CT) {
+      float v = 0.f;
+      if (t < L) {
+        const int q = t / ts;
+        v = gath[q * X3N + D1 + 2 + (t - q * ts)] * scl[q] * inv;
+      }
+      if (t < 256) al[APAD + t] = v;
+      const bool mine = t < L ? (t / ts == g) : (g == CG - 1);
+      if (mine) {
+        p.align[((long)n * S1 + slot) * p.Tia + t] = v;
+        if (p.align_t) stf((T*)p.align_t + ((long)n * S1 + slot) * p.Tia + t, v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <typename C>
+size_t fwd_lds_bytes() {
+  return sizeof(float) * (C::K + C::D1 + CT + C::A + 256 + 2 * APAD + TSMAX + (CT / 64) * (TSMAX / C::QG + 1) + C::UPW + 16 +
+                          CG * C::XMAX + TSMAX * C::A + TSMAX * C::D1 + C::UPW * C::A + (KWMAX + 1) * C::A);
+}
+
+bool cluster_shape_ok(const ns_taco2_attn_params* p) {
+  if (!p || !p->pv || p->D1 != 256 || p->D2 != 128) return false;
+  if (p->A != 256 && p->A != 64) return false;
+  if (p->Ti > 256 || p->Tia > 256 || p->kw > KWMAX || p->S < 1 || p->N < 1) return false;
+  if (p->Dsp < 0) return false;
+  return true;
+}
+}  // namespace
+
+extern "C" int ns_taco2_attn_cluster_supported(const ns_taco2_attn_params* p) { return cluster_shape_ok(p) ? 1 : 0; }
+
+extern "C" size_t ns_taco2_attn_cluster_work_bytes(const ns_taco2_attn_params* p) {
+  if (!p) return 0;
+  // status block + the two exchange buffers (sized for the widest instantiation)
+  return 256 + sizeof(u64) * (size_t)p->N * CG * (size_t)(2 * (256 + 32 + 2 + TSMAX) + 1024);
+}
+
+template <typename T, typename C>
+static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) {
+  ACArgs a;
+  a.p = *p;
+  a.status = (int*)work;
+  a.x2 = (u64*)((char*)work + 256);
+  a.x3 = a.x2 + (size_t)p->N * CG * C::X2N;
+  const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::X2N + C::X3N);
+  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
+  const size_t lds = fwd_lds_bytes<C>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_fwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  // chunks of at most 32 utterances: one workgroup per CU, every cluster of a launch resident at once
+  for (int n0 = 0; n0 < p->N; n0 += 32) {
+    ACArgs b = a;
+    const int nn = min(32, p->N - n0);
+    b.p.N = nn;
+    const long S1 = p->S + 1;
+    const long esz = sizeof(T);
+    // shift every per-utterance base by n0 utterances
+    b.p.lengths = p->lengths ? p->lengths + n0 : nullptr;
+    b.p.keys = p->keys + (long)n0 * p->Pi * p->A;
+    b.p.pv = (const char*)p->pv + (long)n0 * p->Pi * p->D1 * esz;
+    b.p.f1 = p->f1 + (long)n0 * S1 * p->D1;
+    b.p.p1 = (char*)p->p1 + (long)n0 * S1 * p->D1 * esz;
+    b.p.xa = (char*)p->xa + (long)n0 * S1 * (p->D2 + p->Dsp + p->A) * esz;
+    b.p.hc = (char*)p->hc + (long)n0 * S1 * (p->A + p->E) * esz;
+    b.p.ca = p->ca + (long)n0 * S1 * p->A;
+    b.p.ga = (char*)p->ga + (long)n0 * S1 * 4 * p->A * esz;
+    b.p.q = p->q + (long)n0 * S1 * p->A;
+    b.p.align = p->align + (long)n0 * S1 * p->Tia;
+    b.p.align_t = p->align_t ? (char*)p->align_t + (long)n0 * S1 * p->Tia * esz : nullptr;
+    b.x2 = a.x2 + (size_t)n0 * CG * C::X2N;
+    b.x3 = a.x3 + (size_t)n0 * CG * C::X3N;
+    hipLaunchKernelGGL((attn_cluster_fwd_kernel<T, C>), dim3(nn * CG), dim3(CT), lds, s, b);
+  }
+  NS_CHECK_LAUNCH("attn_cluster_fwd");
+  return ns_attn_contexts_after_loop(*p, s);
+}
+
+// Forward of the whole attention RNN in one launch (per 32 utterances).  Same parameter block and the same outputs
+// as ns_taco2_attn_fwd in its projected-memory form (the contexts hc[:, :, A:] come from the same batched product
+// align . memory after the loop).  Reads the natural-layout weights w2 / watt / wq (dtype) instead of the
+// k-contiguous shadows, and needs neither keys_t nor the per-step work buffer.  `work`: ns_taco2_attn_cluster_work_bytes; work[0] (int) is the status word.
+extern "C" int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* work, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && work, "ns_taco2_attn_cluster_fwd: null");
+  NS_CHECK_ARG(cluster_shape_ok(p), "ns_taco2_attn_cluster_fwd: unsupported shape (needs pv, D1 256, D2 128, A 64|256, T_in <= 256)");
+  NS_CHECK_ARG(p->keys && p->f1 && p->w2 && p->watt && p->wq && p->b2 && p->batt && p->wcl && p->v && p->p1 && p->xa &&
+                   p->hc && p->ca && p->ga && p->q && p->align && p->align_t && p->values, "ns_taco2_attn_cluster_fwd: null pointer");
+  if (p->dtype == NS_BF16) {
+    if (p->A == 256) return launch_fwd<bf16_t, Cfg<256, 256, 128>>(p, work, s);
+    return launch_fwd<bf16_t, Cfg<64, 256, 128>>(p, work, s);
+  }
+  if (p->A == 256) return launch_fwd<float, Cfg<256, 256, 128>>(p, work, s);
+  return launch_fwd<float, Cfg<64, 256, 128>>(p, work, s);
+}

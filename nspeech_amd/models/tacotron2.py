@@ -408,6 +408,7 @@ class Tacotron2(object):
         return out
 
     use_cluster = True      # persistent whole-sequence BiLSTM kernels where the shape allows
+    use_attn_cluster = True # persistent attention-RNN cluster kernels where the shape allows
 
     def _run_bilstm(self, direction, pair, tag):
         if self.use_cluster and ops.lstm_cluster_supported(pair[0]):
@@ -591,7 +592,19 @@ class Tacotron2(object):
             work=self._buf("attn_work", N * (E + 9 * Tia + 2 * A + A * Tia) + 64, torch.float32),
             wattT_hi=self.tsh.get("wattT_hi"), wattT_lo=self.tsh.get("wattT_lo"),
             align_t=self._buf("dec_al_t", N * S1 * Tia, T_))
-        ops.taco2_attn("fwd", **self._attn_args)
+        # the natural-layout weights: the persistent kernel keeps them in registers (the backward call needs them anyway)
+        w2 = self._o("decoder/decoder_prenet/dense_2/kernel")
+        wa = self._o("decoder/attention_lstm/kernel")
+        wq = self._o("decoder/attention/query_layer/kernel")
+        self._attn_args.update(w1c=(self._W(self.T), w1 + M * 256), w2=(self._W(self.T), w2),
+                               watt=(self._W(self.T), wa), wq=(self._W(self.T), wq))
+        self._attn_cluster_fwd = self.use_attn_cluster and ops.taco2_attn_cluster_supported("fwd", **self._attn_args)
+        if self._attn_cluster_fwd:
+            cw = self._buf("attn_cluster_work", ops.taco2_attn_cluster_work_floats(**self._attn_args), torch.float32)
+            ops.taco2_attn_cluster("fwd", cw, **self._attn_args)
+            self._status_words[("attn", "fwd")] = cw
+        else:
+            ops.taco2_attn("fwd", **self._attn_args)
         self._tick("attn_rnn")
 
         # ---- decoder LSTMs with hoisted inputs, then the projection (tacotron2.py:67-73)

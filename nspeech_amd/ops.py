@@ -196,7 +196,7 @@ def lstm_seq2(direction, p0, p1):
     L.check(fn(C.byref(p0), C.byref(p1), C.c_void_p(stream())), "ns_lstm_seq2_" + direction)
 
 
-def taco2_attn(direction, **kw):
+def _attn_params(kw):
     p = L.struct("ns_taco2_attn_params")
     for k, v in kw.items():
         if v is None:
@@ -207,7 +207,30 @@ def taco2_attn(direction, **kw):
             v = ptr(v)
         setattr(p, k, v)
     p.f32_passes = F32_PASSES
-    L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", p, stream())
+    return p
+
+
+def taco2_attn(direction, **kw):
+    L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", _attn_params(kw), stream())
+
+
+def taco2_attn_cluster_supported(direction, **kw):
+    fn = "ns_taco2_attn_cluster_supported" if direction == "fwd" else "ns_taco2_attn_cluster_bwd_supported"
+    if not hasattr(L.lib(), fn):
+        return False
+    return bool(getattr(L.lib(), fn)(C.byref(_attn_params(kw))))
+
+
+def taco2_attn_cluster_work_floats(**kw):
+    fn = L.lib().ns_taco2_attn_cluster_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(_attn_params(kw))) + 3) // 4
+
+
+def taco2_attn_cluster(direction, work, **kw):
+    """The attention RNN of all decoder steps as one persistent launch; work[0] is the status word."""
+    fn = getattr(L.lib(), "ns_taco2_attn_cluster_fwd" if direction == "fwd" else "ns_taco2_attn_cluster_bwd")
+    L.check(fn(C.byref(_attn_params(kw)), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_taco2_attn_cluster_" + direction)
 
 
 def lstm_cluster_supported(p0):

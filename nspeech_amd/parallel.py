@@ -84,6 +84,7 @@ class GradReducer(object):
         self.group = group
         self.pending = []
         self.issued = {}
+        self.joined = True            # no step in flight
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())
 
@@ -91,12 +92,16 @@ class GradReducer(object):
         if name not in self.buckets:
             raise KeyError("GradReducer: unknown bucket '%s' (have %s)" % (name, sorted(self.buckets)))
         self.issued[name] = self.issued.get(name, 0) + 1
+        self.joined = False
         if not self.active:
             return
         lo, hi = self.buckets[name]
         self.pending.append(dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
+        if self.joined:               # nothing released since the last complete step (a second wait() is harmless)
+            return
+        self.joined = True
         bad = {n: self.issued.get(n, 0) for n in self.buckets if self.issued.get(n, 0) != 1}
         self.issued = {}
         pending, self.pending = self.pending, []

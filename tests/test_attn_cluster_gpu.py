@@ -1,0 +1,73 @@
+"""The persistent attention-RNN cluster kernels (csrc/attn_cluster.hip) against the launch-per-step kernels
+(csrc/attn.hip, themselves checked against the oracle in test_taco2_gpu.py) on the same operands: every history
+buffer of the forward pass, every gradient of the backward pass.  The model tests cover them against the oracle once
+more, since the cluster path is the default wherever it applies."""
+import numpy as np
+import pytest
+import torch
+
+from util import make_batch, small_hparams
+
+pytestmark = pytest.mark.gpu
+
+HIST = ("dec_p1", "dec_xa", "dec_hc", "dec_ca", "dec_ga", "dec_q", "dec_al", "dec_al_t")
+GRAD = ("d_f1", "d_p2", "d_ga", "d_q", "d_energy", "d_keys", "d_values", "d_wcl")
+
+
+def _run(m, batch, cluster, backward):
+    m.use_attn_cluster = cluster
+    m.initialize(*batch)
+    if backward:
+        m.backward()
+    torch.cuda.synchronize()
+    m.check_status()
+    out = {k: m._bufs[k].float().clone() for k in HIST}
+    if backward:
+        out.update({k: m._bufs[k].float().clone() for k in GRAD})
+        out["flat_g"] = m.flat_g.clone()
+    return out
+
+
+def _hp(full):
+    if full:
+        from nspeech_amd import hparams as hparams_mod
+        return hparams_mod.load("taco2")
+    return small_hparams()
+
+
+@pytest.mark.parametrize("full,shape", [(False, (3, 11, 20)), (False, (1, 3, 20)), (False, (33, 9, 10)), (False, (2, 70, 15)),
+                                        (False, (5, 20, 35)), (True, (4, 37, 25)), (True, (2, 160, 10))])
+@pytest.mark.parametrize("mode", ["fp32", "mixed"])
+def test_cluster_forward_matches_per_step_kernels(dev, full, shape, mode):
+    from nspeech_amd.models import create_model
+    N, Ti, To = shape
+    hp = _hp(full)
+    m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=3)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N)
+    batch = (inputs, lengths, None, mel, lin)
+    ref = _run(m, batch, False, False)
+    assert not m._attn_cluster_fwd
+    got = _run(m, batch, True, False)
+    assert m._attn_cluster_fwd, "the cluster kernel must cover this shape"
+    # fp32: both paths are exact fp32 with different summation orders; mixed: the per-step path runs its products as
+    # three split-bf16 passes (~2^-17), the cluster path in exact fp32
+    tol = 2e-5 if mode == "fp32" else 2e-4
+    for k in HIST:
+        a, b = got[k], ref[k]
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1.0, b.abs().max().item()), (k, err, b.abs().max().item())
+
+
+def test_cluster_forward_with_speakers(dev):
+    from nspeech_amd.models import create_model
+    hp = small_hparams(num_speakers=5)
+    m = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=4)
+    inputs, lengths, mel, lin = make_batch(hp, 4, 13, 20, seed=2)
+    spk = np.array([0, 3, 4, 1], np.int32)
+    batch = (inputs, lengths, spk, mel, lin)
+    ref = _run(m, batch, False, False)
+    got = _run(m, batch, True, False)
+    assert m._attn_cluster_fwd
+    for k in HIST:
+        err = (got[k] - ref[k]).abs().max().item()
+        assert err <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
