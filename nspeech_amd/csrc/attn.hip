@@ -705,6 +705,59 @@ extern "C" int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   return attn_fwd_t<float>(*p, (hipStream_t)s);
 }
 
+// Hoisted part of the backward pass, after the time loop (also the tail of the persistent backward kernel): the sums
+// over all steps that no recurrence needs (dkeys, dv, dWcl), the total context gradients and dvalues.
+template <typename T>
+int ns_attn_bwd_post(const ns_taco2_attn_params& p, hipStream_t s) {
+  const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, HC = A + E;
+  const int dt = p.dtype;
+  const bool pvm = p.pv != nullptr;
+  float* dkeys_t = p.work + (size_t)p.N * (E + (1 + MAXKW) * p.Tia + 2 * A);
+  // ---- hoisted sums over all steps
+  {
+    AttnPost q = {};
+    q.S = p.S; q.Ti = p.Ti; q.A = p.A; q.kw = p.kw; q.Tia = p.Tia; q.lengths = p.lengths;
+    q.keys_t = p.keys_t; q.q = p.q; q.align = p.align; q.de = p.de; q.wcl = p.wcl; q.v = p.v;
+    q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl;
+    dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
+    hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, s, q);
+    NS_CHECK_LAUNCH("attn_post");
+  }
+  if (pvm) {
+    // total context gradients of all steps in one product: dctx[n, slot] = dhc[n, slot, A:] + df1[n, slot+1] . W1c^T
+    // (df1 slot 0 rows are never written, so the row behind an item's last slot contributes zero; the caller keeps
+    // one zero row behind the end of df1 for the very last one)
+    ns_gemm_params g = {};
+    g.dtype = dt; g.M = (int)(p.N * S1); g.N = (int)E; g.K = (int)D1;
+    g.A = (const T*)p.df1 + D1; g.lda = D1; g.a_mode = 0;
+    g.B = p.w1c; g.ldb = D1; g.b_mode = 0;
+    g.C = p.dctx_t; g.ldc = E; g.c_dtype = dt;
+    g.addend = p.dhc + A; g.ld_add = HC; g.addend_dtype = NS_F32;
+    g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
+    int rc = ns_gemm(&g, s);
+    if (rc) return rc;
+  }
+  // dvalues[n] += align[n]^T . dctx[n]   (contraction over the decoder steps)
+  {
+    ns_gemm_params g = {};
+    g.dtype = dt; g.M = p.Ti; g.N = (int)E; g.K = (int)S1;
+    g.A = (const T*)p.align_t; g.lda = p.Tia; g.a_mode = 1;
+    g.B = (const T*)p.dctx_t; g.ldb = E; g.b_mode = 1;
+    g.C = p.dvalues + (long)p.padl_i * E; g.ldc = E; g.c_dtype = NS_F32;
+    g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = S1 * E; g.batch_stride_c = (long)p.Pi * E;
+    g.accumulate = 1; g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
+    int rc = ns_gemm(&g, s);
+    if (rc) return rc;
+  }
+  // dkeys[t][u] += dkeys_t[u][t]
+  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(p.Tia, 32), ceil_div(p.A, 32), p.N), dim3(256), 0, s,
+                     (const float*)p.dkeys, dkeys_t, p.Ti, p.Tia, p.Pi, p.padl_i, p.A, 1);
+  NS_CHECK_LAUNCH("keys_transpose_back");
+  return NS_OK;
+}
+template int ns_attn_bwd_post<float>(const ns_taco2_attn_params&, hipStream_t);
+template int ns_attn_bwd_post<bf16_t>(const ns_taco2_attn_params&, hipStream_t);
+
 template <typename T>
 static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
   const long S1 = p.S + 1, A = p.A, E = p.E, D1 = p.D1, D2 = p.D2;
@@ -802,47 +855,7 @@ static int attn_bwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
       }
     }
   }
-  // ---- hoisted sums over all steps
-  {
-    AttnPost q = {};
-    q.S = p.S; q.Ti = p.Ti; q.A = p.A; q.kw = p.kw; q.Tia = p.Tia; q.lengths = p.lengths;
-    q.keys_t = p.keys_t; q.q = p.q; q.align = p.align; q.de = p.de; q.wcl = p.wcl; q.v = p.v;
-    q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl;
-    dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
-    hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, s, q);
-    NS_CHECK_LAUNCH("attn_post");
-  }
-  if (pvm) {
-    // total context gradients of all steps in one product: dctx[n, slot] = dhc[n, slot, A:] + df1[n, slot+1] . W1c^T
-    // (df1 slot 0 rows are never written, so the row behind an item's last slot contributes zero; the caller keeps
-    // one zero row behind the end of df1 for the very last one)
-    ns_gemm_params g = {};
-    g.dtype = dt; g.M = (int)(p.N * S1); g.N = (int)E; g.K = (int)D1;
-    g.A = (const T*)p.df1 + D1; g.lda = D1; g.a_mode = 0;
-    g.B = p.w1c; g.ldb = D1; g.b_mode = 0;
-    g.C = p.dctx_t; g.ldc = E; g.c_dtype = dt;
-    g.addend = p.dhc + A; g.ld_add = HC; g.addend_dtype = NS_F32;
-    g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
-    int rc = ns_gemm(&g, s);
-    if (rc) return rc;
-  }
-  // dvalues[n] += align[n]^T . dctx[n]   (contraction over the decoder steps)
-  {
-    ns_gemm_params g = {};
-    g.dtype = dt; g.M = p.Ti; g.N = (int)E; g.K = (int)S1;
-    g.A = (const T*)p.align_t; g.lda = p.Tia; g.a_mode = 1;
-    g.B = (const T*)p.dctx_t; g.ldb = E; g.b_mode = 1;
-    g.C = p.dvalues + (long)p.padl_i * E; g.ldc = E; g.c_dtype = NS_F32;
-    g.batch = p.N; g.batch_stride_a = S1 * p.Tia; g.batch_stride_b = S1 * E; g.batch_stride_c = (long)p.Pi * E;
-    g.accumulate = 1; g.alpha = 1.f; g.split_k = 1; g.f32_passes = p.f32_passes;
-    int rc = ns_gemm(&g, s);
-    if (rc) return rc;
-  }
-  // dkeys[t][u] += dkeys_t[u][t]
-  hipLaunchKernelGGL(keys_transpose_kernel, dim3(ceil_div(p.Tia, 32), ceil_div(p.A, 32), p.N), dim3(256), 0, s,
-                     (const float*)p.dkeys, dkeys_t, p.Ti, p.Tia, p.Pi, p.padl_i, p.A, 1);
-  NS_CHECK_LAUNCH("keys_transpose_back");
-  return NS_OK;
+  return ns_attn_bwd_post<T>(p, s);
 }
 
 extern "C" int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t s) {

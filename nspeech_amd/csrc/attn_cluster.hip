@@ -25,6 +25,7 @@
 #include "common.h"
 
 int ns_attn_contexts_after_loop(const ns_taco2_attn_params& p, hipStream_t s);     // attn.hip
+template <typename T> int ns_attn_bwd_post(const ns_taco2_attn_params& p, hipStream_t s);
 
 typedef unsigned long long u64;
 namespace {
@@ -374,9 +375,13 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < CG; ++q) s = fmaf(scl[q], gath[q * X3N + tid], s);
-      const float v = fmaxf(fmaf(s, inv, f1n), 0.f);
+      const float cp = s * inv;                      // sum_t align[s][t] pv[t, c]
+      const float v = fmaxf(cp + f1n, 0.f);
       p1s[tid] = v;
-      if (st + 1 < p.S && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
+      if (tid / (D1 / CG) == g) {
+        if (p.ctxp) p.ctxp[((long)n * S1 + slot) * D1 + tid] = cp;
+        if (st + 1 < p.S) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
+      }
     }
     // the whole alignment (every workgroup needs its neighbours' positions for the location filter)
     for (int t = tid; t < p.Tia; t += CT) {
@@ -391,6 +396,366 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
         p.align[((long)n * S1 + slot) * p.Tia + t] = v;
         if (p.align_t) stf((T*)p.align_t + ((long)n * S1 + slot) * p.Tia + t, v);
       }
+    }
+    __syncthreads();
+  }
+}
+
+// ===================================================================================== backward
+// Backward through time, same clusters and ownership as the forward kernel.  Per step (walking s = S .. 1):
+//   dot   = sum_t align[t] dalign[t] is formed WITHOUT an exchange: dalign = da0 (hoisted) + pv . dp1(s+1) + carry, so
+//           dot = sum_t a da0  (history, every workgroup sums it)  +  ctxp[s] . dp1(s+1)  (ctxp saved by the forward
+//           kernel)  +  sum_g dcar_g  (each workgroup's share of sum_t a[t] carry[t], sent along with exchange 3 of
+//           the step before);
+//   energy pass on the own positions: g1[t,u] = v[u] (1 - tanh^2), laid out as the A operand of the exact fp32 MFMA
+//           (16x16x4): Z[t,k] = sum_u g1[t,u] Wcl[k,u] comes out of the matrix core, dq_part[u] = sum_t de[t] g1[t,u]
+//           out of 16-lane row reductions;
+//   E2:     dq partials (A values)                      -> dq, dh through W_query, cell gradient of the own units
+//   E3:     partial input gradients dga_own . Watt[:, own]^T (K values) + the workgroup's contributions to the next
+//           step's location-filter carry (ts + 6 values) + dcar_g   -> dp2, the recurrent dh, carry, dot
+//   then dp1 = (dp2 . W2^T) masked, redundantly in every workgroup (W2 in registers), which is the next step's dvec.
+template <int A_, int D1_, int D2_>
+struct BCfg : Cfg<A_, D1_, D2_> {
+  using B = Cfg<A_, D1_, D2_>;
+  static constexpr int NQ = 1536 / B::K;                 // column groups of the input-gradient product (4 | 8)
+  static constexpr int CPQ = B::GC / NQ;                 // gate columns per group (32 | 4)
+  static constexpr int PPT = 3;                          // (row, group) pairs per thread: NQ * K = 3 * CT
+  static constexpr int W2H = CT / B::D1, W2K = B::D2 / W2H;       // dp1 product: halves, k per thread
+  static constexpr int CCN = TSMAX + 8;                  // carry contributions (ts + 6 used) + dcar
+  static constexpr int E3N = B::K + CCN;                 // granules per workgroup, exchange 3
+  static constexpr int EMAX = E3N > B::A ? E3N : B::A;
+  static constexpr int UL = B::A / 16;                   // query columns per lane in the dhq product
+  static_assert(NQ * B::K == PPT * CT && B::GC % NQ == 0 && B::D2 % W2H == 0 && B::A % 32 == 0 && B::D1 == 256, "shape");
+};
+
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
+  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+  return v;
+}
+
+template <typename T, typename C>
+__global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
+  constexpr int A = C::A, D1 = C::D1, D2 = C::D2, UPW = C::UPW, GC = C::GC, K = C::K;
+  constexpr int NQ = C::NQ, CPQ = C::CPQ, PPT = C::PPT, W2H = C::W2H, W2K = C::W2K, CCN = C::CCN, E3N = C::E3N, UL = C::UL;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const ns_taco2_attn_params& p = a.p;
+  float* dvec = sm;                        // [D1]  dp1 of the step after (the vector dotted with the pv rows)
+  float* dp2s = dvec + D1;                 // [D2]
+  float* dgs = dp2s + D2;                  // [GC]  gate gradients of the own units, (gate, unit)
+  float* red = dgs + GC;                   // [NQ * K] partial sums
+  float* qs = red + NQ * K;                // [A]
+  float* al = qs + A;                      // [APAD + 256 + APAD] alignment of step s-1
+  float* acur = al + 256 + 2 * APAD;       // [TSMAX] alignment of step s, own positions
+  float* da0s = acur + TSMAX;              // [TSMAX]
+  float* dev = da0s + TSMAX;               // [TSMAX] energy gradients
+  float* carry = dev + TSMAX;              // [TSMAX] location-filter carry for the own positions
+  float* Gs = carry + TSMAX;               // [TSMAX][8]
+  float* zred = Gs + TSMAX * 8;            // [8 waves][TSMAX][8]
+  float* hrec = zred + 8 * TSMAX * 8;      // [UPW] recurrent part of dh for the own units
+  float* dq_s = hrec + UPW;                // [A]
+  float* p1m = dq_s + A;                   // [D1] p1 of this step (ReLU mask)
+  float* p2m = p1m + D1;                   // [D2]
+  float* gts = p2m + D2;                   // [GC] saved gates of the own units
+  float* sc = gts + GC;                    // [16]  [0] dot, [1] dcar, [2] abort, [4..] block_sum scratch
+  float* gath = sc + 48;                   // [CG][EMAX]
+  float* keys_s = gath + CG * C::EMAX;     // [TSMAX][A]
+  float* pv_s = keys_s + TSMAX * A;        // [TSMAX][D1]
+  float* wq_s = pv_s + TSMAX * D1;         // [UPW][A]
+  float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]
+
+  const int tid_ = threadIdx.x;
+  const int n = blockIdx.x / CG, g = blockIdx.x % CG;
+  const long S1 = p.S + 1;
+  const int Dsp = p.Dsp, HC = A + p.E;
+  const int XA = D2 + Dsp + A;
+  const int L = min(p.lengths ? p.lengths[n] : p.Ti, p.Ti);
+  const int ts = max(1, (L + CG - 1) / CG);
+  const int t0 = g * ts, tn = max(0, min(L, t0 + ts) - t0);
+  const int half = (p.kw - 1) / 2;
+  u64* e2 = a.x2 + (size_t)n * CG * A;
+  u64* e3 = a.x3 + (size_t)n * CG * E3N;
+
+  // ---------------------------------------------------------------- resident weights
+  const T* W2 = (const T*)p.w2;            // [D1][D2]
+  const T* Watt = (const T*)p.watt;        // [D2 + Dsp + A][4A]
+  const T* Wq = (const T*)p.wq;            // [A][A]
+  const int tid = tid_;
+  float wxr[PPT][CPQ];                     // Watt[row k][own columns of group qr] for this thread's (k, qr) pairs
+#pragma unroll
+  for (int jj = 0; jj < PPT; ++jj) {
+    const int pi = tid + CT * jj, k = pi % K, qr = pi / K;
+    const T* b = Watt + (long)(k < D2 ? k : k + Dsp) * 4 * A;
+#pragma unroll
+    for (int i = 0; i < CPQ; ++i) {
+      const int c = qr * CPQ + i;
+      wxr[jj][i] = ldf(b + (c / UPW) * A + g * UPW + (c % UPW));
+    }
+  }
+  float w2r[W2K];                          // W2[c1][hf * W2K + i]
+  {
+    const T* b = W2 + (long)(tid % D1) * D2 + (tid / D1) * W2K;
+#pragma unroll
+    for (int i = 0; i < W2K; ++i) w2r[i] = ldf(b + i);
+  }
+  for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
+  for (int i = tid; i < (KWMAX + 1) * A; i += CT) {
+    const int k = i / A, u = i % A;
+    cst_s[i] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
+  }
+  {
+    const float* kn = p.keys + ((long)n * p.Pi + p.padl_i + t0) * A;
+    for (int i = tid; i < TSMAX * A; i += CT) keys_s[i] = (i / A) < tn ? kn[i] : 0.f;
+    const T* pvn = (const T*)p.pv + ((long)n * p.Pi + p.padl_i + t0) * D1;
+    for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
+    for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
+    for (int i = tid; i < D1; i += CT) dvec[i] = 0.f;
+    for (int i = tid; i < TSMAX; i += CT) { carry[i] = 0.f; dev[i] = 0.f; acur[i] = 0.f; da0s[i] = 0.f; }
+    for (int i = tid; i < TSMAX * 8; i += CT) Gs[i] = 0.f;
+    if (tid < UPW) hrec[tid] = 0.f;
+    if (tid < 48) sc[tid] = 0.f;
+  }
+  float dcc = 0.f;                         // cell-state gradient carried to the step before (owner lanes)
+  __syncthreads();
+
+  for (int st = p.S - 1; st >= 0; --st) {
+    const long slot = st + 1;
+    const unsigned tag = (unsigned)(p.S - st);
+    int tid = tid_;
+    asm volatile("" : "+v"(tid));           // see the forward kernel: no loop-invariant address hoisting
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const long rowS = (long)n * S1 + slot;
+
+    // ---- P0/P1: history of this step -> LDS; dot = sum_t a da0 + ctxp . dvec + dcar
+    {
+      float part = 0.f;
+      if (tid < A) qs[tid] = p.q[rowS * A + tid];
+      if (tid < D1) {
+        p1m[tid] = ldf((const T*)p.p1 + rowS * D1 + tid);
+        part = p.ctxp[rowS * D1 + tid] * dvec[tid];
+      }
+      if (tid < D2) p2m[tid] = ldf((const T*)p.xa + rowS * XA + tid);
+      if (tid < 256) {
+        const float ap = tid < p.Tia ? p.align[(rowS - 1) * p.Tia + tid] : 0.f;
+        al[APAD + tid] = ap;
+        if (tid < L) part = fmaf(p.align[rowS * p.Tia + tid], p.da0[rowS * p.Tia + tid], part);
+      }
+      if (tid >= 256 && tid < 256 + TSMAX) {
+        const int tl = tid - 256;
+        acur[tl] = tl < tn ? p.align[rowS * p.Tia + t0 + tl] : 0.f;
+        da0s[tl] = tl < tn ? p.da0[rowS * p.Tia + t0 + tl] : 0.f;
+      }
+      if (tid >= 320 && tid < 320 + GC) {
+        const int c = tid - 320;
+        gts[c] = ldf((const T*)p.ga + rowS * 4 * A + (c / UPW) * A + g * UPW + (c % UPW));
+      }
+      part = wave_sum(part);
+      if (lane == 0) sc[4 + wave] = part;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float d = sc[1];
+#pragma unroll
+      for (int w = 0; w < CT / 64; ++w) d += sc[4 + w];
+      sc[0] = d;
+    }
+    __syncthreads();
+    // ---- P2: dalign and the energy gradients of the own positions: thread = (position tid / 16, 16 columns each)
+    {
+      const int tl = tid >> 4, cq = tid & 15;
+      float s = 0.f;
+      if (tl < tn) {
+        const float* pr = pv_s + tl * D1 + cq * 16;
+        const float* dv = dvec + cq * 16;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+          const float4 x = *(const float4*)(pr + i), y = *(const float4*)(dv + i);
+          s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+        }
+      }
+      s = row16_sum(s);
+      if (cq == 0 && tl < TSMAX) {
+        float de = 0.f;
+        if (tl < tn) {
+          const float da = da0s[tl] + s + carry[tl];
+          de = acur[tl] * (da - sc[0]);
+          p.de[rowS * p.Tia + t0 + tl] = de;
+        }
+        dev[tl] = de;
+      }
+    }
+    __syncthreads();
+    // ---- P3: energy pass in the A-operand layout of v_mfma_f32_16x16x4_f32: row = position, k = unit
+    if (wave < A / 32) {
+      const int r = lane & 15, kq = lane >> 4;
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      float ap0[KWMAX], ap1[KWMAX];
+#pragma unroll
+      for (int k = 0; k < KWMAX; ++k) { ap0[k] = al[APAD + t0 + r - half + k]; ap1[k] = al[APAD + t0 + r + 16 - half + k]; }
+      const float de0 = dev[r], de1 = dev[r + 16];
+#pragma unroll 2
+      for (int j = 0; j < 8; ++j) {
+        const int u = wave * 32 + j * 4 + kq;
+        const float qv = qs[u], vv = cst_s[KWMAX * A + u];
+        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
+#pragma unroll
+        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+        const float th0 = tanhf_(x0), th1 = tanhf_(x1);
+        const float g0 = r < tn ? vv * (1.f - th0 * th0) : 0.f;
+        const float g1 = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
+        const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0, b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, b, acc[1], 0, 0, 0);
+        const float dqp = row16_sum(fmaf(de0, g0, de1 * g1));
+        if (r == 0) put_granule(e2 + (size_t)g * A + u, tag, dqp);
+      }
+      // D: col = lane & 15 (filter tap), row = (lane >> 4) * 4 + reg (position inside the 16-row tile)
+      if (r < 8) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + mt * 16 + kq * 4 + q) * 8 + r] = acc[mt][q];
+      }
+    }
+    __syncthreads();
+    // ---- P4: G[t][k] = de[t] * sum over the unit blocks of Z
+    if (tid < TSMAX * 8) {
+      const int tl = tid >> 3, k = tid & 7;
+      float z = 0.f;
+#pragma unroll
+      for (int w = 0; w < A / 32; ++w) z += zred[(w * TSMAX + tl) * 8 + k];
+      Gs[tid] = (tl < tn && k < p.kw) ? dev[tl] * z : 0.f;
+    }
+    __syncthreads();
+    // ---- P5: this workgroup's contributions to the carry of step s-1 (positions t0-3 .. t0+ts+2) and to its dot
+    float ccv = 0.f;                         // threads < CCN keep their value for the E3 publish
+    if (tid < TSMAX + 6) {
+      // carry[t'] += G[t' - k + half][k]; local: t' = t0 - half + tid  ->  G row (tid - k)
+#pragma unroll
+      for (int k = 0; k < KWMAX; ++k) {
+        const int row = tid - k;
+        if (k < p.kw && row >= 0 && row < TSMAX) ccv += Gs[row * 8 + k];
+      }
+    } else if (tid >= 64 && tid < 128) {     // wave 1: dcar_g = sum_{t,k} G[t][k] a(s-1)[t + k - half]
+      const int tl = tid - 64;
+      float d = 0.f;
+      if (tl < tn) {
+#pragma unroll
+        for (int k = 0; k < KWMAX; ++k) d = fmaf(Gs[tl * 8 + k], al[APAD + t0 + tl + k - half], d);
+      }
+      d = wave_sum(d);
+      if (tl == 0) sc[3] = d;
+    }
+    // ---- gather E2: dq = sum of the partials
+    gather_granules<(CG * A + CT - 1) / CT>(e2, CG * A, tag, gath, tid, a.status, 3);
+    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    __syncthreads();
+    if (sc[2] != 0.f) return;
+    if (tid < A) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s += gath[q * A + tid];
+      dq_s[tid] = s;
+      if (tid / UPW == g) stf((T*)p.dq + rowS * A + tid, s);
+    }
+    __syncthreads();
+    // ---- P6: dh of the own units through W_query, then the cell gradient: thread = (unit tid / 16, UL columns each)
+    {
+      const int j = tid >> 4, uq = tid & 15;
+      float s = 0.f;
+      if (j < UPW) {
+        const float* wr = wq_s + j * A + uq * UL;
+        const float* dq = dq_s + uq * UL;
+#pragma unroll
+        for (int i = 0; i < UL; i += 4) {
+          const float4 x = *(const float4*)(wr + i), y = *(const float4*)(dq + i);
+          s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
+        }
+      }
+      s = row16_sum(s);
+      if (uq == 0 && j < UPW) {
+        const int u = g * UPW + j;
+        const float dh = p.dhc[rowS * HC + u] + s + hrec[j];
+        const float gi = gts[j], gj = gts[UPW + j], gf = gts[2 * UPW + j], go = gts[3 * UPW + j];
+        const float c = p.ca[rowS * A + u];
+        const float cp = st > 0 ? p.ca[(rowS - 1) * A + u] : 0.f;
+        const float tc = tanhf_(c);
+        const float d_o = dh * tc * go * (1.f - go);
+        const float dc = dh * go * (1.f - tc * tc) + dcc;
+        const float d_i = dc * gj * gi * (1.f - gi);
+        const float d_j = dc * gi * (1.f - gj * gj);
+        const float d_f = dc * cp * gf * (1.f - gf);
+        dcc = dc * gf;
+        dgs[j] = d_i; dgs[UPW + j] = d_j; dgs[2 * UPW + j] = d_f; dgs[3 * UPW + j] = d_o;
+        T* dg = (T*)p.dga + rowS * 4 * A;
+        stf(dg + u, d_i); stf(dg + A + u, d_j); stf(dg + 2 * A + u, d_f); stf(dg + 3 * A + u, d_o);
+        if (p.dga_bf16 && sizeof(T) == 4) {
+          bf16_t* db = (bf16_t*)p.dga_bf16 + rowS * 4 * A;
+          db[u] = (bf16_t)d_i; db[A + u] = (bf16_t)d_j; db[2 * A + u] = (bf16_t)d_f; db[3 * A + u] = (bf16_t)d_o;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- P7: partial input gradients dga_own . Watt[k, own]^T for every input row k, published with the carry pieces
+#pragma unroll
+    for (int jj = 0; jj < PPT; ++jj) {
+      const int pi = tid + CT * jj, qr = pi / K;
+      red[pi] = dot_regs<CPQ>(wxr[jj], dgs + qr * CPQ);          // red[qr * K + k], pi = qr * K + k
+    }
+    __syncthreads();
+    if (tid < K) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) s += red[q * K + tid];
+      put_granule(e3 + (size_t)g * E3N + tid, tag, s);
+    }
+    if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, tid == CCN - 1 ? sc[3] : ccv);
+    gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4);
+    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    __syncthreads();
+    if (sc[2] != 0.f) return;
+    // ---- P8: dp2 (masked), recurrent dh, carry and dcar for the step before
+    if (tid < D2) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s += gath[q * E3N + tid];
+      s = p2m[tid] > 0.f ? s : 0.f;
+      dp2s[tid] = s;
+      if (tid / (D2 / CG) == g) stf((T*)p.dp2 + rowS * D2 + tid, s);
+    } else if (tid < D2 + UPW) {
+      const int j = tid - D2;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s += gath[q * E3N + D2 + g * UPW + j];
+      hrec[j] = s;
+    } else if (tid >= 256 && tid < 256 + TSMAX) {
+      const int tl = tid - 256;
+      float s = 0.f;
+      if (tl < tn) {
+        const int tp = t0 + tl;
+#pragma unroll
+        for (int q = 0; q < CG; ++q) {
+          const int j = tp - q * ts + half;            // index into workgroup q's contributions (its t0 - half ...)
+          if (j >= 0 && j < TSMAX + 6) s += gath[q * E3N + K + j];
+        }
+      }
+      carry[tl] = s;
+    } else if (tid == 320) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s += gath[q * E3N + K + CCN - 1];
+      sc[1] = s;
+    }
+    __syncthreads();
+    // ---- P9: dp1 = (dp2 . W2^T) masked: next dvec (every workgroup computes all of it)
+    red[tid] = dot_regs<W2K>(w2r, dp2s + (tid / D1) * W2K);
+    __syncthreads();
+    if (tid < D1) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < W2H; ++q) s += red[q * D1 + tid];
+      s = p1m[tid] > 0.f ? s : 0.f;
+      dvec[tid] = s;
+      if (tid / (D1 / CG) == g) stf((T*)p.df1 + rowS * D1 + tid, s);
     }
     __syncthreads();
   }
@@ -454,6 +819,7 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     b.p.q = p->q + (long)n0 * S1 * p->A;
     b.p.align = p->align + (long)n0 * S1 * p->Tia;
     b.p.align_t = p->align_t ? (char*)p->align_t + (long)n0 * S1 * p->Tia * esz : nullptr;
+    b.p.ctxp = p->ctxp ? p->ctxp + (long)n0 * S1 * p->D1 : nullptr;
     b.x2 = a.x2 + (size_t)n0 * CG * C::X2N;
     b.x3 = a.x3 + (size_t)n0 * CG * C::X3N;
     hipLaunchKernelGGL((attn_cluster_fwd_kernel<T, C>), dim3(nn * CG), dim3(CT), lds, s, b);
@@ -478,4 +844,75 @@ extern "C" int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* wo
   }
   if (p->A == 256) return launch_fwd<float, Cfg<256, 256, 128>>(p, work, s);
   return launch_fwd<float, Cfg<64, 256, 128>>(p, work, s);
+}
+
+template <typename C>
+static size_t bwd_lds_bytes() {
+  return sizeof(float) * (C::D1 + C::D2 + C::GC + C::NQ * C::K + C::A + 256 + 2 * APAD + 4 * TSMAX + TSMAX * 8 + 8 * TSMAX * 8 +
+                          C::UPW + C::A + C::D1 + C::D2 + C::GC + 48 + CG * C::EMAX + TSMAX * C::A + TSMAX * C::D1 +
+                          C::UPW * C::A + (KWMAX + 1) * C::A);
+}
+
+template <typename T, typename C>
+static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) {
+  ACArgs a;
+  a.p = *p;
+  a.status = (int*)work;
+  a.x2 = (u64*)((char*)work + 256);
+  a.x3 = a.x2 + (size_t)p->N * CG * C::A;
+  const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::A + C::E3N);
+  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
+  const size_t lds = bwd_lds_bytes<C>();
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute((const void*)attn_cluster_bwd_kernel<T, C>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  const long S1 = p->S + 1, esz = sizeof(T);
+  for (int n0 = 0; n0 < p->N; n0 += 32) {
+    ACArgs b = a;
+    b.p.N = min(32, p->N - n0);
+    b.p.lengths = p->lengths ? p->lengths + n0 : nullptr;
+    b.p.keys = p->keys + (long)n0 * p->Pi * p->A;
+    b.p.pv = (const char*)p->pv + (long)n0 * p->Pi * p->D1 * esz;
+    b.p.p1 = (char*)p->p1 + (long)n0 * S1 * p->D1 * esz;
+    b.p.xa = (char*)p->xa + (long)n0 * S1 * (p->D2 + p->Dsp + p->A) * esz;
+    b.p.ca = p->ca + (long)n0 * S1 * p->A;
+    b.p.ga = (char*)p->ga + (long)n0 * S1 * 4 * p->A * esz;
+    b.p.q = p->q + (long)n0 * S1 * p->A;
+    b.p.align = p->align + (long)n0 * S1 * p->Tia;
+    b.p.ctxp = p->ctxp + (long)n0 * S1 * p->D1;
+    b.p.da0 = p->da0 + (long)n0 * S1 * p->Tia;
+    b.p.dhc = p->dhc + (long)n0 * S1 * (p->A + p->E);
+    b.p.de = p->de + (long)n0 * S1 * p->Tia;
+    b.p.df1 = (char*)p->df1 + (long)n0 * S1 * p->D1 * esz;
+    b.p.dp2 = (char*)p->dp2 + (long)n0 * S1 * p->D2 * esz;
+    b.p.dga = (char*)p->dga + (long)n0 * S1 * 4 * p->A * esz;
+    b.p.dga_bf16 = p->dga_bf16 ? (char*)p->dga_bf16 + (long)n0 * S1 * 4 * p->A * 2 : nullptr;
+    b.p.dq = (char*)p->dq + (long)n0 * S1 * p->A * esz;
+    b.x2 = a.x2 + (size_t)n0 * CG * C::A;
+    b.x3 = a.x3 + (size_t)n0 * CG * C::E3N;
+    hipLaunchKernelGGL((attn_cluster_bwd_kernel<T, C>), dim3(b.p.N * CG), dim3(CT), lds, s, b);
+  }
+  NS_CHECK_LAUNCH("attn_cluster_bwd");
+  // the hoisted sums need the transposed keys, which the per-step forward would have left behind
+  int rc = ns_taco2_keys_transpose(p->keys, p->keys_t, p->N, p->Ti, p->Tia, p->Pi, p->padl_i, p->A, s);
+  if (rc) return rc;
+  return ns_attn_bwd_post<T>(*p, s);
+}
+
+extern "C" int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && work, "ns_taco2_attn_cluster_bwd: null");
+  NS_CHECK_ARG(cluster_shape_ok(p), "ns_taco2_attn_cluster_bwd: unsupported shape (needs pv, D1 256, D2 128, A 64|256, T_in <= 256)");
+  NS_CHECK_ARG(p->keys && p->values && p->w1c && p->w2 && p->watt && p->wq && p->wcl && p->v && p->p1 && p->xa && p->ca &&
+                   p->ga && p->q && p->align && p->dhc && p->df1 && p->dp2 && p->dga && p->dq && p->dkeys && p->dvalues &&
+                   p->dv && p->dwcl && p->work && p->align_t && p->de && p->dctx_t && p->keys_t && p->da0 && p->ctxp,
+               "ns_taco2_attn_cluster_bwd: null pointer (ctxp comes from ns_taco2_attn_cluster_fwd)");
+  if (p->dtype == NS_BF16) {
+    if (p->A == 256) return launch_bwd<bf16_t, BCfg<256, 256, 128>>(p, work, s);
+    return launch_bwd<bf16_t, BCfg<64, 256, 128>>(p, work, s);
+  }
+  if (p->A == 256) return launch_bwd<float, BCfg<256, 256, 128>>(p, work, s);
+  return launch_bwd<float, BCfg<64, 256, 128>>(p, work, s);
 }

@@ -214,11 +214,8 @@ def taco2_attn(direction, **kw):
     L.call("ns_taco2_attn_fwd" if direction == "fwd" else "ns_taco2_attn_bwd", _attn_params(kw), stream())
 
 
-def taco2_attn_cluster_supported(direction, **kw):
-    fn = "ns_taco2_attn_cluster_supported" if direction == "fwd" else "ns_taco2_attn_cluster_bwd_supported"
-    if not hasattr(L.lib(), fn):
-        return False
-    return bool(getattr(L.lib(), fn)(C.byref(_attn_params(kw))))
+def taco2_attn_cluster_supported(**kw):
+    return bool(L.lib().ns_taco2_attn_cluster_supported(C.byref(_attn_params(kw))))
 
 
 def taco2_attn_cluster_work_floats(**kw):

@@ -71,3 +71,31 @@ def test_cluster_forward_with_speakers(dev):
     for k in HIST:
         err = (got[k] - ref[k]).abs().max().item()
         assert err <= 2e-5 * max(1.0, ref[k].abs().max().item()), (k, err)
+
+
+@pytest.mark.parametrize("full,shape", [(False, (3, 11, 20)), (False, (1, 3, 20)), (False, (33, 9, 10)), (False, (2, 70, 15)),
+                                        (False, (5, 20, 35)), (True, (4, 37, 25)), (True, (2, 160, 10))])
+@pytest.mark.parametrize("mode", ["fp32", "mixed"])
+def test_cluster_backward_matches_per_step_kernels(dev, full, shape, mode):
+    from nspeech_amd.models import create_model
+    N, Ti, To = shape
+    hp = _hp(full)
+    m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=3)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N)
+    batch = (inputs, lengths, None, mel, lin)
+    ref = _run(m, batch, False, True)
+    got = _run(m, batch, True, True)
+    assert m._attn_cluster_fwd
+    # mixed: the per-step backward rounds its operands to bf16 (single pass), the cluster kernels keep fp32, so the two
+    # differ by the bf16 rounding of the reference path; fp32: summation order only (and the upstream forward differences)
+    tol = 1e-4 if mode == "fp32" else 3e-2
+    for k in GRAD:
+        a, b = got[k], ref[k]
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(1e-6, b.abs().max().item()) + 1e-9, (k, err, b.abs().max().item())
+    # every parameter gradient of the model (the attention RNN feeds the encoder's gradients as well)
+    for name, (off, shp) in m.layout.entries.items():
+        n = int(np.prod(shp))
+        a, b = got["flat_g"][off:off + n], ref["flat_g"][off:off + n]
+        err = (a - b).abs().max().item()
+        assert err <= tol * b.abs().max().item() + 1e-7, (name, err, b.abs().max().item())
