@@ -24,22 +24,51 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense, MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 
 
-def synthetic_batch(hp, N, Ti, To, seed):
+def synthetic_speech(rng, seconds, sr):
+    """5 harmonics of f0 ~ U[90, 250] Hz with 4 Hz amplitude modulation + N(0, 0.01) noise, peak 0.8."""
+    L = int(seconds * sr)
+    t = np.arange(L) / sr
+    f0 = rng.uniform(90, 250)
+    y = sum(np.sin(2 * np.pi * f0 * (h + 1) * t) / (h + 1) for h in range(5)) * (0.5 + 0.5 * np.sin(2 * np.pi * 4 * t))
+    return (0.8 * y / np.abs(y).max() + rng.normal(0, 0.01, L)).astype(np.float32)
+
+
+def synthetic_batch(hp, N, Ti, To, seed, features=None):
+    """SURVEY 8d inputs: ids ~ U{2..63} with lengths ~ U{T_in/2..T_in}, EOS last; targets = the reference-style
+    feature extraction (A3 / A4) of synthetic speech-like audio.  `features(wav) -> (linear [F,T], mel [M,T])`: the GPU
+    kernel in the benchmark, the NumPy oracle in the CPU baseline."""
     rng = np.random.default_rng(seed)
     lengths = rng.integers(Ti // 2, Ti + 1, size=N).astype(np.int32)
     inputs = np.zeros((N, Ti), np.int32)
     for n in range(N):
         inputs[n, :lengths[n] - 1] = rng.integers(2, 64, size=lengths[n] - 1)
         inputs[n, lengths[n] - 1] = 1
-    # spectrogram-like targets in [0,1] (saturating normalisation of the reference, Q1)
-    mel = np.clip(rng.normal(0.35, 0.25, size=(N, To, hp.num_mels)), 0, 1).astype(np.float32)
-    lin = np.clip(rng.normal(0.30, 0.25, size=(N, To, hp.num_freq)), 0, 1).astype(np.float32)
+    if features is None:
+        from nspeech_amd.utils import audio as A
+        features = A.spectrogram_and_mel
+    hop = int(hp.frame_shift_ms / 1000 * hp.sample_rate)
+    mel = np.zeros((N, To, hp.num_mels), np.float32)
+    lin = np.zeros((N, To, hp.num_freq), np.float32)
+    for n in range(N):
+        l, m = features(synthetic_speech(rng, To * hop / hp.sample_rate, hp.sample_rate))     # [F, 1 + To], [M, 1 + To]
+        lin[n], mel[n] = l.T[:To], m.T[:To]
     return inputs, lengths, mel, lin
 
 
-def cpu_baseline(hp, seed, budget_s=25.0):
-    """The CPU restatement of the reference (oracle/, torch-CPU fp32) timed on a bounded sample
-    of the same workload: one forward+backward at batch 4, T_in 160, T_out 250."""
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(hp, seed):
+    """The CPU restatement of the reference (oracle/, torch-CPU fp32) timed on a bounded sample of the same workload:
+    whole training steps (forward, backward, clip_by_global_norm, Adam) at batch 8, T_in 160, T_out 500."""
+    from oracle import audio_oracle as AO
     from oracle import taco2_oracle as O
     from nspeech_amd.models import params as P
     from nspeech_amd.utils.text.symbols import symbols
@@ -54,23 +83,36 @@ def cpu_baseline(hp, seed, budget_s=25.0):
     lay, st = P.taco2_layout(hp, len(symbols))
     pv, sv = P.init_values(lay, st, seed)
     N, Ti, To = 8, 160, 500
-    inputs, lengths, mel, lin = synthetic_batch(hp, N, Ti, To, seed)
-    p = {k: torch.tensor(v, requires_grad=True) for k, v in pv.items()}
-    p.update({k: torch.tensor(v) for k, v in sv.items()})
     hpd = hp.values()
+    inputs, lengths, mel, lin = synthetic_batch(hp, N, Ti, To, seed,
+                                                features=lambda w: (AO.spectrogram(w, hpd), AO.melspectrogram(w, hpd)))
+    p = {k: torch.tensor(v, requires_grad=True) for k, v in pv.items()}
+    stats = {k: torch.tensor(v) for k, v in sv.items()}
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    vv = {k: torch.zeros_like(v) for k, v in p.items()}
+    ti, tl, tm, tn = torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin)
     t0 = time.time()
     steps = 0
     while steps < 16 and (steps == 0 or time.time() - t0 < 12.0):    # about 10-30 s of CPU work
         for v in p.values():
             v.grad = None
-        out = O.taco2_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel), torch.tensor(lin))
-        loss, _, _ = O.taco2_loss(hpd, out, torch.tensor(mel), torch.tensor(lin))
+        out = O.taco2_forward(dict(p, **stats), hpd, ti, tl, tm, tn)
+        loss, _, _ = O.taco2_loss(hpd, out, tm, tn)
         loss.backward()
+        with torch.no_grad():
+            g, _ = O.clip_by_global_norm({k: v.grad for k, v in p.items()}, 1.0)
+            q = {k: v.detach() for k, v in p.items()}
+            O.adam_step(q, g, m, vv, steps + 1, O.learning_rate(hpd, steps), hp.adam["beta1"], hp.adam["beta2"])
+            for k in p:
+                p[k].copy_(q[k])
+            for k, v in out["bn_updates"].items():
+                stats[k] = v
         steps += 1
     dt = time.time() - t0
-    return {"value": steps * N * To / dt, "unit": "mel-frames/s", "cores": cores, "kind": "port",
-            "sample": "%d train steps (fwd+bwd, no Adam) at batch %d, T_in %d, T_out %d, fp32 torch-CPU oracle, %.1f s"
-                      % (steps, N, Ti, To, dt)}
+    return {"value": steps * N * To / dt, "unit": "mel-frames/s", "cores": cores, "cpu_model": cpu_model_name(),
+            "kind": "port",
+            "sample": "%d whole train steps (fwd + bwd + clip + Adam) at batch %d, T_in %d, T_out %d, fp32 torch-CPU "
+                      "restatement of the reference (oracle/), %.1f s" % (steps, N, Ti, To, dt)}
 
 
 def griffin_lim_bench(hp, with_cpu):
@@ -246,14 +288,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         one_step()
+        marks[i + 1].record()        # an event record does not synchronise: per-step times for the median
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
     if world > 1:
         t = torch.tensor([dt], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -278,30 +325,48 @@ def main():
     roof = profiling.roofline(model, one_step)
 
     if rank == 0:
-        pd = dict(phases)
-        # decoder gate GEMMs: 2*N*[(768+1024)+(1024+1024)]*4096 flop per decoder step forward, x3 with
-        # the backward; measured over the two decoder-LSTM phases (hoisted input GEMMs + the recurrent launches)
-        hp_ = hp
-        S = args.t_out // hp_.outputs_per_step
-        D = hp_.decoder_lstm_units
-        gate_flop = 3 * 2.0 * args.batch * ((hp_.attention_dim + 2 * hp_.encoder_lstm_units + D) + (D + D)) * 4 * D * S
+        # sub-phases ("dec_lstm:loop1") fold into their phase for the table; the parts feed the gate-GEMM roofline
+        pd = {}
+        for name, v in phases:
+            pd[name.split(":")[0]] = pd.get(name.split(":")[0], 0.0) + v
+        sub = dict(phases)
+        # decoder gate GEMMs (the figure north_star asks for): 2*N*[(768+1024)+(1024+1024)]*4096 flop per
+        # decoder step forward, x3 with the backward, over the time of the two decoder-LSTM phases (hoisted input
+        # GEMMs + the recurrent step launches + their weight-gradient GEMMs), HIP events on the launch stream
+        S = args.t_out // hp.outputs_per_step
+        D = hp.decoder_lstm_units
+        gate_flop = 3 * 2.0 * args.batch * ((hp.attention_dim + 2 * hp.encoder_lstm_units + D) + (D + D)) * 4 * D * S
         gate_ms = pd.get("dec_lstm", 0.0) + pd.get("dec_lstm_bwd", 0.0)
-        w_bytes = 2.0 * (2 * D) * 4 * D * 2          # recurrent weights of both cells, bf16
+        step_flop = 2.0 * args.batch * D * 4 * D              # one recurrent launch: [N, D] x [D, 4D]
+        loops = {k: sub.get(k, 0.0) for k in ("dec_lstm:loop1", "dec_lstm:loop2", "dec_lstm_bwd:loop2", "dec_lstm_bwd:loop1")}
+        from nspeech_amd import profiling as _prof
+        gate_roof = {
+            "bound": "mfma", "kernel": "decoder LSTM(1024) x 2 gate GEMMs: lstm_step_kernel / lstm_bwd_step_kernel (one "
+                                       "launch per decoder step) + the hoisted input and weight-gradient GEMMs",
+            "achieved": gate_flop / (gate_ms * 1e-3) / 1e12 if gate_ms else None, "peak": MFMA_BF16_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": gate_flop / (gate_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gate_ms else None,
+            "gflop_fwd_bwd": gate_flop / 1e9, "ms": gate_ms,
+            "step_launches": {k.replace("dec_lstm", "").strip(":_"): {"launches": S, "avg_launch_us": v * 1e3 / S,
+                                                                      "TFLOPs": step_flop / (v / S * 1e-3) / 1e12 if v else None}
+                              for k, v in loops.items()},
+            "binding_bound": "weight stream at M = 32: %.1f MB (bf16 hi+lo forward, bf16 backward) re-read per launch; "
+                             "HBM floor %.2f ms per step at 8 TB/s" % (2 * D * 4 * D * 4 / 1e6, S * (2 * D * 4 * D) * (4 + 2) / 8e12 * 1e3),
+            "traffic": _prof.pmc_traffic("lstm_step"),
+        }
         res = {
             "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),
             "unit": "mel-frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"mixed": "bf16", "bf16": "bf16", "bf16x3": "bf16", "fp32": "f32"}[args.dtype], "precision_mode": args.dtype, "data": "synthetic",
-            "config": {"workload": "Tacotron-2 train step (fwd+bwd+clip+Adam), batch %d/GPU, T_in %d, T_out %d, r=%d"
+            "ms_per_step": ms, "ms_per_step_median": median_ms, "value_at_median": args.batch * args.t_out * world / (median_ms * 1e-3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"mixed": "bf16", "bf16": "bf16", "bf16x3": "bf16", "fp32": "f32"}[args.dtype], "precision_mode": args.dtype,
+            "data": "synthetic",
+            "config": {"workload": "Tacotron-2 train step (fwd+bwd+clip+Adam), batch %d/GPU, T_in %d, T_out %d, r=%d; "
+                                   "targets = spectrogram features of synthetic speech (SURVEY 8d)"
                                    % (args.batch, args.t_in, args.t_out, hp.outputs_per_step),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world, "loss": loss},
-            "roofline": roof,
-            "decoder_gates": {"gflop_fwd_bwd": gate_flop / 1e9, "ms": gate_ms,
-                              "achieved_TFLOPs": gate_flop / (gate_ms * 1e-3) / 1e12 if gate_ms else None,
-                              "frac_of_mfma_peak": gate_flop / (gate_ms * 1e-3) / 1e12 / 2500.0 if gate_ms else None,
-                              "bound": "weight stream / dependent-launch latency at M=32",
-                              "hbm_floor_ms": 2 * S * w_bytes / 8e12 * 1e3},
-            "phases_ms": {k: round(v, 3) for k, v in phases},
+            "roofline": gate_roof,
+            "roofline_gemm_family": roof,
+            "phases_ms": {k: round(v, 3) for k, v in pd.items()},
         }
         if world == 1 and not args.train_only:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)

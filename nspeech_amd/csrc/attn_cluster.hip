@@ -23,6 +23,7 @@
 // All history the backward pass and the hoisted products read (p1, xa, hc, ca, ga, q, align, align_t) is written in
 // the layouts of ns_taco2_attn_fwd, which stays as the fallback for shapes this kernel does not cover.
 #include "common.h"
+#include <stdlib.h>
 
 int ns_attn_contexts_after_loop(const ns_taco2_attn_params& p, hipStream_t s);     // attn.hip
 template <typename T> int ns_attn_bwd_post(const ns_taco2_attn_params& p, hipStream_t s);
@@ -57,7 +58,12 @@ struct ACArgs {
   ns_taco2_attn_params p;
   u64* x2; u64* x3;          // [N][CG][X2N], [N][CG][X3N]
   int* status;
+  long long* trace;          // NS_ATTN_TRACE=1: [step][16] timestamps (100 MHz) of workgroup 0, else null
 };
+constexpr size_t TRACE_BYTES = 256 * 16 * sizeof(long long);
+__device__ __forceinline__ void stamp(const ACArgs& a, int st, int k) {
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && st < 256) a.trace[st * 16 + k] = wall_clock64();
+}
 
 __device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
   __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     float f1n = 0.f;
     if (tid < D1 && st + 1 < p.S) f1n = p.f1[((long)n * S1 + slot + 1) * D1 + tid];
 
+    stamp(a, st, 0);
     // ---- (1) p2 = relu(p1 . W2 + b2): every workgroup computes all of it
     red[tid] = dot_regs<P2K>(w2r, p1s + p2q * P2K);
     __syncthreads();
@@ -241,6 +248,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (tid / (D2 / CG) == g) stf((T*)p.xa + ((long)n * S1 + slot) * XA + tid, s);
     }
     __syncthreads();
+    stamp(a, st, 1);
     // ---- (2) gates of this workgroup's units, cell update
     red[tid] = dot_regs<GK>(wgr, xs + gq * GK);
     __syncthreads();
@@ -266,6 +274,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, h);
     }
     __syncthreads();
+    stamp(a, st, 2);
     // ---- (3) partial query of this workgroup's h rows, published
     {
       float s = 0.f;
@@ -280,11 +289,13 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       for (int q = 0; q < QG; ++q) s += red[q * A + tid];
       put_granule(x2 + (size_t)g * X2N + tid, tag, s);
     }
+    stamp(a, st, 3);
     // ---- (4) gather X2: q = sum of the partials (fixed order), h of every unit
     gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
     __syncthreads();
     if (sc[2] != 0.f) return;                 // uniform: every thread reads the same LDS word
+    stamp(a, st, 4);
     if (tid < A) {
       float s = 0.f;
 #pragma unroll
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       xs[D2 + tid] = gath[(tid / UPW) * X2N + A + (tid % UPW)];          // h(s) for the next step's gates
     }
     __syncthreads();
+    stamp(a, st, 5);
     // ---- (5) energies of the own positions: thread = (unit qu, t group qq)
     {
       const float qv = qs[qu];
@@ -318,6 +330,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       }
     }
     __syncthreads();
+    stamp(a, st, 6);
     if (wave == 0) {
       // local softmax: lane = local position
       constexpr int TPT = (TSMAX + QG - 1) / QG;
@@ -336,6 +349,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (lane == 0) { sc[0] = m; sc[1] = l; }
     }
     __syncthreads();
+    stamp(a, st, 7);
     // ---- (6) partial next-prenet sums over the own positions, published with the softmax pieces
     {
       const int c = tid % D1, th = tid / D1;
@@ -354,11 +368,13 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     } else if (tid < D1 + 2 + TSMAX) {
       put_granule(x3 + (size_t)g * X3N + tid, tag, es[tid - D1 - 2]);
     }
+    stamp(a, st, 8);
     // ---- (7) gather X3, combine
     gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
     __syncthreads();
     if (sc[2] != 0.f) return;
+    stamp(a, st, 9);
     float mall = -INFINITY;
 #pragma unroll
     for (int q = 0; q < CG; ++q) mall = fmaxf(mall, gath[q * X3N + D1]);
@@ -525,6 +541,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const long rowS = (long)n * S1 + slot;
 
+    stamp(a, p.S - 1 - st, 0);
     // ---- P0/P1: history of this step -> LDS; dot = sum_t a da0 + ctxp . dvec + dcar
     {
       float part = 0.f;
@@ -559,6 +576,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       sc[0] = d;
     }
     __syncthreads();
+    stamp(a, p.S - 1 - st, 1);
     // ---- P2: dalign and the energy gradients of the own positions: thread = (position tid / 16, 16 columns each)
     {
       const int tl = tid >> 4, cq = tid & 15;
@@ -584,6 +602,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       }
     }
     __syncthreads();
+    stamp(a, p.S - 1 - st, 2);
     // ---- P3: energy pass in the A-operand layout of v_mfma_f32_16x16x4_f32: row = position, k = unit
     if (wave < A / 32) {
       const int r = lane & 15, kq = lane >> 4;
@@ -617,6 +636,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       }
     }
     __syncthreads();
+    stamp(a, p.S - 1 - st, 3);
     // ---- P4: G[t][k] = de[t] * sum over the unit blocks of Z
     if (tid < TSMAX * 8) {
       const int tl = tid >> 3, k = tid & 7;
@@ -645,11 +665,13 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       d = wave_sum(d);
       if (tl == 0) sc[3] = d;
     }
+    stamp(a, p.S - 1 - st, 4);
     // ---- gather E2: dq = sum of the partials
     gather_granules<(CG * A + CT - 1) / CT>(e2, CG * A, tag, gath, tid, a.status, 3);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
     __syncthreads();
     if (sc[2] != 0.f) return;
+    stamp(a, p.S - 1 - st, 5);
     if (tid < A) {
       float s = 0.f;
 #pragma unroll
@@ -695,6 +717,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       }
     }
     __syncthreads();
+    stamp(a, p.S - 1 - st, 6);
     // ---- P7: partial input gradients dga_own . Watt[k, own]^T for every input row k, published with the carry pieces
 #pragma unroll
     for (int jj = 0; jj < PPT; ++jj) {
@@ -709,10 +732,12 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       put_granule(e3 + (size_t)g * E3N + tid, tag, s);
     }
     if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, tid == CCN - 1 ? sc[3] : ccv);
+    stamp(a, p.S - 1 - st, 7);
     gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
     __syncthreads();
     if (sc[2] != 0.f) return;
+    stamp(a, p.S - 1 - st, 8);
     // ---- P8: dp2 (masked), recurrent dh, carry and dcar for the step before
     if (tid < D2) {
       float s = 0.f;
@@ -746,6 +771,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       sc[1] = s;
     }
     __syncthreads();
+    stamp(a, p.S - 1 - st, 9);
     // ---- P9: dp1 = (dp2 . W2^T) masked: next dvec (every workgroup computes all of it)
     red[tid] = dot_regs<W2K>(w2r, dp2s + (tid / D1) * W2K);
     __syncthreads();
@@ -781,7 +807,7 @@ extern "C" int ns_taco2_attn_cluster_supported(const ns_taco2_attn_params* p) { 
 extern "C" size_t ns_taco2_attn_cluster_work_bytes(const ns_taco2_attn_params* p) {
   if (!p) return 0;
   // status block + the two exchange buffers (sized for the widest instantiation)
-  return 256 + sizeof(u64) * (size_t)p->N * CG * (size_t)(2 * (256 + 32 + 2 + TSMAX) + 1024);
+  return 256 + sizeof(u64) * (size_t)p->N * CG * (size_t)(2 * (256 + 32 + 2 + TSMAX) + 1024) + TRACE_BYTES;
 }
 
 template <typename T, typename C>
@@ -792,6 +818,7 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.x2 = (u64*)((char*)work + 256);
   a.x3 = a.x2 + (size_t)p->N * CG * C::X2N;
   const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::X2N + C::X3N);
+  a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
   if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
   const size_t lds = fwd_lds_bytes<C>();
   static bool attr = false;
@@ -861,6 +888,7 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.x2 = (u64*)((char*)work + 256);
   a.x3 = a.x2 + (size_t)p->N * CG * C::A;
   const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::A + C::E3N);
+  a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
   if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
   const size_t lds = bwd_lds_bytes<C>();
   static bool attr = false;

@@ -224,10 +224,12 @@ def taco2_attn_cluster_work_floats(**kw):
     return (fn(C.byref(_attn_params(kw))) + 3) // 4
 
 
-def taco2_attn_cluster(direction, work, **kw):
-    """The attention RNN of all decoder steps as one persistent launch; work[0] is the status word."""
+def taco2_attn_cluster(direction, cluster_work, **kw):
+    """The attention RNN of all decoder steps as one persistent launch; cluster_work[0] is the status word (kw may
+    hold the per-step path's own `work` scratch, which the backward post-pass uses)."""
     fn = getattr(L.lib(), "ns_taco2_attn_cluster_fwd" if direction == "fwd" else "ns_taco2_attn_cluster_bwd")
-    L.check(fn(C.byref(_attn_params(kw)), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_taco2_attn_cluster_" + direction)
+    L.check(fn(C.byref(_attn_params(kw)), C.c_void_p(ptr(cluster_work)), C.c_void_p(stream())),
+            "ns_taco2_attn_cluster_" + direction)
 
 
 def lstm_cluster_supported(p0):

@@ -15,6 +15,22 @@ def _last_kernel():
     return fn().decode()
 
 
+PROFILE_ROUND = "r02"
+
+
+def pmc_traffic(key):
+    """Memory-side bytes per launch from THIS round's PMC passes (profiles/<round>_pmc_traffic.json: FETCH_SIZE x2 +
+    WRITE_SIZE as MI355X_MICROARCH.md prescribes, collected offline - rocprofv3 refuses --pmc together with the trace
+    domains a live run would need).  None when the round has no such file: a stale number is worse than none."""
+    import json
+    import os
+    f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "%s_pmc_traffic.json" % PROFILE_ROUND)
+    try:
+        return float(json.load(open(f))[key]["traffic_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def roofline(model, one_step):
     rec = []
     orig = ops.gemm
@@ -31,8 +47,12 @@ def roofline(model, one_step):
         e1.record()
         esz = A.element_size()
         nb = kw.get("batch", 1)
+        # unique bytes: a conv1d 'same' product reads its [rows, C_in] input once although the im2col view is K = k * C_in
+        # wide (lda < K: overlapping rows)
+        lda = a[0] if a else kw.get("lda", K)
+        a_unique = float(M + (K // lda - 1 if lda and K > lda else 0)) * min(lda, K) if kw.get("a_mode", 0) == 0 else float(M * K)
         rec.append((2.0 * M * N * K * nb, e0, e1, passes,
-                    (float(M * K + K * N) * esz + float(M * N) * Cm.element_size()) * nb, _last_kernel()))
+                    (a_unique + float(K * N)) * esz * nb + float(M * N) * Cm.element_size() * nb, _last_kernel()))
 
     ops.gemm = timed
     try:
@@ -46,16 +66,7 @@ def roofline(model, one_step):
     issued = sum(r[0] * r[3] for r in rec)         # MFMA work actually issued (x3 for split-bf16)
     ms = sum(r[1].elapsed_time(r[2]) for r in rec)
     ach = flops / (ms * 1e-3) / 1e12
-    # memory-side traffic of the same kernels from the PMC passes kept under profiles/ (collected offline: rocprofv3
-    # refuses --pmc together with the trace domains this bench would need, and a counter pass serialises the step)
-    traffic = None
-    try:
-        import json
-        import os
-        f = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01_pmc_traffic.json")
-        traffic = float(json.load(open(f))["traffic_bytes_per_launch"])
-    except Exception:
-        pass
+    traffic = pmc_traffic("gemm_family")
     # the same timings per kernel variant, named as rocprofv3 names them (profiles/r01_v6_kernel_stats.csv)
     by = {}
     for r in rec:
@@ -76,4 +87,5 @@ def roofline(model, one_step):
             "algorithmic_bytes_per_launch": sum(r[4] for r in rec) / len(rec),
             "traffic": traffic,
             "traffic_note": "bytes per launch at the L2's fabric side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
-                            "included), rocprofv3 --pmc passes summarised in profiles/r01_pmc_traffic.json"}
+                            "included), rocprofv3 --pmc passes summarised in profiles/%s_pmc_traffic.json; null = not "
+                            "collected this round" % PROFILE_ROUND}
