@@ -137,6 +137,9 @@ typedef struct {
   float eps, momentum;
   int training;
   int row_period, row_lo, row_hi;
+  /* optional (dtype NS_F32): the output also / instead as a pre-split bf16 pair y_hi = bf16(y), y_lo = bf16(y - y_hi),
+   * the operand form of the three-segment 256-tile product (ns_gemm A_lo / B_lo); with them `y` may be NULL */
+  void* y_hi; void* y_lo;
 } ns_bn_fwd_params;
 int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t stream);
 

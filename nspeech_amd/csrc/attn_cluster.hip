@@ -141,8 +141,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   float* qs = red + CT;                    // [A]      query
   float* al = qs + A;                      // [APAD + 256 + APAD] alignment of the previous step, zero margins
   float* es = al + 256 + 2 * APAD;         // [TSMAX]  local unnormalised softmax weights
-  float* ered = es + TSMAX;                // [CT/64][TSMAX/QG + 1] per-wave energy sums
-  float* hloc = ered + (CT / 64) * (TSMAX / QG + 1);    // [UPW] new h of this workgroup's units
+  float* ered = es + TSMAX;                // [CT/64][TSMAX] per-wave energy sums
+  float* hloc = ered + (CT / 64) * TSMAX;  // [UPW] new h of this workgroup's units
   float* sc = hloc + UPW;                  // [16]     [0] local max, [1] local sum, [2] abort flag
   float* gath = sc + 16;                   // [CG][XMAX]
   float* keys_s = gath + CG * C::XMAX;     // [TSMAX][A]
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     __syncthreads();
     stamp(a, st, 1);
     // ---- (2) gates of this workgroup's units, cell update
+    float sv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     red[tid] = dot_regs<GK>(wgr, xs + gq * GK);
     __syncthreads();
     if (tid < UPW) {
@@ -265,13 +266,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       cstate = gf * cstate + gi * gj;
       const float h = go * tanhf_(cstate);
       hloc[tid] = h;
-      const int u = g * UPW + tid;
-      put_granule(x2 + (size_t)g * X2N + A + tid, tag, h);                 // the peers wait for this first
-      p.ca[((long)n * S1 + slot) * A + u] = cstate;
-      T* gp = (T*)p.ga + ((long)n * S1 + slot) * 4 * A;
-      stf(gp + u, gi); stf(gp + A + u, gj); stf(gp + 2 * A + u, gf); stf(gp + 3 * A + u, go);
-      stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, h);
-      if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, h);
+      put_granule(x2 + (size_t)g * X2N + A + tid, tag, h);                 // the peers wait for this
+      sv[0] = gi; sv[1] = gj; sv[2] = gf; sv[3] = go; sv[4] = h;           // saved after the gather (see below)
     }
     __syncthreads();
     stamp(a, st, 2);
@@ -304,43 +300,52 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (tid / UPW == g) p.q[((long)n * S1 + slot) * A + tid] = s;
       xs[D2 + tid] = gath[(tid / UPW) * X2N + A + (tid % UPW)];          // h(s) for the next step's gates
     }
+    if (tid < UPW) {
+      // what the backward pass / the hoisted products read of this step's cell: stored only now, so that these
+      // stores did not sit in front of this wave's polling loads (one vmcnt queue for loads and stores)
+      const int u = g * UPW + tid;
+      p.ca[((long)n * S1 + slot) * A + u] = cstate;
+      T* gp = (T*)p.ga + ((long)n * S1 + slot) * 4 * A;
+      stf(gp + u, sv[0]); stf(gp + A + u, sv[1]); stf(gp + 2 * A + u, sv[2]); stf(gp + 3 * A + u, sv[3]);
+      stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, sv[4]);
+      if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, sv[4]);
+    }
     __syncthreads();
     stamp(a, st, 5);
-    // ---- (5) energies of the own positions: thread = (unit qu, t group qq)
-    {
-      const float qv = qs[qu];
-      float wcl[KWMAX];
+    // ---- (5) energies of the own positions in the A-operand layout of v_mfma_f32_16x16x4_f32 (row = position,
+    //      k = unit) against B = attention_v in column 0: the sum over the units comes out of the matrix core (exact
+    //      fp32), no cross-lane reductions
+    if (wave < A / 32) {
+      const int r = lane & 15, kq = lane >> 4;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      float ap0[KWMAX], ap1[KWMAX];
 #pragma unroll
-      for (int k = 0; k < KWMAX; ++k) wcl[k] = cst_s[k * A + qu];
-      const float vu = cst_s[KWMAX * A + qu];
-      constexpr int TPT = (TSMAX + QG - 1) / QG;
-#pragma unroll 2
-      for (int ti = 0; ti < TPT; ++ti) {
-        const int tl = qq + ti * QG;                 // local position
-        float e = 0.f;
-        if (tl < tn) {
-          const float* ap = al + APAD + t0 + tl - half;
-          float x = keys_s[tl * A + qu] + qv;
+      for (int k = 0; k < KWMAX; ++k) { ap0[k] = al[APAD + t0 + r - half + k]; ap1[k] = al[APAD + t0 + r + 16 - half + k]; }
 #pragma unroll
-          for (int k = 0; k < KWMAX; ++k) x = fmaf(ap[k], wcl[k], x);      // taps past kw carry a zero weight
-          e = vu * tanhf_(x);
-        }
-        e = wave_sum(e);
-        if (lane == 0) ered[wave * (TPT + 1) + ti] = e;
+      for (int j = 0; j < 8; ++j) {
+        const int u = wave * 32 + j * 4 + kq;
+        const float qv = qs[u];
+        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
+#pragma unroll
+        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+        const float b = r == 0 ? cst_s[KWMAX * A + u] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf_(x0), b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf_(x1), b, acc1, 0, 0, 0);
+      }
+      if (r == 0) {        // D: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { ered[wave * TSMAX + kq * 4 + q] = acc0[q]; ered[wave * TSMAX + 16 + kq * 4 + q] = acc1[q]; }
       }
     }
     __syncthreads();
     stamp(a, st, 6);
     if (wave == 0) {
       // local softmax: lane = local position
-      constexpr int TPT = (TSMAX + QG - 1) / QG;
-      constexpr int WPG = A / 64 > 0 ? A / 64 : 1;          // waves per t group (A >= 64)
       float e = -INFINITY;
       if (lane < tn) {
-        const int qg_ = lane % QG, ti = lane / QG;
         e = 0.f;
 #pragma unroll
-        for (int w = 0; w < WPG; ++w) e += ered[(qg_ * WPG + w) * (TPT + 1) + ti];
+        for (int w = 0; w < A / 32; ++w) e += ered[w * TSMAX + lane];
       }
       const float m = wave_max(e);
       const float w = lane < tn ? __expf(e - m) : 0.f;
@@ -444,11 +449,6 @@ struct BCfg : Cfg<A_, D1_, D2_> {
   static_assert(NQ * B::K == PPT * CT && B::GC % NQ == 0 && B::D2 % W2H == 0 && B::A % 32 == 0 && B::D1 == 256, "shape");
 };
 
-__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
-  v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
-  return v;
-}
-
 template <typename T, typename C>
 __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   constexpr int A = C::A, D1 = C::D1, D2 = C::D2, UPW = C::UPW, GC = C::GC, K = C::K;
@@ -531,6 +531,33 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     if (tid < 48) sc[tid] = 0.f;
   }
   float dcc = 0.f;                         // cell-state gradient carried to the step before (owner lanes)
+  // history of a step, one value per thread and role (read straight from the forward pass' buffers)
+  float h_q = 0.f, h_p1 = 0.f, h_ctx = 0.f, h_p2 = 0.f, h_alp = 0.f, h_a = 0.f, h_da0 = 0.f, h_gt = 0.f;
+  float h_dhc = 0.f, h_c = 0.f, h_cp = 0.f;
+  auto load_history = [&](int st_, int tid) {
+    const long rowS = (long)n * S1 + st_ + 1;
+    if (tid < A) h_q = p.q[rowS * A + tid];
+    if (tid < D1) { h_p1 = ldf((const T*)p.p1 + rowS * D1 + tid); h_ctx = p.ctxp[rowS * D1 + tid]; }
+    if (tid < D2) h_p2 = ldf((const T*)p.xa + rowS * XA + tid);
+    h_a = 0.f; h_da0 = 0.f;
+    if (tid < 256) {
+      h_alp = tid < p.Tia ? p.align[(rowS - 1) * p.Tia + tid] : 0.f;
+      if (tid < L) { h_a = p.align[rowS * p.Tia + tid]; h_da0 = p.da0[rowS * p.Tia + tid]; }
+    } else if (tid < 256 + TSMAX) {
+      const int tl = tid - 256;
+      if (tl < tn) { h_a = p.align[rowS * p.Tia + t0 + tl]; h_da0 = p.da0[rowS * p.Tia + t0 + tl]; }
+    } else if (tid >= 320 && tid < 320 + GC) {
+      const int c = tid - 320;
+      h_gt = ldf((const T*)p.ga + rowS * 4 * A + (c / UPW) * A + g * UPW + (c % UPW));
+    }
+    if ((tid & 15) == 0 && (tid >> 4) < UPW) {          // the cell owners (P6)
+      const int u = g * UPW + (tid >> 4);
+      h_dhc = p.dhc[rowS * HC + u];
+      h_c = p.ca[rowS * A + u];
+      h_cp = st_ > 0 ? p.ca[(rowS - 1) * A + u] : 0.f;
+    }
+  };
+  load_history(p.S - 1, tid_);
   __syncthreads();
 
   for (int st = p.S - 1; st >= 0; --st) {
@@ -542,32 +569,24 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     const long rowS = (long)n * S1 + slot;
 
     stamp(a, p.S - 1 - st, 0);
-    // ---- P0/P1: history of this step -> LDS; dot = sum_t a da0 + ctxp . dvec + dcar
+    // ---- P0/P1: history of this step (prefetched into registers during the step before) -> LDS;
+    //      dot = sum_t a da0 + ctxp . dvec + dcar;  then the loads of step s-1 go out and stay in flight
     {
       float part = 0.f;
-      if (tid < A) qs[tid] = p.q[rowS * A + tid];
-      if (tid < D1) {
-        p1m[tid] = ldf((const T*)p.p1 + rowS * D1 + tid);
-        part = p.ctxp[rowS * D1 + tid] * dvec[tid];
-      }
-      if (tid < D2) p2m[tid] = ldf((const T*)p.xa + rowS * XA + tid);
+      if (tid < A) qs[tid] = h_q;
+      if (tid < D1) { p1m[tid] = h_p1; part = h_ctx * dvec[tid]; }
+      if (tid < D2) p2m[tid] = h_p2;
       if (tid < 256) {
-        const float ap = tid < p.Tia ? p.align[(rowS - 1) * p.Tia + tid] : 0.f;
-        al[APAD + tid] = ap;
-        if (tid < L) part = fmaf(p.align[rowS * p.Tia + tid], p.da0[rowS * p.Tia + tid], part);
+        al[APAD + tid] = h_alp;
+        part = fmaf(h_a, h_da0, part);
       }
-      if (tid >= 256 && tid < 256 + TSMAX) {
-        const int tl = tid - 256;
-        acur[tl] = tl < tn ? p.align[rowS * p.Tia + t0 + tl] : 0.f;
-        da0s[tl] = tl < tn ? p.da0[rowS * p.Tia + t0 + tl] : 0.f;
-      }
-      if (tid >= 320 && tid < 320 + GC) {
-        const int c = tid - 320;
-        gts[c] = ldf((const T*)p.ga + rowS * 4 * A + (c / UPW) * A + g * UPW + (c % UPW));
-      }
+      if (tid >= 256 && tid < 256 + TSMAX) { acur[tid - 256] = h_a; da0s[tid - 256] = h_da0; }
+      if (tid >= 320 && tid < 320 + GC) gts[tid - 320] = h_gt;
       part = wave_sum(part);
       if (lane == 0) sc[4 + wave] = part;
     }
+    const float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;      // the cell owners' operands of this step
+    if (st > 0) load_history(st - 1, tid);
     __syncthreads();
     if (tid == 0) {
       float d = sc[1];
@@ -611,21 +630,32 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
 #pragma unroll
       for (int k = 0; k < KWMAX; ++k) { ap0[k] = al[APAD + t0 + r - half + k]; ap1[k] = al[APAD + t0 + r + 16 - half + k]; }
       const float de0 = dev[r], de1 = dev[r + 16];
-#pragma unroll 2
-      for (int j = 0; j < 8; ++j) {
-        const int u = wave * 32 + j * 4 + kq;
-        const float qv = qs[u], vv = cst_s[KWMAX * A + u];
-        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
 #pragma unroll
-        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
-        const float th0 = tanhf_(x0), th1 = tanhf_(x1);
-        const float g0 = r < tn ? vv * (1.f - th0 * th0) : 0.f;
-        const float g1 = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
-        const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0, b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, b, acc[1], 0, 0, 0);
-        const float dqp = row16_sum(fmaf(de0, g0, de1 * g1));
-        if (r == 0) put_granule(e2 + (size_t)g * A + u, tag, dqp);
+      for (int jb = 0; jb < 8; jb += 4) {        // two batches of four units: four independent reductions each
+        float dqp[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const int u = wave * 32 + (jb + jj) * 4 + kq;
+          const float qv = qs[u], vv = cst_s[KWMAX * A + u];
+          float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
+#pragma unroll
+          for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+          const float th0 = tanhf_(x0), th1 = tanhf_(x1);
+          const float g0 = r < tn ? vv * (1.f - th0 * th0) : 0.f;
+          const float g1 = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
+          const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0, b, acc[0], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, b, acc[1], 0, 0, 0);
+          dqp[jj] = fmaf(de0, g0, de1 * g1);
+        }
+        // dq partial of unit u = sum over the 16 positions of a DPP row (the two tiles added in-thread)
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) dqp[jj] = row16_sum(dqp[jj]);
+        if (r == 0) {
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj) put_granule(e2 + (size_t)g * A + wave * 32 + (jb + jj) * 4 + kq, tag, dqp[jj]);
+        }
+        asm volatile("" ::: "memory");
       }
       // D: col = lane & 15 (filter tap), row = (lane >> 4) * 4 + reg (position inside the 16-row tile)
       if (r < 8) {
@@ -696,10 +726,9 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       s = row16_sum(s);
       if (uq == 0 && j < UPW) {
         const int u = g * UPW + j;
-        const float dh = p.dhc[rowS * HC + u] + s + hrec[j];
+        const float dh = o_dhc + s + hrec[j];
         const float gi = gts[j], gj = gts[UPW + j], gf = gts[2 * UPW + j], go = gts[3 * UPW + j];
-        const float c = p.ca[rowS * A + u];
-        const float cp = st > 0 ? p.ca[(rowS - 1) * A + u] : 0.f;
+        const float c = o_c, cp = o_cp;
         const float tc = tanhf_(c);
         const float d_o = dh * tc * go * (1.f - go);
         const float dc = dh * go * (1.f - tc * tc) + dcc;
@@ -789,7 +818,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
 
 template <typename C>
 size_t fwd_lds_bytes() {
-  return sizeof(float) * (C::K + C::D1 + CT + C::A + 256 + 2 * APAD + TSMAX + (CT / 64) * (TSMAX / C::QG + 1) + C::UPW + 16 +
+  return sizeof(float) * (C::K + C::D1 + CT + C::A + 256 + 2 * APAD + TSMAX + (CT / 64) * TSMAX + C::UPW + 16 +
                           CG * C::XMAX + TSMAX * C::A + TSMAX * C::D1 + C::UPW * C::A + (KWMAX + 1) * C::A);
 }
 
@@ -819,7 +848,7 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.x3 = a.x2 + (size_t)p->N * CG * C::X2N;
   const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::X2N + C::X3N);
   a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
-  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
+  { const int zrc = ns_zero_async(work, ((256 + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   const size_t lds = fwd_lds_bytes<C>();
   static bool attr = false;
   if (!attr) {
@@ -852,6 +881,11 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     hipLaunchKernelGGL((attn_cluster_fwd_kernel<T, C>), dim3(nn * CG), dim3(CT), lds, s, b);
   }
   NS_CHECK_LAUNCH("attn_cluster_fwd");
+  // the transposed keys the per-step forward leaves behind for either backward path (hoisted sums over the steps)
+  if (p->keys_t) {
+    int rc = ns_taco2_keys_transpose(p->keys, p->keys_t, p->N, p->Ti, p->Tia, p->Pi, p->padl_i, p->A, s);
+    if (rc) return rc;
+  }
   return ns_attn_contexts_after_loop(*p, s);
 }
 
@@ -889,7 +923,7 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.x3 = a.x2 + (size_t)p->N * CG * C::A;
   const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::A + C::E3N);
   a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
-  if (hipMemsetAsync(work, 0, 256 + xbytes, s) != hipSuccess) { ns_set_error("ns_taco2_attn_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
+  { const int zrc = ns_zero_async(work, ((256 + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   const size_t lds = bwd_lds_bytes<C>();
   static bool attr = false;
   if (!attr) {
@@ -923,10 +957,7 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     hipLaunchKernelGGL((attn_cluster_bwd_kernel<T, C>), dim3(b.p.N * CG), dim3(CT), lds, s, b);
   }
   NS_CHECK_LAUNCH("attn_cluster_bwd");
-  // the hoisted sums need the transposed keys, which the per-step forward would have left behind
-  int rc = ns_taco2_keys_transpose(p->keys, p->keys_t, p->N, p->Ti, p->Tia, p->Pi, p->padl_i, p->A, s);
-  if (rc) return rc;
-  return ns_attn_bwd_post<T>(*p, s);
+  return ns_attn_bwd_post<T>(*p, s);       // keys_t: written by either forward
 }
 
 extern "C" int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stream_t s_) {

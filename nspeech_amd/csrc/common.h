@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 // ---------------------------------------------------------------- errors
 void ns_set_error(const char* fmt, ...);
+int ns_zero_async(void* p, size_t bytes, hipStream_t s);   // core.hip: kernel fill (graph-replay safe, see there)
 
 #define NS_CHECK_ARG(cond, ...)                                   \
   do {                                                            \
@@ -62,14 +63,33 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
+// Cross-lane reductions: inside a DPP row (16 lanes) with VALU-rate DPP moves - quad swaps, then the two row mirrors
+// leave the row's result in every lane - and only the last two steps (lane ^ 16, lane ^ 32) through ds_bpermute.
+#define NS_DPP_F(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
+__device__ __forceinline__ float row16_sum(float v) {      // sum over the 16 lanes that share lane >> 4
+  v += NS_DPP_F(v, 0xB1);     // quad_perm [1,0,3,2]
+  v += NS_DPP_F(v, 0x4E);     // quad_perm [2,3,0,1]
+  v += NS_DPP_F(v, 0x141);    // row_half_mirror
+  v += NS_DPP_F(v, 0x140);    // row_mirror
+  return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, NS_DPP_F(v, 0xB1));
+  v = fmaxf(v, NS_DPP_F(v, 0x4E));
+  v = fmaxf(v, NS_DPP_F(v, 0x141));
+  v = fmaxf(v, NS_DPP_F(v, 0x140));
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v = row16_sum(v);
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = row16_max(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

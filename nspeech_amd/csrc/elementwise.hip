@@ -108,12 +108,68 @@ __global__ void bn_apply_kernel(ns_bn_fwd_params p) {
     stf(y + idx, v);
   }
 }
+// vector form: 4 adjacent channels per thread (16-byte accesses), optional pre-split bf16 outputs
+__device__ __forceinline__ float4 ld4f(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4f(const bf16_t* p) {
+  const bf16x4 v = *(const bf16x4*)p;
+  return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply4_kernel(ns_bn_fwd_params p) {
+  const T* z = (const T*)p.z;
+  const int C4 = p.C >> 2;
+  const long total4 = (long)p.rows * C4;
+  for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+    const int row = (int)(i4 / C4), c = (int)(i4 - (long)row * C4) * 4;
+    bool valid = true;
+    if (p.row_period > 0) {
+      const int t = row % p.row_period;
+      valid = t >= p.row_lo && t < p.row_hi;
+    }
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) {
+      const float4 x = ld4f(z + i4 * 4), m = *(const float4*)(p.mean_out + c), is = *(const float4*)(p.istd_out + c);
+      const float4 g = *(const float4*)(p.gamma + c), b = *(const float4*)(p.beta + c);
+      v.x = (x.x - m.x) * is.x * g.x + b.x; v.y = (x.y - m.y) * is.y * g.y + b.y;
+      v.z = (x.z - m.z) * is.z * g.z + b.z; v.w = (x.w - m.w) * is.w * g.w + b.w;
+    }
+    if (p.y) {
+      if constexpr (sizeof(T) == 4) *(float4*)((float*)p.y + i4 * 4) = v;
+      else {
+        bf16x4 o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
+        *(bf16x4*)((bf16_t*)p.y + i4 * 4) = o;
+      }
+    }
+    if (p.y_hi) {
+      const float f[4] = {v.x, v.y, v.z, v.w};
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { hi[j] = (bf16_t)f[j]; lo[j] = (bf16_t)(f[j] - (float)hi[j]); }
+      *(bf16x4*)((bf16_t*)p.y_hi + i4 * 4) = hi;
+      *(bf16x4*)((bf16_t*)p.y_lo + i4 * 4) = lo;
+    }
+  }
+}
+
 extern "C" int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t s) {
-  NS_CHECK_ARG(p && p->z && p->y && p->gamma && p->beta && p->mean_out && p->istd_out, "ns_bn_fwd: null");
+  NS_CHECK_ARG(p && p->z && (p->y || p->y_hi) && p->gamma && p->beta && p->mean_out && p->istd_out, "ns_bn_fwd: null");
   NS_CHECK_ARG(!p->training || (p->col_sum && p->col_sumsq && p->count > 0), "ns_bn_fwd: training needs stats");
   NS_CHECK_ARG(p->training || (p->moving_mean && p->moving_var), "ns_bn_fwd: inference needs moving stats");
+  NS_CHECK_ARG((p->y_hi != nullptr) == (p->y_lo != nullptr), "ns_bn_fwd: y_hi and y_lo come together");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(p->C, 256)), dim3(256), 0, (hipStream_t)s, *p);
   const long total = (long)p->rows * p->C;
+  auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
+  const int esz = p->dtype == NS_BF16 ? 2 : 4;
+  const bool vec = p->C % 4 == 0 && al(p->z, 4 * esz) && al(p->y, 4 * esz) && al(p->mean_out, 16) && al(p->istd_out, 16) &&
+                   al(p->gamma, 16) && al(p->beta, 16) && al(p->y_hi, 8) && al(p->y_lo, 8);
+  if (vec) {
+    const int grid = (int)min((long)4096, (total / 4 + 255) / 256);
+    if (p->dtype == NS_BF16) hipLaunchKernelGGL(bn_apply4_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+    else hipLaunchKernelGGL(bn_apply4_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+    NS_CHECK_LAUNCH("bn_fwd");
+    return NS_OK;
+  }
+  NS_CHECK_ARG(p->y && !p->y_hi, "ns_bn_fwd: the pre-split outputs need C %% 4 == 0 and 16-byte aligned operands");
   int grid = (int)min((long)8192, (total + 255) / 256);
   if (p->dtype == NS_BF16) hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
   else hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);

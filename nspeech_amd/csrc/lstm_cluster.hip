@@ -928,7 +928,7 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   fill(a, p0, p1, work);
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);
   const size_t xbytes = (chains + 2) * 2 * 16 * (size_t)(a.H / 2) * sizeof(u64);
-  if (hipMemsetAsync(work, 0, 256 + FLAG_BYTES + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_fwd: memset failed"); return NS_ERR_LAUNCH; }
+  { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   if (role_split_ok(a, false)) {
     const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 2 * (2048 + 4096 + 8192) + 32;
     const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && !(a.dbg & 32)) ? 2 : 1;
@@ -964,7 +964,7 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);
   // the role-split kernel exchanges through the dgates array + flags; only the single-role kernel needs the granule buffers
   const size_t xbytes = role_split_ok(a, true) ? 0 : (chains + 2) * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64);
-  if (hipMemsetAsync(work, 0, 256 + FLAG_BYTES + xbytes, s) != hipSuccess) { ns_set_error("ns_lstm_cluster_bwd: memset failed"); return NS_ERR_LAUNCH; }
+  { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)lstm_cluster_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

@@ -210,6 +210,13 @@ class Tacotron2(object):
             for i in range(1, hp.expand_conv_layers):
                 if (kx * Cx) % 64 == 0 and Cx % 128 == 0:
                     tr("expT_%d" % i, "expand/conv_%d/conv1d/kernel" % i, 0, kx * Cx, Cx, self.Tx)
+        # mixed mode: k-contiguous pre-split (hi, lo) shadows of the postnet kernels whose forward product fills the
+        # chip with 256-tiles: the three-pass product then runs on the 256-tile kernel over pre-split operands
+        if self.mode == "mixed":
+            kp, Cp = hp.postnet_conv_width, hp.postnet_conv_channels
+            for i in range(1, hp.postnet_conv_layers):
+                if (kp * Cp) % 64 == 0 and Cp % 128 == 0:
+                    tr("postT_%d" % i, "decoder_postnet/postnet_conv_%d/conv1d/kernel" % i, 0, kp * Cp, Cp, torch.float32)
         # folded location filter Wcl[k,u] = sum_j Wc[k,0,j] Wl[j,u]  (fp32)
         if "wcl" not in self.tsh:
             self.tsh["wcl"] = torch.zeros(7 * A, dtype=torch.float32, device=dev)
@@ -310,36 +317,50 @@ class Tacotron2(object):
             self._bufs["st_used"] = off + ((4 * cout + 63) // 64) * 64
         return m[tag]
 
-    def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None):
-        """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198)."""
+    def _x256_split_ok(self, tag, rows, cin, cout, k):
+        """A three-pass forward convolution that can run on the 256-tile kernel over pre-split operands."""
+        return (self.mode == "mixed" and ("postT_" + tag[4:] + "_hi") in self.tsh and tag.startswith("post")
+                and (k * cin) % 64 == 0 and cout % 128 == 0 and rows >= 1024
+                and ((rows + 255) // 256) * ((cout + 255) // 256) >= 96)
+
+    def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None, xsplit=None,
+                  emit_split=False):
+        """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198).
+        xsplit = (hi, lo): the input as a pre-split bf16 pair (then the product runs as three segments on the 256-tile
+        kernel); emit_split: BatchNorm writes its output as such a pair (returned instead of the fp32 tensor)."""
         kl = (k - 1) // 2
         rows = N * Pp
         a_rows = self.padl - kl
         Mg = rows - (k - 1) - a_rows
         D = D or self.T
         z = self._buf(tag + "_z", rows * cout, D)
-        y = self._buf(tag + "_y", rows * cout, D)
         st = self._stats_buf(tag, cout)
         wT = self.tsh.get("expT_" + tag[3:]) if tag.startswith("exp") and D == torch.bfloat16 else None
-        if wT is not None:      # k-contiguous weight shadow (refresh_shadows)
-            ops.gemm(xin, wT, z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0,
-                     a_off=a_rows * cin, c_off=self.padl * cout,
-                     bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
-                     row_mask=(Pp, self.padl, self.padl + T, self.padl),
-                     col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+        common = dict(a_off=a_rows * cin, c_off=self.padl * cout, bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"),
+                      act=act, row_mask=(Pp, self.padl, self.padl + T, self.padl),
+                      col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+        if xsplit is not None:      # pre-split operands: (hi, hi), (hi, lo), (lo, hi) on the 256-tile kernel
+            key = "postT_" + tag[4:]
+            ops.gemm(xsplit[0], self.tsh[key + "_hi"], z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0,
+                     a_lo=xsplit[1], b_lo=self.tsh[key + "_lo"], **common)
+        elif wT is not None:        # k-contiguous weight shadow (refresh_shadows)
+            ops.gemm(xin, wT, z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0, **common)
         else:
             ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
-                     a_off=a_rows * cin, b_off=self._o(scope + "/conv1d/kernel"), c_off=self.padl * cout,
-                     bias=self.flat_p, bias_off=self._o(scope + "/conv1d/bias"), act=act,
-                     row_mask=(Pp, self.padl, self.padl + T, self.padl),
-                     col_sum=st if training else None, col_sumsq=st[cout:] if training else None)
+                     b_off=self._o(scope + "/conv1d/kernel"), **common)
+        y = yh = yl = None
+        if emit_split:
+            yh = self._buf(tag + "_yhi", rows * cout, torch.bfloat16)
+            yl = self._buf(tag + "_ylo", rows * cout, torch.bfloat16)
+        else:
+            y = self._buf(tag + "_y", rows * cout, D)
         ops.bn_fwd(z, y, rows, cout, st, st[cout:], N * T, self.flat_p, self.flat_p, self.flat_stats,
                    self.flat_stats, st[2 * cout:], st[3 * cout:], training, row_mask=(Pp, self.padl, self.padl + T),
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    beta_off=self._o(scope + "/batch_normalization/beta"),
                    mm_off=self.stat_layout.off(scope + "/batch_normalization/moving_mean"),
-                   mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"))
-        return y
+                   mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"), y_hi=yh, y_lo=yl)
+        return (yh, yl) if emit_split else y
 
     def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False,
                   D=None):
@@ -355,7 +376,10 @@ class Tacotron2(object):
         w16 = self._bf16_w(D)
         Dg = torch.bfloat16 if w16 is not None else D
         dpre = self._buf("dpre_%d" % cout, rows * cout, Dg)
-        if w16 is not None:
+        if isinstance(xin, tuple):          # pre-split layer input (mixed mode): its high part IS the bf16 copy
+            assert w16 is not None
+            xin = xin[0]
+        elif w16 is not None:
             x16 = self._buf("xin16_%d" % cin, rows * cin, torch.bfloat16)
             ops.cast2d(xin, rows, cin, cin, x16, cin, False)
             xin = x16
@@ -648,8 +672,12 @@ class Tacotron2(object):
         Cp = hp.postnet_conv_channels
         for i in range(hp.postnet_conv_layers):
             act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
-            x = self._conv_fwd("decoder_postnet/postnet_conv_%d" % i, x, cin, Cp, hp.postnet_conv_width, act,
-                               N, To, Po, "post%d" % i)
+            # a layer whose consumer runs on the 256-tile kernel hands its output over as a pre-split bf16 pair
+            nxt = i + 1 < hp.postnet_conv_layers and self._x256_split_ok("post%d" % (i + 1), N * Po, Cp, Cp, hp.postnet_conv_width)
+            split_in = isinstance(x, tuple)
+            x = self._conv_fwd("decoder_postnet/postnet_conv_%d" % i, None if split_in else x, cin, Cp,
+                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, xsplit=x if split_in else None,
+                               emit_split=nxt)
             cin = Cp
             self._post_in.append(x)
         mel = self._buf("mel_out", N * Po * M, torch.float32)

@@ -114,8 +114,11 @@ def embedding_bwd(ids, dout, dtable, N, T, P, padl, D, V, dtable_off=0):
 
 
 def bn_fwd(z, y, rows, C, col_sum, col_sumsq, count, gamma, beta, moving_mean, moving_var, mean_out, istd_out,
-           training, row_mask=None, eps=1e-3, momentum=0.99, gamma_off=0, beta_off=0, mm_off=0, mv_off=0):
+           training, row_mask=None, eps=1e-3, momentum=0.99, gamma_off=0, beta_off=0, mm_off=0, mv_off=0,
+           y_hi=None, y_lo=None):
     p = L.struct("ns_bn_fwd_params")
+    if y_hi is not None:
+        p.y_hi, p.y_lo = ptr(y_hi), ptr(y_lo)
     _fill(p, z=ptr(z), y=ptr(y), dtype=dt(z), rows=rows, C=C, col_sum=ptr(col_sum), col_sumsq=ptr(col_sumsq),
           count=float(count), gamma=ptr(gamma, gamma_off), beta=ptr(beta, beta_off),
           moving_mean=ptr(moving_mean, mm_off), moving_var=ptr(moving_var, mv_off),

@@ -77,29 +77,40 @@ def test_cluster_forward_with_speakers(dev):
                                         (False, (5, 20, 35)), (True, (4, 37, 25)), (True, (2, 160, 10))])
 @pytest.mark.parametrize("mode", ["fp32", "mixed"])
 def test_cluster_backward_matches_per_step_kernels(dev, full, shape, mode):
+    """ONE forward pass (cluster kernel), then the backward pass twice over the same saved state: attention RNN through
+    the per-step kernels, and through the persistent kernel.  Same operands, same upstream gradients: only the
+    arithmetic of the two paths differs (fp32: summation order; mixed: the per-step path rounds its operands to bf16
+    for a single MFMA pass, the persistent kernel keeps exact fp32)."""
     from nspeech_amd.models import create_model
     N, Ti, To = shape
     hp = _hp(full)
     m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=3)
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N)
-    batch = (inputs, lengths, None, mel, lin)
-    ref = _run(m, batch, False, True)
-    got = _run(m, batch, True, True)
+    m.use_attn_cluster = True
+    m.initialize(inputs, lengths, None, mel, lin)
     assert m._attn_cluster_fwd
-    # mixed: the per-step backward rounds its operands to bf16 (single pass), the cluster kernels keep fp32, so the two
-    # differ by the bf16 rounding of the reference path; fp32: summation order only (and the upstream forward differences)
-    # a ReLU mask of the prenet that sits on the other side of zero in the other path moves single elements by their
-    # own (small) size, hence the max-norm slack in fp32 as well
-    tol = 5e-3 if mode == "fp32" else 6e-2
+    res = []
+    for cluster in (False, True):
+        m._attn_cluster_fwd = cluster            # backward() picks its attention path from this
+        m.backward()
+        torch.cuda.synchronize()
+        m.check_status()
+        out = {k: m._bufs[k].float().clone() for k in GRAD}
+        out["flat_g"] = m.flat_g.clone()
+        res.append(out)
+    ref, got = res
+    tol = 2e-5 if mode == "fp32" else 3e-2
     for k in GRAD:
         a, b = got[k], ref[k]
         err = (a - b).abs().max().item()
-        assert err <= tol * max(1e-6, b.abs().max().item()) + 1e-9, (k, err, b.abs().max().item())
-    # every parameter gradient of the model (the attention RNN feeds the encoder's gradients as well)
+        assert err <= tol * b.abs().max().item() + 1e-12, (k, err, b.abs().max().item())
+    # every parameter gradient downstream of the attention RNN (the encoder's as well); in mixed mode the encoder's
+    # single-pass bf16 backward amplifies the reference path's own rounding, so only fp32 is held to a tight bound
+    ftol = 1e-4 if mode == "fp32" else 0.1
     for name, (off, shp) in m.layout.entries.items():
         if name.endswith("conv1d/bias"):          # in front of BatchNorm: the true gradient is zero, the rest is noise
             continue
         n = int(np.prod(shp))
         a, b = got["flat_g"][off:off + n], ref["flat_g"][off:off + n]
         err = (a - b).abs().max().item()
-        assert err <= tol * b.abs().max().item() + 1e-7, (name, err, b.abs().max().item())
+        assert err <= ftol * b.abs().max().item() + 1e-9, (name, err, b.abs().max().item())
