@@ -425,10 +425,6 @@ typedef struct {
    * written into columns D2..D2+Dsp of every slot by the caller, wattT / watt hold all D2+Dsp+A input rows, and the
    * caller forms the projection's gradient from dga (sum over the slots) after the backward call. */
   int Dsp;
-  /* Cluster kernels only: fp32 [N,S+1,D1], slot s = sum_t align[s][t] pv[t,:] (what step s hands to the prenet of
-   * step s+1 before the frame term and the ReLU).  Written by ns_taco2_attn_cluster_fwd, read by _bwd: with it the
-   * softmax-backward dot product sum_t align.dalign needs no exchange between the workgroups of a cluster. */
-  float* ctxp;
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
@@ -445,7 +441,7 @@ int ns_taco2_attn_cluster_supported(const ns_taco2_attn_params* p);
 size_t ns_taco2_attn_cluster_work_bytes(const ns_taco2_attn_params* p);
 int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* work, ns_stream_t stream);
 /* Backward through time of the same recurrence, one persistent launch; takes what ns_taco2_attn_bwd takes (da0
- * included) plus ctxp from the cluster forward, writes df1 / dp2 / dga (/ dga_bf16) / dq / de and then runs the same
+ * included), writes df1 / dp2 / dga (/ dga_bf16) / dq / de and then runs the same
  * hoisted post-pass (dkeys, dv, dWcl, dctx_t, dvalues) as ns_taco2_attn_bwd. */
 int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stream_t stream);
 

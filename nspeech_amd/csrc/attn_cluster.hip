@@ -57,6 +57,7 @@ struct Cfg {
 struct ACArgs {
   ns_taco2_attn_params p;
   u64* x2; u64* x3;          // [N][CG][X2N], [N][CG][X3N]
+  u64* x1;                   // backward: [N][CG] dot-product shares
   int* status;
   long long* trace;          // NS_ATTN_TRACE=1: [step][16] timestamps (100 MHz) of workgroup 0, else null
 };
@@ -396,13 +397,9 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < CG; ++q) s = fmaf(scl[q], gath[q * X3N + tid], s);
-      const float cp = s * inv;                      // sum_t align[s][t] pv[t, c]
-      const float v = fmaxf(cp + f1n, 0.f);
+      const float v = fmaxf(fmaf(s, inv, f1n), 0.f);
       p1s[tid] = v;
-      if (tid / (D1 / CG) == g) {
-        if (p.ctxp) p.ctxp[((long)n * S1 + slot) * D1 + tid] = cp;
-        if (st + 1 < p.S) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
-      }
+      if (st + 1 < p.S && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
     }
     // the whole alignment (every workgroup needs its neighbours' positions for the location filter)
     for (int t = tid; t < p.Tia; t += CT) {
@@ -424,16 +421,17 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
 
 // ===================================================================================== backward
 // Backward through time, same clusters and ownership as the forward kernel.  Per step (walking s = S .. 1):
-//   dot   = sum_t align[t] dalign[t] is formed WITHOUT an exchange: dalign = da0 (hoisted) + pv . dp1(s+1) + carry, so
-//           dot = sum_t a da0  (history, every workgroup sums it)  +  ctxp[s] . dp1(s+1)  (ctxp saved by the forward
-//           kernel)  +  sum_g dcar_g  (each workgroup's share of sum_t a[t] carry[t], sent along with exchange 3 of
-//           the step before);
+//   dalign of the own positions = da0 (hoisted) + pv . dp1(s+1) + carry;  its share of the softmax-backward dot product
+//           sum_t align[t] dalign[t] goes out at once (E1, ONE granule per workgroup) and is collected only after the
+//           energy pass, which does not need it - the exchange latency is hidden.  (Assembling the dot product from
+//           forward-pass sums instead would avoid E1, but de = a (dalign - dot) is a difference of nearly equal numbers
+//           in a peaked softmax: only a dot product summed from the SAME dalign values keeps the rounding errors
+//           common-mode; measured 3e-3 against 1e-4 on the encoder gradients.)
 //   energy pass on the own positions: g1[t,u] = v[u] (1 - tanh^2), laid out as the A operand of the exact fp32 MFMA
-//           (16x16x4): Z[t,k] = sum_u g1[t,u] Wcl[k,u] comes out of the matrix core, dq_part[u] = sum_t de[t] g1[t,u]
-//           out of 16-lane row reductions;
-//   E2:     dq partials (A values)                      -> dq, dh through W_query, cell gradient of the own units
+//           (16x16x4): Z[t,k] = sum_u g1[t,u] Wcl[k,u] comes out of the matrix core, g1 stays in registers;
+//   E2:     dq partials sum_t de[t] g1[t,u] (16-lane row reductions)   -> dq, dh through W_query, cell gradient
 //   E3:     partial input gradients dga_own . Watt[:, own]^T (K values) + the workgroup's contributions to the next
-//           step's location-filter carry (ts + 6 values) + dcar_g   -> dp2, the recurrent dh, carry, dot
+//           step's location-filter carry (ts + 6 values)               -> dp2, the recurrent dh, carry
 //   then dp1 = (dp2 . W2^T) masked, redundantly in every workgroup (W2 in registers), which is the next step's dvec.
 template <int A_, int D1_, int D2_>
 struct BCfg : Cfg<A_, D1_, D2_> {
@@ -463,7 +461,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   float* al = qs + A;                      // [APAD + 256 + APAD] alignment of step s-1
   float* acur = al + 256 + 2 * APAD;       // [TSMAX] alignment of step s, own positions
   float* da0s = acur + TSMAX;              // [TSMAX]
-  float* dev = da0s + TSMAX;               // [TSMAX] energy gradients
+  float* dav = da0s + TSMAX;               // [TSMAX] dalign
+  float* dev = dav + TSMAX;                // [TSMAX] energy gradients
   float* carry = dev + TSMAX;              // [TSMAX] location-filter carry for the own positions
   float* Gs = carry + TSMAX;               // [TSMAX][8]
   float* zred = Gs + TSMAX * 8;            // [8 waves][TSMAX][8]
@@ -488,6 +487,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   const int ts = max(1, (L + CG - 1) / CG);
   const int t0 = g * ts, tn = max(0, min(L, t0 + ts) - t0);
   const int half = (p.kw - 1) / 2;
+  u64* e1 = a.x1 + (size_t)n * CG;
   u64* e2 = a.x2 + (size_t)n * CG * A;
   u64* e3 = a.x3 + (size_t)n * CG * E3N;
 
@@ -525,24 +525,23 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
     for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
     for (int i = tid; i < D1; i += CT) dvec[i] = 0.f;
-    for (int i = tid; i < TSMAX; i += CT) { carry[i] = 0.f; dev[i] = 0.f; acur[i] = 0.f; da0s[i] = 0.f; }
+    for (int i = tid; i < TSMAX; i += CT) { carry[i] = 0.f; dev[i] = 0.f; dav[i] = 0.f; acur[i] = 0.f; da0s[i] = 0.f; }
     for (int i = tid; i < TSMAX * 8; i += CT) Gs[i] = 0.f;
     if (tid < UPW) hrec[tid] = 0.f;
     if (tid < 48) sc[tid] = 0.f;
   }
   float dcc = 0.f;                         // cell-state gradient carried to the step before (owner lanes)
   // history of a step, one value per thread and role (read straight from the forward pass' buffers)
-  float h_q = 0.f, h_p1 = 0.f, h_ctx = 0.f, h_p2 = 0.f, h_alp = 0.f, h_a = 0.f, h_da0 = 0.f, h_gt = 0.f;
+  float h_q = 0.f, h_p1 = 0.f, h_p2 = 0.f, h_alp = 0.f, h_a = 0.f, h_da0 = 0.f, h_gt = 0.f;
   float h_dhc = 0.f, h_c = 0.f, h_cp = 0.f;
   auto load_history = [&](int st_, int tid) {
     const long rowS = (long)n * S1 + st_ + 1;
     if (tid < A) h_q = p.q[rowS * A + tid];
-    if (tid < D1) { h_p1 = ldf((const T*)p.p1 + rowS * D1 + tid); h_ctx = p.ctxp[rowS * D1 + tid]; }
+    if (tid < D1) h_p1 = ldf((const T*)p.p1 + rowS * D1 + tid);
     if (tid < D2) h_p2 = ldf((const T*)p.xa + rowS * XA + tid);
     h_a = 0.f; h_da0 = 0.f;
     if (tid < 256) {
       h_alp = tid < p.Tia ? p.align[(rowS - 1) * p.Tia + tid] : 0.f;
-      if (tid < L) { h_a = p.align[rowS * p.Tia + tid]; h_da0 = p.da0[rowS * p.Tia + tid]; }
     } else if (tid < 256 + TSMAX) {
       const int tl = tid - 256;
       if (tl < tn) { h_a = p.align[rowS * p.Tia + t0 + tl]; h_da0 = p.da0[rowS * p.Tia + t0 + tl]; }
@@ -569,34 +568,22 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     const long rowS = (long)n * S1 + slot;
 
     stamp(a, p.S - 1 - st, 0);
-    // ---- P0/P1: history of this step (prefetched into registers during the step before) -> LDS;
-    //      dot = sum_t a da0 + ctxp . dvec + dcar;  then the loads of step s-1 go out and stay in flight
+    // ---- P0/P1: history of this step (prefetched into registers during the step before) -> LDS; then the loads of
+    //      step s-1 go out and stay in flight
     {
-      float part = 0.f;
       if (tid < A) qs[tid] = h_q;
-      if (tid < D1) { p1m[tid] = h_p1; part = h_ctx * dvec[tid]; }
+      if (tid < D1) p1m[tid] = h_p1;
       if (tid < D2) p2m[tid] = h_p2;
-      if (tid < 256) {
-        al[APAD + tid] = h_alp;
-        part = fmaf(h_a, h_da0, part);
-      }
+      if (tid < 256) al[APAD + tid] = h_alp;
       if (tid >= 256 && tid < 256 + TSMAX) { acur[tid - 256] = h_a; da0s[tid - 256] = h_da0; }
       if (tid >= 320 && tid < 320 + GC) gts[tid - 320] = h_gt;
-      part = wave_sum(part);
-      if (lane == 0) sc[4 + wave] = part;
     }
     const float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;      // the cell owners' operands of this step
     if (st > 0) load_history(st - 1, tid);
     __syncthreads();
-    if (tid == 0) {
-      float d = sc[1];
-#pragma unroll
-      for (int w = 0; w < CT / 64; ++w) d += sc[4 + w];
-      sc[0] = d;
-    }
-    __syncthreads();
     stamp(a, p.S - 1 - st, 1);
-    // ---- P2: dalign and the energy gradients of the own positions: thread = (position tid / 16, 16 columns each)
+    // ---- P2: dalign of the own positions: thread = (position tid / 16, 16 columns each); then this workgroup's share
+    //      of the softmax-backward dot product sum_t align[t] dalign[t] goes out (exchange 1, one granule)
     {
       const int tl = tid >> 4, cq = tid & 15;
       float s = 0.f;
@@ -610,52 +597,37 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
         }
       }
       s = row16_sum(s);
-      if (cq == 0 && tl < TSMAX) {
-        float de = 0.f;
-        if (tl < tn) {
-          const float da = da0s[tl] + s + carry[tl];
-          de = acur[tl] * (da - sc[0]);
-          p.de[rowS * p.Tia + t0 + tl] = de;
-        }
-        dev[tl] = de;
-      }
+      if (cq == 0 && tl < TSMAX) dav[tl] = tl < tn ? da0s[tl] + s + carry[tl] : 0.f;
     }
     __syncthreads();
+    if (wave == 7) {                         // a wave that takes no part in the energy pass for A = 64 either
+      const float d = wave_sum(lane < tn ? acur[lane] * dav[lane] : 0.f);
+      if (lane == 0) put_granule(e1 + g, tag, d);
+    }
     stamp(a, p.S - 1 - st, 2);
-    // ---- P3: energy pass in the A-operand layout of v_mfma_f32_16x16x4_f32: row = position, k = unit
+    // ---- P3: energy pass in the A-operand layout of v_mfma_f32_16x16x4_f32: row = position, k = unit.  Needs no dot
+    //      product yet: g1 = v (1 - tanh^2) stays in registers, Z = g1 . Wcl^T comes out of the matrix core
+    float g1v[16];
+    const int r = lane & 15, kq = lane >> 4;
     if (wave < A / 32) {
-      const int r = lane & 15, kq = lane >> 4;
       f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
       float ap0[KWMAX], ap1[KWMAX];
 #pragma unroll
       for (int k = 0; k < KWMAX; ++k) { ap0[k] = al[APAD + t0 + r - half + k]; ap1[k] = al[APAD + t0 + r + 16 - half + k]; }
-      const float de0 = dev[r], de1 = dev[r + 16];
 #pragma unroll
-      for (int jb = 0; jb < 8; jb += 4) {        // two batches of four units: four independent reductions each
-        float dqp[4];
+      for (int j = 0; j < 8; ++j) {
+        const int u = wave * 32 + j * 4 + kq;
+        const float qv = qs[u], vv = cst_s[KWMAX * A + u];
+        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const int u = wave * 32 + (jb + jj) * 4 + kq;
-          const float qv = qs[u], vv = cst_s[KWMAX * A + u];
-          float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
-#pragma unroll
-          for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
-          const float th0 = tanhf_(x0), th1 = tanhf_(x1);
-          const float g0 = r < tn ? vv * (1.f - th0 * th0) : 0.f;
-          const float g1 = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
-          const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
-          acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g0, b, acc[0], 0, 0, 0);
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1, b, acc[1], 0, 0, 0);
-          dqp[jj] = fmaf(de0, g0, de1 * g1);
-        }
-        // dq partial of unit u = sum over the 16 positions of a DPP row (the two tiles added in-thread)
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) dqp[jj] = row16_sum(dqp[jj]);
-        if (r == 0) {
-#pragma unroll
-          for (int jj = 0; jj < 4; ++jj) put_granule(e2 + (size_t)g * A + wave * 32 + (jb + jj) * 4 + kq, tag, dqp[jj]);
-        }
-        asm volatile("" ::: "memory");
+        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+        const float th0 = tanhf_(x0), th1 = tanhf_(x1);
+        g1v[2 * j] = r < tn ? vv * (1.f - th0 * th0) : 0.f;
+        g1v[2 * j + 1] = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
+        const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j], b, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j + 1], b, acc[1], 0, 0, 0);
+        if ((j & 3) == 3) asm volatile("" ::: "memory");
       }
       // D: col = lane & 15 (filter tap), row = (lane >> 4) * 4 + reg (position inside the 16-row tile)
       if (r < 8) {
@@ -665,9 +637,35 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
           for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + mt * 16 + kq * 4 + q) * 8 + r] = acc[mt][q];
       }
     }
+    // ---- exchange 1 has been under way all along: the dot product, then the energy gradients
+    if (wave == 7) {
+      gather_granules<1>(e1, CG, tag, gath, lane < CG ? lane : CG, a.status, 5);      // lanes >= CG read nothing
+      float d = lane < CG ? gath[lane] : 0.f;
+      d = wave_sum(d);
+      if (lane == 0) sc[0] = d;
+    }
     __syncthreads();
     stamp(a, p.S - 1 - st, 3);
-    // ---- P4: G[t][k] = de[t] * sum over the unit blocks of Z
+    if (tid < TSMAX) {
+      float de = 0.f;
+      if (tid < tn) {
+        de = acur[tid] * (dav[tid] - sc[0]);
+        p.de[rowS * p.Tia + t0 + tid] = de;
+      }
+      dev[tid] = de;
+    }
+    __syncthreads();
+    // ---- P4: dq partial of unit u = sum over the positions of de[t] g1[t, u] (a DPP row holds 16 positions, the two
+    //      tiles add in-thread), published as exchange 2;  G[t][k] = de[t] * sum over the unit blocks of Z
+    if (wave < A / 32) {
+      const float de0 = dev[r], de1 = dev[r + 16];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g1v[j] = row16_sum(fmaf(de0, g1v[2 * j], de1 * g1v[2 * j + 1]));
+      if (r == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) put_granule(e2 + (size_t)g * A + wave * 32 + j * 4 + kq, tag, g1v[j]);
+      }
+    }
     if (tid < TSMAX * 8) {
       const int tl = tid >> 3, k = tid & 7;
       float z = 0.f;
@@ -676,7 +674,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       Gs[tid] = (tl < tn && k < p.kw) ? dev[tl] * z : 0.f;
     }
     __syncthreads();
-    // ---- P5: this workgroup's contributions to the carry of step s-1 (positions t0-3 .. t0+ts+2) and to its dot
+    // ---- P5: this workgroup's contributions to the carry of step s-1 (positions t0-half .. t0+ts+kw-half-2)
     float ccv = 0.f;                         // threads < CCN keep their value for the E3 publish
     if (tid < TSMAX + 6) {
       // carry[t'] += G[t' - k + half][k]; local: t' = t0 - half + tid  ->  G row (tid - k)
@@ -685,15 +683,6 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
         const int row = tid - k;
         if (k < p.kw && row >= 0 && row < TSMAX) ccv += Gs[row * 8 + k];
       }
-    } else if (tid >= 64 && tid < 128) {     // wave 1: dcar_g = sum_{t,k} G[t][k] a(s-1)[t + k - half]
-      const int tl = tid - 64;
-      float d = 0.f;
-      if (tl < tn) {
-#pragma unroll
-        for (int k = 0; k < KWMAX; ++k) d = fmaf(Gs[tl * 8 + k], al[APAD + t0 + tl + k - half], d);
-      }
-      d = wave_sum(d);
-      if (tl == 0) sc[3] = d;
     }
     stamp(a, p.S - 1 - st, 4);
     // ---- gather E2: dq = sum of the partials
@@ -760,7 +749,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       for (int q = 0; q < NQ; ++q) s += red[q * K + tid];
       put_granule(e3 + (size_t)g * E3N + tid, tag, s);
     }
-    if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, tid == CCN - 1 ? sc[3] : ccv);
+    if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, ccv);
     stamp(a, p.S - 1 - st, 7);
     gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
@@ -793,11 +782,6 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
         }
       }
       carry[tl] = s;
-    } else if (tid == 320) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < CG; ++q) s += gath[q * E3N + K + CCN - 1];
-      sc[1] = s;
     }
     __syncthreads();
     stamp(a, p.S - 1 - st, 9);
@@ -875,7 +859,6 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     b.p.q = p->q + (long)n0 * S1 * p->A;
     b.p.align = p->align + (long)n0 * S1 * p->Tia;
     b.p.align_t = p->align_t ? (char*)p->align_t + (long)n0 * S1 * p->Tia * esz : nullptr;
-    b.p.ctxp = p->ctxp ? p->ctxp + (long)n0 * S1 * p->D1 : nullptr;
     b.x2 = a.x2 + (size_t)n0 * CG * C::X2N;
     b.x3 = a.x3 + (size_t)n0 * CG * C::X3N;
     hipLaunchKernelGGL((attn_cluster_fwd_kernel<T, C>), dim3(nn * CG), dim3(CT), lds, s, b);
@@ -909,7 +892,7 @@ extern "C" int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* wo
 
 template <typename C>
 static size_t bwd_lds_bytes() {
-  return sizeof(float) * (C::D1 + C::D2 + C::GC + C::NQ * C::K + C::A + 256 + 2 * APAD + 4 * TSMAX + TSMAX * 8 + 8 * TSMAX * 8 +
+  return sizeof(float) * (C::D1 + C::D2 + C::GC + C::NQ * C::K + C::A + 256 + 2 * APAD + 5 * TSMAX + TSMAX * 8 + 8 * TSMAX * 8 +
                           C::UPW + C::A + C::D1 + C::D2 + C::GC + 48 + CG * C::EMAX + TSMAX * C::A + TSMAX * C::D1 +
                           C::UPW * C::A + (KWMAX + 1) * C::A);
 }
@@ -921,7 +904,8 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.status = (int*)work;
   a.x2 = (u64*)((char*)work + 256);
   a.x3 = a.x2 + (size_t)p->N * CG * C::A;
-  const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::A + C::E3N);
+  a.x1 = a.x3 + (size_t)p->N * CG * C::E3N;
+  const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::A + C::E3N + 1);
   a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
   { const int zrc = ns_zero_async(work, ((256 + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   const size_t lds = bwd_lds_bytes<C>();
@@ -943,7 +927,6 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     b.p.ga = (char*)p->ga + (long)n0 * S1 * 4 * p->A * esz;
     b.p.q = p->q + (long)n0 * S1 * p->A;
     b.p.align = p->align + (long)n0 * S1 * p->Tia;
-    b.p.ctxp = p->ctxp + (long)n0 * S1 * p->D1;
     b.p.da0 = p->da0 + (long)n0 * S1 * p->Tia;
     b.p.dhc = p->dhc + (long)n0 * S1 * (p->A + p->E);
     b.p.de = p->de + (long)n0 * S1 * p->Tia;
@@ -954,6 +937,7 @@ static int launch_bwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
     b.p.dq = (char*)p->dq + (long)n0 * S1 * p->A * esz;
     b.x2 = a.x2 + (size_t)n0 * CG * C::A;
     b.x3 = a.x3 + (size_t)n0 * CG * C::E3N;
+    b.x1 = a.x1 + (size_t)n0 * CG;
     hipLaunchKernelGGL((attn_cluster_bwd_kernel<T, C>), dim3(b.p.N * CG), dim3(CT), lds, s, b);
   }
   NS_CHECK_LAUNCH("attn_cluster_bwd");
@@ -966,8 +950,8 @@ extern "C" int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* wo
   NS_CHECK_ARG(cluster_shape_ok(p), "ns_taco2_attn_cluster_bwd: unsupported shape (needs pv, D1 256, D2 128, A 64|256, T_in <= 256)");
   NS_CHECK_ARG(p->keys && p->values && p->w1c && p->w2 && p->watt && p->wq && p->wcl && p->v && p->p1 && p->xa && p->ca &&
                    p->ga && p->q && p->align && p->dhc && p->df1 && p->dp2 && p->dga && p->dq && p->dkeys && p->dvalues &&
-                   p->dv && p->dwcl && p->work && p->align_t && p->de && p->dctx_t && p->keys_t && p->da0 && p->ctxp,
-               "ns_taco2_attn_cluster_bwd: null pointer (ctxp comes from ns_taco2_attn_cluster_fwd)");
+                   p->dv && p->dwcl && p->work && p->align_t && p->de && p->dctx_t && p->keys_t && p->da0,
+               "ns_taco2_attn_cluster_bwd: null pointer");
   if (p->dtype == NS_BF16) {
     if (p->A == 256) return launch_bwd<bf16_t, BCfg<256, 256, 128>>(p, work, s);
     return launch_bwd<bf16_t, BCfg<64, 256, 128>>(p, work, s);

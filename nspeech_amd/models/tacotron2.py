@@ -624,7 +624,6 @@ class Tacotron2(object):
                                watt=(self._W(self.T), wa), wq=(self._W(self.T), wq))
         self._attn_cluster_fwd = self.use_attn_cluster and ops.taco2_attn_cluster_supported(**self._attn_args)
         if self._attn_cluster_fwd:
-            self._attn_args["ctxp"] = self._buf("dec_ctxp", N * S1 * 256, torch.float32)
             cw = self._buf("attn_cluster_work", ops.taco2_attn_cluster_work_floats(**self._attn_args), torch.float32)
             ops.taco2_attn_cluster("fwd", cw, **self._attn_args)
             self._status_words[("attn", "fwd")] = cw
@@ -885,7 +884,7 @@ class Tacotron2(object):
                     dga_bf16=self._dgb("d_gab", rows * 4 * A, T_),
                     de=self._buf("d_energy", rows * Tia, torch.float32),
                     dctx_t=self._buf("d_ctx_t", rows * E, T_))
-        if self._attn_cluster_fwd:          # the persistent backward kernel reads ctxp of the persistent forward
+        if self._attn_cluster_fwd:
             cw = self._buf("attn_cluster_work_b", ops.taco2_attn_cluster_work_floats(**args), torch.float32)
             ops.taco2_attn_cluster("bwd", cw, **args)
             self._status_words[("attn", "bwd")] = cw

@@ -15,8 +15,8 @@ from nspeech_amd import hparams as hparams_mod  # noqa: E402
 from nspeech_amd.models import create_model  # noqa: E402
 
 FWD = ["p2", "gates+cell", "q partial", "X2 wait", "q sum", "energies", "softmax", "ctx partial", "X3 wait", "combine"]
-BWD = ["history+dot", "dalign", "energy pass (MFMA)", "G + carry", "E2 wait", "dq sum + cell", "input grads + publish",
-       "E3 wait", "dp2 / carry", "dp1"]
+BWD = ["history -> LDS", "dalign + E1 publish", "energy pass (MFMA) + E1 wait", "de, dq partials, G, carry", "E2 wait",
+       "dq sum + cell", "input grads + publish", "E3 wait", "dp2 / carry", "dp1"]
 
 
 def report(name, work, labels, S):

@@ -18,3 +18,15 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _reset_product_modes():
+    """ops.F32_PASSES is process-wide state that a model sets for its own precision mode: a test that calls ops.gemm
+    on fp32 operands directly must not inherit the mode of whatever model ran before it."""
+    try:
+        from nspeech_amd import ops
+        ops.F32_PASSES = 0
+    except Exception:
+        pass
+    yield

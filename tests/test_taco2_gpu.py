@@ -56,6 +56,7 @@ def test_taco2_fp32_forward_backward_matches_oracle(dev, shape):
         # of the 33-utterance case; a ReLU on the wrong side of its kink would show as 2e-2 .. 8e-2)
         if err > 3e-3 * scale + 5e-6:      # the floor covers conv biases in front of BatchNorm (true gradient 0)
             bad.append((k, float(err), float(scale)))
+    print("gradient tensors over the bound:", bad)
     assert not bad, bad
     # BatchNorm moving statistics (UPDATE_OPS)
     st = m.numpy_stats()
