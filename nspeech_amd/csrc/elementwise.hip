@@ -2,6 +2,7 @@
 // backward (+ activation and bias gradient), column sums, L1 loss + gradient, Adam with global
 // norm clipping, transposing casts.  All grid-stride, vectorised where layouts allow.
 #include "common.h"
+#include <stdlib.h>
 
 __device__ __forceinline__ float ld_dyn(const void* p, int dtype, long i) {
   return dtype == NS_BF16 ? (float)((const bf16_t*)p)[i] : ((const float*)p)[i];

@@ -22,18 +22,15 @@ import torch.nn.functional as F
 BN_EPS = 1e-3          # tf.layers.batch_normalization default epsilon
 BN_MOMENTUM = 0.99     # tf.layers.batch_normalization default momentum
 
-# Test aid: when set to a list, every ReLU appends the smallest non-zero |pre-activation| it saw.  A float32
-# implementation can only be held to a tight gradient bound on inputs whose ReLU kinks are not within rounding noise
-# of zero (an element on the other side of the kink changes every gradient upstream of it by a finite amount).
-KINK_LOG = None
+# Test aid: when set to a list, every ReLU appends its branch mask (pre-activation > 0) in call order.  A float32
+# implementation whose forward pass differs by rounding can land on the other side of a kink whose pre-activation is
+# within that rounding of zero; the parity tests compare gradients on inputs where both take the same branch everywhere.
+MASK_LOG = None
 
 
 def _relu(x):
-    if KINK_LOG is not None:
-        a = x.detach().abs()
-        nz = a[a > 0]
-        if nz.numel():
-            KINK_LOG.append(float(nz.min()))
+    if MASK_LOG is not None:
+        MASK_LOG.append((x.detach() > 0).numpy())
     return torch.relu(x)
 
 

@@ -96,3 +96,54 @@ def test_name_mapping_onto_the_tacotron2_layout(tmp_path):
     bad["model/inference/embedding/embedding"] = np.zeros((3, 3), np.float32)
     with pytest.raises(ValueError):
         B.map_checkpoint(bad, lay, st)
+
+
+def test_reader_against_hand_assembled_bundle(tmp_path):
+    """A bundle assembled byte by byte from the published LevelDB table format and tensor_bundle.proto by
+    tests/golden/make_bundle_known_answer.py, which shares no code with nspeech_amd.utils.tf_bundle (its CRC-32C is the
+    bitwise form, its varints / protobuf fields / block entries are written out literally): the reader must accept
+    the footer magic, both block trailers and the prefix-compressed keys, and return the three tensors.  (Still not
+    a file written by TensorFlow: none exists here - SURVEY 8c.)"""
+    import json
+    import os
+
+    import numpy as np
+
+    from nspeech_amd.utils import tf_bundle as B
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "bundle_known_answer.json")))
+    index, data = bytes.fromhex(gold["index_hex"]), bytes.fromhex(gold["data_hex"])
+    assert index[-8:] == bytes.fromhex("57fb808b247547db")                    # kTableMagicNumber, little-endian
+    n = gold["data_block_bytes"]
+    trailer = index[n:n + 5]
+    assert trailer.hex() == gold["data_block_trailer_hex"] and trailer[0] == 0              # uncompressed
+    assert B.unmask_crc(int.from_bytes(trailer[1:], "little")) == B.crc32c(index[:n] + b"\x00")
+    prefix = str(tmp_path / "model.ckpt-7")
+    open(prefix + ".index", "wb").write(index)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    assert B.is_bundle(prefix)
+    got = B.load_tf_checkpoint(prefix, check_crc=True)
+    assert sorted(got) == sorted(gold["tensors"])
+    for name, t in gold["tensors"].items():
+        assert got[name].dtype == np.dtype(t["dtype"]) and list(got[name].shape) == t["shape"]
+        assert got[name].ravel().tolist() == t["values"]
+    # a flipped payload bit is caught by the per-tensor checksum, a flipped index bit by the block trailer
+    bad = bytearray(data)
+    bad[13] ^= 0x10
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(bad))
+    with __import__("pytest").raises(ValueError):
+        B.load_tf_checkpoint(prefix, check_crc=True)
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    badi = bytearray(index)
+    badi[20] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(badi))
+    with __import__("pytest").raises(ValueError):
+        B.load_tf_checkpoint(prefix)
+    # and this build's writer produces the same table bytes for the same content
+    tensors = {k: np.asarray(t["values"], dtype=t["dtype"]).reshape(t["shape"]) for k, t in gold["tensors"].items()}
+    p2 = str(tmp_path / "again")
+    B.save_tf_checkpoint(p2, tensors)
+    assert open(p2 + ".data-00000-of-00001", "rb").read() == data
+    mine = B.read_table(p2 + ".index")
+    assert [k for k, _ in mine] == [b"", b"a/bias", b"a/kernel", b"b"]
+    open(prefix + ".index", "wb").write(index)
+    assert [v for _, v in mine][1:] == [v for _, v in B.read_table(prefix + ".index")][1:]     # identical entry protos
