@@ -431,6 +431,18 @@ class Tacotron2(object):
         self._run_bilstm("fwd", pair, tag)
         return out
 
+    use_wide = True         # persistent whole-sequence kernels for the wide decoder LSTMs where the shape allows
+
+    def _run_lstm(self, direction, tag, *a, **kw):
+        """One decoder LSTM over all steps: the persistent wide-cell kernel when it applies, else one launch per step."""
+        p = ops.lstm_seq_params(*a, **kw)
+        if self.use_wide and ops.lstm_wide_supported(p, direction == "bwd"):
+            w = self._buf("lstm_wide_work_%s_%s" % (tag, direction), ops.lstm_wide_work_floats(p), torch.float32)
+            ops.lstm_wide(direction, p, w)
+            self._status_words[(tag, direction)] = w
+        else:
+            ops.lstm_seq_call(direction, p)
+
     use_cluster = True      # persistent whole-sequence BiLSTM kernels where the shape allows
     use_attn_cluster = True # persistent attention-RNN cluster kernels where the shape allows
 
@@ -641,8 +653,8 @@ class Tacotron2(object):
         c1 = self._buf("dec_c1", rows * D, torch.float32)
         g1 = self._buf("dec_g1", rows * 4 * D, T_)
         self._tick("dec_lstm:xg1")
-        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1,
-                     whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"))
+        self._run_lstm("fwd", "dec1", N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1,
+                       whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"))
         self._tick("dec_lstm:loop1")
         xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
         ops.gemm(h1, self._W(self.T), xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
@@ -651,8 +663,8 @@ class Tacotron2(object):
         c2 = self._buf("dec_c2", rows * D, torch.float32)
         g2 = self._buf("dec_g2", rows * 4 * D, T_)
         self._tick("dec_lstm:xg2")
-        ops.lstm_seq("fwd", T_, N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2,
-                     whT_hi=self.tsh.get("l2_whT_hi"), whT_lo=self.tsh.get("l2_whT_lo"))
+        self._run_lstm("fwd", "dec2", N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2,
+                       whT_hi=self.tsh.get("l2_whT_hi"), whT_lo=self.tsh.get("l2_whT_lo"))
         self._tick("dec_lstm:loop2")
         dec = self._buf("dec_out", rows * M * r, torch.float32)
         ops.gemm(h2, self._W(self.T), dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
@@ -810,9 +822,10 @@ class Tacotron2(object):
         dg2 = self._buf("d_g2", rows * 4 * D, T_)
         self._dgb("d_g2b", rows * 4 * D, T_)
         self._tick("dec_lstm_bwd:proj")
-        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D, B["dec_c2"],
-                     B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
-                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D, dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_))
+        self._run_lstm("bwd", "dec2", N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D,
+                       B["dec_c2"], B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
+                       wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D,
+                       dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_))
         self._tick("dec_lstm_bwd:loop2")
         w16 = self._bf16_w(T_)
         dg2b = self._bufs.get("d_g2b") if w16 is not None else None
@@ -833,10 +846,10 @@ class Tacotron2(object):
         dg1 = self._buf("d_g1", rows * 4 * D, T_)
         self._dgb("d_g1b", rows * 4 * D, T_)
         self._tick("dec_lstm_bwd:wgrad2")
-        ops.lstm_seq("bwd", T_, N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D, B["dec_c1"],
-                     B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
-                     wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D,
-                     dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
+        self._run_lstm("bwd", "dec1", N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D,
+                       B["dec_c1"], B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
+                       wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D,
+                       dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
         self._tick("dec_lstm_bwd:loop1")
         dg1b = self._bufs.get("d_g1b") if w16 is not None else None
         self._lstm_wgrads(b16("dec_hc_16", hc, A + E), A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1,

@@ -193,6 +193,26 @@ def lstm_seq(direction, dtype_t, *a, **kw):
     L.call("ns_lstm_seq_fwd" if direction == "fwd" else "ns_lstm_seq_bwd", p, stream())
 
 
+def lstm_wide_supported(p, backward):
+    return bool(L.lib().ns_lstm_wide_supported(C.byref(p), int(backward)))
+
+
+def lstm_wide_work_floats(p):
+    fn = L.lib().ns_lstm_wide_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(p)) + 3) // 4
+
+
+def lstm_wide(direction, p, wide_work):
+    """Persistent whole-sequence recurrence for wide cells (one launch); wide_work[0] is the status word."""
+    fn = getattr(L.lib(), "ns_lstm_wide_fwd" if direction == "fwd" else "ns_lstm_wide_bwd")
+    L.check(fn(C.byref(p), C.c_void_p(ptr(wide_work)), C.c_void_p(stream())), "ns_lstm_wide_" + direction)
+
+
+def lstm_seq_call(direction, p):
+    L.call("ns_lstm_seq_fwd" if direction == "fwd" else "ns_lstm_seq_bwd", p, stream())
+
+
 def lstm_seq2(direction, p0, p1):
     """Two independent recurrences (BiLSTM directions) advanced together, one launch per step."""
     fn = getattr(L.lib(), "ns_lstm_seq2_fwd" if direction == "fwd" else "ns_lstm_seq2_bwd")
