@@ -265,14 +265,15 @@ int ns_lstm_cluster_bwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* 
 
 /* Persistent variant of ns_lstm_seq_* for WIDE cells at small batch (the decoder LSTMs of tacotron2.py:67-73: 1024
  * units, 32 rows): ONE launch for the whole sequence.  A workgroup keeps its slice of W_h in registers (forward: 8
- * units x 4 gates; backward: 16 units) and only the state travels, through the history arrays themselves: h[t-1]
- * (backward: the bf16 gate gradients of step t+1) is stored write-through, counted in per-row-group arrival counters
- * and read back by every workgroup of the row group with L1-bypassing loads.
+ * units x 4 gates; backward: 16 units) and only the state travels, through the history arrays themselves: the call
+ * first fills h[:, 0..T) (backward: the bf16 gate gradients) with an all-ones NaN sentinel, the producers store
+ * h[t] write-through and every workgroup of the row group polls and fetches h[t-1] (backward: the gate gradients of
+ * step t+1) with L1/L2-bypassing loads until no element is the sentinel - the data is its own flag.
  * Forward: dtype NS_BF16, or NS_F32 with whT_hi / whT_lo and f32_passes == 3.  Backward: NS_BF16, or NS_F32 with
  * wh_bf16 + dgates_bf16 and f32_passes == 1.  H in {256, 512, 1024}, reverse == 0, and the grid (16-row groups x H/8
  * forward, x H/16 backward) must fit the device at one workgroup per CU (<= 256).  ns_lstm_wide_supported() says
  * whether a parameter block qualifies.  work: ns_lstm_wide_work_bytes(); work[0] (int) is a status word, non-zero
- * after the call completes = a wait timed out and the outputs are invalid. */
+ * after the call completes = a wait timed out and the outputs are invalid (they may then hold the sentinel). */
 int ns_lstm_wide_supported(const ns_lstm_seq_params* p, int backward);
 size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p);
 int ns_lstm_wide_fwd(const ns_lstm_seq_params* p, void* work, ns_stream_t stream);

@@ -5,67 +5,138 @@
 // every CU each step and pay a dependent-launch boundary on top: ~9.9 us per step.  Here a workgroup keeps its slice of
 // W_h in REGISTERS for all steps (forward: 8 units x 4 gates x H as hi / lo MFMA B fragments, 64 VGPRs per lane), the
 // cell state too, and only the state travels - through the history array the kernel has to write anyway:
-//   workgroup (rg, ub) = 16 batch rows x 8 units (forward) / 16 units (backward); its 8 waves split K
-//   per step:  wait until every workgroup of the row group has published step t-1 (8 counters per row group, one
-//              per 128-byte line, bumped by one lane per workgroup AFTER its write-through stores have drained),
-//              load the own K slice of h[t-1] (backward: of the bf16 gate gradients of step t+1) with 16-byte sc1
-//              loads - all 8 waves, 8..16 loads in flight per lane, served by the XCD's L2 after the first touch:
-//              64 KB per CU in ~1.1 us measured (profiles/tools/allgather_bench.hip) -, MFMA, partial sums meet in
-//              LDS, cell update, h[t] (backward: dgates[t] as bf16) out as 16-byte sc1 stores, drain, signal.
-// This is the hand-off form of the cdna guide's G16 table, first row: payload stored sc1 and drained, ONE lane per
-// storing workgroup adds to a counter (sharded), the consumer polls the counter with sc1 loads and every load of the
-// payload is an sc1 load issued after the poll matched.  Every spin is bounded; a timeout raises the status word and
-// all waves of the workgroup leave together.  The grid (row groups x unit blocks <= 256 workgroups, one per CU) must
-// be resident at once: ns_lstm_wide_supported() refuses shapes that do not fit.
+//   workgroup (rg, ub) = 16 batch rows x 8 units (forward) / 8 or 16 rows x 16 units (backward)
+//   before the launch: a fill kernel writes an all-ones NaN pattern (the SENTINEL, a value the recurrence never
+//              stores) over every (row, step) of the exchanged array;
+//   per step:  8 SWEEPER waves split K.  Each polls ONE 16-byte piece per producing workgroup of its K slice (sc1 =
+//              L1- and L2-bypassing loads) and fetches the 16 rows of a producer's units as soon as that producer's
+//              piece is no longer the sentinel - the data is its own flag: a step costs one store -> load hop with
+//              no drain, no counter and no second round trip -, then MFMA and partial sums into LDS;
+//              2 (backward: 4) CELL waves add the partials, update the cell, publish h[t] (backward: dgates[t] as
+//              bf16) with 16-byte sc1 write-through stores and do every other memory access of the step.
+// 16-byte sc1 stores arrive as untorn 8-byte halves on gfx950 (MI355X_MICROARCH.md, hand-off table) and every element
+// of every fetched piece is checked, so a piece passes only when all of it is new; a stale piece is fetched again.
+// The cell update never produces the sentinel (a NaN of that bit pattern is rewritten to the canonical quiet NaN).
+//
+// Why the roles are separate waves: a wave's vector-memory operations complete in issue order, so a polling load
+// queued behind the write-through publish store, the late stores or an operand fetch from HBM returns only after
+// those.  Why a probe instead of polling with the sweep itself: 256 CUs re-reading 64 KB each per pass is 16 MB per
+// pass on the memory side (sc1 loads do not hit in L2) - the passes then take 2.2 us each and the CU's own publish
+// store queues behind them.  Measured per step at the benchmark shape (profiles/r02_wide_trace.txt), forward /
+// backward: arrival counters + drained stores 8.7 / 6.65 us; sentinel polling by full sweeps 7.9 / 10.7; probe,
+// then one sweep 5.2 / 7.3; probe and sweep interleaved 4.9 / 7.0; backward with 8-row groups 6.6.  What is left is
+// the hop itself: store -> visible + one probe round trip (1.9 us) + one data round trip (1.5 us; 2.2 us for the
+// backward pass's 64 KB per CU), then ~1.5 us of MFMA, barrier and cell update.
+// Every spin is bounded; a timeout raises the status word and all waves of the workgroup leave together.  The grid
+// (row groups x unit blocks <= 256 workgroups, one per CU) must be resident at once: ns_lstm_wide_supported() refuses
+// shapes that do not fit.
 #include "common.h"
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace {
 constexpr int WT = 512, WW = WT / 64;
-constexpr unsigned WSPIN = 3000000u;
-constexpr int CNT_STRIDE = 32;       // uints between counter shards: 128 bytes, one line each
+constexpr unsigned WSPIN = 1000000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr size_t WIDE_TRACE_BYTES = 256 * 8 * sizeof(long long);
 
 struct WideArgs {
   ns_lstm_seq_params p;
-  unsigned* cnt;        // [row groups][8 shards][CNT_STRIDE]
   int* status;
+  long long* trace;     // NS_WIDE_TRACE=1: [step][8] timestamps (100 MHz) of workgroup 0, else null
   int nub;              // unit blocks per row group
 };
+__device__ __forceinline__ void wstamp(const WideArgs& a, int st, int k) {
+  if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && st < 256) a.trace[st * 8 + k] = wall_clock64();
+}
 
-__device__ __forceinline__ bool wait_counters(const unsigned* c, unsigned need, int lane, int* status, int* abortf, int code) {
-  unsigned spins = 0;
-  for (;;) {
-    const unsigned v = lane < 8 ? __hip_atomic_load(c + lane * CNT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-    if (__all(v >= need)) return true;
-    ++spins;
-    if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return false; }
-    if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return false; }
+// ---- the sentinel: all ones (a NaN in both storage types)
+template <typename T> __device__ __forceinline__ bool has_sentinel(const u32x4& v);
+template <> __device__ __forceinline__ bool has_sentinel<float>(const u32x4& v) {
+  return (v[0] == 0xffffffffu) | (v[1] == 0xffffffffu) | (v[2] == 0xffffffffu) | (v[3] == 0xffffffffu);
+}
+template <> __device__ __forceinline__ bool has_sentinel<bf16_t>(const u32x4& v) {
+  bool b = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) b = b | ((v[i] & 0xffffu) == 0xffffu) | (v[i] >= 0xffff0000u);
+  return b;
+}
+__device__ __forceinline__ float clean(float x, float*) { return __float_as_uint(x) == 0xffffffffu ? __uint_as_float(0x7fc00000u) : x; }
+__device__ __forceinline__ bf16_t clean(float x, bf16_t*) {
+  const bf16_t b = (bf16_t)x;
+  return __builtin_bit_cast(unsigned short, b) == 0xffffu ? __builtin_bit_cast(bf16_t, (unsigned short)0x7fc0u) : b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void wide_fill_kernel(T* base, int N, long P, int padl, int T_, long ld, int width) {
+  // 16-byte pieces of rows (n, padl + t), t < T_
+  const int ppr = width * (int)sizeof(T) / 16;
+  const long total = (long)N * T_ * ppr;
+  const u32x4 s = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / ppr;
+    const int pc = (int)(i - row * ppr);
+    const long n = row / T_, t = row - n * T_;
+    *(u32x4*)((char*)(base + (n * P + padl + t) * ld) + pc * 16) = s;
   }
 }
 
-// 8 consecutive state values as an MFMA A fragment pair (hi, lo), read with sc1 (L1-bypassing) 16-byte loads
-__device__ __forceinline__ void ld_frag_sc1(const float* base, size_t bytes_total, unsigned off_bytes, bool ok, bf16x8& hi, bf16x8& lo) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_total, 0x00020000);
-  u32x4 a = {0u, 0u, 0u, 0u}, b = a;
-  if (ok) { a = __builtin_amdgcn_raw_buffer_load_b128(rs, off_bytes, 0, 16); b = __builtin_amdgcn_raw_buffer_load_b128(rs, off_bytes + 16, 0, 16); }
-  const float f[8] = {__uint_as_float(a[0]), __uint_as_float(a[1]), __uint_as_float(a[2]), __uint_as_float(a[3]),
-                      __uint_as_float(b[0]), __uint_as_float(b[1]), __uint_as_float(b[2]), __uint_as_float(b[3])};
+// Probe and sweep interleaved: the wave polls one piece per producer of its K slice (as probe()) and issues each of its NL
+// sweep loads as soon as the PPCH producers that load covers (LPC consecutive loads share them) have published, so that
+// when the last producer arrives only its own pieces are still to be fetched.  Every piece is checked once all are in
+// (the probe looked at one row only) and a stale one is fetched again.
+template <typename T, int NL, int LPC, int PPCH>
+__device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t bytes, unsigned poff0, unsigned pstride,
+                                                      unsigned off0, unsigned in_grp, unsigned per_grp, u32x4 (&v)[NL], int lane,
+                                                      int* status, int* abortf, int code, long long* tslot) {
+  constexpr int NP = (NL / LPC) * PPCH;                       // producers of this wave's K slice
+  constexpr unsigned long long ALLP = NP >= 64 ? ~0ull : ((1ull << NP) - 1ull);
+  constexpr unsigned ALLL = (1u << NL) - 1u;
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+  const int nrec = __builtin_amdgcn_readfirstlane((int)bytes);
+  const unsigned poff = lane < NP ? poff0 + (unsigned)lane * pstride : 0x80000000u;
+  unsigned long long ready = 0ull;
+  unsigned done = 0u, spins = 0u;
+  for (;;) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, nrec, 0x00020000);
+    if (ready != ALLP) {
+      const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, poff, 0, 16);
+      ready |= __builtin_amdgcn_ballot_w64(lane < NP && !has_sentinel<T>(pv));
+      if (tslot && ready == ALLP && blockIdx.x == 0 && threadIdx.x == 0) *tslot = wall_clock64();
+    }
 #pragma unroll
-  for (int i = 0; i < 8; ++i) { const bf16_t h = (bf16_t)f[i]; hi[i] = h; lo[i] = (bf16_t)(f[i] - (float)h); }
-}
-__device__ __forceinline__ void ld_frag_sc1(const bf16_t* base, size_t bytes_total, unsigned off_bytes, bool ok, bf16x8& hi, bf16x8& lo) {
-  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes_total, 0x00020000);
-  u32x4 a = {0u, 0u, 0u, 0u};
-  if (ok) a = __builtin_amdgcn_raw_buffer_load_b128(rs, off_bytes, 0, 16);
-  hi = *(bf16x8*)&a;
-  (void)lo;
+    for (int l = 0; l < NL; ++l) {
+      constexpr unsigned long long one = 1ull;
+      const unsigned long long m = ((one << PPCH) - one) << ((l / LPC) * PPCH);
+      if (!(done & (1u << l)) && (ready & m) == m) {
+        const unsigned o = off0 + (unsigned)(l % LPC) * in_grp + (unsigned)(l / LPC) * per_grp;
+        v[l] = __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 16);      // sc1, as every load of handed-off bytes
+        done |= 1u << l;
+      }
+    }
+    ++spins;
+    if (done == ALLL) {
+      unsigned stale = 0u;
+#pragma unroll
+      for (int l = 0; l < NL; ++l) if (__any(has_sentinel<T>(v[l]))) stale |= 1u << l;
+      if (!stale) return spins;
+      done &= ~stale;
+    }
+    if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
+    if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return 0; }
+  }
 }
 
 // ===================================================================================== forward
-// NCH = 32-wide K chunks per wave (H / 256); PASSES = 3: fp32 state, hi / lo weight planes; 1: bf16 everywhere
+// Waves 0..7 (the sweepers) split K: sweep, MFMA, partial sums into LDS.  Waves 8, 9 (the cell waves; thread = (row,
+// unit)) add the partials, update the cell, publish h[t] and do every other memory access of the step.  The roles are
+// separate because a wave's vector-memory operations complete in issue order: a polling load queued behind the
+// write-through publish store, the late stores or an operand fetch from HBM returns only after those (the one-role
+// version measured 3.7 us for a sweep that succeeded at its first pass).
+// NCH = 32-wide K chunks per sweeper (H / 256); PASSES = 3: fp32 state, hi / lo weight planes; 1: bf16 everywhere
+constexpr int WTF = WT + 128;
 template <typename T, int PASSES, int NCH>
-__global__ __launch_bounds__(WT) void lstm_wide_fwd_kernel(WideArgs a) {
+__global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
   __shared__ float red[WW][16][33];
   __shared__ __attribute__((aligned(16))) T hst[16][8];
   __shared__ int abortf;
@@ -74,31 +145,85 @@ __global__ __launch_bounds__(WT) void lstm_wide_fwd_kernel(WideArgs a) {
   const int H = p.H, NUB = a.nub;
   const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
   const int n0 = rg * 16, u0 = ub * 8;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int k0 = wave * (H / WW);
   if (tid == 0) abortf = 0;
-  // ---- resident weight fragments: tile j, column r16 -> gate 2j + (r16 >> 3), unit u0 + (r16 & 7)
-  bf16x8 bh[2][NCH], bl[2][NCH];
+  const size_t hbytes = (size_t)p.N * p.P * p.ld_h * sizeof(T);
+  constexpr int PPC = 8 * (int)sizeof(T) / 16;        // 16-byte pieces per 8-value fragment (2 for fp32, 1 for bf16)
+  __syncthreads();
+
+  if (wave < WW) {
+    // ------------------------------------------------------------------ sweepers
+    const int r16 = lane & 15, g = lane >> 4;
+    const int k0 = wave * (H / WW);
+    // resident weight fragments: tile j, column r16 -> gate 2j + (r16 >> 3), unit u0 + (r16 & 7)
+    bf16x8 bh[2][NCH], bl[2][NCH];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long wrow = ((long)(2 * j + (r16 >> 3)) * H + u0 + (r16 & 7)) * H + k0 + g * 8;
+    for (int j = 0; j < 2; ++j) {
+      const long wrow = ((long)(2 * j + (r16 >> 3)) * H + u0 + (r16 & 7)) * H + k0 + g * 8;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      if constexpr (PASSES == 3) {
-        bh[j][c] = *(const bf16x8*)((const bf16_t*)p.whT_hi + wrow + c * 32);
-        bl[j][c] = *(const bf16x8*)((const bf16_t*)p.whT_lo + wrow + c * 32);
-      } else {
-        bh[j][c] = *(const bf16x8*)((const bf16_t*)p.whT + wrow + c * 32);
-        bl[j][c] = bh[j][c];
+      for (int c = 0; c < NCH; ++c) {
+        if constexpr (PASSES == 3) {
+          bh[j][c] = *(const bf16x8*)((const bf16_t*)p.whT_hi + wrow + c * 32);
+          bl[j][c] = *(const bf16x8*)((const bf16_t*)p.whT_lo + wrow + c * 32);
+        } else {
+          bh[j][c] = *(const bf16x8*)((const bf16_t*)p.whT + wrow + c * 32);
+          bl[j][c] = bh[j][c];
+        }
       }
     }
+    const bool ok = n0 + r16 < p.N;
+    // the probed row differs from workgroup to workgroup and wave to wave: 2,000 waves polling the same few lines would
+    // all queue on the same memory channels
+    const int prb = (ub * WW + wave) % min(16, p.N - n0);
+    for (int t = 0; t < p.T; ++t) {
+      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      wstamp(a, t, 0);
+      if (t > 0) {
+        const unsigned rowoff = ok ? (unsigned)(((long)(n0 + r16) * p.P + p.padl + t - 1) * p.ld_h + k0 + g * 8) * (unsigned)sizeof(T) : 0x80000000u;
+        u32x4 v[NCH * PPC];
+        const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t - 1) * p.ld_h + k0) * (unsigned)sizeof(T);
+        const unsigned got = sweep_progressive<T, NCH * PPC, PPC, 4>(p.h, hbytes, prow, 8u * (unsigned)sizeof(T), rowoff, 16u, 32u * (unsigned)sizeof(T),
+                                                                     v, lane, a.status, &abortf, 1, a.trace && t < 256 ? a.trace + t * 8 + 6 : nullptr);
+        wstamp(a, t, 1);
+        if (a.trace && blockIdx.x == 0 && tid == 0 && t < 256) a.trace[t * 8 + 5] = got;
+        if (got) {
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            bf16x8 ah, al;
+            if constexpr (sizeof(T) == 4) {
+              const u32x4 x = v[2 * c], y = v[2 * c + 1];
+              const float f[8] = {__uint_as_float(x[0]), __uint_as_float(x[1]), __uint_as_float(x[2]), __uint_as_float(x[3]),
+                                  __uint_as_float(y[0]), __uint_as_float(y[1]), __uint_as_float(y[2]), __uint_as_float(y[3])};
+#pragma unroll
+              for (int i = 0; i < 8; ++i) { const bf16_t h = (bf16_t)f[i]; ah[i] = h; al[i] = (bf16_t)(f[i] - (float)h); }
+            } else {
+              ah = *(bf16x8*)&v[c];
+              al = ah;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              if constexpr (PASSES == 3) acc[j] = mfma_split<3>(ah, al, bh[j][c], bl[j][c], acc[j]);
+              else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[j][c], acc[j], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][j * 16 + r16] = acc[j][q];
+      __syncthreads();
+      if (abortf) return;
+      wstamp(a, t, 2);
+    }
+    return;
   }
-  // ---- epilogue ownership: threads < 128 = (row er, unit eu)
-  const int er = tid >> 3, eu = tid & 7;
-  const bool eown = tid < 128;
+  // -------------------------------------------------------------------- cell waves: thread = (row er, unit eu)
+  const int e = tid - WT, er = e >> 3, eu = e & 7;
   const int en = n0 + er;
-  const bool eok = eown && en < p.N;
+  const bool eok = en < p.N;
   const int elen = (eok && p.lengths) ? p.lengths[en] : p.T;
+  const auto hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.h, 0, (int)hbytes, 0x00020000);
+  const bool tr = a.trace && blockIdx.x == 0 && e == 0;
   float cst = 0.f;
   float pz[4] = {0.f, 0.f, 0.f, 0.f};
   auto load_xg = [&](int t) {
@@ -109,68 +234,36 @@ __global__ __launch_bounds__(WT) void lstm_wide_fwd_kernel(WideArgs a) {
     }
   };
   load_xg(0);
-  const size_t hbytes = (size_t)p.N * p.P * p.ld_h * sizeof(T);
-  unsigned* mycnt = a.cnt + (size_t)(rg * 8 + (ub & 7)) * CNT_STRIDE;
-  const unsigned* rgcnt = a.cnt + (size_t)rg * 8 * CNT_STRIDE;
-  const unsigned per_shard = (unsigned)(NUB / 8);
-  __syncthreads();
-
   for (int t = 0; t < p.T; ++t) {
-    f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (t > 0) {
-      wait_counters(rgcnt, per_shard * (unsigned)t, lane, a.status, &abortf, 1);
-      const unsigned rowoff = (unsigned)(((long)(n0 + r16) * p.P + p.padl + t - 1) * p.ld_h + k0 + g * 8) * (unsigned)sizeof(T);
-      const bool ok = n0 + r16 < p.N;
-      bf16x8 ah[NCH], al[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) ld_frag_sc1((const T*)p.h, hbytes, rowoff + c * 32 * (unsigned)sizeof(T), ok, ah[c], al[c]);
-#pragma unroll
-      for (int c = 0; c < NCH; ++c)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if constexpr (PASSES == 3) acc[j] = mfma_split<3>(ah[c], al[c], bh[j][c], bl[j][c], acc[j]);
-          else acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[c], bh[j][c], acc[j], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][j * 16 + r16] = acc[j][q];
     __syncthreads();
     if (abortf) return;
-    float gi = 0.f, gj = 0.f, gf = 0.f, go = 0.f, hv = 0.f;
-    if (eown) {
-      float z[4];
+    if (tr && t < 256) a.trace[t * 8 + 3] = wall_clock64();
+    float z[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float s = pz[j];
+    for (int j = 0; j < 4; ++j) {
+      float s = pz[j];
 #pragma unroll
-        for (int w = 0; w < WW; ++w) s += red[w][er][(j >> 1) * 16 + (j & 1) * 8 + eu];
-        z[j] = s;
-      }
-      gi = sigmoidf_(z[0]); gj = tanhf_(z[1]); gf = sigmoidf_(z[2] + p.forget_bias); go = sigmoidf_(z[3]);
-      cst = gf * cst + gi * gj;
-      hv = go * tanhf_(cst);
-      if (t >= elen) { cst = 0.f; hv = 0.f; gi = gj = gf = go = 0.f; }
-      hst[er][eu] = (T)hv;
+      for (int w = 0; w < WW; ++w) s += red[w][er][(j >> 1) * 16 + (j & 1) * 8 + eu];
+      z[j] = s;
     }
-    __syncthreads();
-    // ---- publish h[t]: 16-byte write-through stores by wave 0, drained, then ONE counter add
-    if (wave == 0) {
-      constexpr int PPR = 8 * (int)sizeof(T) / 16;        // 16-byte pieces per row (2 for fp32, 1 for bf16)
-      if (lane < 16 * PPR) {
-        const int row = lane / PPR, pc = lane % PPR;
-        if (n0 + row < p.N) {
-          const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.h, 0, (int)hbytes, 0x00020000);
-          const u32x4 v = *(const u32x4*)((const char*)&hst[row][0] + pc * 16);
-          const unsigned off = (unsigned)(((long)(n0 + row) * p.P + p.padl + t) * p.ld_h + u0) * (unsigned)sizeof(T) + pc * 16;
-          __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);             // aux 16 = sc1
-        }
+    float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + p.forget_bias), go = sigmoidf_(z[3]);
+    cst = gf * cst + gi * gj;
+    float hv = go * tanhf_(cst);
+    if (t >= elen) { cst = 0.f; hv = 0.f; gi = gj = gf = go = 0.f; }
+    hst[er][eu] = clean(hv, (T*)nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write -> read inside this wave (its own 8 rows)
+    __builtin_amdgcn_wave_barrier();
+    // ---- publish h[t]: 16-byte write-through stores, each cell wave its own 8 rows
+    if (lane < 8 * PPC) {
+      const int row = (wave - WW) * 8 + lane / PPC, pc = lane % PPC;
+      if (n0 + row < p.N) {
+        const u32x4 x = *(const u32x4*)((const char*)&hst[row][0] + pc * 16);
+        const unsigned off = (unsigned)(((long)(n0 + row) * p.P + p.padl + t) * p.ld_h + u0) * (unsigned)sizeof(T) + pc * 16;
+        __builtin_amdgcn_raw_buffer_store_b128(x, hrs, off, 0, 16);            // aux 16 = sc1
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0 && t + 1 < p.T) __hip_atomic_fetch_add(mycnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- what only the backward pass reads (plain stores, off the critical path), next step's input gates
+    if (tr && t < 256) a.trace[t * 8 + 4] = wall_clock64();
+    // ---- what only the backward pass reads, next step's input gates
     if (eok) {
       const long rowi = (long)en * p.P + p.padl + t;
       p.c[rowi * H + u0 + eu] = cst;
@@ -184,11 +277,15 @@ __global__ __launch_bounds__(WT) void lstm_wide_fwd_kernel(WideArgs a) {
 }
 
 // ===================================================================================== backward
-// dh[t] = dh_out[t] + dgates[t+1] . Wh^T.  Workgroup = 16 rows x 16 units (rows of Wh [H, 4H], K = 4H split over the 8
-// waves, NCH = 32-wide chunks per wave = H / 64); the exchanged payload is the bf16 copy of the gate gradients
-// (dgates_bf16, or dgates itself when the storage type is bf16).
-template <typename T, int NCH>
-__global__ __launch_bounds__(WT) void lstm_wide_bwd_kernel(WideArgs a) {
+// dh[t] = dh_out[t] + dgates[t+1] . Wh^T.  Workgroup = RPG rows x 16 units; RPG = 8 (the MFMA tile's other 8 rows stay
+// zero, their lanes load nothing) when that still fits the device: the sweep is bound by what ONE CU can load per step
+// (RPG x 4H bf16 = 64 KB at 8 rows), and 4 row groups x 64 unit blocks use all 256 CUs where 2 x 64 used half.
+// Workgroup = RPG rows x 16 units (rows of Wh [H, 4H], K = 4H split over the 8
+// sweepers, NCH = 32-wide chunks per sweeper = H / 64) + 4 cell waves (thread = (row, unit)); the exchanged payload is
+// the bf16 copy of the gate gradients (dgates_bf16, or dgates itself when the storage type is bf16).
+constexpr int WTB = WT + 256;
+template <typename T, int NCH, int RPG>
+__global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
   __shared__ float red[WW][16][17];
   __shared__ __attribute__((aligned(16))) bf16_t dst[16][4][16];      // this step's gate gradients (row, gate, unit)
   __shared__ int abortf;
@@ -196,24 +293,62 @@ __global__ __launch_bounds__(WT) void lstm_wide_bwd_kernel(WideArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, K = 4 * H, NUB = a.nub;
   const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
-  const int n0 = rg * 16, u0 = ub * 16;
-  const int r16 = lane & 15, g = lane >> 4;
-  const int k0 = wave * (K / WW);
+  const int n0 = rg * RPG, u0 = ub * 16;
   if (tid == 0) abortf = 0;
-  const bf16_t* W = sizeof(T) == 2 ? (const bf16_t*)p.wh : (const bf16_t*)p.wh_bf16;
   bf16_t* xb = sizeof(T) == 2 ? (bf16_t*)p.dgates : (bf16_t*)p.dgates_bf16;     // exchange payload [N*P, 4H] bf16
-  bf16x8 bw[NCH];
-  {
-    const bf16_t* row = W + (long)(u0 + r16) * K + k0 + g * 8;
+  const size_t xbytes = (size_t)p.N * p.P * K * sizeof(bf16_t);
+  __syncthreads();
+
+  if (wave < WW) {
+    // ------------------------------------------------------------------ sweepers
+    const int r16 = lane & 15, g = lane >> 4;
+    const int k0 = wave * (K / WW);
+    const bf16_t* W = sizeof(T) == 2 ? (const bf16_t*)p.wh : (const bf16_t*)p.wh_bf16;
+    bf16x8 bw[NCH];
+    {
+      const bf16_t* row = W + (long)(u0 + r16) * K + k0 + g * 8;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) bw[c] = *(const bf16x8*)(row + c * 32);
+      for (int c = 0; c < NCH; ++c) bw[c] = *(const bf16x8*)(row + c * 32);
+    }
+    const bool ok = r16 < RPG && n0 + r16 < p.N;
+    const int prb = (ub * WW + wave) % min(RPG, p.N - n0);     // as in the forward kernel
+    for (int t = p.T - 1; t >= 0; --t) {
+      const int bs = p.T - 1 - t;                       // backward step index
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      wstamp(a, bs, 0);
+      if (bs > 0) {
+        const unsigned rowoff = ok ? (unsigned)(((long)(n0 + r16) * p.P + p.padl + t + 1) * K + k0 + g * 8) * 2u : 0x80000000u;
+        u32x4 av[NCH];
+        const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t + 1) * K + k0) * 2u;
+        const unsigned got = sweep_progressive<bf16_t, NCH, 1, 2>(xb, xbytes, prow, 32u, rowoff, 0u, 64u, av, lane, a.status, &abortf, 2, a.trace && bs < 256 ? a.trace + bs * 8 + 6 : nullptr);
+        wstamp(a, bs, 1);
+        if (a.trace && blockIdx.x == 0 && tid == 0 && bs < 256) a.trace[bs * 8 + 5] = got;
+        if (got) {
+          f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int c = 0; c < NCH; c += 2) {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av[c], bw[c], acc, 0, 0, 0);
+            if (c + 1 < NCH) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av[c + 1], bw[c + 1], acc2, 0, 0, 0);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][r16] = acc[q];
+      __syncthreads();
+      if (abortf) return;
+      wstamp(a, bs, 2);
+    }
+    return;
   }
-  // epilogue ownership: threads < 256 = (row er, unit eu)
-  const int er = tid >> 4, eu = tid & 15;
-  const bool eown = tid < 256;
+  // -------------------------------------------------------------------- cell waves: thread = (row er, unit eu)
+  const int e = tid - WT, er = e >> 4, eu = e & 15;
   const int en = n0 + er;
-  const bool eok = eown && en < p.N;
+  const bool eok = er < RPG && en < p.N;
   const int elen = (eok && p.lengths) ? p.lengths[en] : p.T;
+  const auto xrs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
+  const bool tr = a.trace && blockIdx.x == 0 && e == 0;
   float dcc = 0.f;
   float pg[4] = {0.f, 0.f, 0.f, 0.f}, pdh = 0.f, pc = 0.f, pcp = 0.f;
   auto load_ops = [&](int t) {
@@ -228,67 +363,38 @@ __global__ __launch_bounds__(WT) void lstm_wide_bwd_kernel(WideArgs a) {
     }
   };
   load_ops(p.T - 1);
-  const size_t xbytes = (size_t)p.N * p.P * K * sizeof(bf16_t);
-  unsigned* mycnt = a.cnt + (size_t)(rg * 8 + (ub & 7)) * CNT_STRIDE;
-  const unsigned* rgcnt = a.cnt + (size_t)rg * 8 * CNT_STRIDE;
-  const unsigned per_shard = (unsigned)(NUB / 8);
-  __syncthreads();
-
   for (int t = p.T - 1; t >= 0; --t) {
-    const int bs = p.T - 1 - t;                       // backward step index
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (bs > 0) {
-      wait_counters(rgcnt, per_shard * (unsigned)bs, lane, a.status, &abortf, 2);
-      const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
-      const unsigned rowoff = (unsigned)(((long)(n0 + r16) * p.P + p.padl + t + 1) * K + k0 + g * 8) * 2u;
-      const bool ok = n0 + r16 < p.N;
-      u32x4 av[NCH];
-#pragma unroll
-      for (int c = 0; c < NCH; ++c) av[c] = ok ? __builtin_amdgcn_raw_buffer_load_b128(rs, rowoff + c * 64, 0, 16) : (u32x4){0u, 0u, 0u, 0u};
-      f32x4 acc2 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int c = 0; c < NCH; c += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av[c], bw[c], acc, 0, 0, 0);
-        if (c + 1 < NCH) acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*(bf16x8*)&av[c + 1], bw[c + 1], acc2, 0, 0, 0);
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) acc[q] += acc2[q];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][r16] = acc[q];
+    const int bs = p.T - 1 - t;
     __syncthreads();
     if (abortf) return;
-    float dgv[4] = {0.f, 0.f, 0.f, 0.f};
-    if (eown) {
-      float dh = pdh;
+    if (tr && bs < 256) a.trace[bs * 8 + 3] = wall_clock64();
+    float dh = pdh;
 #pragma unroll
-      for (int w = 0; w < WW; ++w) dh += red[w][er][eu];
-      const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3];
-      const float tc = tanhf_(pc);
-      const float dc = dh * go * (1.f - tc * tc) + dcc;
-      dgv[0] = dc * gj * gi * (1.f - gi);
-      dgv[1] = dc * gi * (1.f - gj * gj);
-      dgv[2] = dc * pcp * gf * (1.f - gf);
-      dgv[3] = dh * tc * go * (1.f - go);
-      dcc = dc * gf;
-      if (t >= elen || !eok) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; dcc = 0.f; }
+    for (int w = 0; w < WW; ++w) dh += red[w][er][eu];
+    const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3];
+    const float tc = tanhf_(pc);
+    const float dc = dh * go * (1.f - tc * tc) + dcc;
+    float dgv[4];
+    dgv[0] = dc * gj * gi * (1.f - gi);
+    dgv[1] = dc * gi * (1.f - gj * gj);
+    dgv[2] = dc * pcp * gf * (1.f - gf);
+    dgv[3] = dh * tc * go * (1.f - go);
+    dcc = dc * gf;
+    if (t >= elen || !eok) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; dcc = 0.f; }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) dst[er][j][eu] = (bf16_t)dgv[j];
-    }
-    __syncthreads();
-    // ---- publish dgates[t] (bf16): 16 rows x 4 gates x 32 bytes = 128 pieces of 16 bytes, waves 0 and 1
-    if (wave < 2) {
-      const int piece = wave * 64 + lane, row = piece >> 3, gate = (piece >> 1) & 3, hf = piece & 1;
-      if (n0 + row < p.N) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)xbytes, 0x00020000);
-        const u32x4 v = *(const u32x4*)((const char*)&dst[row][gate][0] + hf * 16);
+    for (int j = 0; j < 4; ++j) dst[er][j][eu] = clean(dgv[j], (bf16_t*)nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write -> read inside this wave (its own 4 rows)
+    __builtin_amdgcn_wave_barrier();
+    // ---- publish dgates[t] (bf16): this wave's 4 rows x 4 gates x 32 bytes = 32 pieces of 16 bytes
+    if (lane < 32) {
+      const int row = (wave - WW) * 4 + (lane >> 3), gate = (lane >> 1) & 3, hf = lane & 1;
+      if (row < RPG && n0 + row < p.N) {
+        const u32x4 x = *(const u32x4*)((const char*)&dst[row][gate][0] + hf * 16);
         const unsigned off = (unsigned)(((long)(n0 + row) * p.P + p.padl + t) * K + (long)gate * H + u0) * 2u + hf * 16;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(x, xrs, off, 0, 16);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
-    if (tid == 0 && t > 0) __hip_atomic_fetch_add(mycnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr && bs < 256) a.trace[bs * 8 + 4] = wall_clock64();
     // ---- fp32 copy of the gate gradients for the weight-gradient products (storage type float), next operands
     if (eok && sizeof(T) == 4) {
       float* dg = (float*)p.dgates + ((long)en * p.P + p.padl + t) * K + u0 + eu;
@@ -318,6 +424,7 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
     if (p->dtype == NS_F32 && !(p->f32_passes == 1 && p->wh_bf16 && p->dgates_bf16)) return false;
     if (p->dtype == NS_BF16 && !p->wh) return false;
     if (!p->gates || !p->c || !p->dh || !p->dgates) return false;
+    if (!al16(p->dtype == NS_BF16 ? p->dgates : p->dgates_bf16)) return false;
     if ((double)p->N * p->P * 4 * H * 2 >= 2.0e9) return false;
   }
   return true;
@@ -327,15 +434,15 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
 extern "C" int ns_lstm_wide_supported(const ns_lstm_seq_params* p, int backward) { return wide_shape_ok(p, backward, nullptr) ? 1 : 0; }
 extern "C" size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
-  return 256 + sizeof(unsigned) * (size_t)((p->N + 15) / 16) * 8 * CNT_STRIDE;
+  return 256 + WIDE_TRACE_BYTES;       // status word (+ the NS_WIDE_TRACE timestamps)
 }
 
 template <typename T, int PASSES>
 static int launch_wide_fwd(const WideArgs& a, int grid, hipStream_t s) {
   switch (a.p.H) {
-    case 256: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 1>), dim3(grid), dim3(WT), 0, s, a); break;
-    case 512: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 2>), dim3(grid), dim3(WT), 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 4>), dim3(grid), dim3(WT), 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 1>), dim3(grid), dim3(WTF), 0, s, a); break;
+    case 512: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 2>), dim3(grid), dim3(WTF), 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_wide_fwd_kernel<T, PASSES, 4>), dim3(grid), dim3(WTF), 0, s, a); break;
   }
   NS_CHECK_LAUNCH("lstm_wide_fwd");
   return NS_OK;
@@ -351,20 +458,27 @@ extern "C" int ns_lstm_wide_fwd(const ns_lstm_seq_params* p, void* work, ns_stre
   NS_CHECK_ARG(wide_shape_ok(p, 0, &nub), "ns_lstm_wide_fwd: unsupported (needs H in {256, 512, 1024}, row groups x H/8 <= 256, "
                "fp32 with pre-split whT_hi / whT_lo and f32_passes 3, or bf16)");
   WideArgs a;
-  a.p = *p; a.status = (int*)work; a.cnt = (unsigned*)((char*)work + 256); a.nub = nub;
-  int rc = ns_zero_async(work, (ns_lstm_wide_work_bytes(p) + 15) & ~(size_t)15, s);
+  a.p = *p; a.status = (int*)work; a.nub = nub;
+  a.trace = getenv("NS_WIDE_TRACE") ? (long long*)((char*)work + 256) : nullptr;
+  int rc = ns_zero_async(work, 256, s);
   if (rc) return rc;
   const int grid = ((p->N + 15) / 16) * nub;
-  if (p->dtype == NS_BF16) return launch_wide_fwd<bf16_t, 1>(a, grid, s);
+  if (p->dtype == NS_BF16) {
+    hipLaunchKernelGGL(wide_fill_kernel<bf16_t>, dim3(512), dim3(256), 0, s, (bf16_t*)p->h, p->N, (long)p->P, p->padl, p->T, (long)p->ld_h, p->H);
+    NS_CHECK_LAUNCH("lstm_wide_fill");
+    return launch_wide_fwd<bf16_t, 1>(a, grid, s);
+  }
+  hipLaunchKernelGGL(wide_fill_kernel<float>, dim3(512), dim3(256), 0, s, (float*)p->h, p->N, (long)p->P, p->padl, p->T, (long)p->ld_h, p->H);
+  NS_CHECK_LAUNCH("lstm_wide_fill");
   return launch_wide_fwd<float, 3>(a, grid, s);
 }
 
-template <typename T>
+template <typename T, int RPG>
 static int launch_wide_bwd(const WideArgs& a, int grid, hipStream_t s) {
   switch (a.p.H) {
-    case 256: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 4>), dim3(grid), dim3(WT), 0, s, a); break;
-    case 512: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 8>), dim3(grid), dim3(WT), 0, s, a); break;
-    default: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 16>), dim3(grid), dim3(WT), 0, s, a); break;
+    case 256: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 4, RPG>), dim3(grid), dim3(WTB), 0, s, a); break;
+    case 512: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 8, RPG>), dim3(grid), dim3(WTB), 0, s, a); break;
+    default: hipLaunchKernelGGL((lstm_wide_bwd_kernel<T, 16, RPG>), dim3(grid), dim3(WTB), 0, s, a); break;
   }
   NS_CHECK_LAUNCH("lstm_wide_bwd");
   return NS_OK;
@@ -377,10 +491,15 @@ extern "C" int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stre
   NS_CHECK_ARG(wide_shape_ok(p, 1, &nub), "ns_lstm_wide_bwd: unsupported (needs H in {256, 512, 1024}, row groups x H/16 <= 256, "
                "bf16, or fp32 with wh_bf16 + dgates_bf16 and f32_passes 1)");
   WideArgs a;
-  a.p = *p; a.status = (int*)work; a.cnt = (unsigned*)((char*)work + 256); a.nub = nub;
-  int rc = ns_zero_async(work, (ns_lstm_wide_work_bytes(p) + 15) & ~(size_t)15, s);
+  a.p = *p; a.status = (int*)work; a.nub = nub;
+  a.trace = getenv("NS_WIDE_TRACE") ? (long long*)((char*)work + 256) : nullptr;
+  int rc = ns_zero_async(work, 256, s);
   if (rc) return rc;
-  const int grid = ((p->N + 15) / 16) * nub;
-  if (p->dtype == NS_BF16) return launch_wide_bwd<bf16_t>(a, grid, s);
-  return launch_wide_bwd<float>(a, grid, s);
+  const bool r8 = ((p->N + 7) / 8) * nub <= 256;
+  const int grid = (r8 ? (p->N + 7) / 8 : (p->N + 15) / 16) * nub;
+  bf16_t* xb = p->dtype == NS_BF16 ? (bf16_t*)p->dgates : (bf16_t*)p->dgates_bf16;
+  hipLaunchKernelGGL(wide_fill_kernel<bf16_t>, dim3(1024), dim3(256), 0, s, xb, p->N, (long)p->P, p->padl, p->T, 4L * p->H, 4 * p->H);
+  NS_CHECK_LAUNCH("lstm_wide_fill");
+  if (p->dtype == NS_BF16) return r8 ? launch_wide_bwd<bf16_t, 8>(a, grid, s) : launch_wide_bwd<bf16_t, 16>(a, grid, s);
+  return r8 ? launch_wide_bwd<float, 8>(a, grid, s) : launch_wide_bwd<float, 16>(a, grid, s);
 }

@@ -1,5 +1,5 @@
 """The persistent wide-cell LSTM kernels (csrc/lstm_wide.hip: register-resident W_h, state exchanged through the
-history arrays behind per-row-group arrival counters) against the one-launch-per-step kernels on the same operands,
+sentinel-filled history arrays themselves) against the one-launch-per-step kernels on the same operands,
 forward and backward: bf16 storage, and fp32 storage in the `mixed` arrangement (forward three split-bf16 passes over
 pre-split weights, backward one bf16 pass over bf16 copies).  Partial row groups, per-row lengths, repeated launches,
 the status word."""
@@ -53,7 +53,7 @@ def _run(dev, d, wide):
     if wide:
         assert ops.lstm_wide_supported(fp, False) and ops.lstm_wide_supported(bp, True)
         w = torch.zeros(ops.lstm_wide_work_floats(fp), device=dev)
-        for _ in range(2):      # a second launch re-initialises the counters itself
+        for _ in range(2):      # a second launch re-fills the sentinel itself
             ops.lstm_wide("fwd", fp, w)
         torch.cuda.synchronize()
         assert int(w[:1].view(torch.int32).item()) == 0
