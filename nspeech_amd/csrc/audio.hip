@@ -275,6 +275,214 @@ __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ Griffin-Lim, n_fft = 2048: one WAVE per frame
+// The 1024-point complex transform lives in the registers of one wavefront (16 points per lane) as 16 x 16 x 4:
+//   pass 1: lane n' holds z[64 n1 + n'], a 16-point DFT over n1 in registers, twiddle W_1024^(n' k1)
+//   one LDS exchange (transpose; the wave's own 8.5 KB, no workgroup barrier: LDS is in order inside a wave)
+//   pass 2: lane (k1, n3) holds the 16 values n2 of n' = 4 n2 + n3, 16-point DFT over n2, twiddle W_64^(n3 k2)
+//   pass 3: the 4-point DFT over n3 runs ACROSS the four lanes of a quad with DPP quad_perm moves
+// which leaves Z[k1 + 16 k2 + 256 k3] in lane (k1, k3), register k2.  An iteration is: overlap-add gather of the
+// previous iteration's frames (4 neighbours, float2 loads) -> window -> FFT -> Z to LDS in natural order -> every lane
+// takes the bins 64 n1 + n' (what pass 1 of the next transform wants) and their partners M - k: real-input split, unit
+// phase x magnitude, merge -> FFT of conj -> window -> frame out.  3 LDS exchanges and no barrier per iteration where
+// the 256-thread kernel above needs 10 barriers; 4 frames per workgroup share the W_1024 table.
+constexpr int GW_PAD = 1088;                 // float2 per wave: 16 rows of 68 (transpose) / 1024 + 8 per 256 (natural)
+
+__device__ __forceinline__ void fft4(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr, float& di) {
+  const float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+  const float t2r = br + dr, t2i = bi + di;
+  const float t3r = bi - di, t3i = dr - br;                    // -i (b - d)
+  ar = t0r + t2r; ai = t0i + t2i;
+  cr = t0r - t2r; ci = t0i - t2i;
+  br = t1r + t3r; bi = t1i + t3i;
+  dr = t1r - t3r; di = t1i - t3i;
+}
+__device__ __forceinline__ void cmulc(float& r, float& i, float a, float b) {   // (r + i i) *= (a + i b)
+  const float t = r * a - i * b;
+  i = r * b + i * a;
+  r = t;
+}
+// 16-point forward DFT in registers, natural order in and out (4 x 4, the digit reversal is register renaming)
+__device__ __forceinline__ void fft16(float (&r)[16], float (&i)[16]) {
+  constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, HH = 0.70710678118654752f;
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) fft4(r[n2], i[n2], r[4 + n2], i[4 + n2], r[8 + n2], i[8 + n2], r[12 + n2], i[12 + n2]);
+  // element 4 k1 + n2 times W_16^(n2 k1)
+  cmulc(r[5], i[5], C1, -S1);  cmulc(r[6], i[6], HH, -HH);   cmulc(r[7], i[7], S1, -C1);
+  cmulc(r[9], i[9], HH, -HH);  { const float t = r[10]; r[10] = i[10]; i[10] = -t; }  cmulc(r[11], i[11], -HH, -HH);
+  cmulc(r[13], i[13], S1, -C1); cmulc(r[14], i[14], -HH, -HH); cmulc(r[15], i[15], -C1, S1);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) fft4(r[4 * k1], i[4 * k1], r[4 * k1 + 1], i[4 * k1 + 1], r[4 * k1 + 2], i[4 * k1 + 2], r[4 * k1 + 3], i[4 * k1 + 3]);
+  // position 4 k1 + k2 holds X[k1 + 4 k2]
+  float tr[16], ti[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) { tr[(p >> 2) + 4 * (p & 3)] = r[p]; ti[(p >> 2) + 4 * (p & 3)] = i[p]; }
+#pragma unroll
+  for (int p = 0; p < 16; ++p) { r[p] = tr[p]; i[p] = ti[p]; }
+}
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt lgkmcnt(0): LDS is in order inside a wave
+  __builtin_amdgcn_wave_barrier();
+}
+// in: lane n' = lane holds z[64 n1 + n'] in (r, i)[n1];  out: lane (k1 = lane >> 2, k3 = lane & 3) holds
+// Z[k1 + 16 k2 + 256 k3] in (r, i)[k2].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD float2.
+__device__ __forceinline__ void fft1024_wave(float (&r)[16], float (&i)[16], float2* buf, const float2* tw, int lane) {
+  fft16(r, i);
+#pragma unroll
+  for (int k1 = 1; k1 < 16; ++k1) { const float2 w = tw[lane * k1]; cmulc(r[k1], i[k1], w.x, w.y); }
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = make_float2(r[k1], i[k1]);
+  wave_lds_fence();
+  const int k1l = lane >> 2, n3 = lane & 3;
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) { const float2 v = buf[k1l * 68 + 4 * n2 + n3]; r[n2] = v.x; i[n2] = v.y; }
+  wave_lds_fence();                                             // the buffer is free again
+  fft16(r, i);
+#pragma unroll
+  for (int k2 = 1; k2 < 16; ++k2) { const float2 w = tw[16 * n3 * k2]; cmulc(r[k2], i[k2], w.x, w.y); }
+  // 4-point DFT over n3 across the quad: out(k3) = (b0 + s b2) + (-i)^k3 (b1 + s b3), s = (-1)^k3
+  const float sg = (n3 & 1) ? -1.f : 1.f;
+  const float cr = n3 == 0 ? 1.f : (n3 == 2 ? -1.f : 0.f), ci = n3 == 1 ? -1.f : (n3 == 3 ? 1.f : 0.f);
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) {
+    const float b0r = NS_DPP_F(r[k2], 0x00), b1r = NS_DPP_F(r[k2], 0x55), b2r = NS_DPP_F(r[k2], 0xAA), b3r = NS_DPP_F(r[k2], 0xFF);
+    const float b0i = NS_DPP_F(i[k2], 0x00), b1i = NS_DPP_F(i[k2], 0x55), b2i = NS_DPP_F(i[k2], 0xAA), b3i = NS_DPP_F(i[k2], 0xFF);
+    const float er = b0r + sg * b2r, ei = b0i + sg * b2i, orr = b1r + sg * b3r, oi = b1i + sg * b3i;
+    r[k2] = er + (cr * orr - ci * oi);
+    i[k2] = ei + (cr * oi + ci * orr);
+  }
+}
+__device__ __forceinline__ int gw_nat(int k) { return k + 8 * (k >> 8); }    // natural order, conflict-free for the (k1, k3) writers
+
+template <bool INIT>
+__global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const ns_griffin_lim_params& p = g.p;
+  constexpr int M = 1024, N = 2048, F = M + 1;
+  float2* tw = (float2*)sm;                                    // [1024] W_1024^j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float2* buf = tw + M + wave * GW_PAD;
+  for (int j = tid; j < M; j += 256) {
+    const float2 t = ((const float2*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
+    tw[j] = j < 512 ? t : make_float2(-t.x, -t.y);
+  }
+  __syncthreads();
+  const int t = blockIdx.x * 4 + wave, n = blockIdx.y;
+  if (t >= p.T) return;
+  float* mag = g.mag + ((long)n * p.T + t) * F;
+  float zr[16], zi[16];
+  float mkv[16], mpv[16];
+  float2 wv[16];
+  // per-lane base pointers: every access below is base[constant]
+  const float2* tw2l = (const float2*)p.twiddle + lane;        // exp(-2 pi i k / 2048), k = 64 n1 + lane
+  const float* magk = mag + lane;                              // mag[64 n1 + lane]
+  const float* magp = mag + (M - lane);                        // mag[M - k] = magp[-64 n1]
+  const float2* winl = (const float2*)p.window + lane;         // window[2 (64 n1 + lane)], [.. + 1]
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) wv[n1] = tw2l[64 * n1];
+  if constexpr (!INIT) {
+    // ---- overlap-add gather (the previous iteration's windowed frames) -> window -> z[m] = (x[2m], x[2m+1]).
+    //      Sample j of frame t lies in frames t + q0, t + q0 - 1, ... (at most 4: the host checks win <= 4 hop) at
+    //      offsets o0, o0 + hop, ...: element index e0 + dq (hop - win) of this clip's frames.  Range-checked buffer
+    //      loads (an out-of-range lane reads 0) and every load in flight before the first is used.
+    const int hop = p.hop, win = p.win;
+    const float inv_hop = 1.f / hop;
+    const auto frs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.fprev + (long)n * p.T * win), 0, p.T * win * 4, 0x00020000);
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    u32x2_t xs[8][4];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; ++n1) {
+      const int j = 2 * (64 * n1 + lane);
+      int q0 = (int)((j + 0.5f) * inv_hop);       // the quotient of two small integers through a float reciprocal: exact
+      q0 = min(q0, p.T - 1 - t);
+      const int o0 = j - q0 * hop;
+      const int e0 = (t + q0) * win + o0;
+#pragma unroll
+      for (int dq = 0; dq < 4; ++dq) {
+        const bool ok = j < win && t + q0 - dq >= 0 && o0 + dq * hop < win;
+        xs[n1][dq] = __builtin_amdgcn_raw_buffer_load_b64(frs, ok ? (unsigned)(e0 + dq * (hop - win)) * 4u : 0x80000000u, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      float v0 = 0.f, v1 = 0.f;
+      if (n1 < 8) {
+        const float2 wd = 2 * (64 * n1 + lane) < win ? winl[64 * n1] : make_float2(0.f, 0.f);
+        v0 = ((__uint_as_float(xs[n1 & 7][0][0]) + __uint_as_float(xs[n1 & 7][1][0])) + (__uint_as_float(xs[n1 & 7][2][0]) + __uint_as_float(xs[n1 & 7][3][0]))) * wd.x;
+        v1 = ((__uint_as_float(xs[n1 & 7][0][1]) + __uint_as_float(xs[n1 & 7][1][1])) + (__uint_as_float(xs[n1 & 7][2][1]) + __uint_as_float(xs[n1 & 7][3][1]))) * wd.y;
+      }
+      zr[n1] = v0; zi[n1] = v1;
+    }
+    fft1024_wave(zr, zi, buf, tw, lane);
+    float2* nat = buf + ((lane >> 2) + 264 * (lane & 3));      // natural order k + 8 (k >> 8), k = k1 + 16 k2 + 256 k3
+#pragma unroll
+    for (int k2 = 0; k2 < 16; ++k2) nat[16 * k2] = make_float2(zr[k2], zi[k2]);
+    wave_lds_fence();
+  } else {
+    // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
+    const float* sp = p.spec + ((long)n * p.T + t) * F;
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) {
+      const int k = 64 * n1 + lane;
+      const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
+      mkv[n1] = __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mpv[n1] = __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mag[k] = mkv[n1];
+      if (k == 0) mag[M] = mpv[n1];
+    }
+  }
+  // ---- own bins k = 64 n1 + lane with their partners M - k: split -> unit phase x magnitude -> merge; conj(Zt[k]) is
+  //      the next transform's input in the pass-1 layout
+  const float2* own = buf + lane;                              // Z[k] at own[64 n1 + 8 (n1 >> 2)]
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const float mk = mkv[n1], mp = mpv[n1];
+    const float2 w = wv[n1];
+    float2 xa, xb;
+    if constexpr (INIT) {
+      xa = make_float2(mk, 0.f); xb = make_float2(mp, 0.f);
+    } else {
+      const float2 A = own[64 * n1 + 8 * (n1 >> 2)];
+      // the partner (M - k) & 1023 in the padded natural order; lane 0's partner of bin 64 n1 is bin 64 (16 - n1) (bin 0
+      // for n1 = 0), one pad step further than the other lanes'
+      constexpr int P0[16] = {0, 984, 920, 856, 792, 720, 656, 592, 528, 456, 392, 328, 264, 192, 128, 64};
+      const float2 B = buf[lane == 0 ? P0[n1] : (64 - lane) + 64 * (15 - n1) + 8 * ((15 - n1) >> 2)];
+      // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
+      // (the factor 1/2 drops out of the unit phase)
+      const float s1x = A.x + B.x, s1y = A.y - B.y, d1x = A.x - B.x, d1y = A.y + B.y;
+      const float wdx = w.x * d1x - w.y * d1y, wdy = w.x * d1y + w.y * d1x;      // w d1
+      const float eax = s1x + wdy, eay = s1y - wdx;
+      const float ebx = s1x - wdy, eby = -s1y - wdx;           // conj(w) d2 with d2 = (-d1x, d1y):  (-(wdx), wdy) -> eb = (s1x - wdy, -s1y - wdx)
+      // m e / max(1e-8, |e|) with e = ea / 2
+      const float sa = mk * __builtin_amdgcn_rsqf(fmaxf(4e-16f, eax * eax + eay * eay));
+      const float sb = mp * __builtin_amdgcn_rsqf(fmaxf(4e-16f, ebx * ebx + eby * eby));
+      xa = make_float2(eax * sa, eay * sa);
+      xb = make_float2(ebx * sb, eby * sb);
+    }
+    // Zt[k] = (xa + conj xb) + i conj(w) (xa - conj xb)
+    const float t1x = xa.x + xb.x, t1y = xa.y - xb.y, u1x = xa.x - xb.x, u1y = xa.y + xb.y;
+    const float c1x = w.x * u1x + w.y * u1y, c1y = w.x * u1y - w.y * u1x;          // conj(w) u1
+    zr[n1] = t1x - c1y;
+    zi[n1] = -(t1y + c1x);
+  }
+  wave_lds_fence();                                             // every lane has read Z before the buffer is reused
+  fft1024_wave(zr, zi, buf, tw, lane);
+  // ---- y[2m] = Re Y[m] / N, y[2m+1] = -Im Y[m] / N, windowed; m = k1 + 16 k2 + 256 k3
+  const float invN = 1.f / N;
+  const int m0 = (lane >> 2) + 256 * (lane & 3);
+  float2* fo = (float2*)(g.fnext + ((long)n * p.T + t) * p.win) + m0;
+  const float2* wo = (const float2*)p.window + m0;
+#pragma unroll
+  for (int k2 = 0; k2 < 16; ++k2) {
+    if (2 * (m0 + 16 * k2) < p.win) {
+      const float2 wd = wo[16 * k2];
+      fo[16 * k2] = make_float2(zr[k2] * invN * wd.x, -zi[k2] * invN * wd.y);
+    }
+  }
+}
+
 __global__ void gl_ola_kernel(GlArgs g, int Lout) {
   const ns_griffin_lim_params& p = g.p;
   const int n = blockIdx.y;
@@ -286,7 +494,7 @@ __global__ void gl_ola_kernel(GlArgs g, int Lout) {
 extern "C" size_t ns_griffin_lim_work_bytes(const ns_griffin_lim_params* p) {
   if (!p) return 0;
   const size_t F = p->n_fft / 2 + 1;
-  return sizeof(float) * ((size_t)p->N * p->T * F + 2 * (size_t)p->N * p->T * p->win) + 256;
+  return sizeof(float) * ((((size_t)p->N * p->T * F + 1) & ~(size_t)1) + 2 * (size_t)p->N * p->T * p->win) + 256;
 }
 
 extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
@@ -300,21 +508,34 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
   GlArgs g;
   g.p = *p;
   g.mag = p->work;
-  float* fa = p->work + (size_t)p->N * p->T * F;
+  float* fa = p->work + (((size_t)p->N * p->T * F + 1) & ~(size_t)1);     // 8-byte aligned frames (float2 accesses)
   float* fb = fa + (size_t)p->N * p->T * p->win;
   const size_t lds = sizeof(float2) * (p->n_fft + p->n_fft / 2);
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gl_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gl_wave_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)gl_wave_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  dim3 grid(p->T, p->N);
+  // n_fft 2048 with even hop / window (the shipped hparams): the wave-per-frame kernel; anything else: one workgroup
+  // per frame with the transforms in LDS
+  const bool wavek = p->n_fft == 2048 && (p->hop & 1) == 0 && (p->win & 1) == 0 && p->win <= 4 * p->hop && p->win <= 1024 &&
+                     (((uintptr_t)p->window) & 7) == 0 &&
+                     (((uintptr_t)p->work) & 7) == 0;
+  const size_t lds_w = sizeof(float2) * (1024 + 4 * GW_PAD);
+  dim3 grid(p->T, p->N), grid_w(ceil_div(p->T, 4), p->N);
+  auto launch = [&]() {
+    if (wavek && g.init) hipLaunchKernelGGL(gl_wave_kernel<true>, grid_w, dim3(256), lds_w, s, g);
+    else if (wavek) hipLaunchKernelGGL(gl_wave_kernel<false>, grid_w, dim3(256), lds_w, s, g);
+    else hipLaunchKernelGGL(gl_frame_kernel, grid, dim3(FT), lds, s, g);
+  };
   g.init = 1; g.fprev = nullptr; g.fnext = fa;
-  hipLaunchKernelGGL(gl_frame_kernel, grid, dim3(FT), lds, s, g);
+  launch();
   float* cur = fa; float* nxt = fb;
   for (int it = 0; it < p->iters; ++it) {
     g.init = 0; g.fprev = cur; g.fnext = nxt;
-    hipLaunchKernelGGL(gl_frame_kernel, grid, dim3(FT), lds, s, g);
+    launch();
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
   const int Lout = (p->T - 1) * p->hop + p->win;
