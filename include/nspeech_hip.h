@@ -354,7 +354,11 @@ int ns_taco2_keys_transpose_add(float* keys, const float* keys_t, int N, int Ti,
  *  mode 1: h = u*h_prev + (1-u)*c  (0 past length) -> h_out (dtype) (+ h_out2)
  *  mode 2: backward A: dzc = dh*(1-u)*(1-c^2); dzu = dh*(h_prev-c)*u*(1-u) -> dzg[:,H:]; carry = dh*u
  *  mode 3: backward B: dzr = drh*h_prev*r*(1-r) -> dzg[:,:H]; carry += drh*r
- * rows with t >= lengths[n] produce zeros (modes 1-3). */
+ * rows with t >= lengths[n] produce zeros (modes 1-3) and leave `carry` as it is (mode 2): the state, and so its
+ * gradient, passes a step beyond the length unchanged (tf.nn.dynamic_rnn).
+ * Non-zero initial state (modules.py:165-181, the speaker projection as initial_state_fw / _bw): with h_init set,
+ * h_prev is h_init[n] at a sequence's first step - t == 0, or with `reverse` t == len(n) - 1 where len(n) =
+ * lengths ? lengths[n] : T - instead of what h_prev points at. */
 typedef struct {
   int mode, dtype, N, H, t;
   const int* lengths;
@@ -366,6 +370,10 @@ typedef struct {
   void* dzg; int64_t dzg_sn;              /* (dtype) [N,2H] rows (modes 2, 3) */
   const float* dh; int64_t dh_sn;         /* modes 2: total grad wrt h (fp32); mode 3: drh */
   float* carry; int64_t carry_sn;         /* fp32 [N,H] */
+  const float* dh_add; int64_t dha_sn;    /* mode 2, optional: added to dh where the row is valid (the gradient wrt this
+                                             step's output; dh itself then only carries the recurrent part) */
+  const float* h_init; int64_t hi_sn;     /* optional fp32 [N,H] initial state */
+  int reverse, T;
 } ns_gru_pointwise_params;
 int ns_gru_pointwise(const ns_gru_pointwise_params* p, ns_stream_t stream);
 

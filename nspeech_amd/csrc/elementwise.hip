@@ -692,8 +692,10 @@ __global__ void gru_pointwise_kernel(ns_gru_pointwise_params p) {
   const int H = p.H;
   for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
     const int n = idx / H, u = idx % H;
-    const bool masked = p.lengths && p.t >= p.lengths[n];
-    const float hp = p.h_prev ? ldf((const T*)p.h_prev + (long)n * p.hp_sn + u) : 0.f;
+    const int len = p.lengths ? p.lengths[n] : p.T;
+    const bool masked = p.lengths && p.t >= len;
+    const bool first = p.h_init && (p.reverse ? p.t == len - 1 : p.t == 0);
+    const float hp = first ? p.h_init[(long)n * p.hi_sn + u] : (p.h_prev ? ldf((const T*)p.h_prev + (long)n * p.hp_sn + u) : 0.f);
     const float r = p.ru ? p.ru[(long)n * p.ru_sn + u] : 0.f;
     const float uu = p.ru ? p.ru[(long)n * p.ru_sn + H + u] : 0.f;
     if (p.mode == 0) {
@@ -705,10 +707,10 @@ __global__ void gru_pointwise_kernel(ns_gru_pointwise_params p) {
       if (p.out2) stf((T*)p.out2 + (long)n * p.out2_sn + u, h);
     } else if (p.mode == 2) {
       const float c = p.c[(long)n * p.c_sn + u];
-      const float dh = masked ? 0.f : p.dh[(long)n * p.dh_sn + u];
+      const float dh = masked ? 0.f : p.dh[(long)n * p.dh_sn + u] + (p.dh_add ? p.dh_add[(long)n * p.dha_sn + u] : 0.f);
       stf((T*)p.out + (long)n * p.out_sn + u, dh * (1.f - uu) * (1.f - c * c));
       stf((T*)p.dzg + (long)n * p.dzg_sn + H + u, dh * (hp - c) * uu * (1.f - uu));
-      p.carry[(long)n * p.carry_sn + u] = dh * uu;
+      if (!masked) p.carry[(long)n * p.carry_sn + u] = dh * uu;
     } else {
       const float drh = masked ? 0.f : p.dh[(long)n * p.dh_sn + u];
       stf((T*)p.dzg + (long)n * p.dzg_sn + u, drh * hp * r * (1.f - r));

@@ -145,7 +145,13 @@ def _gru(trainable, scope, nin, units):
     trainable.add(scope + "/candidate/bias", (units,))
 
 
-def _cbhg(tr, st, scope, K, cin, proj, gru_units=128, highways=4):
+def cbhg_highway_widths(speaker_dim, highways=4):
+    """Input width of each highway layer.  With a speaker embedding every layer first concatenates a softsign
+    projection as wide as its input (modules.py:157-162), so the width doubles per layer: 256, 512, 1024, 2048."""
+    return [128 * (2 ** (i + 1) if speaker_dim else 1) for i in range(highways)]
+
+
+def _cbhg(tr, st, scope, K, cin, proj, gru_units=128, highways=4, speaker_dim=0):
     for k in range(1, K + 1):
         _conv_bn(tr, st, "%s/conv_bank/conv1d_%d" % (scope, k), k, cin, 128)
     c = K * 128
@@ -153,14 +159,22 @@ def _cbhg(tr, st, scope, K, cin, proj, gru_units=128, highways=4):
         _conv_bn(tr, st, "%s/proj_%d" % (scope, i + 1), 3, c, size)
         c = size
     if c != 128:
+        assert not speaker_dim          # the initial-state projection below would then be dense_1 in the reference
         tr.add(scope + "/dense/kernel", (c, 128))
         tr.add(scope + "/dense/bias", (128,))
+    widths = cbhg_highway_widths(speaker_dim, highways)
     for i in range(highways):
+        if speaker_dim:                 # modules.py:157-160: dense(speaker_embd, h.shape[-1], softsign) inside highway_i
+            tr.add("%s/highway_%d/dense/kernel" % (scope, i), (speaker_dim, widths[i] // 2))
+            tr.add("%s/highway_%d/dense/bias" % (scope, i), (widths[i] // 2,))
         for g in ("H", "T"):
-            tr.add("%s/highway_%d/highway/%s/kernel" % (scope, i, g), (128, 128))
-            tr.add("%s/highway_%d/highway/%s/bias" % (scope, i, g), (128,))
+            tr.add("%s/highway_%d/highway/%s/kernel" % (scope, i, g), (widths[i], widths[i]))
+            tr.add("%s/highway_%d/highway/%s/bias" % (scope, i, g), (widths[i],))
+    if speaker_dim:                     # modules.py:165-167: the BiGRU's initial state (both directions)
+        tr.add(scope + "/dense/kernel", (speaker_dim, gru_units))
+        tr.add(scope + "/dense/bias", (gru_units,))
     for d in ("fw", "bw"):
-        _gru(tr, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), 128, gru_units)
+        _gru(tr, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), widths[-1], gru_units)
 
 
 def taco1_layout(hp, vocab_size):
@@ -168,15 +182,22 @@ def taco1_layout(hp, vocab_size):
     tr, st = Layout(), Layout()
     M, emb = hp.num_mels, hp.embedding_dim
     tr.add("embedding/embedding", (vocab_size, emb))
+    n_spk = int(getattr(hp, "num_speakers", 1) or 1)
+    dsp = taco2_speaker_width(hp)                 # the decoder prenet site is the same wrapper (rnn_wrappers.py:28-30)
+    sd = hp.speaker_embed_dim if dsp else 0
+    if dsp:                                       # tacotron.py:41-48
+        tr.add("speaker/speaker_embed", (n_spk, sd))
     pn = list(hp.encoder_prenet)
     tr.add("prenet/dense_1/kernel", (emb, pn[0])); tr.add("prenet/dense_1/bias", (pn[0],))
     tr.add("prenet/dense_2/kernel", (pn[0], pn[1])); tr.add("prenet/dense_2/bias", (pn[1],))
-    _cbhg(tr, st, "encoder_cbhg", hp.encoder_cbhg_banks, pn[1], list(hp.encoder_cbhg_bank_sizes))
+    _cbhg(tr, st, "encoder_cbhg", hp.encoder_cbhg_banks, pn[1], list(hp.encoder_cbhg_bank_sizes), speaker_dim=sd)
     E, A, D = 256, hp.attention_dim, hp.decoder_dim
     tr.add("attention_decoder/memory_layer/kernel", (E, A))
     tr.add("decoder/decoder_prenet/dense_1/kernel", (M + E, 256)); tr.add("decoder/decoder_prenet/dense_1/bias", (256,))
     tr.add("decoder/decoder_prenet/dense_2/kernel", (256, 128)); tr.add("decoder/decoder_prenet/dense_2/bias", (128,))
-    _gru(tr, "decoder/attention_gru", 128, A)
+    if dsp:
+        tr.add("decoder/dense/kernel", (sd, dsp)); tr.add("decoder/dense/bias", (dsp,))
+    _gru(tr, "decoder/attention_gru", 128 + dsp, A)
     tr.add("decoder/attention/query_layer/kernel", (A, A))
     tr.add("decoder/attention/attention_v", (A,))
     tr.add("decoder/attention_projection/kernel", (A + E, D)); tr.add("decoder/attention_projection/bias", (D,))

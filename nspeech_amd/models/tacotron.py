@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH
+from .._lib import ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_SOFTSIGN, ACT_TANH
 from . import params as P_
 from .tacotron2 import Tacotron2, _LazyAudio, _round_up
 
@@ -51,13 +51,10 @@ class Tacotron(Tacotron2):
     LAYOUT = staticmethod(P_.taco1_layout)
     KW = 1    # Bahdanau = location-sensitive kernel with a 1-tap zero filter
 
-    @staticmethod
-    def _speaker_width(hp):
-        """The reference's Tacotron-1 threads the speaker embedding through the CBHG highway stack and the BiGRU
-        (modules.py:157-169) as well; only the Tacotron-2 form is built here, so refuse instead of ignoring it."""
-        if int(getattr(hp, "num_speakers", 1) or 1) > 1:
-            raise NotImplementedError("taco1 with num_speakers > 1 is not supported; use --model taco2")
-        return 0
+    # num_speakers > 1 (tacotron.py:41-66): a 128-wide projection joins the decoder prenet output as in Tacotron-2
+    # (rnn_wrappers.py:28-30); the encoder CBHG takes one per highway layer and one as the BiGRU's initial state
+    # (modules.py:157-169, _cbhg below)
+    _speaker_width = staticmethod(P_.taco2_speaker_width)
 
     # ------------------------------------------------------------------ shadows
     def refresh_shadows(self, full=False):
@@ -77,15 +74,17 @@ class Tacotron(Tacotron2):
             tr(key + "_gT", scope + "/gates/kernel", cin, H, 2 * H)
             tr(key + "_cT", scope + "/candidate/kernel", cin, H, H)
 
+        Dsp = self.Dsp
         for cb in ("encoder_cbhg", "post_cbhg"):
+            cin = P_.cbhg_highway_widths(hp.speaker_embed_dim if Dsp and cb == "encoder_cbhg" else 0)[-1]
             for d in ("fw", "bw"):
-                gru("%s_%s" % (cb, d), "%s/bidirectional_rnn/%s/gru_cell" % (cb, d), 128, 128)
+                gru("%s_%s" % (cb, d), "%s/bidirectional_rnn/%s/gru_cell" % (cb, d), cin, 128)
         A, D, M, E = hp.attention_dim, hp.decoder_dim, hp.num_mels, 256
         gru("gru_1", "decoder/gru_1", D, D)
         gru("gru_2", "decoder/gru_2", D, D)
         # attention GRU: the whole [x | h] kernels transposed (x = prenet output is not hoistable)
-        tr("att_gT", "decoder/attention_gru/gates/kernel", 0, 128 + A, 2 * A)
-        tr("att_cT", "decoder/attention_gru/candidate/kernel", 0, 128 + A, A)
+        tr("att_gT", "decoder/attention_gru/gates/kernel", 0, 128 + Dsp + A, 2 * A)
+        tr("att_cT", "decoder/attention_gru/candidate/kernel", 0, 128 + Dsp + A, A)
         tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
         tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
         tr("wqT", "decoder/attention/query_layer/kernel", 0, A, A)
@@ -159,6 +158,20 @@ class Tacotron(Tacotron2):
         self._tape.append(bwd)
         return y
 
+    def _concat_time_bcast(self, name, x, v):
+        """[x | v tiled over time] (modules.py:160-162): v is one row per utterance (an Act with P = 1)."""
+        C, Cv = x.C, v.C
+        y = self._new(name, x, C + Cv)
+        ops.copy3d(x.buf, y.buf, 1, x.rows, C, (0, C), (0, C + Cv))
+        ops.copy3d(v.buf, y.buf, x.N, x.P, Cv, (Cv, 0), (x.P * (C + Cv), C + Cv), dst_off=C)
+
+        def bwd():
+            ops.copy3d(y.grad, x.grad, 1, x.rows, C, (0, C + Cv), (0, C), accumulate=1)
+            for n in range(x.N):        # column sums over the utterance's rows (pad rows carry zero gradient)
+                ops.colsum(y.grad, C + Cv, x.P, Cv, v.grad, x_off=n * x.P * (C + Cv) + C, out_off=n * Cv)
+        self._tape.append(bwd)
+        return y
+
     def _add(self, name, a, b):
         y = self._new(name, a, a.C)
         ops.copy3d(a.buf, y.buf, 1, a.rows, a.C, (0, a.C), (0, a.C))
@@ -199,7 +212,12 @@ class Tacotron(Tacotron2):
         return y
 
     # ---- GRU over time (tf GRUCell); h history lives in out.buf columns [col, col+H)
-    def _gru_seq(self, tag, x, scope, key, H, lengths, reverse, out, col):
+    def _gru_seq(self, tag, x, scope, key, H, lengths, reverse, out, col, h0=None):
+        """h0: optional Act [N, 1, H], the initial state (modules.py:165-181).  The recurrent products read the state
+        history, where the slot in front of a sequence's first step holds zeros, so the initial state enters three
+        ways: h0 . Wg_h is added to the input-side gate pre-activations of the first step (t = 0; reversed: t =
+        len(n) - 1), the element-wise kernels substitute h0 for h_prev there (h_init), and the weight gradient of the
+        recurrent gate kernel gets the first steps' h0^T . dzg on top of the shifted-history product."""
         N, P, padl, T = x.N, x.P, x.padl, x.T
         rows, cin, ldh = x.rows, x.C, out.C
         W, g = self._W(self.T), self.flat_g
@@ -214,18 +232,31 @@ class Tacotron(Tacotron2):
         rh = self._buf("gru:%s_rh" % tag, rows * H, self.T)
         gT, cT = self.tsh[key + "_gT"], self.tsh[key + "_cT"]
         hb = out.buf
+        hi = {}
+        if h0 is not None:
+            h0f = self._buf("gru:%s_h0f" % tag, N * H, torch.float32)
+            ops.copy3d(h0.buf, h0f, 1, N, H, (0, H), (0, H))
+            hi = dict(h_init=(h0f, 0), hi_sn=H, reverse=reverse, T=T)
+            # first step of utterance n: row `first[n]` of the time axis
+            lens = self._host_lengths if lengths is not None else [T] * N
+            first = [int(lens[n]) - 1 if reverse else 0 for n in range(N)]
+            sg = self._buf("gru:%s_h0g" % tag, N * 2 * H, torch.float32)
+            ops.gemm(h0.buf, gT, sg, N, 2 * H, H, H, H, 2 * H)
+            for n in range(N):
+                ops.copy3d(sg, xg, 1, 1, 2 * H, (0, 0), (0, 0), src_off=n * 2 * H, dst_off=(n * P + padl + first[n]) * 2 * H,
+                           accumulate=1)
         order = range(T - 1, -1, -1) if reverse else range(T)
         for t in order:
             row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
             ops.gemm(hb, gT, ru, N, 2 * H, H, P * ldh, H, P * 2 * H, a_off=prow * ldh + col, c_off=row * 2 * H,
                      act=ACT_SIGMOID, addend=xg, addend_off=row * 2 * H, ld_add=P * 2 * H)
             ops.gru_pointwise(0, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
-                              h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(rh, row * H), out_sn=P * H)
+                              h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(rh, row * H), out_sn=P * H, **hi)
             ops.gemm(rh, cT, cc, N, H, H, P * H, H, P * H, a_off=row * H, c_off=row * H, act=ACT_TANH, addend=xc,
                      addend_off=row * H, ld_add=P * H)
             ops.gru_pointwise(1, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
                               c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(hb, row * ldh + col),
-                              out_sn=P * ldh)
+                              out_sn=P * ldh, **hi)
 
         def bwd():
             dzg = self._buf("gru:%s_dzg" % tag, rows * 2 * H, self.T)
@@ -238,15 +269,16 @@ class Tacotron(Tacotron2):
             dh = out.grad
             for t in (range(T) if reverse else range(T - 1, -1, -1)):
                 row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
-                ops.copy3d(dh, carry, N, 1, H, (P * ldh, 0), (H, 0), src_off=row * ldh + col, accumulate=1)
+                # dh = the recurrent part (carry) + the gradient wrt this step's output where the step is valid; past the
+                # length the carry passes unchanged
                 ops.gru_pointwise(2, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
                                   c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(dzc, row * H),
                                   out_sn=P * H, dzg=(dzg, row * 2 * H), dzg_sn=P * 2 * H, dh=(carry, 0), dh_sn=H,
-                                  carry=(carry, 0), carry_sn=H)
+                                  carry=(carry, 0), carry_sn=H, dh_add=(dh, row * ldh + col), dha_sn=P * ldh, **hi)
                 ops.gemm(dzc, W, drh, N, H, H, P * H, H, H, a_off=row * H, b_off=oc + cin * H)
                 ops.gru_pointwise(3, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
                                   h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, dzg=(dzg, row * 2 * H),
-                                  dzg_sn=P * 2 * H, dh=(drh, 0), dh_sn=H, carry=(carry, 0), carry_sn=H)
+                                  dzg_sn=P * 2 * H, dh=(drh, 0), dh_sn=H, carry=(carry, 0), carry_sn=H, **hi)
                 ops.gemm(dzg, W, carry, N, H, 2 * H, P * 2 * H, 2 * H, H, a_off=row * 2 * H, b_off=og + cin * 2 * H,
                          accumulate=1)
             sk = self._splitk
@@ -263,13 +295,23 @@ class Tacotron(Tacotron2):
                          c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
             ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
                      split_k=sk(rows, H, H))
+            if h0 is not None:
+                # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
+                ops.copy3d(carry, h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
+                dz0 = self._buf("gru:%s_dz0" % tag, N * 2 * H, self.T)
+                for n in range(N):
+                    ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + first[n]) * 2 * H,
+                               dst_off=n * 2 * H)
+                ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
+                         accumulate=2)
             ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=bg)
             ops.colsum(dzc, H, rows, H, g, out_off=bc)
             ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
             ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
         self._tape.append(bwd)
 
-    def _cbhg(self, name, x, lengths, scope, K, proj, training):
+    def _cbhg(self, name, x, lengths, scope, K, proj, training, spk=None):
+        """spk: the speaker embedding rows (Act [N, 1, speaker_embed_dim]) for the encoder CBHG, modules.py:157-169."""
         banks = [self._conv("%s_b%d" % (name, k), x, "%s/conv_bank/conv1d_%d" % (scope, k), k, 128, ACT_RELU, training)
                  for k in range(1, K + 1)]
         bank = self._concat(name + "_bank", banks)
@@ -282,20 +324,34 @@ class Tacotron(Tacotron2):
         if hw.C != 128:
             hw = self._dense(name + "_dense", hw, scope + "/dense", 128, ACT_NONE)
         for i in range(4):
+            if spk is not None:
+                sp = self._dense("%s_sp%d" % (name, i), spk, "%s/highway_%d/dense" % (scope, i), hw.C, ACT_SOFTSIGN, mask=False)
+                hw = self._concat_time_bcast("%s_hs%d" % (name, i), hw, sp)
             hw = self._highway("%s_hw%d" % (name, i), hw, "%s/highway_%d/highway" % (scope, i))
+        h0 = self._dense(name + "_h0", spk, scope + "/dense", 128, ACT_SOFTSIGN, mask=False) if spk is not None else None
         out = self._new(name + "_out", hw, 256)
         out.buf.zero_()
         for di, d in enumerate(("fw", "bw")):
             self._gru_seq("%s_%s" % (name, d), hw, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), "%s_%s" % (scope, d),
-                          128, lengths, d == "bw", out, di * 128)
+                          128, lengths, d == "bw", out, di * 128, h0=h0)
         return out
+
+    def _speaker_rows(self, N):
+        """tacotron.py:41-48: speaker_embed[speaker_ids] as an Act [N, 1, speaker_embed_dim] (None for one speaker)."""
+        if not self.Dsp:
+            return None
+        sd = self._hparams.speaker_embed_dim
+        e = Act(self, "spk_e", N, 1, 0, 1, sd)
+        ops.embedding_fwd(self.speaker_ids, self.flat_p, e.buf, N, 1, 1, 0, sd, self.n_speakers,
+                          table_off=self._o("speaker/speaker_embed"))
+        self._tape.append(lambda: ops.embedding_bwd(self.speaker_ids, e.grad, self.flat_g, N, 1, 1, 0, sd, self.n_speakers,
+                                                    dtable_off=self._o("speaker/speaker_embed")))
+        return e
 
     def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
         if linear_targets is not None:
             return Tacotron2.initialize(self, text_inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
-        dev = self.device
-        self.inputs = torch.as_tensor(np.asarray(text_inputs)).to(dev, torch.int32).contiguous()
-        self.input_lengths = torch.as_tensor(np.asarray(input_lengths)).to(dev, torch.int32).contiguous()
+        self._set_inputs(text_inputs, input_lengths, speaker_ids)
         self.is_training = False
         self.mel_targets = self.linear_targets = None
         return self.forward_infer()
@@ -352,13 +408,18 @@ class Tacotron(Tacotron2):
         pn = list(hp.encoder_prenet)
         x = self._dense("pre1", emb, "prenet/dense_1", pn[0], ACT_RELU)
         x = self._dense("pre2", x, "prenet/dense_2", pn[1], ACT_RELU)
-        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), False)
+        spk = self._speaker_rows(N)
+        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), False,
+                         spk=spk)
+        Dsp = self.Dsp
+        XI = 128 + Dsp
+        spk_dec = self._dense("spk_dec", spk, "decoder/dense", Dsp, ACT_SOFTSIGN, mask=False) if Dsp else None
         keys = buf("keys", N * Pi * A, torch.float32)
         ops.gemm(enc.buf, W, keys, N * Pi, A, E, E, A, A, b_mode=1, b_off=o("attention_decoder/memory_layer/kernel"))
         Tia = _round_up(Ti, 8)
         keys_t = buf("keys_t", N * A * Tia, torch.float32)
         ops.keys_transpose(keys, keys_t, N, Ti, Tia, Pi, self.padl, A)
-        XP, XA, HC, X1 = M + E, 128 + A, A + E, 2 * D
+        XP, XA, HC, X1 = M + E, XI + A, A + E, 2 * D
         xp = buf("i_xp", N * S1 * XP, T_); p1 = buf("i_p1", N * 256, T_)
         xa = buf("i_xa", N * S1 * XA, T_); xc = buf("i_xc", N * max(XA, X1), T_)
         hc = buf("i_hc", N * S1 * HC, T_)
@@ -369,6 +430,8 @@ class Tacotron(Tacotron2):
         er = buf("i_er", N * Tia, torch.float32); dec = buf("i_dec", N * S1 * M * r, torch.float32)
         for b in (xp, xa, hc, g1, g2, al):
             b.zero_()
+        if Dsp:
+            ops.copy3d(spk_dec.buf, xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
         ov = o("decoder/attention/attention_v")
         for s in range(S):
             sl, nx = s + 1, s + 2
@@ -378,7 +441,7 @@ class Tacotron(Tacotron2):
                      bias_off=o("decoder/decoder_prenet/dense_2/bias"), act=ACT_RELU)
             self._gru_step_infer(xa, sl * XA, S1 * XA, XA, tsh["att_gT"], tsh["att_cT"], o("decoder/attention_gru/gates/bias"),
                                  o("decoder/attention_gru/candidate/bias"), xc, A, 0, hc, sl * HC, S1 * HC, xa,
-                                 nx * XA + 128, S1 * XA, ru, cc, N)
+                                 nx * XA + XI, S1 * XA, ru, cc, N)
             ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, A, a_off=sl * HC)
             ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, 0), A,
                                (al, s * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, (xp, nx * XP + M),
@@ -444,8 +507,12 @@ class Tacotron(Tacotron2):
         pn = list(hp.encoder_prenet)
         x = self._dense("pre1", emb, "prenet/dense_1", pn[0], ACT_RELU)
         x = self._dense("pre2", x, "prenet/dense_2", pn[1], ACT_RELU)
-        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), True)
+        spk = self._speaker_rows(N)
+        enc = self._cbhg("enc", x, lengths, "encoder_cbhg", hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), True,
+                         spk=spk)
         self._enc = enc
+        Dsp = self.Dsp
+        self._spk_dec = self._dense("spk_dec", spk, "decoder/dense", Dsp, ACT_SOFTSIGN, mask=False) if Dsp else None
 
         # ---- attention memory
         keys = self._buf("keys", N * Pi * A, torch.float32)
@@ -455,8 +522,9 @@ class Tacotron(Tacotron2):
         keys_t = self._buf("keys_t", N * A * Tia, torch.float32)
         ops.keys_transpose(keys, keys_t, N, Ti, Tia, Pi, self.padl, A)
 
-        # ---- attention RNN over all steps (teacher forced): prenet -> GRU(A) -> Bahdanau
-        XA, HC = 128 + A, A + E
+        # ---- attention RNN over all steps (teacher forced): prenet (-> | speaker projection) -> GRU(A) -> Bahdanau
+        XI = 128 + Dsp                            # the GRU's input width
+        XA, HC = XI + A, A + E
         fr = self._buf("dec_fr", N * S1 * M, T_)
         if S > 1:
             ops.copy3d(self.mel_targets, fr, N, S - 1, M, (To * M, r * M), (S1 * M, M), src_off=(r - 1) * M, dst_off=2 * M)
@@ -465,8 +533,8 @@ class Tacotron(Tacotron2):
         b1, b2 = o("decoder/decoder_prenet/dense_1/bias"), o("decoder/decoder_prenet/dense_2/bias")
         ops.gemm(fr, W, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=self.flat_p, bias_off=b1)
         p1 = self._buf("dec_p1", N * S1 * 256, T_)
-        xa = self._buf("dec_xa", N * S1 * XA, T_)     # [p2 | h_prev]
-        xc = self._buf("dec_xc", N * S1 * XA, T_)     # [p2 | r*h_prev]
+        xa = self._buf("dec_xa", N * S1 * XA, T_)     # [p2 | speaker projection | h_prev]
+        xc = self._buf("dec_xc", N * S1 * XA, T_)     # [p2 | speaker projection | r*h_prev]
         hc = self._buf("dec_hc", N * S1 * HC, T_)     # [h | ctx]
         ru = self._buf("dec_ru", N * S1 * 2 * A, torch.float32)
         cc = self._buf("dec_cc", N * S1 * A, torch.float32)
@@ -476,6 +544,8 @@ class Tacotron(Tacotron2):
         er = self._buf("dec_eraw", N * Tia, torch.float32)
         for b in (xa, xc, hc, al):
             b.zero_()
+        if Dsp:                                   # rnn_wrappers.py:28-30: the same projection in every step's input
+            ops.copy3d(self._spk_dec.buf, xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
         tsh = self.tsh
         ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
         abg, abc = o("decoder/attention_gru/gates/bias"), o("decoder/attention_gru/candidate/bias")
@@ -486,16 +556,16 @@ class Tacotron(Tacotron2):
                      addend=f1, addend_off=sl * 256, ld_add=S1 * 256)
             ops.gemm(p1, tsh["w2T"], xa, N, 128, 256, S1 * 256, 256, S1 * XA, a_off=sl * 256, c_off=sl * XA,
                      bias=self.flat_p, bias_off=b2, act=ACT_RELU)
-            ops.copy3d(xa, xc, N, 1, 128, (S1 * XA, 0), (S1 * XA, 0), src_off=sl * XA, dst_off=sl * XA)
+            ops.copy3d(xa, xc, N, 1, XI, (S1 * XA, 0), (S1 * XA, 0), src_off=sl * XA, dst_off=sl * XA)
             ops.gemm(xa, tsh["att_gT"], ru, N, 2 * A, XA, S1 * XA, XA, S1 * 2 * A, a_off=sl * XA, c_off=sl * 2 * A,
                      bias=self.flat_p, bias_off=abg, act=ACT_SIGMOID)
-            ops.gru_pointwise(0, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + 128),
-                              hp_sn=S1 * XA, out=(xc, sl * XA + 128), out_sn=S1 * XA)
+            ops.gru_pointwise(0, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
+                              hp_sn=S1 * XA, out=(xc, sl * XA + XI), out_sn=S1 * XA)
             ops.gemm(xc, tsh["att_cT"], cc, N, A, XA, S1 * XA, XA, S1 * A, a_off=sl * XA, c_off=sl * A, bias=self.flat_p,
                      bias_off=abc, act=ACT_TANH)
             ops.gru_pointwise(1, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
-                              h_prev=(xa, sl * XA + 128), hp_sn=S1 * XA, out=(hc, sl * HC), out_sn=S1 * HC,
-                              out2=(xa, (sl + 1) * XA + 128) if s + 1 < S else None, out2_sn=S1 * XA)
+                              h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(hc, sl * HC), out_sn=S1 * HC,
+                              out2=(xa, (sl + 1) * XA + XI) if s + 1 < S else None, out2_sn=S1 * XA)
             ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, S1 * A, a_off=sl * HC, c_off=sl * A)
             ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, sl * A), S1 * A,
                                (al, pv * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, None, 0,
@@ -597,7 +667,9 @@ class Tacotron(Tacotron2):
         M = hp.num_mels
         A, E = hp.attention_dim, 256
         S1, Tia = S + 1, st["Tia"]
-        XA, HC = 128 + A, A + E
+        Dsp = self.Dsp
+        XI = 128 + Dsp
+        XA, HC = XI + A, A + E
         g, W, o, tsh, sk = self.flat_g, self._W(T_), self._o, self.tsh, self._splitk
         enc, lengths = self._enc, self.input_lengths
         keys, keys_t, fr, p1, xa, xc, hc, ru, cc, q, al, al_t = (st[k] for k in (
@@ -631,13 +703,13 @@ class Tacotron(Tacotron2):
             ops.copy3d(dhc, carry_h, N, 1, A, (S1 * HC, 0), (A, 0), src_off=sl * HC, accumulate=1)
             ops.gemm(dq, W, carry_h, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=wq, accumulate=1)
             ops.gru_pointwise(2, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
-                              h_prev=(xa, sl * XA + 128), hp_sn=S1 * XA, out=(dzc, sl * A), out_sn=S1 * A,
+                              h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(dzc, sl * A), out_sn=S1 * A,
                               dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(carry_h, 0), dh_sn=A, carry=(carry_h, 0), carry_sn=A)
-            ops.gemm(dzc, W, drh, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=ac_ + 128 * A)
-            ops.gru_pointwise(3, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + 128),
+            ops.gemm(dzc, W, drh, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=ac_ + XI * A)
+            ops.gru_pointwise(3, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
                               hp_sn=S1 * XA, dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(drh, 0), dh_sn=A,
                               carry=(carry_h, 0), carry_sn=A)
-            ops.gemm(dzg, W, carry_h, N, A, 2 * A, S1 * 2 * A, 2 * A, A, a_off=sl * 2 * A, b_off=ag + 128 * 2 * A, accumulate=1)
+            ops.gemm(dzg, W, carry_h, N, A, 2 * A, S1 * 2 * A, 2 * A, A, a_off=sl * 2 * A, b_off=ag + XI * 2 * A, accumulate=1)
             # dp2pre = (dzg . Wg[:128]^T + dzc . Wc[:128]^T) * (p2 > 0)
             ops.gemm(dzg, W, tmp128, N, 128, 2 * A, S1 * 2 * A, 2 * A, 128, a_off=sl * 2 * A, b_off=ag,
                      gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
@@ -648,6 +720,14 @@ class Tacotron(Tacotron2):
                      gate=p1, gate_off=sl * 256, ld_gate=S1 * 256)
             if s > 0:
                 ops.gemm(df1, W, dctx_carry, N, E, 256, S1 * 256, 256, E, a_off=sl * 256, b_off=w1 + M * 256)
+        if Dsp:
+            # the speaker projection sits in rows 128 .. 128 + Dsp of both GRU kernels in every slot: its gradient is the
+            # sum over an utterance's slots of dzg . Wg[128:XI]^T + dzc . Wc[128:XI]^T
+            dsp_rows = buf("att_dspk", rows * Dsp, torch.float32)
+            ops.gemm(dzg, W, dsp_rows, rows, Dsp, 2 * A, 2 * A, 2 * A, Dsp, a_mode=0, b_mode=0, b_off=ag + 128 * 2 * A)
+            ops.gemm(dzc, W, dsp_rows, rows, Dsp, A, A, A, Dsp, a_mode=0, b_mode=0, b_off=ac_ + 128 * A, accumulate=1)
+            for n in range(N):
+                ops.colsum(dsp_rows, Dsp, S1, Dsp, self._spk_dec.grad, x_off=n * S1 * Dsp, out_off=n * Dsp)
         # ---- hoisted weight gradients
         ops.gemm(fr, df1, g, M, 256, rows, M, 256, 256, a_mode=1, b_mode=1, c_off=w1, accumulate=2, split_k=sk(rows, M, 256))
         ops.gemm(hc, df1, g, E, 256, rows - 1, HC, 256, 256, a_mode=1, b_mode=1, a_off=A, b_off=256, c_off=w1 + M * 256,

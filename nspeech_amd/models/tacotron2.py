@@ -255,15 +255,15 @@ class Tacotron2(object):
             self.timing.append((label, ev))
 
     # ------------------------------------------------------------------ reference API
-    def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
-        """tacotron2.py:15-128.  Training mode iff linear_targets is given.  Tensors may be numpy
-        arrays or torch tensors; they are moved to the GPU once and the forward pass runs."""
+    def _set_inputs(self, text_inputs, input_lengths, speaker_ids):
         dev = self.device
         self.inputs = torch.as_tensor(np.asarray(text_inputs) if not torch.is_tensor(text_inputs) else text_inputs
                                       ).to(dev, torch.int32).contiguous()
         self.input_lengths = torch.as_tensor(
             np.asarray(input_lengths) if not torch.is_tensor(input_lengths) else input_lengths
         ).to(dev, torch.int32).contiguous()
+        self._host_lengths = (input_lengths.cpu().numpy() if torch.is_tensor(input_lengths) else np.asarray(input_lengths)
+                              ).reshape(-1).astype(np.int64)
         self.speaker_ids = None
         if self.Dsp:
             if speaker_ids is None:
@@ -273,6 +273,12 @@ class Tacotron2(object):
             if ids.shape[0] != self.inputs.shape[0] or ids.min() < 0 or ids.max() >= self.n_speakers:
                 raise ValueError("speaker_ids must hold one id in [0, %d) per utterance" % self.n_speakers)
             self.speaker_ids = torch.from_numpy(ids.astype(np.int32)).to(dev)
+
+    def initialize(self, text_inputs, input_lengths, speaker_ids=None, mel_targets=None, linear_targets=None):
+        """tacotron2.py:15-128.  Training mode iff linear_targets is given.  Tensors may be numpy
+        arrays or torch tensors; they are moved to the GPU once and the forward pass runs."""
+        dev = self.device
+        self._set_inputs(text_inputs, input_lengths, speaker_ids)
         self.is_training = linear_targets is not None
         if self.is_training:
             self.mel_targets = torch.as_tensor(mel_targets).to(dev, torch.float32).contiguous()

@@ -294,14 +294,16 @@ def highway(h, t, x, n, y=None, dy=None, dhpre=None, dtpre=None, dx=None):
 
 
 def gru_pointwise(mode, like, N, H, t, lengths, ru=None, ru_sn=0, c=None, c_sn=0, h_prev=None, hp_sn=0, out=None,
-                  out_sn=0, out2=None, out2_sn=0, dzg=None, dzg_sn=0, dh=None, dh_sn=0, carry=None, carry_sn=0):
+                  out_sn=0, out2=None, out2_sn=0, dzg=None, dzg_sn=0, dh=None, dh_sn=0, carry=None, carry_sn=0,
+                  dh_add=None, dha_sn=0, h_init=None, hi_sn=0, reverse=False, T=0):
     """Pointers are (tensor, element offset) pairs or None."""
     def P(x):
         return None if x is None else ptr(x[0], x[1])
     p = L.struct("ns_gru_pointwise_params")
     _fill(p, mode=mode, dtype=dt(like), N=N, H=H, t=t, lengths=ptr(lengths), ru=P(ru), ru_sn=ru_sn, c=P(c), c_sn=c_sn,
           h_prev=P(h_prev), hp_sn=hp_sn, out=P(out), out_sn=out_sn, out2=P(out2), out2_sn=out2_sn, dzg=P(dzg),
-          dzg_sn=dzg_sn, dh=P(dh), dh_sn=dh_sn, carry=P(carry), carry_sn=carry_sn)
+          dzg_sn=dzg_sn, dh=P(dh), dh_sn=dh_sn, carry=P(carry), carry_sn=carry_sn, dh_add=P(dh_add), dha_sn=dha_sn,
+          h_init=P(h_init), hi_sn=hi_sn, reverse=int(bool(reverse)), T=T)
     L.call("ns_gru_pointwise", p, stream())
 
 

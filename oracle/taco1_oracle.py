@@ -10,6 +10,12 @@ import torch
 from .taco2_oracle import conv1d_bn, prenet
 
 
+def softsign_dense(e, p, scope):
+    """tf.layers.dense(speaker_embd, units, activation=tf.nn.softsign): x / (1 + |x|) of e . W + b."""
+    z = e @ p[scope + "/kernel"] + p[scope + "/bias"]
+    return z / (1.0 + z.abs())
+
+
 def gru_cell(x, h, Wg, bg, Wc, bc):
     ru = torch.sigmoid(torch.cat([x, h], -1) @ Wg + bg)
     r, u = ru.chunk(2, dim=-1)
@@ -17,15 +23,17 @@ def gru_cell(x, h, Wg, bg, Wc, bc):
     return u * h + (1 - u) * c
 
 
-def bigru(x, lengths, p, scope, units):
-    """modules.py:172-181: bidirectional_dynamic_rnn(GRUCell, GRUCell, sequence_length=lengths)."""
+def bigru(x, lengths, p, scope, units, h0=None):
+    """modules.py:172-181: bidirectional_dynamic_rnn(GRUCell, GRUCell, initial_state_fw = initial_state_bw = s,
+    sequence_length=lengths): past a sequence's length the state is carried unchanged and the output is zero, so the
+    backward cell meets the initial state at the sequence's last valid step."""
     N, T, _ = x.shape
     if lengths is None:
         lengths = torch.full((N,), T, dtype=torch.long)
     outs = []
     for d in ("fw", "bw"):
         pre = "%s/%s/gru_cell" % (scope, d)
-        h = x.new_zeros(N, units)
+        h = x.new_zeros(N, units) if h0 is None else h0
         ys = [None] * T
         order = range(T) if d == "fw" else range(T - 1, -1, -1)
         for t in order:
@@ -45,9 +53,11 @@ def highwaynet(x, p, scope):
     return h * t + x * (1.0 - t)
 
 
-def cbhg(x, lengths, p, scope, K, c, training, bn_updates, num_highways=4, gru_units=128):
+def cbhg(x, lengths, p, scope, K, c, training, bn_updates, num_highways=4, gru_units=128, speaker_embd=None):
     """modules.py:133-182.  The max-pool result is overwritten before use: the first
-    projection reads the conv bank directly."""
+    projection reads the conv bank directly.  With a speaker embedding (modules.py:157-169) every highway layer reads
+    [h | softsign(dense(e)) tiled over time] - the projection as wide as h, so the width doubles per layer - and a
+    further projection is the initial state of both GRU directions."""
     bank = torch.cat([conv1d_bn(x, p, "%s/conv_bank/conv1d_%d" % (scope, k), torch.relu, training, bn_updates)
                       for k in range(1, K + 1)], dim=-1)
     y = bank
@@ -58,8 +68,12 @@ def cbhg(x, lengths, p, scope, K, c, training, bn_updates, num_highways=4, gru_u
     if hw.shape[2] != 128:
         hw = hw @ p[scope + "/dense/kernel"] + p[scope + "/dense/bias"]
     for i in range(num_highways):
+        if speaker_embd is not None:
+            sp = softsign_dense(speaker_embd, p, "%s/highway_%d/dense" % (scope, i))       # [N, width of hw]
+            hw = torch.cat([hw, sp[:, None, :].expand(-1, hw.shape[1], -1)], dim=-1)
         hw = highwaynet(hw, p, "%s/highway_%d/highway" % (scope, i))
-    return bigru(hw, lengths, p, scope + "/bidirectional_rnn", gru_units)
+    h0 = softsign_dense(speaker_embd, p, scope + "/dense") if speaker_embd is not None else None
+    return bigru(hw, lengths, p, scope + "/bidirectional_rnn", gru_units, h0)
 
 
 def bahdanau_alignments(query, keys, lengths, p, scope):
@@ -73,8 +87,10 @@ def bahdanau_alignments(query, keys, lengths, p, scope):
     return torch.softmax(score, dim=1)
 
 
-def taco1_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets=None, max_iters=None):
-    """tacotron.py:16-122.  Training iff linear_targets is given."""
+def taco1_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets=None, max_iters=None, speaker_ids=None):
+    """tacotron.py:16-122.  Training iff linear_targets is given.  num_speakers > 1 (tacotron.py:41-48): the embedding
+    of speaker_ids goes to the encoder CBHG (tacotron.py:57-62) and to the decoder's PrenetWrapper (modules.py:95-97,
+    rnn_wrappers.py:28-30); the post CBHG gets none (tacotron.py:93)."""
     training = linear_targets is not None
     N, Ti = inputs.shape
     M, r = hp["num_mels"], hp["outputs_per_step"]
@@ -82,8 +98,10 @@ def taco1_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets
     lengths = input_lengths.long()
     x = p["embedding/embedding"][inputs.long()]
     x = prenet(x, p, "prenet")                                                    # tacotron.py:52-56
+    spk = p["speaker/speaker_embed"][speaker_ids.long()] if hp.get("num_speakers", 1) > 1 else None
     enc = cbhg(x, lengths, p, "encoder_cbhg", hp["encoder_cbhg_banks"], hp["encoder_cbhg_bank_sizes"], training,
-               bn_updates)                                                        # [N,Ti,256]
+               bn_updates, speaker_embd=spk)                                      # [N,Ti,256]
+    spk_dec = softsign_dense(spk, p, "decoder/dense") if spk is not None else None
     mask = (torch.arange(Ti)[None, :] < lengths[:, None]).to(enc.dtype)
     values = enc * mask[:, :, None]
     keys = values @ p["attention_decoder/memory_layer/kernel"]
@@ -105,6 +123,8 @@ def taco1_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets
     Dd = "decoder"
     for s in range(steps):
         pre = prenet(torch.cat([frame, ctx], -1), p, Dd + "/decoder_prenet")      # Q8
+        if spk_dec is not None:
+            pre = torch.cat([pre, spk_dec], -1)                                   # rnn_wrappers.py:28-30
         h_att = gru_cell(pre, h_att, p[Dd + "/attention_gru/gates/kernel"], p[Dd + "/attention_gru/gates/bias"],
                          p[Dd + "/attention_gru/candidate/kernel"], p[Dd + "/attention_gru/candidate/bias"])
         align = bahdanau_alignments(h_att, keys, lengths, p, Dd + "/attention")

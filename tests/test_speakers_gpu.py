@@ -44,11 +44,6 @@ def test_layout_has_the_speaker_variables_only_when_multi_speaker(dev):
         m.initialize(inputs, lengths, None, mel, lin)               # ids are required
     with pytest.raises(ValueError):
         m.initialize(inputs, lengths, np.array([0, 3]), mel, lin)   # out of range
-    with pytest.raises(NotImplementedError):
-        from nspeech_amd import hparams as H
-        h1 = H.load("taco1")
-        h1.num_speakers = 2
-        create_model("taco1", h1, device="cuda:0", dtype="fp32")
 
 
 @pytest.mark.parametrize("shape", [(4, 9, 20), (3, 12, 15)])

@@ -19,27 +19,28 @@ def _hp():
     return hp
 
 
-def _oracle(hp, params, stats, inputs, lengths, mel, lin):
+def _oracle(hp, params, stats, inputs, lengths, mel, lin, spk=None):
     from oracle import taco1_oracle as O
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in params.items()}
     p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in stats.items()})
     hpd = hp.values()
     out = O.taco1_forward(p, hpd, torch.tensor(inputs), torch.tensor(lengths), torch.tensor(mel, dtype=torch.float64),
-                          torch.tensor(lin, dtype=torch.float64))
+                          torch.tensor(lin, dtype=torch.float64), speaker_ids=None if spk is None else torch.tensor(spk))
     loss, ml, ll = O.taco1_loss(hpd, out, torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
     loss.backward()
     grads = {k: (p[k].grad.numpy() if p[k].grad is not None else np.zeros_like(params[k])) for k in params}
     return out, (float(loss.detach()), float(ml.detach()), float(ll.detach())), grads
 
 
-def _stabilise(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3):
+def _stabilise(hp, params, stats, inputs, lengths, mel, lin, margin=2e-3, spk=None):
     from oracle import taco1_oracle as O
     mel, lin = mel.copy(), lin.copy()
     p = {k: torch.tensor(v, dtype=torch.float64) for k, v in list(params.items()) + list(stats.items())}
     for _ in range(4):
         with torch.no_grad():
             out = O.taco1_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
-                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+                                  torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64),
+                                  speaker_ids=None if spk is None else torch.tensor(spk))
         bm = np.abs(out["mel_outputs"].numpy() - mel) < margin
         bl = np.abs(out["linear_outputs"].numpy() - lin) < margin
         if not bm.any() and not bl.any():
@@ -81,6 +82,95 @@ def test_taco1_fp32_matches_oracle(dev, shape):
     st = m.numpy_stats()
     for k, v in out["bn_updates"].items():
         assert np.abs(st[k] - v.numpy()).max() < 1e-4, k
+
+
+def _spread_speaker_path(m):
+    """The default initialisation leaves the speaker path almost inert; spread the table and the biases so that a wrong
+    lookup, a wrong row block of a kernel, a missed initial state or a missing softsign derivative shows."""
+    p = m.numpy_params()
+    rs = np.random.RandomState(11)
+    p["speaker/speaker_embed"] = rs.uniform(-2.0, 2.0, size=p["speaker/speaker_embed"].shape).astype(np.float32)
+    for k in p:
+        if k.endswith("/dense/bias") and ("highway_" in k or k in ("encoder_cbhg/dense/bias", "decoder/dense/bias")):
+            p[k] = rs.uniform(-0.5, 0.5, size=p[k].shape).astype(np.float32)
+    m.load_numpy(p, m.numpy_stats())
+
+
+@pytest.mark.parametrize("shape", [(3, 11, 15), (4, 8, 10)])
+def test_taco1_multi_speaker_matches_oracle(dev, shape):
+    """modules.py:157-169 + rnn_wrappers.py:28-30: the speaker projection in front of every encoder highway layer (the
+    width doubles per layer: 256 .. 2048), as the initial state of both encoder GRU directions - ragged lengths, so
+    the backward direction meets it at a different step per utterance - and behind the decoder prenet.  Outputs,
+    losses and every gradient (table, the six projections, the widened kernels) against the float64 oracle."""
+    from nspeech_amd.models import create_model
+    N, Ti, To = shape
+    hp = _hp()
+    hp.num_speakers = 3
+    m = create_model("taco1", hp, device="cuda:0", dtype="fp32", seed=4)
+    A = hp.attention_dim
+    assert m.layout.shape("encoder_cbhg/highway_3/highway/H/kernel") == (2048, 2048)
+    assert m.layout.shape("encoder_cbhg/bidirectional_rnn/bw/gru_cell/gates/kernel") == (2048 + 128, 256)
+    assert m.layout.shape("decoder/attention_gru/gates/kernel") == (128 + 128 + A, 2 * A)
+    _spread_speaker_path(m)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=N + 30)
+    lengths = np.asarray(lengths).copy()
+    lengths[0], lengths[-1] = Ti, max(2, Ti // 2)                   # a full row and a short one
+    spk = np.array([2, 0, 2, 1][:N], np.int32)                      # a repeated speaker: scatter-add in the table gradient
+    with pytest.raises(ValueError):
+        m.initialize(inputs, lengths, None, mel, lin)
+    params, stats = m.numpy_params(), m.numpy_stats()
+    mel, lin = _stabilise(hp, params, stats, inputs, lengths, mel, lin, spk=spk)
+    out, (loss, ml, ll), grads = _oracle(hp, params, stats, inputs, lengths, mel, lin, spk=spk)
+    m.initialize(inputs, lengths, spk, mel, lin)
+    m.backward()
+    m.read_losses()
+
+    def rel(a, b):
+        return np.abs(np.asarray(a, np.float64) - b).max() / (np.abs(b).max() + 1e-12)
+    assert rel(m._enc.buf.float().cpu().numpy().reshape(N, -1, 256)[:, m.padl:m.padl + Ti],
+               out["encoder_outputs"].detach().numpy()) < 2e-4
+    assert rel(m.alignments.cpu().numpy(), out["alignments"].detach().numpy()) < 2e-4
+    assert rel(m.mel_outputs.cpu().numpy(), out["mel_outputs"].detach().numpy()) < 5e-4
+    assert rel(m.linear_outputs.cpu().numpy(), out["linear_outputs"].detach().numpy()) < 5e-4
+    assert abs(m.loss - loss) < 1e-5 * max(1.0, abs(loss))
+    got = m.numpy_grads()
+    bad = []
+    for k in grads:
+        scale = np.abs(grads[k]).max()
+        err = np.abs(got[k] - grads[k]).max()
+        if err > 2e-3 * scale + 2e-6:
+            bad.append((k, float(err), float(scale)))
+    assert not bad, bad[:8]
+    for k in ("speaker/speaker_embed", "encoder_cbhg/highway_0/dense/kernel", "encoder_cbhg/highway_3/dense/bias",
+              "encoder_cbhg/dense/kernel", "decoder/dense/kernel"):
+        assert np.abs(grads[k]).max() > 1e-7, k                     # the comparison above is not vacuous
+
+
+def test_taco1_multi_speaker_synthesis_matches_oracle(dev):
+    """Free-running synthesis (TacoTestHelper feedback) with speaker ids: the same sites on the inference path."""
+    from nspeech_amd.models import create_model
+    from oracle import taco1_oracle as O
+    hp = _hp()
+    hp.num_speakers = 3
+    hp.max_iters = 6
+    m = create_model("taco1", hp, device="cuda:0", dtype="fp32", seed=7)
+    _spread_speaker_path(m)
+    N, Ti = 3, 9
+    inputs, lengths, _, _ = make_batch(hp, N, Ti, 10, seed=3)
+    lengths = np.asarray(lengths).copy()
+    lengths[1] = 5
+    spk = np.array([1, 2, 0], np.int32)
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in list(m.numpy_params().items()) + list(m.numpy_stats().items())}
+    with torch.no_grad():
+        out = O.taco1_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths), speaker_ids=torch.tensor(spk))
+    m.initialize(inputs, lengths, spk)
+    a, b = m.mel_outputs.cpu().numpy(), out["mel_outputs"].numpy()
+    assert np.abs(a - b).max() < 2e-3 * np.abs(b).max()
+    a, b = m.linear_outputs.cpu().numpy(), out["linear_outputs"].numpy()
+    assert np.abs(a - b).max() < 2e-3 * np.abs(b).max()
+    other = m.mel_outputs.clone()
+    m.initialize(inputs, lengths, np.array([0, 0, 0], np.int32))
+    assert (m.mel_outputs - other).abs().max().item() > 1e-4       # the speaker changes the output
 
 
 def test_taco1_train_steps_bf16_and_noam_schedule(dev):
