@@ -538,6 +538,7 @@ typedef struct {
   const float* mel_basis; int n_mels;
   float ref_level_db, min_level_db;
   float* lin_out; float* mel_out;
+  float* stft_out;   /* optional: the complex transform itself (audio._stft, audio.py:106-108), [T, n_fft/2+1] (re, im) */
 } ns_spectrogram_params;
 int ns_spectrogram(const ns_spectrogram_params* p, ns_stream_t stream);
 
@@ -551,9 +552,40 @@ typedef struct {
   const float* window; const float* twiddle;
   float* wav;
   float* work;   /* ns_griffin_lim_work_bytes() */
+  int raw_magnitude;   /* 1: spec already holds the magnitudes S^power (audio._griffin_lim_tensorflow, audio.py:90-103) */
 } ns_griffin_lim_params;
 int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t stream);
 size_t ns_griffin_lim_work_bytes(const ns_griffin_lim_params* p);
+
+/* The transforms behind the features and the vocoder as calls of their own (audio.py:106-123).
+ * ns_stft_tf: tf.contrib.signal.stft(signals, win, hop, n_fft, pad_end=False) of ONE signal: frames of `win` samples
+ *   every `hop`, periodic Hann, zero-padded at the end to n_fft; out [T, n_fft/2+1] (re, im), T = 1 + (L - win) / hop.
+ * ns_istft: the inverse of a one-sided spectrum spec [T, n_fft/2+1] (re, im).
+ *   center == 0: tf.contrib.signal.inverse_stft(stfts, win, hop, n_fft): irfft[:win] x Hann, overlap-add, no
+ *                window-sum normalisation; wav [(T-1) hop + win].
+ *   center == 1: librosa 0.6.0 istft(hop, win): the window centred in the n_fft frame, overlap-add, divided by the
+ *                summed squared window where that exceeds FLT_MIN, n_fft/2 trimmed at both ends; wav [(T-1) hop].
+ *   work: T * win floats. */
+typedef struct {
+  const float* wav; int L;
+  int n_fft, hop, win, T;
+  const float* window; const float* twiddle;
+  float* out;
+} ns_stft_tf_params;
+int ns_stft_tf(const ns_stft_tf_params* p, ns_stream_t stream);
+typedef struct {
+  const float* spec; int T;
+  int n_fft, hop, win, center;
+  const float* window; const float* twiddle;
+  float* wav; float* work;
+} ns_istft_params;
+int ns_istft(const ns_istft_params* p, ns_stream_t stream);
+
+/* Element-wise conversions of audio.py:150-171 on device arrays: mode 0 _amp_to_db 20 log10(max(1e-5, x)); 1 _db_to_amp
+ * 10^(x / 20); 2 _normalize clip((x - min_level_db) / -min_level_db, 0, 1); 3 _denormalize clip(x, 0, 1) * -min_level_db
+ * + min_level_db. */
+typedef struct { const float* x; float* y; int64_t n; int mode; float min_level_db; } ns_audio_pointwise_params;
+int ns_audio_pointwise(const ns_audio_pointwise_params* p, ns_stream_t stream);
 
 /* audio.preemphasis (inverse=0: y[n] = x[n] - c x[n-1]) and audio.inv_preemphasis
  * (inverse=1: y[n] = x[n] + c y[n-1]), scipy.signal.lfilter with zero initial state. */

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(FT) void spectrogram_kernel(ns_spectrogram_params p
   for (int k = tid; k < F; k += FT) {
     const float m = sqrtf(X[k].x * X[k].x + X[k].y * X[k].y);
     mag[k] = m;
+    if (p.stft_out) ((float2*)p.stft_out)[(long)t * F + k] = X[k];
     if (p.lin_out) {
       const float db = 20.f * log10f(fmaxf(1e-5f, m)) - p.ref_level_db;
       p.lin_out[(long)t * F + k] = fminf(1.f, fmaxf(0.f, (db - p.min_level_db) * inv_min));
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
     for (int k = tid; k < F; k += FT) {
       const float x = fminf(1.f, fmaxf(0.f, sp[k]));
       const float db = x * -p.min_level_db + p.min_level_db + p.ref_level_db;
-      mag[k] = __powf(__powf(10.f, db * 0.05f), p.power);
+      mag[k] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, db * 0.05f), p.power);
     }
     __syncthreads();                          // mag[] of this frame is re-read below by other threads
   } else {
@@ -427,8 +428,8 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
     for (int n1 = 0; n1 < 16; ++n1) {
       const int k = 64 * n1 + lane;
       const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
-      mkv[n1] = __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-      mpv[n1] = __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
       mag[k] = mkv[n1];
       if (k == 0) mag[M] = mpv[n1];
     }
@@ -542,6 +543,111 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
   g.fprev = cur;
   hipLaunchKernelGGL(gl_ola_kernel, dim3(ceil_div(Lout, 256), p->N), dim3(256), 0, s, g, Lout);
   NS_CHECK_LAUNCH("griffin_lim");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ the transforms as calls of their own
+__global__ __launch_bounds__(FT) void stft_tf_kernel(ns_stft_tf_params p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.n_fft, F = N / 2 + 1;
+  float2* bufa = (float2*)sm;
+  float2* bufb = bufa + N;
+  float2* tw = bufb + N;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  for (int m = tid; m < N / 2; m += FT) tw[m] = ((const float2*)p.twiddle)[m];
+  for (int j = tid; j < N; j += FT) bufa[j] = make_float2(j < p.win ? p.wav[(long)t * p.hop + j] * p.window[j] : 0.f, 0.f);
+  __syncthreads();
+  const float2* X = fft_lds(bufa, bufb, tw, N, tid);
+  for (int k = tid; k < F; k += FT) ((float2*)p.out)[(long)t * F + k] = X[k];
+}
+extern "C" int ns_stft_tf(const ns_stft_tf_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->wav && p->window && p->twiddle && p->out, "ns_stft_tf: null");
+  NS_CHECK_ARG(p->n_fft >= 64 && (p->n_fft & (p->n_fft - 1)) == 0 && p->n_fft <= 4096, "ns_stft_tf: n_fft must be a power of two in [64, 4096]");
+  NS_CHECK_ARG(p->win <= p->n_fft && p->hop > 0 && p->T >= 0 && (p->T == 0 || (long)(p->T - 1) * p->hop + p->win <= p->L),
+               "ns_stft_tf: the last frame ends beyond the signal");
+  if (p->T <= 0) return NS_OK;
+  const size_t lds = sizeof(float2) * (2 * p->n_fft + p->n_fft / 2);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)stft_tf_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(stft_tf_kernel, dim3(p->T), dim3(FT), lds, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("stft_tf");
+  return NS_OK;
+}
+
+// frame t: Hermitian extension of the one-sided spectrum, inverse transform as conj(FFT(conj X)) / N, the window
+__global__ __launch_bounds__(FT) void istft_frame_kernel(ns_istft_params p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int N = p.n_fft, F = N / 2 + 1;
+  float2* bufa = (float2*)sm;
+  float2* bufb = bufa + N;
+  float2* tw = bufb + N;
+  const int t = blockIdx.x, tid = threadIdx.x;
+  for (int m = tid; m < N / 2; m += FT) tw[m] = ((const float2*)p.twiddle)[m];
+  const float2* X = (const float2*)p.spec + (long)t * F;
+  for (int k = tid; k < N; k += FT) {
+    float2 v;
+    if (k < F) v = X[k]; else { v = X[N - k]; v.y = -v.y; }
+    if (k == 0 || k == N / 2) v.y = 0.f;                     // irfft ignores the imaginary part of DC and Nyquist
+    bufa[k] = make_float2(v.x, -v.y);
+  }
+  __syncthreads();
+  const float2* Y = fft_lds(bufa, bufb, tw, N, tid);
+  const int off = p.center ? (N - p.win) / 2 : 0;
+  const float invN = 1.f / N;
+  for (int j = tid; j < p.win; j += FT) p.work[(long)t * p.win + j] = Y[off + j].x * invN * p.window[j];
+}
+__global__ void istft_ola_kernel(ns_istft_params p, int Lout) {
+  // segment f starts at f hop (+ the centring offset, which the trim removes again: both are (n_fft - win) / 2 + win / 2 ...)
+  const int shift = p.center ? p.n_fft / 2 - (p.n_fft - p.win) / 2 : 0;     // output sample 0 in segment-grid coordinates
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < Lout; i += gridDim.x * blockDim.x) {
+    const int pos = i + shift;
+    int f1 = pos / p.hop;
+    if (f1 > p.T - 1) f1 = p.T - 1;
+    float s = 0.f, ws = 0.f;
+    for (int f = f1; f >= 0; --f) {
+      const int o = pos - f * p.hop;
+      if (o >= p.win) break;
+      s += p.work[(long)f * p.win + o];
+      ws += p.window[o] * p.window[o];
+    }
+    p.wav[i] = (p.center && ws > 1.17549435e-38f) ? s / ws : s;
+  }
+}
+extern "C" int ns_istft(const ns_istft_params* p, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(p && p->spec && p->window && p->twiddle && p->wav && p->work, "ns_istft: null");
+  NS_CHECK_ARG(p->n_fft >= 64 && (p->n_fft & (p->n_fft - 1)) == 0 && p->n_fft <= 4096, "ns_istft: n_fft must be a power of two in [64, 4096]");
+  NS_CHECK_ARG(p->win <= p->n_fft && p->hop > 0 && p->hop <= p->win, "ns_istft: bad window / hop");
+  if (p->T <= 0) return NS_OK;
+  const size_t lds = sizeof(float2) * (2 * p->n_fft + p->n_fft / 2);
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)istft_frame_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+  hipLaunchKernelGGL(istft_frame_kernel, dim3(p->T), dim3(FT), lds, s, *p);
+  const int Lout = p->center ? (p->T - 1) * p->hop : (p->T - 1) * p->hop + p->win;
+  if (Lout > 0) hipLaunchKernelGGL(istft_ola_kernel, dim3(min(1024, ceil_div(Lout, 256))), dim3(256), 0, s, *p, Lout);
+  NS_CHECK_LAUNCH("istft");
+  return NS_OK;
+}
+
+__global__ void audio_pointwise_kernel(ns_audio_pointwise_params p) {
+  const float mn = p.min_level_db;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x) {
+    const float x = p.x[i];
+    float y;
+    switch (p.mode) {
+      case 0: y = 20.f * log10f(fmaxf(1e-5f, x)); break;
+      case 1: y = powf(10.f, x * 0.05f); break;
+      case 2: y = fminf(1.f, fmaxf(0.f, (x - mn) / -mn)); break;
+      default: y = fminf(1.f, fmaxf(0.f, x)) * -mn + mn; break;
+    }
+    p.y[i] = y;
+  }
+}
+extern "C" int ns_audio_pointwise(const ns_audio_pointwise_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->x && p->y && p->mode >= 0 && p->mode <= 3, "ns_audio_pointwise: null / bad mode");
+  if (p->n <= 0) return NS_OK;
+  hipLaunchKernelGGL(audio_pointwise_kernel, dim3((int)min((long)4096, (long)((p->n + 255) / 256))), dim3(256), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("audio_pointwise");
   return NS_OK;
 }
 

@@ -200,7 +200,7 @@ def inv_preemphasis(x):
 
 
 # ---------------------------------------------------------------- spectrograms
-def _spectrograms(y, want_lin, want_mel):
+def _spectrograms(y, want_lin, want_mel, want_stft=False):
     hp = get_hparams()
     n_fft, hop, win = _stft_parameters()
     tb = _get_tables()
@@ -211,13 +211,18 @@ def _spectrograms(y, want_lin, want_mel):
     lin = torch.empty(T * hp.num_freq, dtype=torch.float32, device=dev) if want_lin else None
     mel = torch.empty(T * hp.num_mels, dtype=torch.float32, device=dev) if want_mel else None
     p = L.struct("ns_spectrogram_params")
-    p.wav, p.L, p.preemph = ops.ptr(wav), Lw, float(hp.preemphasis)
+    p.wav, p.L, p.preemph = ops.ptr(wav), Lw, 0.0 if want_stft else float(hp.preemphasis)
+    if want_stft:           # the transform alone (_stft): no pre-emphasis, complex bins out
+        cx = torch.empty(T * hp.num_freq * 2, dtype=torch.float32, device=dev)
+        p.stft_out = ops.ptr(cx)
     p.n_fft, p.hop, p.win, p.T = n_fft, hop, win, T
     p.window, p.twiddle = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"])
     p.mel_basis, p.n_mels = ops.ptr(tb["mel_basis"]), hp.num_mels
     p.ref_level_db, p.min_level_db = float(hp.ref_level_db), float(hp.min_level_db)
     p.lin_out, p.mel_out = ops.ptr(lin), ops.ptr(mel)
     L.call("ns_spectrogram", p, ops.stream())
+    if want_stft:
+        return torch.view_as_complex(cx.view(T, hp.num_freq, 2)).t().cpu().numpy()
     out_lin = lin.view(T, hp.num_freq).t().cpu().numpy() if want_lin else None
     out_mel = mel.view(T, hp.num_mels).t().cpu().numpy() if want_mel else None
     return out_lin, out_mel
@@ -237,9 +242,9 @@ def spectrogram_and_mel(y):
     return np.ascontiguousarray(a), np.ascontiguousarray(b)
 
 
-def griffin_lim_gpu(spec, iters=None):
-    """spec: torch CUDA tensor or array [T, F] / [N, T, F] (normalised).  Returns a CUDA tensor
-    [L] / [N, L], L = (T-1)*hop + win, before inv_preemphasis (audio.py:51-58)."""
+def griffin_lim_gpu(spec, iters=None, raw_magnitude=False):
+    """spec: torch CUDA tensor or array [T, F] / [N, T, F] (normalised; with raw_magnitude the magnitudes S^power
+    themselves).  Returns a CUDA tensor [L] / [N, L], L = (T-1)*hop + win, before inv_preemphasis (audio.py:51-58)."""
     hp = get_hparams()
     n_fft, hop, win = _stft_parameters()
     tb = _get_tables()
@@ -259,6 +264,7 @@ def griffin_lim_gpu(spec, iters=None):
     p.iters = int(hp.griffin_lim_iters if iters is None else iters)
     p.power, p.ref_level_db, p.min_level_db = float(hp.power), float(hp.ref_level_db), float(hp.min_level_db)
     p.window, p.twiddle, p.wav = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"]), ops.ptr(wav)
+    p.raw_magnitude = int(bool(raw_magnitude))
     nbytes = L.lib().ns_griffin_lim_work_bytes
     nbytes.restype = __import__("ctypes").c_size_t
     work = torch.empty((nbytes(__import__("ctypes").byref(p)) + 3) // 4, dtype=torch.float32, device=dev)
@@ -280,6 +286,129 @@ def inv_spectrogram(spectrogram):
     so this uses the same deterministic zero-phase Griffin-Lim, then inverts the pre-emphasis."""
     wav = griffin_lim_gpu(np.asarray(spectrogram, dtype=np.float32).T).cpu().numpy()
     return inv_preemphasis(wav)
+
+
+# ---------------------------------------------------------------- the reference's private helpers (audio.py:77-171)
+# Same names, NumPy in / NumPy out (the *_tensorflow forms also take and then return CUDA tensors), each one a HIP call.
+def _pointwise(x, mode):
+    is_t = torch.is_tensor(x)
+    xt = (x if is_t else torch.as_tensor(np.ascontiguousarray(x, dtype=np.float32))).to(_dev(), torch.float32).contiguous()
+    y = torch.empty_like(xt)
+    p = L.struct("ns_audio_pointwise_params")
+    p.x, p.y, p.n, p.mode, p.min_level_db = ops.ptr(xt), ops.ptr(y), xt.numel(), mode, float(get_hparams().min_level_db)
+    L.call("ns_audio_pointwise", p, ops.stream())
+    return y if is_t else y.cpu().numpy()
+
+
+def _amp_to_db(x):
+    return _pointwise(x, 0)
+
+
+def _db_to_amp(x):
+    return _pointwise(x, 1)
+
+
+def _normalize(S):
+    return _pointwise(S, 2)
+
+
+def _denormalize(S):
+    return _pointwise(S, 3)
+
+
+_db_to_amp_tensorflow = _db_to_amp
+_denormalize_tensorflow = _denormalize
+
+
+def _linear_to_mel(spectrogram):
+    """audio.py:138-142: mel_basis [n_mels, F] . spectrogram [F, T] (one fp32 product)."""
+    tb = _get_tables()
+    S = torch.as_tensor(np.ascontiguousarray(spectrogram, dtype=np.float32)).to(_dev())
+    F, T = S.shape
+    n_mels = tb["mel_basis"].numel() // F
+    out = torch.empty(n_mels * T, dtype=torch.float32, device=S.device)
+    keep, ops.F32_PASSES = ops.F32_PASSES, 0
+    try:
+        ops.gemm(tb["mel_basis"], S.reshape(-1), out, n_mels, T, F, F, T, T, b_mode=1)
+    finally:
+        ops.F32_PASSES = keep
+    return out.view(n_mels, T).cpu().numpy()
+
+
+def _stft(y):
+    """audio.py:106-108: librosa.stft(y, n_fft, hop, win) - centred, reflect-padded; complex64 [F, T]."""
+    return _spectrograms(y, False, False, want_stft=True)
+
+
+def _complex_rows(x):
+    """complex array [..., F] -> float32 CUDA tensor [..., F, 2]"""
+    a = np.ascontiguousarray(np.asarray(x).astype(np.complex64))
+    return torch.view_as_real(torch.from_numpy(a)).to(_dev()).contiguous()
+
+
+def _istft_call(spec_tf, center):
+    """spec_tf: CUDA float32 [T, F, 2]."""
+    n_fft, hop, win = _stft_parameters()
+    tb = _get_tables()
+    T = spec_tf.shape[0]
+    Lout = (T - 1) * hop + (0 if center else win)
+    wav = torch.zeros(max(Lout, 1), dtype=torch.float32, device=spec_tf.device)
+    work = torch.empty(max(T * win, 1), dtype=torch.float32, device=spec_tf.device)
+    p = L.struct("ns_istft_params")
+    p.spec, p.T, p.n_fft, p.hop, p.win, p.center = ops.ptr(spec_tf), T, n_fft, hop, win, int(center)
+    p.window, p.twiddle, p.wav, p.work = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"]), ops.ptr(wav), ops.ptr(work)
+    L.call("ns_istft", p, ops.stream())
+    return wav[:Lout]
+
+
+def _istft(y):
+    """audio.py:111-113: librosa.istft(D [F, T], hop, win): window-sum normalised overlap-add, centred trim."""
+    return _istft_call(_complex_rows(np.asarray(y).T), True).cpu().numpy()
+
+
+def _stft_tensorflow(signals):
+    """audio.py:116-118: tf.contrib.signal.stft(signals [B, L], win, hop, n_fft, pad_end=False) -> complex64 [B, T, F]."""
+    n_fft, hop, win = _stft_parameters()
+    tb = _get_tables()
+    is_t = torch.is_tensor(signals)
+    x = (signals if is_t else torch.as_tensor(np.ascontiguousarray(signals, dtype=np.float32))).to(_dev(), torch.float32)
+    single = x.dim() == 1
+    x = x.reshape(-1, x.shape[-1]).contiguous()
+    B, Lw = x.shape
+    T = max(0, 1 + (Lw - win) // hop)
+    F = n_fft // 2 + 1
+    out = torch.zeros(B, T, F, 2, dtype=torch.float32, device=x.device)
+    for b in range(B):
+        p = L.struct("ns_stft_tf_params")
+        p.wav, p.L, p.n_fft, p.hop, p.win, p.T = ops.ptr(x, b * Lw), Lw, n_fft, hop, win, T
+        p.window, p.twiddle, p.out = ops.ptr(tb["window"]), ops.ptr(tb["twiddle"]), ops.ptr(out, b * T * F * 2)
+        L.call("ns_stft_tf", p, ops.stream())
+    c = torch.view_as_complex(out)
+    c = c[0] if single else c
+    return c if is_t else c.cpu().numpy()
+
+
+def _istft_tensorflow(stfts):
+    """audio.py:121-123: tf.contrib.signal.inverse_stft(stfts [B, T, F], win, hop, n_fft) -> [B, (T-1) hop + win]."""
+    is_t = torch.is_tensor(stfts)
+    x = torch.view_as_real(stfts.to(torch.complex64)).to(_dev()).contiguous() if is_t else _complex_rows(stfts)
+    single = x.dim() == 3
+    x = x.reshape(-1, x.shape[-3], x.shape[-2], 2)
+    out = torch.stack([_istft_call(x[b].contiguous(), False) for b in range(x.shape[0])])
+    out = out[0] if single else out
+    return out if is_t else out.cpu().numpy()
+
+
+def _griffin_lim_tensorflow(S):
+    """audio.py:90-103: S [T, F] = the magnitudes (already denormalised, dB -> amplitude, ^power)."""
+    out = griffin_lim_gpu(S, raw_magnitude=True)
+    return out if torch.is_tensor(S) else out.cpu().numpy()
+
+
+def _griffin_lim(S):
+    """audio.py:77-87 takes [F, T].  The reference draws a random initial phase (and uses np.complex, gone from NumPy
+    1.24: dead code there); this is the deterministic zero-phase TF variant on the same magnitudes."""
+    return griffin_lim_gpu(np.asarray(S, dtype=np.float32).T, raw_magnitude=True).cpu().numpy()
 
 
 def find_endpoint(wav, threshold_db=-40, min_silence_sec=0.8):

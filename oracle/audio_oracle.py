@@ -121,6 +121,25 @@ def melspectrogram(y, hp):
     return normalize(S, hp).astype(np.float32)
 
 
+def librosa_istft(D, n_fft, hop, win):
+    """librosa 0.6.0 istft(stft_matrix [F, T], hop_length, win_length) [3P, SURVEY appendix C]: the periodic Hann window
+    centred in the n_fft frame times irfft(frame), overlap-added every hop, divided by the summed squared window where
+    that exceeds the smallest normal float32, n_fft // 2 trimmed from both ends."""
+    D = np.asarray(D)
+    T = D.shape[1]
+    lpad = (n_fft - win) // 2
+    w = np.zeros(n_fft)
+    w[lpad:lpad + win] = hann_periodic(win)
+    y = np.zeros(n_fft + hop * (T - 1))
+    ws = np.zeros_like(y)
+    for t in range(T):
+        y[t * hop:t * hop + n_fft] += w * np.fft.irfft(D[:, t], n=n_fft)
+        ws[t * hop:t * hop + n_fft] += w * w
+    nz = ws > np.finfo(np.float32).tiny
+    y[nz] /= ws[nz]
+    return y[n_fft // 2:len(y) - n_fft // 2]
+
+
 def tf_stft(y, n_fft, hop, win):
     """tf.contrib.signal.stft(y, win, hop, n_fft, pad_end=False): frames of `win` every `hop`,
     periodic Hann, rfft zero-padded AT THE END to n_fft.  Returns [T, 1+n_fft//2]."""

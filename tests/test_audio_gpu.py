@@ -106,3 +106,52 @@ def test_griffin_lim_at_the_benchmarked_size(audio):
     Sg, Sr = np.abs(AO.tf_stft(got, 2048, 250, 1000)), np.abs(AO.tf_stft(ref, 2048, 250, 1000))
     rel = np.linalg.norm(Sg - Sr) / np.linalg.norm(Sr)
     assert rel < 1e-3, rel
+
+
+def test_private_helpers_of_the_reference_module(audio):
+    """audio.py:77-171: every `_`-helper the reference's callers could reach, against the float64 oracle."""
+    A, hp = audio
+    n_fft, hop, win = AO.stft_parameters(HP)
+    y = _speechlike(7000, 9)
+    # librosa-style pair (features): centred transform and its window-sum normalised inverse
+    D = A._stft(y)
+    R = AO.librosa_stft(y, n_fft, hop, win)
+    assert D.shape == R.shape and D.dtype == np.complex64
+    assert np.abs(D - R).max() < 2e-4 * np.abs(R).max()
+    back = A._istft(R.astype(np.complex64))
+    ref = AO.librosa_istft(R, n_fft, hop, win)
+    assert back.shape == ref.shape
+    assert np.abs(back - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
+    assert np.abs(back[n_fft:-n_fft] - y[n_fft:len(back) - n_fft]).max() < 1e-4         # perfect reconstruction inside
+    # TF-style pair (Griffin-Lim): un-centred, no normalisation; a batch axis like the graph ops
+    E = A._stft_tensorflow(y[None, :])
+    Rt = AO.tf_stft(y, n_fft, hop, win)
+    assert E.shape == (1,) + Rt.shape
+    assert np.abs(E[0] - Rt).max() < 2e-4 * np.abs(Rt).max()
+    w = A._istft_tensorflow(Rt[None].astype(np.complex64))
+    rt = AO.tf_istft(Rt, n_fft, hop, win)
+    assert w.shape == (1, len(rt))
+    assert np.abs(w[0] - rt).max() < 2e-5 * np.abs(rt).max()
+    # element-wise conversions and the mel projection
+    x = np.abs(R).astype(np.float32)
+    assert np.abs(A._amp_to_db(x) - AO.amp_to_db(x)).max() < 2e-4
+    db = np.linspace(-120, 20, 57, dtype=np.float32)
+    assert np.abs(A._db_to_amp(db) / np.power(10.0, db * 0.05) - 1).max() < 1e-5
+    S = np.linspace(-150, 150, 61, dtype=np.float32)
+    assert np.abs(A._normalize(S) - AO.normalize(S, HP)).max() < 1e-6
+    u = np.linspace(-0.5, 1.5, 41, dtype=np.float32)
+    assert np.abs(A._denormalize(u) - AO.denormalize(u, HP)).max() < 1e-4
+    assert np.abs(A._linear_to_mel(x) - AO.mel_basis(HP["sample_rate"], n_fft, HP["num_mels"]) @ x).max() < 1e-4 * x.max()
+    # the reference's own composition of the helpers reproduces its public function
+    lin = A._normalize(A._amp_to_db(np.abs(A._stft(A.preemphasis(y)))) - hp.ref_level_db)
+    assert np.abs(lin - A.spectrogram(y)).max() < 2e-4
+    # magnitudes in, waveform out (audio.py:90-103)
+    spec = AO.spectrogram(y, dict(HP, min_level_db=-100)).T[:20]
+    hp.min_level_db = -100
+    try:
+        mags = np.power(A._db_to_amp(A._denormalize(spec) + hp.ref_level_db), hp.power).astype(np.float32)
+        a = A._griffin_lim_tensorflow(mags)
+        b = A.inv_spectrogram_tensorflow(spec)
+    finally:
+        hp.min_level_db = 100
+    assert np.abs(a - b).max() < 2e-3 * np.abs(b).max()

@@ -116,3 +116,14 @@ def test_resample_22050_to_20000_against_polyphase_reference(tmp_path):
         f.writeframes((x * 32767).astype("<i2").tobytes())
     w = audio.load_wav(path)
     assert len(w) == len(y) and np.abs(w[mid] - y[mid]).max() < 1e-3
+
+
+def test_librosa_istft_inverts_the_centred_transform():
+    """librosa_istft (window-sum normalised overlap-add, centred trim) is the exact inverse of librosa_stft for the
+    shipped window / hop (win = 4 hop): the restatement the GPU `_istft` is checked against."""
+    n_fft, hop, win = AO.stft_parameters(HP)
+    y = _speechlike(6000, 3)
+    D = AO.librosa_stft(y, n_fft, hop, win)
+    back = AO.librosa_istft(D, n_fft, hop, win)
+    assert len(back) == hop * (D.shape[1] - 1)
+    assert np.abs(back - y[:len(back)]).max() < 1e-9
