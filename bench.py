@@ -340,18 +340,24 @@ def main():
         step_flop = 2.0 * args.batch * D * 4 * D              # one recurrent launch: [N, D] x [D, 4D]
         loops = {k: sub.get(k, 0.0) for k in ("dec_lstm:loop1", "dec_lstm:loop2", "dec_lstm_bwd:loop2", "dec_lstm_bwd:loop1")}
         from nspeech_amd import profiling as _prof
+        state_mb = args.batch * D * 4 / 1e6
         gate_roof = {
-            "bound": "mfma", "kernel": "decoder LSTM(1024) x 2 gate GEMMs: lstm_step_kernel / lstm_bwd_step_kernel (one "
-                                       "launch per decoder step) + the hoisted input and weight-gradient GEMMs",
+            "bound": "mfma", "kernel": "decoder LSTM(1024) x 2 gate GEMMs: lstm_wide_fwd_kernel / lstm_wide_bwd_kernel (ONE "
+                                       "persistent launch per LSTM and direction, W_h register-resident, %d steps each) + the "
+                                       "hoisted input and weight-gradient GEMMs" % S,
             "achieved": gate_flop / (gate_ms * 1e-3) / 1e12 if gate_ms else None, "peak": MFMA_BF16_PEAK_TFLOPS,
             "unit": "TFLOP/s", "frac": gate_flop / (gate_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if gate_ms else None,
             "gflop_fwd_bwd": gate_flop / 1e9, "ms": gate_ms,
-            "step_launches": {k.replace("dec_lstm", "").strip(":_"): {"launches": S, "avg_launch_us": v * 1e3 / S,
-                                                                      "TFLOPs": step_flop / (v / S * 1e-3) / 1e12 if v else None}
-                              for k, v in loops.items()},
-            "binding_bound": "weight stream at M = 32: %.1f MB (bf16 hi+lo forward, bf16 backward) re-read per launch; "
-                             "HBM floor %.2f ms per step at 8 TB/s" % (2 * D * 4 * D * 4 / 1e6, S * (2 * D * 4 * D) * (4 + 2) / 8e12 * 1e3),
-            "traffic": _prof.pmc_traffic("lstm_step"),
+            "recurrence": {k.replace("dec_lstm", "").strip(":_"): {"launches": 1, "steps": S, "us_per_step": v * 1e3 / S,
+                                                                   "TFLOPs": step_flop / (v / S * 1e-3) / 1e12 if v else None}
+                           for k, v in loops.items()},
+            "binding_bound": "weight-stationary: W_h never leaves the registers, so the HBM weight stream of the launch-per-step "
+                             "form (33.6 MB per step) is gone; each step is one store -> visible -> load hop of the state "
+                             "between the CUs (%.2f MB published, 64 KB fetched per CU = 16 MB chip-wide through the memory "
+                             "side) and costs 4.9 us forward / 6.6 us backward against a 3.4 / 5.4 us hop "
+                             "(profiles/r02_wide_trace.txt); MFMA time per step is ~0.1 us" % state_mb,
+            "traffic": _prof.pmc_traffic("lstm_wide"),
+            "traffic_note": "bytes per LAUNCH (= %d steps) at the L2's fabric side, profiles/r02_pmc_traffic.json" % S,
         }
         res = {
             "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),

@@ -168,24 +168,30 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
   }
 }
 
-// second stage of the BatchNorm statistics: adds the 64-row slots up in a fixed order
-__global__ __launch_bounds__(256) void gemm_stats_finalize_kernel(const float* part, int slots, int N, float* col_sum,
-                                                                  float* col_sumsq) {
-  __shared__ float red[4][64][2];
-  const int c = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + c;
+// second stage of the BatchNorm statistics: adds the 64-row slots up in a fixed order.  Block = 32 columns x 32 slot
+// lanes (1024 threads): lane q adds slots q, q + 32, ... in order, then the 32 partial sums pairwise in a fixed tree.
+__global__ __launch_bounds__(1024) void gemm_stats_finalize_kernel(const float* part, int slots, int N, float* col_sum,
+                                                                   float* col_sumsq) {
+  __shared__ float red[32][33][2];
+  const int c = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int n = blockIdx.x * 32 + c;
   float a = 0.f, b = 0.f;
   if (n < N) {
-    for (int s = q; s < slots; s += 4) {
+    for (int s = q; s < slots; s += 32) {
       a += part[(long)s * N + n];
       b += part[((long)slots + s) * N + n];
     }
   }
   red[q][c][0] = a; red[q][c][1] = b;
   __syncthreads();
+#pragma unroll
+  for (int h = 16; h >= 1; h >>= 1) {
+    if (q < h) { red[q][c][0] += red[q + h][c][0]; red[q][c][1] += red[q + h][c][1]; }
+    __syncthreads();
+  }
   if (q == 0 && n < N) {
-    col_sum[n] = (red[0][c][0] + red[1][c][0]) + (red[2][c][0] + red[3][c][0]);
-    if (col_sumsq) col_sumsq[n] = (red[0][c][1] + red[1][c][1]) + (red[2][c][1] + red[3][c][1]);
+    col_sum[n] = red[0][c][0];
+    if (col_sumsq) col_sumsq[n] = red[0][c][1];
   }
 }
 
@@ -960,7 +966,7 @@ extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   p.stat_slots = 0;
   int rc = gemm_dispatch(p, stream);
   if (rc || !p.stat_part || p.M == 0 || p.N == 0) return rc;
-  hipLaunchKernelGGL(gemm_stats_finalize_kernel, dim3(ceil_div(p.N, 64)), dim3(256), 0, stream, p.stat_part, p.stat_slots,
+  hipLaunchKernelGGL(gemm_stats_finalize_kernel, dim3(ceil_div(p.N, 32)), dim3(1024), 0, stream, p.stat_part, p.stat_slots,
                      p.N, p.col_sum, p.col_sumsq);
   NS_CHECK_LAUNCH("gemm_stats_finalize");
   return NS_OK;

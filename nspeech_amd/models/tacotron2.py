@@ -200,6 +200,14 @@ class Tacotron2(object):
             tr("exp_%s_whT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, Cx, Hx, 4 * Hx, self.Tx)
         tr("l1_whT", "decoder/lstm_1/kernel", A + E, D, 4 * D)
         tr("l2_whT", "decoder/lstm_2/kernel", D, D, 4 * D)
+        # the hoisted input products on the 256-tile kernel: k-contiguous [4H, C_in] shadows of the input rows of the
+        # LSTM kernels (mixed: pre-split (hi, lo) pairs for the three-segment product; bf16 expand net: plain)
+        if self.mode == "mixed" and (A + E) % 64 == 0 and D % 64 == 0 and (4 * D) % 128 == 0:
+            tr("l1_xT", "decoder/lstm_1/kernel", 0, A + E, 4 * D, torch.float32)
+            tr("l2_xT", "decoder/lstm_2/kernel", 0, D, 4 * D, torch.float32)
+        if self.Tx == torch.bfloat16 and Cx % 64 == 0 and (4 * Hx) % 128 == 0:
+            for d in ("fw", "bw"):
+                tr("exp_%s_xT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, 0, Cx, 4 * Hx, self.Tx)
         tr("w1cT", "decoder/decoder_prenet/dense_1/kernel", M, E, 256)
         tr("w2T", "decoder/decoder_prenet/dense_2/kernel", 0, 256, 128)
         tr("wattT", "decoder/attention_lstm/kernel", 0, 128 + self.Dsp + A, 4 * A)
@@ -417,6 +425,25 @@ class Tacotron2(object):
         sk = max(1, min(32, 512 // max(tiles, 1)))
         return max(1, min(sk, K // 512))
 
+    def _x256_fits(self, rows, cout):
+        return rows >= 1024 and ((rows + 255) // 256) * ((cout + 255) // 256) >= 96
+
+    def _xg_gemm(self, x, xg, rows, cin, cout, key, woff, boff, D=None):
+        """Hoisted LSTM input product xg = x . W_x + b.  With a k-contiguous shadow of W_x (refresh_shadows) it runs on the
+        256-tile kernel: three segments over pre-split operands where the storage is fp32 (mixed), one where it is bf16."""
+        D = D or self.T
+        sh = self.tsh.get(key)
+        if sh is not None and self._x256_fits(rows, cout) and D == torch.float32 and key + "_hi" in self.tsh:
+            xh = self._buf("xgs_hi_" + key, rows * cin, torch.bfloat16)
+            xl = self._buf("xgs_lo_" + key, rows * cin, torch.bfloat16)
+            ops.split_hi_lo(x, xh, xl, rows * cin)
+            ops.gemm(xh, self.tsh[key + "_hi"], xg, rows, cout, cin, cin, cin, cout, a_mode=0, b_mode=0, a_lo=xl,
+                     b_lo=self.tsh[key + "_lo"], bias=self.flat_p, bias_off=boff)
+        elif sh is not None and self._x256_fits(rows, cout) and D == torch.bfloat16 and sh.dtype == torch.bfloat16:
+            ops.gemm(x, sh, xg, rows, cout, cin, cin, cin, cout, a_mode=0, b_mode=0, bias=self.flat_p, bias_off=boff)
+        else:
+            ops.gemm(x, self._W(D), xg, rows, cout, cin, cin, cout, cout, b_mode=1, b_off=woff, bias=self.flat_p, bias_off=boff)
+
     def _bilstm_fwd(self, scope, x, cin, H, N, T, Pp, lengths, tag, key, D=None):
         rows = N * Pp
         D = D or self.T
@@ -425,8 +452,8 @@ class Tacotron2(object):
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             xg = self._buf("%s_xg_%s" % (tag, d), rows * 4 * H, torch.float32)
-            ops.gemm(x, self._W(D), xg, rows, 4 * H, cin, cin, 4 * H, 4 * H, b_mode=1, b_off=self._o(kname),
-                     bias=self.flat_p, bias_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
+            self._xg_gemm(x, xg, rows, cin, 4 * H, "%s_%s_xT" % (key, d), self._o(kname),
+                          self._o("%s/%s/lstm_cell/bias" % (scope, d)), D)
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
             gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
             wk = "%s_%s_whT" % (key, d)
@@ -653,8 +680,7 @@ class Tacotron2(object):
         rows = N * S1
         k1, k2 = self._o("decoder/lstm_1/kernel"), self._o("decoder/lstm_2/kernel")
         xg1 = self._buf("dec_xg1", rows * 4 * D, torch.float32)
-        ops.gemm(hc, self._W(self.T), xg1, rows, 4 * D, A + E, A + E, 4 * D, 4 * D, b_mode=1, b_off=k1,
-                 bias=self.flat_p, bias_off=self._o("decoder/lstm_1/bias"))
+        self._xg_gemm(hc, xg1, rows, A + E, 4 * D, "l1_xT", k1, self._o("decoder/lstm_1/bias"))
         h1 = self._buf("dec_h1", rows * D, T_)
         c1 = self._buf("dec_c1", rows * D, torch.float32)
         g1 = self._buf("dec_g1", rows * 4 * D, T_)
@@ -663,8 +689,7 @@ class Tacotron2(object):
                        whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"))
         self._tick("dec_lstm:loop1")
         xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
-        ops.gemm(h1, self._W(self.T), xg2, rows, 4 * D, D, D, 4 * D, 4 * D, b_mode=1, b_off=k2,
-                 bias=self.flat_p, bias_off=self._o("decoder/lstm_2/bias"))
+        self._xg_gemm(h1, xg2, rows, D, 4 * D, "l2_xT", k2, self._o("decoder/lstm_2/bias"))
         h2 = self._buf("dec_h2", rows * D, T_)
         c2 = self._buf("dec_c2", rows * D, torch.float32)
         g2 = self._buf("dec_g2", rows * 4 * D, T_)
