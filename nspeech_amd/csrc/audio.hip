@@ -289,68 +289,65 @@ __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
 // the 256-thread kernel above needs 10 barriers; 4 frames per workgroup share the W_1024 table.
 constexpr int GW_PAD = 1088;                 // float2 per wave: 16 rows of 68 (transpose) / 1024 + 8 per 256 (natural)
 
-__device__ __forceinline__ void fft4(float& ar, float& ai, float& br, float& bi, float& cr, float& ci, float& dr, float& di) {
-  const float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
-  const float t2r = br + dr, t2i = bi + di;
-  const float t3r = bi - di, t3i = dr - br;                    // -i (b - d)
-  ar = t0r + t2r; ai = t0i + t2i;
-  cr = t0r - t2r; ci = t0i - t2i;
-  br = t1r + t3r; bi = t1i + t3i;
-  dr = t1r - t3r; di = t1i - t3i;
+// complex values as packed pairs (re, im): an add is one v_pk_add_f32, a product two packed operations
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f mul_neg_i(v2f v) { return (v2f){v.y, -v.x}; }
+__device__ __forceinline__ v2f cmulv(v2f x, float a, float b) {          // x * (a + i b)
+  return x * (v2f){a, a} + (v2f){-x.y, x.x} * (v2f){b, b};
 }
-__device__ __forceinline__ void cmulc(float& r, float& i, float a, float b) {   // (r + i i) *= (a + i b)
-  const float t = r * a - i * b;
-  i = r * b + i * a;
-  r = t;
+__device__ __forceinline__ void fft4(v2f& a, v2f& b, v2f& c, v2f& d) {   // in place: X0..X3 of x0..x3
+  const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
+  a = t0 + t2; c = t0 - t2; b = t1 + t3; d = t1 - t3;
 }
 // 16-point forward DFT in registers, natural order in and out (4 x 4, the digit reversal is register renaming)
-__device__ __forceinline__ void fft16(float (&r)[16], float (&i)[16]) {
+__device__ __forceinline__ void fft16(v2f (&x)[16]) {
   constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, HH = 0.70710678118654752f;
 #pragma unroll
-  for (int n2 = 0; n2 < 4; ++n2) fft4(r[n2], i[n2], r[4 + n2], i[4 + n2], r[8 + n2], i[8 + n2], r[12 + n2], i[12 + n2]);
+  for (int n2 = 0; n2 < 4; ++n2) fft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
   // element 4 k1 + n2 times W_16^(n2 k1)
-  cmulc(r[5], i[5], C1, -S1);  cmulc(r[6], i[6], HH, -HH);   cmulc(r[7], i[7], S1, -C1);
-  cmulc(r[9], i[9], HH, -HH);  { const float t = r[10]; r[10] = i[10]; i[10] = -t; }  cmulc(r[11], i[11], -HH, -HH);
-  cmulc(r[13], i[13], S1, -C1); cmulc(r[14], i[14], -HH, -HH); cmulc(r[15], i[15], -C1, S1);
+  x[5] = cmulv(x[5], C1, -S1);   x[6] = cmulv(x[6], HH, -HH);    x[7] = cmulv(x[7], S1, -C1);
+  x[9] = cmulv(x[9], HH, -HH);   x[10] = mul_neg_i(x[10]);       x[11] = cmulv(x[11], -HH, -HH);
+  x[13] = cmulv(x[13], S1, -C1); x[14] = cmulv(x[14], -HH, -HH); x[15] = cmulv(x[15], -C1, S1);
 #pragma unroll
-  for (int k1 = 0; k1 < 4; ++k1) fft4(r[4 * k1], i[4 * k1], r[4 * k1 + 1], i[4 * k1 + 1], r[4 * k1 + 2], i[4 * k1 + 2], r[4 * k1 + 3], i[4 * k1 + 3]);
+  for (int k1 = 0; k1 < 4; ++k1) fft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
   // position 4 k1 + k2 holds X[k1 + 4 k2]
-  float tr[16], ti[16];
+  v2f t[16];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) { tr[(p >> 2) + 4 * (p & 3)] = r[p]; ti[(p >> 2) + 4 * (p & 3)] = i[p]; }
+  for (int p = 0; p < 16; ++p) t[(p >> 2) + 4 * (p & 3)] = x[p];
 #pragma unroll
-  for (int p = 0; p < 16; ++p) { r[p] = tr[p]; i[p] = ti[p]; }
+  for (int p = 0; p < 16; ++p) x[p] = t[p];
 }
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt lgkmcnt(0): LDS is in order inside a wave
   __builtin_amdgcn_wave_barrier();
 }
-// in: lane n' = lane holds z[64 n1 + n'] in (r, i)[n1];  out: lane (k1 = lane >> 2, k3 = lane & 3) holds
-// Z[k1 + 16 k2 + 256 k3] in (r, i)[k2].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD float2.
-__device__ __forceinline__ void fft1024_wave(float (&r)[16], float (&i)[16], float2* buf, const float2* tw, int lane) {
-  fft16(r, i);
+// in: lane n' = lane holds z[64 n1 + n'] in x[n1];  out: lane (k1 = lane >> 2, k3 = lane & 3) holds
+// Z[k1 + 16 k2 + 256 k3] in x[k2].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD complex values.
+__device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* tw, int lane) {
+  fft16(x);
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) { const float2 w = tw[lane * k1]; cmulc(r[k1], i[k1], w.x, w.y); }
+  for (int k1 = 1; k1 < 16; ++k1) { const v2f w = tw[lane * k1]; x[k1] = cmulv(x[k1], w.x, w.y); }
 #pragma unroll
-  for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = make_float2(r[k1], i[k1]);
+  for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = x[k1];
   wave_lds_fence();
   const int k1l = lane >> 2, n3 = lane & 3;
 #pragma unroll
-  for (int n2 = 0; n2 < 16; ++n2) { const float2 v = buf[k1l * 68 + 4 * n2 + n3]; r[n2] = v.x; i[n2] = v.y; }
+  for (int n2 = 0; n2 < 16; ++n2) x[n2] = buf[k1l * 68 + 4 * n2 + n3];
   wave_lds_fence();                                             // the buffer is free again
-  fft16(r, i);
+  fft16(x);
 #pragma unroll
-  for (int k2 = 1; k2 < 16; ++k2) { const float2 w = tw[16 * n3 * k2]; cmulc(r[k2], i[k2], w.x, w.y); }
+  for (int k2 = 1; k2 < 16; ++k2) { const v2f w = tw[16 * n3 * k2]; x[k2] = cmulv(x[k2], w.x, w.y); }
   // 4-point DFT over n3 across the quad: out(k3) = (b0 + s b2) + (-i)^k3 (b1 + s b3), s = (-1)^k3
   const float sg = (n3 & 1) ? -1.f : 1.f;
   const float cr = n3 == 0 ? 1.f : (n3 == 2 ? -1.f : 0.f), ci = n3 == 1 ? -1.f : (n3 == 3 ? 1.f : 0.f);
 #pragma unroll
   for (int k2 = 0; k2 < 16; ++k2) {
-    const float b0r = NS_DPP_F(r[k2], 0x00), b1r = NS_DPP_F(r[k2], 0x55), b2r = NS_DPP_F(r[k2], 0xAA), b3r = NS_DPP_F(r[k2], 0xFF);
-    const float b0i = NS_DPP_F(i[k2], 0x00), b1i = NS_DPP_F(i[k2], 0x55), b2i = NS_DPP_F(i[k2], 0xAA), b3i = NS_DPP_F(i[k2], 0xFF);
-    const float er = b0r + sg * b2r, ei = b0i + sg * b2i, orr = b1r + sg * b3r, oi = b1i + sg * b3i;
-    r[k2] = er + (cr * orr - ci * oi);
-    i[k2] = ei + (cr * oi + ci * orr);
+    const float xr = x[k2].x, xi = x[k2].y;
+    const float b0r = NS_DPP_F(xr, 0x00), b1r = NS_DPP_F(xr, 0x55), b2r = NS_DPP_F(xr, 0xAA), b3r = NS_DPP_F(xr, 0xFF);
+    const float b0i = NS_DPP_F(xi, 0x00), b1i = NS_DPP_F(xi, 0x55), b2i = NS_DPP_F(xi, 0xAA), b3i = NS_DPP_F(xi, 0xFF);
+    const v2f sg2 = {sg, sg};
+    const v2f e = (v2f){b0r, b0i} + sg2 * (v2f){b2r, b2i}, o = (v2f){b1r, b1i} + sg2 * (v2f){b3r, b3i};
+    x[k2] = e + (v2f){cr, cr} * o + (v2f){ci, ci} * (v2f){-o.y, o.x};
   }
 }
 __device__ __forceinline__ int gw_nat(int k) { return k + 8 * (k >> 8); }    // natural order, conflict-free for the (k1, k3) writers
@@ -360,25 +357,29 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const ns_griffin_lim_params& p = g.p;
   constexpr int M = 1024, N = 2048, F = M + 1;
-  float2* tw = (float2*)sm;                                    // [1024] W_1024^j
+  v2f* tw = (v2f*)sm;                                          // [1024] W_1024^j
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  float2* buf = tw + M + wave * GW_PAD;
-  for (int j = tid; j < M; j += 256) {
-    const float2 t = ((const float2*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
-    tw[j] = j < 512 ? t : make_float2(-t.x, -t.y);
-  }
-  __syncthreads();
-  const int t = blockIdx.x * 4 + wave, n = blockIdx.y;
-  if (t >= p.T) return;
+  v2f* buf = tw + M + wave * GW_PAD;
+  // the W_1024 table is built AFTER this wave's operand loads are in flight (one latency instead of two); a wave
+  // beyond the last frame walks the last frame's loads up to the barrier and leaves
+  auto build_table = [&]() {
+    for (int j = tid; j < M; j += 256) {
+      const v2f v = ((const v2f*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
+      tw[j] = j < 512 ? v : -v;
+    }
+    __syncthreads();
+  };
+  const int traw = blockIdx.x * 4 + wave, n = blockIdx.y;
+  const int t = min(traw, p.T - 1);
   float* mag = g.mag + ((long)n * p.T + t) * F;
-  float zr[16], zi[16];
+  v2f z[16];
   float mkv[16], mpv[16];
-  float2 wv[16];
+  v2f wv[16];
   // per-lane base pointers: every access below is base[constant]
-  const float2* tw2l = (const float2*)p.twiddle + lane;        // exp(-2 pi i k / 2048), k = 64 n1 + lane
+  const v2f* tw2l = (const v2f*)p.twiddle + lane;              // exp(-2 pi i k / 2048), k = 64 n1 + lane
   const float* magk = mag + lane;                              // mag[64 n1 + lane]
   const float* magp = mag + (M - lane);                        // mag[M - k] = magp[-64 n1]
-  const float2* winl = (const float2*)p.window + lane;         // window[2 (64 n1 + lane)], [.. + 1]
+  const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) wv[n1] = tw2l[64 * n1];
   if constexpr (!INIT) {
@@ -406,22 +407,29 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
     }
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
+    build_table();
+    if (traw >= p.T) return;
 #pragma unroll
     for (int n1 = 0; n1 < 16; ++n1) {
-      float v0 = 0.f, v1 = 0.f;
+      v2f v = {0.f, 0.f};
       if (n1 < 8) {
-        const float2 wd = 2 * (64 * n1 + lane) < win ? winl[64 * n1] : make_float2(0.f, 0.f);
-        v0 = ((__uint_as_float(xs[n1 & 7][0][0]) + __uint_as_float(xs[n1 & 7][1][0])) + (__uint_as_float(xs[n1 & 7][2][0]) + __uint_as_float(xs[n1 & 7][3][0]))) * wd.x;
-        v1 = ((__uint_as_float(xs[n1 & 7][0][1]) + __uint_as_float(xs[n1 & 7][1][1])) + (__uint_as_float(xs[n1 & 7][2][1]) + __uint_as_float(xs[n1 & 7][3][1]))) * wd.y;
+        const v2f wd = 2 * (64 * n1 + lane) < win ? winl[64 * n1] : (v2f){0.f, 0.f};
+        const v2f a0 = {__uint_as_float(xs[n1 & 7][0][0]), __uint_as_float(xs[n1 & 7][0][1])};
+        const v2f a1 = {__uint_as_float(xs[n1 & 7][1][0]), __uint_as_float(xs[n1 & 7][1][1])};
+        const v2f a2 = {__uint_as_float(xs[n1 & 7][2][0]), __uint_as_float(xs[n1 & 7][2][1])};
+        const v2f a3 = {__uint_as_float(xs[n1 & 7][3][0]), __uint_as_float(xs[n1 & 7][3][1])};
+        v = ((a0 + a1) + (a2 + a3)) * wd;
       }
-      zr[n1] = v0; zi[n1] = v1;
+      z[n1] = v;
     }
-    fft1024_wave(zr, zi, buf, tw, lane);
-    float2* nat = buf + ((lane >> 2) + 264 * (lane & 3));      // natural order k + 8 (k >> 8), k = k1 + 16 k2 + 256 k3
+    fft1024_wave(z, buf, tw, lane);
+    v2f* nat = buf + ((lane >> 2) + 264 * (lane & 3));         // natural order k + 8 (k >> 8), k = k1 + 16 k2 + 256 k3
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) nat[16 * k2] = make_float2(zr[k2], zi[k2]);
+    for (int k2 = 0; k2 < 16; ++k2) nat[16 * k2] = z[k2];
     wave_lds_fence();
   } else {
+    build_table();
+    if (traw >= p.T) return;
     // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
     const float* sp = p.spec + ((long)n * p.T + t) * F;
 #pragma unroll
@@ -436,51 +444,52 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   }
   // ---- own bins k = 64 n1 + lane with their partners M - k: split -> unit phase x magnitude -> merge; conj(Zt[k]) is
   //      the next transform's input in the pass-1 layout
-  const float2* own = buf + lane;                              // Z[k] at own[64 n1 + 8 (n1 >> 2)]
+  const v2f* own = buf + lane;                                 // Z[k] at own[64 n1 + 8 (n1 >> 2)]
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
     const float mk = mkv[n1], mp = mpv[n1];
-    const float2 w = wv[n1];
-    float2 xa, xb;
+    const v2f w = wv[n1];
+    v2f xa, xb;
     if constexpr (INIT) {
-      xa = make_float2(mk, 0.f); xb = make_float2(mp, 0.f);
+      xa = (v2f){mk, 0.f}; xb = (v2f){mp, 0.f};
     } else {
-      const float2 A = own[64 * n1 + 8 * (n1 >> 2)];
+      const v2f A = own[64 * n1 + 8 * (n1 >> 2)];
       // the partner (M - k) & 1023 in the padded natural order; lane 0's partner of bin 64 n1 is bin 64 (16 - n1) (bin 0
       // for n1 = 0), one pad step further than the other lanes'
       constexpr int P0[16] = {0, 984, 920, 856, 792, 720, 656, 592, 528, 456, 392, 328, 264, 192, 128, 64};
-      const float2 B = buf[lane == 0 ? P0[n1] : (64 - lane) + 64 * (15 - n1) + 8 * ((15 - n1) >> 2)];
+      const v2f B = buf[lane == 0 ? P0[n1] : (64 - lane) + 64 * (15 - n1) + 8 * ((15 - n1) >> 2)];
       // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
-      // (the factor 1/2 drops out of the unit phase)
-      const float s1x = A.x + B.x, s1y = A.y - B.y, d1x = A.x - B.x, d1y = A.y + B.y;
-      const float wdx = w.x * d1x - w.y * d1y, wdy = w.x * d1y + w.y * d1x;      // w d1
-      const float eax = s1x + wdy, eay = s1y - wdx;
-      const float ebx = s1x - wdy, eby = -s1y - wdx;           // conj(w) d2 with d2 = (-d1x, d1y):  (-(wdx), wdy) -> eb = (s1x - wdy, -s1y - wdx)
+      // (the factor 1/2 drops out of the unit phase).  With s1 = A + conj B, d1 = A - conj B, wd = w d1:
+      //   2 X[k] = s1 - i wd = (s1.x + wd.y, s1.y - wd.x);   2 X[M-k] = (s1.x - wd.y, -s1.y - wd.x)
+      const v2f cB = {B.x, -B.y};
+      const v2f s1 = A + cB, d1 = A - cB;
+      const v2f wd = cmulv(d1, w.x, w.y);
+      const v2f ea = {s1.x + wd.y, s1.y - wd.x};
+      const v2f eb = {s1.x - wd.y, -s1.y - wd.x};
       // m e / max(1e-8, |e|) with e = ea / 2
-      const float sa = mk * __builtin_amdgcn_rsqf(fmaxf(4e-16f, eax * eax + eay * eay));
-      const float sb = mp * __builtin_amdgcn_rsqf(fmaxf(4e-16f, ebx * ebx + eby * eby));
-      xa = make_float2(eax * sa, eay * sa);
-      xb = make_float2(ebx * sb, eby * sb);
+      const v2f na = ea * ea, nb = eb * eb;
+      const float sa = mk * __builtin_amdgcn_rsqf(fmaxf(4e-16f, na.x + na.y));
+      const float sb = mp * __builtin_amdgcn_rsqf(fmaxf(4e-16f, nb.x + nb.y));
+      xa = ea * (v2f){sa, sa};
+      xb = eb * (v2f){sb, sb};
     }
-    // Zt[k] = (xa + conj xb) + i conj(w) (xa - conj xb)
-    const float t1x = xa.x + xb.x, t1y = xa.y - xb.y, u1x = xa.x - xb.x, u1y = xa.y + xb.y;
-    const float c1x = w.x * u1x + w.y * u1y, c1y = w.x * u1y - w.y * u1x;          // conj(w) u1
-    zr[n1] = t1x - c1y;
-    zi[n1] = -(t1y + c1x);
+    // Zt[k] = (xa + conj xb) + i conj(w) (xa - conj xb); the next transform takes conj(Zt[k])
+    const v2f cxb = {xb.x, -xb.y};
+    const v2f t1 = xa + cxb, u1 = xa - cxb;
+    const v2f c1 = cmulv(u1, w.x, -w.y);                        // conj(w) u1
+    z[n1] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};
   }
   wave_lds_fence();                                             // every lane has read Z before the buffer is reused
-  fft1024_wave(zr, zi, buf, tw, lane);
+  fft1024_wave(z, buf, tw, lane);
   // ---- y[2m] = Re Y[m] / N, y[2m+1] = -Im Y[m] / N, windowed; m = k1 + 16 k2 + 256 k3
   const float invN = 1.f / N;
   const int m0 = (lane >> 2) + 256 * (lane & 3);
-  float2* fo = (float2*)(g.fnext + ((long)n * p.T + t) * p.win) + m0;
-  const float2* wo = (const float2*)p.window + m0;
+  v2f* fo = (v2f*)(g.fnext + ((long)n * p.T + t) * p.win) + m0;
+  const v2f* wo = (const v2f*)p.window + m0;
+  const v2f sc = {invN, -invN};
 #pragma unroll
   for (int k2 = 0; k2 < 16; ++k2) {
-    if (2 * (m0 + 16 * k2) < p.win) {
-      const float2 wd = wo[16 * k2];
-      fo[16 * k2] = make_float2(zr[k2] * invN * wd.x, -zi[k2] * invN * wd.y);
-    }
+    if (2 * (m0 + 16 * k2) < p.win) fo[16 * k2] = z[k2] * sc * wo[16 * k2];
   }
 }
 

@@ -26,7 +26,7 @@ def test_checkpoint_retention_keeps_five_and_one_every_two_hours(tmp_path):
     assert have[-5:] == [12000, 13000, 14000, 15000, 16000]
     assert have[:-5] == [5000, 9000], have        # written at 2.5 h (> 2 h mark) and 4.5 h (> 4 h mark)
     with open(os.path.join(tmp_path, "checkpoint")) as f:
-        assert f.read().strip() == 'model_checkpoint_path: "model.ckpt-16000"'
+        assert f.read().strip().splitlines()[-1] == 'model_checkpoint_path: "model.ckpt-16000"'
 
 
 def test_checkpoint_retention_plain_window(tmp_path):

@@ -61,6 +61,9 @@ class CheckpointSaver(object):
         path = os.path.join(self.log_dir, "model.ckpt-%d" % step)
         torch.save(model.state_dict(), path)
         with open(os.path.join(self.log_dir, "checkpoint"), "w") as f:
+            # the state file of tf.train.Saver, for tools that look up the newest step; the comment line (legal in a
+            # text proto) says what the file it names is, since it is not a TensorBundle
+            f.write('# model.ckpt-%d is a torch.save dictionary (nspeech_amd); tf_bundle.export_model writes TF bundles\n' % step)
             f.write('model_checkpoint_path: "model.ckpt-%d"\n' % step)
         self.recent = [r for r in self.recent if r[0] != path] + [(path, self.clock())]
         while len(self.recent) > self.max_to_keep:
