@@ -354,7 +354,7 @@ def main():
             "binding_bound": "weight-stationary: W_h never leaves the registers, so the HBM weight stream of the launch-per-step "
                              "form (33.6 MB per step) is gone; each step is one store -> visible -> load hop of the state "
                              "between the CUs (%.2f MB published, 64 KB fetched per CU = 16 MB chip-wide through the memory "
-                             "side) and costs 4.9 us forward / 6.6 us backward against a 3.4 / 5.4 us hop "
+                             "side) and costs 5.0 us forward / 5.9 us backward against a 3.4 / 4.6 us hop "
                              "(profiles/r02_wide_trace.txt); MFMA time per step is ~0.1 us" % state_mb,
             "traffic": _prof.pmc_traffic("lstm_wide"),
             "traffic_note": "bytes per LAUNCH (= %d steps) at the L2's fabric side, profiles/r02_pmc_traffic.json" % S,

@@ -24,7 +24,10 @@
 // pass on the memory side (sc1 loads do not hit in L2) - the passes then take 2.2 us each and the CU's own publish
 // store queues behind them.  Measured per step at the benchmark shape (profiles/r02_wide_trace.txt), forward /
 // backward: arrival counters + drained stores 8.7 / 6.65 us; sentinel polling by full sweeps 7.9 / 10.7; probe,
-// then one sweep 5.2 / 7.3; probe and sweep interleaved 4.9 / 7.0; backward with 8-row groups 6.6.  What is left is
+// then one sweep 5.2 / 7.3; probe and sweep interleaved 4.9 / 7.0; backward with 8-row groups 6.6; backward with a
+// PROBER wave (an idle cell wave polls for the whole workgroup with nothing else in its memory queue and hands the
+// producers' bits over in LDS) 6.0 - the forward kernel got slower with one (5.25) and keeps the sweepers' own probes.
+// What is left is
 // the hop itself: store -> visible + one probe round trip (1.9 us) + one data round trip (1.5 us; 2.2 us for the
 // backward pass's 64 KB per CU), then ~1.5 us of MFMA, barrier and cell update.
 // Every spin is bounded; a timeout raises the status word and all waves of the workgroup leave together.  The grid
@@ -88,7 +91,8 @@ __global__ __launch_bounds__(256) void wide_fill_kernel(T* base, int N, long P, 
 template <typename T, int NL, int LPC, int PPCH>
 __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t bytes, unsigned poff0, unsigned pstride,
                                                       unsigned off0, unsigned in_grp, unsigned per_grp, u32x4 (&v)[NL], int lane,
-                                                      int* status, int* abortf, int code, long long* tslot) {
+                                                      int* status, int* abortf, int code, long long* tslot,
+                                                      const volatile unsigned long long* pmask = nullptr, int pbit0 = 0) {
   constexpr int NP = (NL / LPC) * PPCH;                       // producers of this wave's K slice
   constexpr unsigned long long ALLP = NP >= 64 ? ~0ull : ((1ull << NP) - 1ull);
   constexpr unsigned ALLL = (1u << NL) - 1u;
@@ -100,8 +104,12 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
   for (;;) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, nrec, 0x00020000);
     if (ready != ALLP) {
-      const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, poff, 0, 16);
-      ready |= __builtin_amdgcn_ballot_w64(lane < NP && !has_sentinel<T>(pv));
+      if (pmask) {            // a prober wave polls for the whole workgroup and keeps the producers' bits in LDS
+        ready = (pmask[pbit0 >> 6] >> (pbit0 & 63)) & ALLP;
+      } else {
+        const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, poff, 0, 16);
+        ready |= __builtin_amdgcn_ballot_w64(lane < NP && !has_sentinel<T>(pv));
+      }
       if (tslot && ready == ALLP && blockIdx.x == 0 && threadIdx.x == 0) *tslot = wall_clock64();
     }
 #pragma unroll
@@ -122,8 +130,40 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
       if (!stale) return spins;
       done &= ~stale;
     }
+    if (pmask) {              // the prober owns the time-out and the look at the status word
+      if (*(volatile int*)abortf) return 0;
+      if (spins > 64u * WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
+      continue;
+    }
     if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
     if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return 0; }
+  }
+}
+
+// The prober wave of a workgroup: polls ONE 16-byte piece per producing workgroup of the row group (lane l: producers
+// l, l + 64; byte offset poff0 + producer * pstride) with nothing else in its memory queue, and keeps the bits of the
+// producers that have published in pm[0..1] (LDS) for the sweepers.  Returns false on time-out / raised status.
+template <typename T>
+__device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsigned poff0, unsigned pstride, int np,
+                                          volatile unsigned long long* pm, int lane, int* status, int* abortf, int code) {
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+  const unsigned o0 = lane < np ? poff0 + (unsigned)lane * pstride : 0x80000000u;
+  const unsigned o1 = lane + 64 < np ? poff0 + (unsigned)(lane + 64) * pstride : 0x80000000u;
+  const unsigned long long all0 = np >= 64 ? ~0ull : ((1ull << np) - 1ull);
+  const unsigned long long all1 = np > 64 ? (np >= 128 ? ~0ull : ((1ull << (np - 64)) - 1ull)) : 0ull;
+  unsigned long long m0 = 0ull, m1 = 0ull;
+  unsigned spins = 0;
+  for (;;) {
+    const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 16);
+    const u32x4 v1 = np > 64 ? __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 16) : (u32x4){0u, 0u, 0u, 0u};
+    m0 |= __builtin_amdgcn_ballot_w64(lane < np && !has_sentinel<T>(v0));
+    m1 |= __builtin_amdgcn_ballot_w64(lane + 64 < np && !has_sentinel<T>(v1));
+    if (lane == 0) { pm[0] = m0; pm[1] = m1; }
+    if (m0 == all0 && m1 == all1) return true;
+    ++spins;
+    if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return false; }
+    if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return false; }
   }
 }
 
@@ -134,18 +174,21 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
 // write-through publish store, the late stores or an operand fetch from HBM returns only after those (the one-role
 // version measured 3.7 us for a sweep that succeeded at its first pass).
 // NCH = 32-wide K chunks per sweeper (H / 256); PASSES = 3: fp32 state, hi / lo weight planes; 1: bf16 everywhere
-constexpr int WTF = WT + 128;
+constexpr bool FWD_PROBER = false;          // measured: 5.25 us per step with a prober wave, 5.04 with the sweepers' own probes
+constexpr int WTF = WT + 128 + (FWD_PROBER ? 64 : 0);
 template <typename T, int PASSES, int NCH>
 __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
   __shared__ float red[WW][16][33];
   __shared__ __attribute__((aligned(16))) T hst[16][8];
   __shared__ int abortf;
+  __shared__ unsigned long long pmask[2][2];       // [step parity][producers 0..63, 64..127] published bits (prober wave)
   const ns_lstm_seq_params& p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, NUB = a.nub;
   const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
   const int n0 = rg * 16, u0 = ub * 8;
   if (tid == 0) abortf = 0;
+  if (tid < 4) pmask[tid >> 1][tid & 1] = 0ull;
   const size_t hbytes = (size_t)p.N * p.P * p.ld_h * sizeof(T);
   constexpr int PPC = 8 * (int)sizeof(T) / 16;        // 16-byte pieces per 8-value fragment (2 for fp32, 1 for bf16)
   __syncthreads();
@@ -182,7 +225,8 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
         u32x4 v[NCH * PPC];
         const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t - 1) * p.ld_h + k0) * (unsigned)sizeof(T);
         const unsigned got = sweep_progressive<T, NCH * PPC, PPC, 4>(p.h, hbytes, prow, 8u * (unsigned)sizeof(T), rowoff, 16u, 32u * (unsigned)sizeof(T),
-                                                                     v, lane, a.status, &abortf, 1, a.trace && t < 256 ? a.trace + t * 8 + 6 : nullptr);
+                                                                     v, lane, a.status, &abortf, 1, a.trace && t < 256 ? a.trace + t * 8 + 6 : nullptr,
+                                                                     FWD_PROBER ? &pmask[t & 1][0] : nullptr, wave * (H / (8 * WW)));
         wstamp(a, t, 1);
         if (a.trace && blockIdx.x == 0 && tid == 0 && t < 256) a.trace[t * 8 + 5] = got;
         if (got) {
@@ -214,6 +258,20 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
       __syncthreads();
       if (abortf) return;
       wstamp(a, t, 2);
+    }
+    return;
+  }
+  if (FWD_PROBER && wave == WW + 2) {
+    // ------------------------------------------------------------------ prober: one piece per producer of the row group
+    const int prb = ub % min(16, p.N - n0);            // the probed row differs from workgroup to workgroup
+    for (int t = 0; t < p.T; ++t) {
+      if (t > 0) {
+        const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t - 1) * p.ld_h) * (unsigned)sizeof(T);
+        probe_all<T>(p.h, hbytes, prow, 8u * (unsigned)sizeof(T), H / 8, &pmask[t & 1][0], lane, a.status, &abortf, 1);
+      }
+      if (lane < 2) pmask[(t + 1) & 1][lane] = 0ull;  // nobody reads the other parity before the barrier
+      __syncthreads();
+      if (abortf) return;
     }
     return;
   }
@@ -289,12 +347,15 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
   __shared__ float red[WW][16][17];
   __shared__ __attribute__((aligned(16))) bf16_t dst[16][4][16];      // this step's gate gradients (row, gate, unit)
   __shared__ int abortf;
+  __shared__ unsigned long long pmask[2][2];
+  constexpr bool PROBER = RPG == 8;                // 8-row groups leave the last two cell waves idle: one of them probes
   const ns_lstm_seq_params& p = a.p;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, K = 4 * H, NUB = a.nub;
   const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
   const int n0 = rg * RPG, u0 = ub * 16;
   if (tid == 0) abortf = 0;
+  if (tid < 4) pmask[tid >> 1][tid & 1] = 0ull;
   bf16_t* xb = sizeof(T) == 2 ? (bf16_t*)p.dgates : (bf16_t*)p.dgates_bf16;     // exchange payload [N*P, 4H] bf16
   const size_t xbytes = (size_t)p.N * p.P * K * sizeof(bf16_t);
   __syncthreads();
@@ -320,7 +381,9 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
         const unsigned rowoff = ok ? (unsigned)(((long)(n0 + r16) * p.P + p.padl + t + 1) * K + k0 + g * 8) * 2u : 0x80000000u;
         u32x4 av[NCH];
         const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t + 1) * K + k0) * 2u;
-        const unsigned got = sweep_progressive<bf16_t, NCH, 1, 2>(xb, xbytes, prow, 32u, rowoff, 0u, 64u, av, lane, a.status, &abortf, 2, a.trace && bs < 256 ? a.trace + bs * 8 + 6 : nullptr);
+        const unsigned got = sweep_progressive<bf16_t, NCH, 1, 2>(xb, xbytes, prow, 32u, rowoff, 0u, 64u, av, lane, a.status, &abortf, 2,
+                                                                  a.trace && bs < 256 ? a.trace + bs * 8 + 6 : nullptr,
+                                                                  PROBER ? &pmask[bs & 1][0] : nullptr, (wave & 1) * (H / 32));
         wstamp(a, bs, 1);
         if (a.trace && blockIdx.x == 0 && tid == 0 && bs < 256) a.trace[bs * 8 + 5] = got;
         if (got) {
@@ -339,6 +402,22 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
       __syncthreads();
       if (abortf) return;
       wstamp(a, bs, 2);
+    }
+    return;
+  }
+  if (PROBER && wave == WW + 3) {
+    // ------------------------------------------------------------------ prober (see the forward kernel): gate 0's piece of
+    //                                                                      every producer's 16 units
+    const int prb = ub % min(RPG, p.N - n0);
+    for (int t = p.T - 1; t >= 0; --t) {
+      const int bs = p.T - 1 - t;
+      if (bs > 0) {
+        const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t + 1) * K) * 2u;
+        probe_all<bf16_t>(xb, xbytes, prow, 32u, H / 16, &pmask[bs & 1][0], lane, a.status, &abortf, 2);
+      }
+      if (lane < 2) pmask[(bs + 1) & 1][lane] = 0ull;
+      __syncthreads();
+      if (abortf) return;
     }
     return;
   }
