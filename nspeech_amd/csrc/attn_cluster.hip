@@ -35,6 +35,8 @@ constexpr int CT = 512;            // threads per workgroup
 constexpr int TSMAX = 32;          // memory positions per workgroup (T_in <= 256)
 constexpr int KWMAX = 8;
 constexpr int APAD = 8;            // zero margin around the alignment vector in LDS
+constexpr int KPAD = 4;            // row pad of the keys image: the energy pass reads keys[r][u] with r across 16 lanes and u
+                                   // across 4 - a row stride of A floats puts all 16 rows on one bank (16-way conflict)
 constexpr unsigned SPIN_LIMIT = 2000000u;
 
 template <int A_, int D1_, int D2_>
@@ -146,8 +148,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   float* hloc = ered + (CT / 64) * TSMAX;  // [UPW] new h of this workgroup's units
   float* sc = hloc + UPW;                  // [16]     [0] local max, [1] local sum, [2] abort flag
   float* gath = sc + 16;                   // [CG][XMAX]
-  float* keys_s = gath + CG * C::XMAX;     // [TSMAX][A]
-  float* pv_s = keys_s + TSMAX * A;        // [TSMAX][D1]
+  float* keys_s = gath + CG * C::XMAX;     // [TSMAX][A + KPAD]
+  float* pv_s = keys_s + TSMAX * (A + KPAD);        // [TSMAX][D1]
   float* wq_s = pv_s + TSMAX * D1;         // [UPW][A]  W_query rows of the own units
   float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]  folded location filter, attention_v
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
   for (int i = tid; i < (KWMAX + 1) * A; i += CT) {
     const int k = i / A, u = i % A;
-    cst_s[i] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
+    cst_s[k * (A + KPAD) + u] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
   }
   // cell owner threads: tid < UPW
   float cstate = 0.f;
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   // ---------------------------------------------------------------- per-utterance LDS images
   {
     const float* kn = p.keys + ((long)n * p.Pi + p.padl_i + t0) * A;
-    for (int i = tid; i < TSMAX * A; i += CT) keys_s[i] = (i / A) < tn ? kn[i] : 0.f;
+    for (int i = tid; i < TSMAX * A; i += CT) keys_s[(i / A) * (A + KPAD) + i % A] = (i / A) < tn ? kn[i] : 0.f;
     const T* pvn = (const T*)p.pv + ((long)n * p.Pi + p.padl_i + t0) * D1;
     for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
     for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
@@ -326,10 +328,10 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       for (int j = 0; j < 8; ++j) {
         const int u = wave * 32 + j * 4 + kq;
         const float qv = qs[u];
-        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
+        float x0 = keys_s[r * (A + KPAD) + u] + qv, x1 = keys_s[(r + 16) * (A + KPAD) + u] + qv;
 #pragma unroll
-        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
-        const float b = r == 0 ? cst_s[KWMAX * A + u] : 0.f;
+        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * (A + KPAD) + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+        const float b = r == 0 ? cst_s[KWMAX * (A + KPAD) + u] : 0.f;
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf_(x0), b, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(tanhf_(x1), b, acc1, 0, 0, 0);
       }
@@ -473,8 +475,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   float* gts = p2m + D2;                   // [GC] saved gates of the own units
   float* sc = gts + GC;                    // [16]  [0] dot, [1] dcar, [2] abort, [4..] block_sum scratch
   float* gath = sc + 48;                   // [CG][EMAX]
-  float* keys_s = gath + CG * C::EMAX;     // [TSMAX][A]
-  float* pv_s = keys_s + TSMAX * A;        // [TSMAX][D1]
+  float* keys_s = gath + CG * C::EMAX;     // [TSMAX][A + KPAD]
+  float* pv_s = keys_s + TSMAX * (A + KPAD);        // [TSMAX][D1]
   float* wq_s = pv_s + TSMAX * D1;         // [UPW][A]
   float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]
 
@@ -516,11 +518,11 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
   for (int i = tid; i < (KWMAX + 1) * A; i += CT) {
     const int k = i / A, u = i % A;
-    cst_s[i] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
+    cst_s[k * (A + KPAD) + u] = k < p.kw ? p.wcl[k * A + u] : (k == KWMAX ? p.v[u] : 0.f);
   }
   {
     const float* kn = p.keys + ((long)n * p.Pi + p.padl_i + t0) * A;
-    for (int i = tid; i < TSMAX * A; i += CT) keys_s[i] = (i / A) < tn ? kn[i] : 0.f;
+    for (int i = tid; i < TSMAX * A; i += CT) keys_s[(i / A) * (A + KPAD) + i % A] = (i / A) < tn ? kn[i] : 0.f;
     const T* pvn = (const T*)p.pv + ((long)n * p.Pi + p.padl_i + t0) * D1;
     for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
     for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
@@ -617,14 +619,14 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int u = wave * 32 + j * 4 + kq;
-        const float qv = qs[u], vv = cst_s[KWMAX * A + u];
-        float x0 = keys_s[r * A + u] + qv, x1 = keys_s[(r + 16) * A + u] + qv;
+        const float qv = qs[u], vv = cst_s[KWMAX * (A + KPAD) + u];
+        float x0 = keys_s[r * (A + KPAD) + u] + qv, x1 = keys_s[(r + 16) * (A + KPAD) + u] + qv;
 #pragma unroll
-        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * A + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
+        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * (A + KPAD) + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
         const float th0 = tanhf_(x0), th1 = tanhf_(x1);
         g1v[2 * j] = r < tn ? vv * (1.f - th0 * th0) : 0.f;
         g1v[2 * j + 1] = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
-        const float b = r < KWMAX ? cst_s[r * A + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
+        const float b = r < KWMAX ? cst_s[r * (A + KPAD) + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j], b, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j + 1], b, acc[1], 0, 0, 0);
         if ((j & 3) == 3) asm volatile("" ::: "memory");
@@ -803,7 +805,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
 template <typename C>
 size_t fwd_lds_bytes() {
   return sizeof(float) * (C::K + C::D1 + CT + C::A + 256 + 2 * APAD + TSMAX + (CT / 64) * TSMAX + C::UPW + 16 +
-                          CG * C::XMAX + TSMAX * C::A + TSMAX * C::D1 + C::UPW * C::A + (KWMAX + 1) * C::A);
+                          CG * C::XMAX + TSMAX * (C::A + KPAD) + TSMAX * C::D1 + C::UPW * C::A + (KWMAX + 1) * (C::A + KPAD));
 }
 
 bool cluster_shape_ok(const ns_taco2_attn_params* p) {
@@ -893,8 +895,8 @@ extern "C" int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* wo
 template <typename C>
 static size_t bwd_lds_bytes() {
   return sizeof(float) * (C::D1 + C::D2 + C::GC + C::NQ * C::K + C::A + 256 + 2 * APAD + 5 * TSMAX + TSMAX * 8 + 8 * TSMAX * 8 +
-                          C::UPW + C::A + C::D1 + C::D2 + C::GC + 48 + CG * C::EMAX + TSMAX * C::A + TSMAX * C::D1 +
-                          C::UPW * C::A + (KWMAX + 1) * C::A);
+                          C::UPW + C::A + C::D1 + C::D2 + C::GC + 48 + CG * C::EMAX + TSMAX * (C::A + KPAD) + TSMAX * C::D1 +
+                          C::UPW * C::A + (KWMAX + 1) * (C::A + KPAD));
 }
 
 template <typename T, typename C>

@@ -155,3 +155,32 @@ def test_private_helpers_of_the_reference_module(audio):
     finally:
         hp.min_level_db = 100
     assert np.abs(a - b).max() < 2e-3 * np.abs(b).max()
+
+
+def test_other_transform_sizes_take_the_generic_kernels(audio):
+    """num_freq 513 (n_fft 1024), 16 kHz: features, Griffin-Lim (the one-workgroup-per-frame LDS kernel; the
+    wave-per-frame kernel is for n_fft 2048 only) and the TF-style transform pair against the oracle."""
+    A, hp = audio
+    keep = {k: getattr(hp, k) for k in ("num_freq", "sample_rate", "min_level_db")}
+    hp.num_freq, hp.sample_rate, hp.min_level_db = 513, 16000, -100
+    H2 = dict(HP, num_freq=513, sample_rate=16000, min_level_db=-100)
+    try:
+        n_fft, hop, win = AO.stft_parameters(H2)
+        assert (n_fft, hop, win) == (1024, 200, 800)
+        y = _speechlike(9000, 21)
+        lin, mel = A.spectrogram_and_mel(y)
+        assert np.abs(lin - AO.spectrogram(y, H2)).max() < 2e-4
+        assert np.abs(mel - AO.melspectrogram(y, H2)).max() < 2e-4
+        spec = AO.spectrogram(y, H2).T[:25].copy()
+        for iters in (0, 2):
+            got = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
+            ref = AO.inv_spectrogram_tensorflow(spec, H2, iters=iters)
+            assert got.shape == ref.shape == (24 * hop + win,)
+            assert np.abs(got - ref).max() < (2e-4 if iters == 0 else 2e-3) * np.abs(ref).max(), iters
+        E = A._stft_tensorflow(y)
+        Rt = AO.tf_stft(y, n_fft, hop, win)
+        assert np.abs(E - Rt).max() < 2e-4 * np.abs(Rt).max()
+        assert np.abs(A._istft_tensorflow(Rt.astype(np.complex64)) - AO.tf_istft(Rt, n_fft, hop, win)).max() < 2e-5 * np.abs(y).max() * 10
+    finally:
+        for k, v in keep.items():
+            setattr(hp, k, v)
