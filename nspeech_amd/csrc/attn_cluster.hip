@@ -68,6 +68,12 @@ __device__ __forceinline__ void stamp(const ACArgs& a, int st, int k) {
   if (a.trace && blockIdx.x == 0 && threadIdx.x == 0 && st < 256) a.trace[st * 16 + k] = wall_clock64();
 }
 
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the vector-memory queue (s_waitcnt vmcnt(0)):
+// inside the step loops that would wait, at every barrier, for whatever is in flight - the history prefetch from HBM,
+// the write-through acknowledgement of a publish (1.3 us).  The waves of a workgroup talk through LDS only; what goes
+// through global memory is either tag-polled (the exchanges) or read by later kernels.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
   __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     stamp(a, st, 0);
     // ---- (1) p2 = relu(p1 . W2 + b2): every workgroup computes all of it
     red[tid] = dot_regs<P2K>(w2r, p1s + p2q * P2K);
-    __syncthreads();
+    lds_barrier();
     if (tid < D2) {
       float s = b2c;
 #pragma unroll
@@ -250,12 +256,12 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       xs[tid] = s;
       if (tid / (D2 / CG) == g) stf((T*)p.xa + ((long)n * S1 + slot) * XA + tid, s);
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, st, 1);
     // ---- (2) gates of this workgroup's units, cell update
     float sv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
     red[tid] = dot_regs<GK>(wgr, xs + gq * GK);
-    __syncthreads();
+    lds_barrier();
     if (tid < UPW) {
       float z[4];
 #pragma unroll
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       put_granule(x2 + (size_t)g * X2N + A + tid, tag, h);                 // the peers wait for this
       sv[0] = gi; sv[1] = gj; sv[2] = gf; sv[3] = go; sv[4] = h;           // saved after the gather (see below)
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, st, 2);
     // ---- (3) partial query of this workgroup's h rows, published
     {
@@ -281,7 +287,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       for (int i = 0; i < QK; ++i) s = fmaf(wq_s[(qq * QK + i) * A + qu], hloc[qq * QK + i], s);
       red[tid] = s;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < A) {
       float s = 0.f;
 #pragma unroll
@@ -292,7 +298,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     // ---- (4) gather X2: q = sum of the partials (fixed order), h of every unit
     gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
-    __syncthreads();
+    lds_barrier();
     if (sc[2] != 0.f) return;                 // uniform: every thread reads the same LDS word
     stamp(a, st, 4);
     if (tid < A) {
@@ -313,7 +319,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, sv[4]);
       if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, sv[4]);
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, st, 5);
     // ---- (5) energies of the own positions in the A-operand layout of v_mfma_f32_16x16x4_f32 (row = position,
     //      k = unit) against B = attention_v in column 0: the sum over the units comes out of the matrix core (exact
@@ -340,7 +346,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
         for (int q = 0; q < 4; ++q) { ered[wave * TSMAX + kq * 4 + q] = acc0[q]; ered[wave * TSMAX + 16 + kq * 4 + q] = acc1[q]; }
       }
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, st, 6);
     if (wave == 0) {
       // local softmax: lane = local position
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (lane < TSMAX) es[lane] = w;
       if (lane == 0) { sc[0] = m; sc[1] = l; }
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, st, 7);
     // ---- (6) partial next-prenet sums over the own positions, published with the softmax pieces
     {
@@ -365,7 +371,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       for (int tl = th; tl < tn; tl += CXG) s = fmaf(es[tl], pv_s[tl * D1 + c], s);
       red[tid] = s;
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < D1) {
       float s = 0.f;
 #pragma unroll
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     // ---- (7) gather X3, combine
     gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
-    __syncthreads();
+    lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, st, 9);
     float mall = -INFINITY;
@@ -394,7 +400,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       lsum = fmaf(lq, scl[q], lsum);
     }
     const float inv = 1.f / lsum;
-    __syncthreads();                                   // al / p1s are rewritten below: everyone is done with step s
+    lds_barrier();                                   // al / p1s are rewritten below: everyone is done with step s
     if (tid < D1) {
       float s = 0.f;
 #pragma unroll
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
         if (p.align_t) stf((T*)p.align_t + ((long)n * S1 + slot) * p.Tia + t, v);
       }
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -459,26 +465,36 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   float* dp2s = dvec + D1;                 // [D2]
   float* dgs = dp2s + D2;                  // [GC]  gate gradients of the own units, (gate, unit)
   float* red = dgs + GC;                   // [NQ * K] partial sums
-  float* qs = red + NQ * K;                // [A]
-  float* al = qs + A;                      // [APAD + 256 + APAD] alignment of step s-1
-  float* acur = al + 256 + 2 * APAD;       // [TSMAX] alignment of step s, own positions
-  float* da0s = acur + TSMAX;              // [TSMAX]
-  float* dav = da0s + TSMAX;               // [TSMAX] dalign
+  // the per-step history images exist twice (parity of the step): the next step's are filled in the middle of this
+  // one, when its loads have long landed - at the top of a step they would wait behind the write-through stores
+  // that end the step before (one vmcnt queue: 1.1 us per step)
+  float* qs0 = red + NQ * K;               // [A]
+  float* al0 = qs0 + A;                    // [APAD + 256 + APAD] alignment of step s-1
+  float* acur0 = al0 + 256 + 2 * APAD;     // [TSMAX] alignment of step s, own positions
+  float* da0s0 = acur0 + TSMAX;            // [TSMAX]
+  float* dav = da0s0 + TSMAX;              // [TSMAX] dalign
   float* dev = dav + TSMAX;                // [TSMAX] energy gradients
   float* carry = dev + TSMAX;              // [TSMAX] location-filter carry for the own positions
   float* Gs = carry + TSMAX;               // [TSMAX][8]
   float* zred = Gs + TSMAX * 8;            // [8 waves][TSMAX][8]
   float* hrec = zred + 8 * TSMAX * 8;      // [UPW] recurrent part of dh for the own units
   float* dq_s = hrec + UPW;                // [A]
-  float* p1m = dq_s + A;                   // [D1] p1 of this step (ReLU mask)
-  float* p2m = p1m + D1;                   // [D2]
-  float* gts = p2m + D2;                   // [GC] saved gates of the own units
-  float* sc = gts + GC;                    // [16]  [0] dot, [1] dcar, [2] abort, [4..] block_sum scratch
+  float* p1m0 = dq_s + A;                  // [D1] p1 of this step (ReLU mask)
+  float* p2m0 = p1m0 + D1;                 // [D2]
+  float* gts0 = p2m0 + D2;                 // [GC] saved gates of the own units
+  float* sc = gts0 + GC;                   // [16]  [0] dot, [1] dcar, [2] abort, [4..] block_sum scratch
   float* gath = sc + 48;                   // [CG][EMAX]
   float* keys_s = gath + CG * C::EMAX;     // [TSMAX][A + KPAD]
   float* pv_s = keys_s + TSMAX * (A + KPAD);        // [TSMAX][D1]
   float* wq_s = pv_s + TSMAX * D1;         // [UPW][A]
-  float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]
+  float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A + KPAD]
+  float* qs1 = cst_s + (KWMAX + 1) * (A + KPAD);
+  float* al1 = qs1 + A;
+  float* acur1 = al1 + 256 + 2 * APAD;
+  float* da0s1 = acur1 + TSMAX;
+  float* p1m1 = da0s1 + TSMAX;
+  float* p2m1 = p1m1 + D1;
+  float* gts1 = p2m1 + D2;                 // ... + GC
 
   const int tid_ = threadIdx.x;
   const int n = blockIdx.x / CG, g = blockIdx.x % CG;
@@ -525,9 +541,9 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     for (int i = tid; i < TSMAX * A; i += CT) keys_s[(i / A) * (A + KPAD) + i % A] = (i / A) < tn ? kn[i] : 0.f;
     const T* pvn = (const T*)p.pv + ((long)n * p.Pi + p.padl_i + t0) * D1;
     for (int i = tid; i < TSMAX * D1; i += CT) pv_s[i] = (i / D1) < tn ? ldf(pvn + i) : 0.f;
-    for (int i = tid; i < 256 + 2 * APAD; i += CT) al[i] = 0.f;
+    for (int i = tid; i < 256 + 2 * APAD; i += CT) { al0[i] = 0.f; al1[i] = 0.f; }
     for (int i = tid; i < D1; i += CT) dvec[i] = 0.f;
-    for (int i = tid; i < TSMAX; i += CT) { carry[i] = 0.f; dev[i] = 0.f; dav[i] = 0.f; acur[i] = 0.f; da0s[i] = 0.f; }
+    for (int i = tid; i < TSMAX; i += CT) { carry[i] = 0.f; dev[i] = 0.f; dav[i] = 0.f; acur0[i] = 0.f; da0s0[i] = 0.f; acur1[i] = 0.f; da0s1[i] = 0.f; }
     for (int i = tid; i < TSMAX * 8; i += CT) Gs[i] = 0.f;
     if (tid < UPW) hrec[tid] = 0.f;
     if (tid < 48) sc[tid] = 0.f;
@@ -558,7 +574,21 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       h_cp = st_ > 0 ? p.ca[(rowS - 1) * A + u] : 0.f;
     }
   };
+  // history registers -> the LDS images of parity `par`
+  auto store_history = [&](int par, int tid) {
+    float* const qs = par ? qs1 : qs0; float* const al = par ? al1 : al0; float* const acur = par ? acur1 : acur0;
+    float* const da0s = par ? da0s1 : da0s0; float* const p1m = par ? p1m1 : p1m0; float* const p2m = par ? p2m1 : p2m0;
+    float* const gts = par ? gts1 : gts0;
+    if (tid < A) qs[tid] = h_q;
+    if (tid < D1) p1m[tid] = h_p1;
+    if (tid < D2) p2m[tid] = h_p2;
+    if (tid < 256) al[APAD + tid] = h_alp;
+    if (tid >= 256 && tid < 256 + TSMAX) { acur[tid - 256] = h_a; da0s[tid - 256] = h_da0; }
+    if (tid >= 320 && tid < 320 + GC) gts[tid - 320] = h_gt;
+  };
   load_history(p.S - 1, tid_);
+  store_history((p.S - 1) & 1, tid_);
+  float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;              // the cell owners' operands of the current step
   __syncthreads();
 
   for (int st = p.S - 1; st >= 0; --st) {
@@ -567,22 +597,17 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     int tid = tid_;
     asm volatile("" : "+v"(tid));           // see the forward kernel: no loop-invariant address hoisting
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int par = st & 1;
+    float* const qs = par ? qs1 : qs0; float* const al = par ? al1 : al0; float* const acur = par ? acur1 : acur0;
+    float* const da0s = par ? da0s1 : da0s0; float* const p1m = par ? p1m1 : p1m0; float* const p2m = par ? p2m1 : p2m0;
+    float* const gts = par ? gts1 : gts0;
     const long rowS = (long)n * S1 + slot;
 
     stamp(a, p.S - 1 - st, 0);
-    // ---- P0/P1: history of this step (prefetched into registers during the step before) -> LDS; then the loads of
-    //      step s-1 go out and stay in flight
-    {
-      if (tid < A) qs[tid] = h_q;
-      if (tid < D1) p1m[tid] = h_p1;
-      if (tid < D2) p2m[tid] = h_p2;
-      if (tid < 256) al[APAD + tid] = h_alp;
-      if (tid >= 256 && tid < 256 + TSMAX) { acur[tid - 256] = h_a; da0s[tid - 256] = h_da0; }
-      if (tid >= 320 && tid < 320 + GC) gts[tid - 320] = h_gt;
-    }
-    const float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;      // the cell owners' operands of this step
+    // ---- P0/P1: the history images of this step were filled in the middle of the step before; the loads of step
+    //      s-1 go out now and stay in flight until the middle of this step
     if (st > 0) load_history(st - 1, tid);
-    __syncthreads();
+    lds_barrier();
     stamp(a, p.S - 1 - st, 1);
     // ---- P2: dalign of the own positions: thread = (position tid / 16, 16 columns each); then this workgroup's share
     //      of the softmax-backward dot product sum_t align[t] dalign[t] goes out (exchange 1, one granule)
@@ -590,18 +615,20 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       const int tl = tid >> 4, cq = tid & 15;
       float s = 0.f;
       if (tl < tn) {
-        const float* pr = pv_s + tl * D1 + cq * 16;
-        const float* dv = dvec + cq * 16;
+        // columns cq * 4 + 64 i: the 16 lanes of a position read consecutive 16-byte chunks (16 columns in a row per
+        // lane would put every fourth lane on the same banks)
+        const float* pr = pv_s + tl * D1 + cq * 4;
+        const float* dv = dvec + cq * 4;
 #pragma unroll
-        for (int i = 0; i < 16; i += 4) {
-          const float4 x = *(const float4*)(pr + i), y = *(const float4*)(dv + i);
+        for (int i = 0; i < D1 / 4; i += 16) {
+          const float4 x = *(const float4*)(pr + 4 * i), y = *(const float4*)(dv + 4 * i);
           s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
         }
       }
       s = row16_sum(s);
       if (cq == 0 && tl < TSMAX) dav[tl] = tl < tn ? da0s[tl] + s + carry[tl] : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     if (wave == 7) {                         // a wave that takes no part in the energy pass for A = 64 either
       const float d = wave_sum(lane < tn ? acur[lane] * dav[lane] : 0.f);
       if (lane == 0) put_granule(e1 + g, tag, d);
@@ -646,7 +673,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       d = wave_sum(d);
       if (lane == 0) sc[0] = d;
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, p.S - 1 - st, 3);
     if (tid < TSMAX) {
       float de = 0.f;
@@ -656,7 +683,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       }
       dev[tid] = de;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- P4: dq partial of unit u = sum over the positions of de[t] g1[t, u] (a DPP row holds 16 positions, the two
     //      tiles add in-thread), published as exchange 2;  G[t][k] = de[t] * sum over the unit blocks of Z
     if (wave < A / 32) {
@@ -675,7 +702,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       for (int w = 0; w < A / 32; ++w) z += zred[(w * TSMAX + tl) * 8 + k];
       Gs[tid] = (tl < tn && k < p.kw) ? dev[tl] * z : 0.f;
     }
-    __syncthreads();
+    lds_barrier();
     // ---- P5: this workgroup's contributions to the carry of step s-1 (positions t0-half .. t0+ts+kw-half-2)
     float ccv = 0.f;                         // threads < CCN keep their value for the E3 publish
     if (tid < TSMAX + 6) {
@@ -690,9 +717,10 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     // ---- gather E2: dq = sum of the partials
     gather_granules<(CG * A + CT - 1) / CT>(e2, CG * A, tag, gath, tid, a.status, 3);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
-    __syncthreads();
+    lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, p.S - 1 - st, 5);
+    if (st > 0) store_history(par ^ 1, tid);       // step s-1's history: loaded at the top of this step, landed long ago
     if (tid < A) {
       float s = 0.f;
 #pragma unroll
@@ -700,17 +728,17 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       dq_s[tid] = s;
       if (tid / UPW == g) stf((T*)p.dq + rowS * A + tid, s);
     }
-    __syncthreads();
+    lds_barrier();
     // ---- P6: dh of the own units through W_query, then the cell gradient: thread = (unit tid / 16, UL columns each)
     {
       const int j = tid >> 4, uq = tid & 15;
       float s = 0.f;
       if (j < UPW) {
-        const float* wr = wq_s + j * A + uq * UL;
-        const float* dq = dq_s + uq * UL;
+        const float* wr = wq_s + j * A + uq * 4;                // columns uq * 4 + 64 i, as in P2
+        const float* dq = dq_s + uq * 4;
 #pragma unroll
         for (int i = 0; i < UL; i += 4) {
-          const float4 x = *(const float4*)(wr + i), y = *(const float4*)(dq + i);
+          const float4 x = *(const float4*)(wr + 16 * i), y = *(const float4*)(dq + 16 * i);
           s = fmaf(x.x, y.x, s); s = fmaf(x.y, y.y, s); s = fmaf(x.z, y.z, s); s = fmaf(x.w, y.w, s);
         }
       }
@@ -736,7 +764,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
         }
       }
     }
-    __syncthreads();
+    if (st > 0) { o_dhc = h_dhc; o_c = h_c; o_cp = h_cp; }
+    lds_barrier();
     stamp(a, p.S - 1 - st, 6);
     // ---- P7: partial input gradients dga_own . Watt[k, own]^T for every input row k, published with the carry pieces
 #pragma unroll
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       const int pi = tid + CT * jj, qr = pi / K;
       red[pi] = dot_regs<CPQ>(wxr[jj], dgs + qr * CPQ);          // red[qr * K + k], pi = qr * K + k
     }
-    __syncthreads();
+    lds_barrier();
     if (tid < K) {
       float s = 0.f;
 #pragma unroll
@@ -755,7 +784,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     stamp(a, p.S - 1 - st, 7);
     gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4);
     if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
-    __syncthreads();
+    lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, p.S - 1 - st, 8);
     // ---- P8: dp2 (masked), recurrent dh, carry and dcar for the step before
@@ -785,11 +814,11 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       }
       carry[tl] = s;
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a, p.S - 1 - st, 9);
     // ---- P9: dp1 = (dp2 . W2^T) masked: next dvec (every workgroup computes all of it)
     red[tid] = dot_regs<W2K>(w2r, dp2s + (tid / D1) * W2K);
-    __syncthreads();
+    lds_barrier();
     if (tid < D1) {
       float s = 0.f;
 #pragma unroll
@@ -798,7 +827,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       dvec[tid] = s;
       if (tid / (D1 / CG) == g) stf((T*)p.df1 + rowS * D1 + tid, s);
     }
-    __syncthreads();
+    lds_barrier();
   }
 }
 
@@ -896,7 +925,8 @@ template <typename C>
 static size_t bwd_lds_bytes() {
   return sizeof(float) * (C::D1 + C::D2 + C::GC + C::NQ * C::K + C::A + 256 + 2 * APAD + 5 * TSMAX + TSMAX * 8 + 8 * TSMAX * 8 +
                           C::UPW + C::A + C::D1 + C::D2 + C::GC + 48 + CG * C::EMAX + TSMAX * (C::A + KPAD) + TSMAX * C::D1 +
-                          C::UPW * C::A + (KWMAX + 1) * (C::A + KPAD));
+                          C::UPW * C::A + (KWMAX + 1) * (C::A + KPAD) +
+                          C::A + 256 + 2 * APAD + 2 * TSMAX + C::D1 + C::D2 + C::GC);      // second set of history images
 }
 
 template <typename T, typename C>
