@@ -651,7 +651,7 @@ constexpr int SKW = 8;      // waves per workgroup
 constexpr int SKG = 4;      // K chunks in flight per wave
 template <int NT>
 __global__ __launch_bounds__(SKW * 64) void gemm_skinny_kernel(ns_gemm_params p) {
-  __shared__ float red[SKW][32][NT * 16 + 1];
+  __shared__ float red[SKW][32][NT * 16 + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * (NT * 16);
   const bf16_t* A = (const bf16_t*)p.A;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
 // launches are latency bound and a handful of workgroups leaves the load queues of most CUs idle).
 template <int PASSES, int MT, int NC>
 __global__ __launch_bounds__(SKW * 64) void gemm_skinny_f32_kernel(ns_gemm_params p) {
-  __shared__ float red[SKW][16 * MT][17];
+  __shared__ float red[SKW][16 * MT][20];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int n0 = blockIdx.x * NC;
   const int m0 = blockIdx.y * 16 * MT;

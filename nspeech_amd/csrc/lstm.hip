@@ -21,7 +21,7 @@ __device__ __forceinline__ bf16x8 zero8() { return (bf16x8){0, 0, 0, 0, 0, 0, 0,
 template <typename T, bool HALF>
 __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp) {
   constexpr int UPW = HALF ? 8 : 16, RPW = HALF ? 16 : 32, MT = RPW / 16, NTL = UPW / 4;
-  __shared__ float red[LW][RPW][NTL * 16 + 1];
+  __shared__ float red[LW][RPW][NTL * 16 + 4];   // row stride = 4 mod 16 floats: the MFMA C layout writes rows g*4+q from four lane groups, +1 would put them 4 banks apart
   const LstmStep<T>& a = pp.s[blockIdx.z];
   const int tid = threadIdx.x;
   const int u0 = blockIdx.x * UPW;
@@ -233,7 +233,7 @@ template int lstm_step_launch2<bf16_t>(const LstmStepPair<bf16_t>&, hipStream_t)
 template <typename T, bool HALF>
 __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair<T> pp) {
   constexpr int UPW = HALF ? 8 : 16, RPW = HALF ? 16 : 32, MT = RPW / 16;
-  __shared__ float red[LW][RPW][17];
+  __shared__ float red[LW][RPW][20];
   const LstmBwdStep<T>& a = pp.s[blockIdx.z];
   const int tid = threadIdx.x;
   const int u0 = blockIdx.x * UPW;

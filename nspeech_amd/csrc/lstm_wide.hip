@@ -178,7 +178,7 @@ constexpr bool FWD_PROBER = false;          // measured: 5.25 us per step with a
 constexpr int WTF = WT + 128 + (FWD_PROBER ? 64 : 0);
 template <typename T, int PASSES, int NCH>
 __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
-  __shared__ float red[WW][16][33];
+  __shared__ float red[WW][16][36];   // row stride = 4 mod 16 floats: conflict-free for the MFMA C layout's writes (+1 is not)
   __shared__ __attribute__((aligned(16))) T hst[16][8];
   __shared__ int abortf;
   __shared__ unsigned long long pmask[2][2];       // [step parity][producers 0..63, 64..127] published bits (prober wave)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
 constexpr int WTB = WT + 256;
 template <typename T, int NCH, int RPG>
 __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
-  __shared__ float red[WW][16][17];
+  __shared__ float red[WW][16][20];
   __shared__ __attribute__((aligned(16))) bf16_t dst[16][4][16];      // this step's gate gradients (row, gate, unit)
   __shared__ int abortf;
   __shared__ unsigned long long pmask[2][2];
