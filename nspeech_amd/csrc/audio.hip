@@ -281,13 +281,13 @@ __global__ __launch_bounds__(FT) void gl_frame_kernel(GlArgs g) {
 //   pass 1: lane n' holds z[64 n1 + n'], a 16-point DFT over n1 in registers, twiddle W_1024^(n' k1)
 //   one LDS exchange (transpose; the wave's own 8.5 KB, no workgroup barrier: LDS is in order inside a wave)
 //   pass 2: lane (k1, n3) holds the 16 values n2 of n' = 4 n2 + n3, 16-point DFT over n2, twiddle W_64^(n3 k2)
-//   pass 3: the 4-point DFT over n3 runs ACROSS the four lanes of a quad with DPP quad_perm moves
-// which leaves Z[k1 + 16 k2 + 256 k3] in lane (k1, k3), register k2.  An iteration is: overlap-add gather of the
+//   a second LDS exchange brings the four n3 of a (k1, k2) into one lane, pass 3 = a 4-point DFT over n3 in registers
+// which leaves Z[k1 + 16 k2 + 256 k3] in lane (k1, k2 >> 2), register (k2 & 3, k3).  An iteration is: overlap-add gather of the
 // previous iteration's frames (4 neighbours, float2 loads) -> window -> FFT -> Z to LDS in natural order -> every lane
 // takes the bins 64 n1 + n' (what pass 1 of the next transform wants) and their partners M - k: real-input split, unit
-// phase x magnitude, merge -> FFT of conj -> window -> frame out.  3 LDS exchanges and no barrier per iteration where
+// phase x magnitude, merge -> FFT of conj -> window -> frame out.  5 LDS exchanges and no barrier per iteration where
 // the 256-thread kernel above needs 10 barriers; 4 frames per workgroup share the W_1024 table.
-constexpr int GW_PAD = 1088;                 // float2 per wave: 16 rows of 68 (transpose) / 1024 + 8 per 256 (natural)
+constexpr int GW_PAD = 1280;                 // float2 per wave: 16 rows of 68 (transposes) / 1024 + 16 per 64 (natural)
 
 // complex values as packed pairs (re, im): an add is one v_pk_add_f32, a product two packed operations
 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -321,8 +321,8 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // s_waitcnt lgkmcnt(0): LDS is in order inside a wave
   __builtin_amdgcn_wave_barrier();
 }
-// in: lane n' = lane holds z[64 n1 + n'] in x[n1];  out: lane (k1 = lane >> 2, k3 = lane & 3) holds
-// Z[k1 + 16 k2 + 256 k3] in x[k2].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD complex values.
+// in: lane n' = lane holds z[64 n1 + n'] in x[n1];  out: lane (k1 = lane >> 2, k2hi = lane & 3) holds
+// Z[k1 + 16 (4 k2hi + k2lo) + 256 k3] in x[4 k2lo + k3].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD complex values.
 __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* tw, int lane) {
   fft16(x);
 #pragma unroll
@@ -337,20 +337,21 @@ __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* 
   fft16(x);
 #pragma unroll
   for (int k2 = 1; k2 < 16; ++k2) { const v2f w = tw[16 * n3 * k2]; x[k2] = cmulv(x[k2], w.x, w.y); }
-  // 4-point DFT over n3 across the quad: out(k3) = (b0 + s b2) + (-i)^k3 (b1 + s b3), s = (-1)^k3
-  const float sg = (n3 & 1) ? -1.f : 1.f;
-  const float cr = n3 == 0 ? 1.f : (n3 == 2 ? -1.f : 0.f), ci = n3 == 1 ? -1.f : (n3 == 3 ? 1.f : 0.f);
+  // second exchange: the four n3 of a (k1, k2) come together in one lane - lane (k1 = lane >> 2, k2hi = lane & 3) takes
+  // k2 = 4 k2hi + k2lo - and the last radix-4 runs in registers (a DPP quad version of this pass cost 290 VALU
+  // instructions per transform where this costs 40 and two dozen LDS instructions)
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) {
-    const float xr = x[k2].x, xi = x[k2].y;
-    const float b0r = NS_DPP_F(xr, 0x00), b1r = NS_DPP_F(xr, 0x55), b2r = NS_DPP_F(xr, 0xAA), b3r = NS_DPP_F(xr, 0xFF);
-    const float b0i = NS_DPP_F(xi, 0x00), b1i = NS_DPP_F(xi, 0x55), b2i = NS_DPP_F(xi, 0xAA), b3i = NS_DPP_F(xi, 0xFF);
-    const v2f sg2 = {sg, sg};
-    const v2f e = (v2f){b0r, b0i} + sg2 * (v2f){b2r, b2i}, o = (v2f){b1r, b1i} + sg2 * (v2f){b3r, b3i};
-    x[k2] = e + (v2f){cr, cr} * o + (v2f){ci, ci} * (v2f){-o.y, o.x};
-  }
+  for (int k2 = 0; k2 < 16; ++k2) buf[k1l * 68 + k2 * 4 + n3] = x[k2];
+  wave_lds_fence();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) x[q] = buf[k1l * 68 + n3 * 16 + q];          // q = k2lo * 4 + n3'
+  wave_lds_fence();
+#pragma unroll
+  for (int k2lo = 0; k2lo < 4; ++k2lo) fft4(x[4 * k2lo], x[4 * k2lo + 1], x[4 * k2lo + 2], x[4 * k2lo + 3]);
 }
-__device__ __forceinline__ int gw_nat(int k) { return k + 8 * (k >> 8); }    // natural order, conflict-free for the (k1, k3) writers
+// natural order with 16 values of padding per 64: the writers of a transform's output (lane = (k1, k2hi), register
+// (k2lo, k3): k = k1 + 64 k2hi + 16 k2lo + 256 k3) and the readers of the bins 64 n1 + lane both stay (nearly) conflict free
+__device__ __forceinline__ int gw_nat(int k) { return k + 16 * (k >> 6); }
 
 template <bool INIT>
 __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
@@ -423,9 +424,9 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
       z[n1] = v;
     }
     fft1024_wave(z, buf, tw, lane);
-    v2f* nat = buf + ((lane >> 2) + 264 * (lane & 3));         // natural order k + 8 (k >> 8), k = k1 + 16 k2 + 256 k3
+    v2f* nat = buf + ((lane >> 2) + 80 * (lane & 3));          // gw_nat(k1 + 64 k2hi + 16 k2lo + 256 k3)
 #pragma unroll
-    for (int k2 = 0; k2 < 16; ++k2) nat[16 * k2] = z[k2];
+    for (int q = 0; q < 16; ++q) nat[16 * (q >> 2) + 320 * (q & 3)] = z[q];
     wave_lds_fence();
   } else {
     build_table();
@@ -444,7 +445,7 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   }
   // ---- own bins k = 64 n1 + lane with their partners M - k: split -> unit phase x magnitude -> merge; conj(Zt[k]) is
   //      the next transform's input in the pass-1 layout
-  const v2f* own = buf + lane;                                 // Z[k] at own[64 n1 + 8 (n1 >> 2)]
+  const v2f* own = buf + lane;                                 // Z[k] at own[80 n1]
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) {
     const float mk = mkv[n1], mp = mpv[n1];
@@ -453,11 +454,10 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
     if constexpr (INIT) {
       xa = (v2f){mk, 0.f}; xb = (v2f){mp, 0.f};
     } else {
-      const v2f A = own[64 * n1 + 8 * (n1 >> 2)];
+      const v2f A = own[80 * n1];
       // the partner (M - k) & 1023 in the padded natural order; lane 0's partner of bin 64 n1 is bin 64 (16 - n1) (bin 0
-      // for n1 = 0), one pad step further than the other lanes'
-      constexpr int P0[16] = {0, 984, 920, 856, 792, 720, 656, 592, 528, 456, 392, 328, 264, 192, 128, 64};
-      const v2f B = buf[lane == 0 ? P0[n1] : (64 - lane) + 64 * (15 - n1) + 8 * ((15 - n1) >> 2)];
+      // for n1 = 0), one 64-block further than the other lanes'
+      const v2f B = buf[lane == 0 ? (n1 == 0 ? 0 : 80 * (16 - n1)) : (64 - lane) + 80 * (15 - n1)];
       // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
       // (the factor 1/2 drops out of the unit phase).  With s1 = A + conj B, d1 = A - conj B, wd = w d1:
       //   2 X[k] = s1 - i wd = (s1.x + wd.y, s1.y - wd.x);   2 X[M-k] = (s1.x - wd.y, -s1.y - wd.x)
@@ -483,13 +483,14 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   fft1024_wave(z, buf, tw, lane);
   // ---- y[2m] = Re Y[m] / N, y[2m+1] = -Im Y[m] / N, windowed; m = k1 + 16 k2 + 256 k3
   const float invN = 1.f / N;
-  const int m0 = (lane >> 2) + 256 * (lane & 3);
+  const int m0 = (lane >> 2) + 64 * (lane & 3);                // m = k1 + 64 k2hi + 16 k2lo + 256 k3
   v2f* fo = (v2f*)(g.fnext + ((long)n * p.T + t) * p.win) + m0;
   const v2f* wo = (const v2f*)p.window + m0;
   const v2f sc = {invN, -invN};
 #pragma unroll
-  for (int k2 = 0; k2 < 16; ++k2) {
-    if (2 * (m0 + 16 * k2) < p.win) fo[16 * k2] = z[k2] * sc * wo[16 * k2];
+  for (int q = 0; q < 16; ++q) {
+    const int dm = 16 * (q >> 2) + 256 * (q & 3);
+    if (2 * (m0 + dm) < p.win) fo[dm] = z[q] * sc * wo[dm];
   }
 }
 
