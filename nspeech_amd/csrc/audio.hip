@@ -374,15 +374,16 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   const int t = min(traw, p.T - 1);
   float* mag = g.mag + ((long)n * p.T + t) * F;
   v2f z[16];
-  float mkv[16], mpv[16];
-  v2f wv[16];
+  constexpr int NP = 9;                                        // pairs (k, M - k) per lane: k = 64 n1 + lane, n1 < 8; n1 = 8 is lane 0's (512, 512)
+  float mkv[NP], mpv[NP];
+  v2f wv[NP];
   // per-lane base pointers: every access below is base[constant]
   const v2f* tw2l = (const v2f*)p.twiddle + lane;              // exp(-2 pi i k / 2048), k = 64 n1 + lane
   const float* magk = mag + lane;                              // mag[64 n1 + lane]
   const float* magp = mag + (M - lane);                        // mag[M - k] = magp[-64 n1]
   const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) wv[n1] = tw2l[64 * n1];
+  for (int n1 = 0; n1 < NP; ++n1) wv[n1] = tw2l[64 * n1];
   if constexpr (!INIT) {
     // ---- overlap-add gather (the previous iteration's windowed frames) -> window -> z[m] = (x[2m], x[2m+1]).
     //      Sample j of frame t lies in frames t + q0, t + q0 - 1, ... (at most 4: the host checks win <= 4 hop) at
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
       }
     }
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
+    for (int n1 = 0; n1 < NP; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
     build_table();
     if (traw >= p.T) return;
 #pragma unroll
@@ -434,30 +435,31 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
     // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
     const float* sp = p.spec + ((long)n * p.T + t) * F;
 #pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
+    for (int n1 = 0; n1 < NP; ++n1) {
       const int k = 64 * n1 + lane;
       const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
       mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
       mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-      mag[k] = mkv[n1];
-      if (k == 0) mag[M] = mpv[n1];
+      if (n1 < 8 || lane == 0) { mag[k] = mkv[n1]; mag[M - k] = mpv[n1]; }
     }
   }
-  // ---- own bins k = 64 n1 + lane with their partners M - k: split -> unit phase x magnitude -> merge; conj(Zt[k]) is
-  //      the next transform's input in the pass-1 layout
-  const v2f* own = buf + lane;                                 // Z[k] at own[80 n1]
+  // ---- the pairs (k, M - k), k = 64 n1 + lane (n1 < 8; lane 0 also takes (512, 512)): split -> unit phase x magnitude
+  //      -> merge, ONCE per pair for both bins; the two results replace Z[k] and Z[M - k] in the natural-order image
+  //      (no other lane touches those two cells), then every lane reads its pass-1 inputs conj(Zt[64 n1 + lane]).
+  //      With t1 = Xn[k] + conj Xn[M-k], c1 = conj(w) (Xn[k] - conj Xn[M-k]):  conj Zt[k] = conj(t1 + i c1),
+  //      conj Zt[M-k] = t1 - i c1.
 #pragma unroll
-  for (int n1 = 0; n1 < 16; ++n1) {
+  for (int n1 = 0; n1 < NP; ++n1) {
     const float mk = mkv[n1], mp = mpv[n1];
     const v2f w = wv[n1];
+    // natural-order cells of the two bins: gw_nat(k) = 80 n1 + lane; the partner (M - k) & 1023 (bin 0 for k = 0)
+    const int ik = 80 * n1 + lane;
+    const int ip = lane == 0 ? (n1 == 0 ? 0 : 80 * (16 - n1)) : (64 - lane) + 80 * (15 - n1);
     v2f xa, xb;
     if constexpr (INIT) {
       xa = (v2f){mk, 0.f}; xb = (v2f){mp, 0.f};
     } else {
-      const v2f A = own[80 * n1];
-      // the partner (M - k) & 1023 in the padded natural order; lane 0's partner of bin 64 n1 is bin 64 (16 - n1) (bin 0
-      // for n1 = 0), one 64-block further than the other lanes'
-      const v2f B = buf[lane == 0 ? (n1 == 0 ? 0 : 80 * (16 - n1)) : (64 - lane) + 80 * (15 - n1)];
+      const v2f A = buf[ik], B = buf[ip];
       // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
       // (the factor 1/2 drops out of the unit phase).  With s1 = A + conj B, d1 = A - conj B, wd = w d1:
       //   2 X[k] = s1 - i wd = (s1.x + wd.y, s1.y - wd.x);   2 X[M-k] = (s1.x - wd.y, -s1.y - wd.x)
@@ -473,12 +475,17 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
       xa = ea * (v2f){sa, sa};
       xb = eb * (v2f){sb, sb};
     }
-    // Zt[k] = (xa + conj xb) + i conj(w) (xa - conj xb); the next transform takes conj(Zt[k])
     const v2f cxb = {xb.x, -xb.y};
     const v2f t1 = xa + cxb, u1 = xa - cxb;
     const v2f c1 = cmulv(u1, w.x, -w.y);                        // conj(w) u1
-    z[n1] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};
+    if (n1 < 8 || lane == 0) {
+      if (!(n1 == 0 && lane == 0)) buf[ip] = (v2f){t1.x + c1.y, t1.y - c1.x};     // bin M - k (bin M itself does not exist)
+      buf[ik] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};
+    }
   }
+  wave_lds_fence();
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) z[n1] = buf[80 * n1 + lane];
   wave_lds_fence();                                             // every lane has read Z before the buffer is reused
   fft1024_wave(z, buf, tw, lane);
   // ---- y[2m] = Re Y[m] / N, y[2m+1] = -Im Y[m] / N, windowed; m = k1 + 16 k2 + 256 k3
