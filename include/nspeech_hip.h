@@ -500,6 +500,12 @@ typedef struct {
   void* dlogits; int64_t ld_d; int d_dtype;
 } ns_wavenet_ce_params;
 int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t stream);
+/* predict_proba (wavenet_simple.py:436-453): probs fp32 [rows, Q] = softmax of logits [rows, ld] evaluated in float64. */
+typedef struct {
+  const float* logits; int64_t ld; int rows, Q;
+  float* probs;
+} ns_wavenet_softmax_params;
+int ns_wavenet_softmax(const ns_wavenet_softmax_params* p, ns_stream_t stream);
 
 /* Sample-by-sample generation (generate_wavenet.py:56-142): B waveforms, one workgroup each.  ids [B, total] holds
  * n_seed seed codes per waveform (n_seed >= receptive field for results equal to the full network) and receives the

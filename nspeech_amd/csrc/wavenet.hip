@@ -5,6 +5,7 @@
 // never read by a valid output.
 //   ns_wavenet_input      one-hot causal layer as two table look-ups           (wavenet_simple.py:246-252, 385-397)
 //   ns_wavenet_gate       tanh(filter) * sigmoid(gate) and its gradient         (:325)
+//   ns_wavenet_softmax    float64 softmax of logit rows (predict_proba)                  (:436-453)
 //   ns_wavenet_softmax_ce mean softmax cross-entropy against integer targets    (:479-502) and d/dlogits
 //   ns_wavenet_generate   incremental sample-by-sample generation (persistent)  (generate_wavenet.py:56-142)
 #include "common.h"
@@ -159,6 +160,26 @@ extern "C" int ns_wavenet_softmax_ce(const ns_wavenet_ce_params* p, ns_stream_t 
   const unsigned blocks = (unsigned)min((long)1024, (long)((p->rows + 3) / 4));
   hipLaunchKernelGGL(wn_softmax_ce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("wavenet_softmax_ce");
+  return NS_OK;
+}
+
+// ------------------------------------------------------------------ float64 softmax of logit rows (predict_proba)
+// wavenet_simple.py:436-453 casts the last position's logits to float64 before the softmax; one wave per row.
+__global__ __launch_bounds__(64) void wn_softmax_f64_kernel(ns_wavenet_softmax_params p) {
+  const int lane = threadIdx.x;
+  const float* lg = p.logits + (long)blockIdx.x * p.ld;
+  float m = -3.0e38f;
+  for (int c = lane; c < p.Q; c += 64) m = fmaxf(m, lg[c]);
+  m = wave_max(m);
+  double se = 0.0;
+  for (int c = lane; c < p.Q; c += 64) se += exp((double)lg[c] - (double)m);
+  for (int o = 32; o; o >>= 1) se += __shfl_xor(se, o, 64);
+  for (int c = lane; c < p.Q; c += 64) p.probs[(long)blockIdx.x * p.Q + c] = (float)(exp((double)lg[c] - (double)m) / se);
+}
+extern "C" int ns_wavenet_softmax(const ns_wavenet_softmax_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->logits && p->probs && p->rows > 0 && p->Q > 0 && p->ld >= p->Q, "ns_wavenet_softmax: bad arguments");
+  hipLaunchKernelGGL(wn_softmax_f64_kernel, dim3(p->rows), dim3(64), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("wavenet_softmax");
   return NS_OK;
 }
 

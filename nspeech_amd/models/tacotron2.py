@@ -15,6 +15,7 @@ MI355X-first restructuring of the training step (results identical to the refere
   * every weight gradient is a hoisted GEMM over all time steps.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -93,6 +94,10 @@ class Tacotron2(object):
         self._sig = None
         self.timing = None
         self.reducer = None       # parallel.GradReducer when data-parallel
+        self._side = None         # second HIP stream for deferred weight gradients (created on first use)
+        self._deferred = []
+        self._side_groups = set()
+        self._side_busy = False
         self.use_pv = True        # projected-memory form of the attention loop (ns_taco2_attn_params.pv)
         self._status_words = {}
         pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
@@ -254,9 +259,66 @@ class Tacotron2(object):
     _BUCKET_AFTER = {"expand_conv_bwd": "head", "postnet_bwd": "postnet", "attn_wgrad": "decoder",
                      "encoder_bwd": "encoder"}
 
+    # Weight gradients feed nothing before the optimiser, so they run on a second stream:
+    #  * eager ones (convolutions, expand BiLSTM) start as soon as their operands are final and share the chip with the
+    #    main stream's BatchNorm-backward passes (HBM-bound) and data-gradient products;
+    #  * queued ones (decoder LSTMs, attention RNN: their operands stay untouched for the rest of the backward pass) go
+    #    out when the encoder BiLSTM's per-step launches begin - the one stretch of the step that leaves most CUs idle
+    #    (<= 64 small workgroups per launch).  Between the persistent decoder recurrences they would gain nothing: those
+    #    kernels' workgroups hold the whole register file of every CU (494 - 504 of 512 VGPRs per SIMD lane), a GEMM
+    #    workgroup cannot sit beside them.
+    overlap_wgrads = os.environ.get("NS_OVERLAP_WGRADS", "1") != "0"
+
+    def _side_stream(self):
+        """The second stream, made to wait for everything enqueued on the main stream so far."""
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        self._side.wait_event(ev)
+        self._side_busy = True
+        return self._side
+
+    def _defer(self, group, fn, eager=False):
+        """Run fn in line, or - with overlap_wgrads - on the second stream: now (eager) or at _flush_deferred.  group =
+        the gradient bucket (parallel.bucket_ranges) the call writes into: its release to the reducer follows the call
+        onto that stream.  The caller guarantees that nothing overwrites fn's operands before _join_deferred."""
+        if not (self.overlap_wgrads and self.device.type == "cuda"):
+            fn()
+        elif eager:
+            self._side_groups.add(group)
+            with torch.cuda.stream(self._side_stream()):
+                fn()
+        else:
+            self._deferred.append((group, fn))
+
+    def _flush_deferred(self):
+        if not self._deferred:
+            return
+        calls, self._deferred = self._deferred, []
+        with torch.cuda.stream(self._side_stream()):
+            for _, fn in calls:
+                fn()
+
+    def _join_deferred(self):
+        self._flush_deferred()
+        if self._side_busy:
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            torch.cuda.current_stream(self.device).wait_event(ev)
+            self._side_busy = False
+        self._side_groups = set()
+
     def _tick(self, label):
         if self.reducer is not None and label in self._BUCKET_AFTER:
-            self.reducer.bucket_ready(self._BUCKET_AFTER[label])   # gradients of this group are final
+            name = self._BUCKET_AFTER[label]                       # gradients of this group are final ...
+            if any(grp == name for grp, _ in self._deferred):      # ... once its queued weight gradients have run
+                self._deferred.append((name, lambda: self.reducer.bucket_ready(name)))
+            elif name in self._side_groups:                        # ... or the ones already on the second stream
+                with torch.cuda.stream(self._side_stream()):
+                    self.reducer.bucket_ready(name)
+            else:
+                self.reducer.bucket_ready(name)
         if self.timing is not None:
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -377,8 +439,9 @@ class Tacotron2(object):
         return (yh, yl) if emit_split else y
 
     def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False,
-                  D=None):
-        """Backward of _conv_fwd.  dy fp32 [rows,cout] -> grads in flat_g, dx fp32 [rows,cin]."""
+                  D=None, defer=None):
+        """Backward of _conv_fwd.  dy fp32 [rows,cout] -> grads in flat_g, dx fp32 [rows,cin].  defer = bucket name: the
+        weight gradient goes through _defer, on operand buffers of this layer's own."""
         kl = (k - 1) // 2
         kr = k - 1 - kl
         rows = N * Pp
@@ -389,12 +452,13 @@ class Tacotron2(object):
         # layer input in bf16 instead (half the bytes, the bf16 kernels, the 256-tile data-gradient kernel)
         w16 = self._bf16_w(D)
         Dg = torch.bfloat16 if w16 is not None else D
-        dpre = self._buf("dpre_%d" % cout, rows * cout, Dg)
+        own = "_" + tag if (defer and self.overlap_wgrads) else ""
+        dpre = self._buf("dpre_%d%s" % (cout, own), rows * cout, Dg)
         if isinstance(xin, tuple):          # pre-split layer input (mixed mode): its high part IS the bf16 copy
             assert w16 is not None
             xin = xin[0]
         elif w16 is not None:
-            x16 = self._buf("xin16_%d" % cin, rows * cin, torch.bfloat16)
+            x16 = self._buf("xin16_%d%s" % (cin, own), rows * cin, torch.bfloat16)
             ops.cast2d(xin, rows, cin, cin, x16, cin, False)
             xin = x16
         work = self._buf("bn_work", 64 * max(2048, cout), torch.float32)
@@ -408,9 +472,14 @@ class Tacotron2(object):
         # weight gradient: dW[(k,ci),co] += sum_rows X[row+k, ci] * dpre[row, co]
         a_rows = self.padl - kl
         Mg = rows - (k - 1) - a_rows
-        ops.gemm(xin, dpre, g, k * cin, cout, Mg, cin, cout, cout, a_mode=1, b_mode=1,
-                 a_off=a_rows * cin, b_off=self.padl * cout, c_off=self._o(scope + "/conv1d/kernel"),
-                 accumulate=2, split_k=self._splitk(Mg, k * cin, cout))
+        def wgrad():
+            ops.gemm(xin, dpre, g, k * cin, cout, Mg, cin, cout, cout, a_mode=1, b_mode=1,
+                     a_off=a_rows * cin, b_off=self.padl * cout, c_off=self._o(scope + "/conv1d/kernel"),
+                     accumulate=2, split_k=self._splitk(Mg, k * cin, cout))
+        if defer:
+            self._defer(defer, wgrad, eager=True)
+        else:
+            wgrad()
         if need_dx:
             a2 = self.padl - kr
             Mg2 = rows - (k - 1) - a2
@@ -495,7 +564,7 @@ class Tacotron2(object):
             if v != 0:
                 raise RuntimeError("persistent LSTM kernel %s timed out (status %d)" % (key, v))
 
-    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None):
+    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None, defer=None):
         """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients."""
         rows = N * Pp
         D = D or self.T
@@ -520,18 +589,24 @@ class Tacotron2(object):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             ko = self._o(kname)
             dg = self._bufs["%s_dg_%s" % (tag, d)]
-            # dWx += X^T dgates ; dWh += Hprev^T dgates ; db += colsum
-            ops.gemm(x, dg, g, cin, 4 * H, rows, cin, 4 * H, 4 * H, a_mode=1, b_mode=1, c_off=ko, accumulate=2,
-                     split_k=self._splitk(rows, cin, 4 * H))
-            if d == "fw":   # h_prev(row) = h(row-1)
-                ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
-                         a_off=di * H, b_off=4 * H, c_off=ko + cin * 4 * H, accumulate=2,
-                         split_k=self._splitk(rows, H, 4 * H))
-            else:           # h_prev(row) = h(row+1)
-                ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
-                         a_off=2 * H + di * H, b_off=0, c_off=ko + cin * 4 * H, accumulate=2,
-                         split_k=self._splitk(rows, H, 4 * H))
-            ops.colsum(dg, 4 * H, rows, 4 * H, g, out_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
+
+            def wgrads(d=d, di=di, ko=ko, dg=dg):
+                # dWx += X^T dgates ; dWh += Hprev^T dgates ; db += colsum
+                ops.gemm(x, dg, g, cin, 4 * H, rows, cin, 4 * H, 4 * H, a_mode=1, b_mode=1, c_off=ko, accumulate=2,
+                         split_k=self._splitk(rows, cin, 4 * H))
+                if d == "fw":   # h_prev(row) = h(row-1)
+                    ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
+                             a_off=di * H, b_off=4 * H, c_off=ko + cin * 4 * H, accumulate=2,
+                             split_k=self._splitk(rows, H, 4 * H))
+                else:           # h_prev(row) = h(row+1)
+                    ops.gemm(hbuf, dg, g, H, 4 * H, rows - 1, 2 * H, 4 * H, 4 * H, a_mode=1, b_mode=1,
+                             a_off=2 * H + di * H, b_off=0, c_off=ko + cin * 4 * H, accumulate=2,
+                             split_k=self._splitk(rows, H, 4 * H))
+                ops.colsum(dg, 4 * H, rows, 4 * H, g, out_off=self._o("%s/%s/lstm_cell/bias" % (scope, d)))
+            if defer:       # x, the state history and the gate gradients are this layer's own buffers
+                self._defer(defer, wgrads, eager=True)
+            else:
+                wgrads()
             # dx (+)= dgates . Wx^T
             ops.gemm(dg, self._W(D), dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
                      accumulate=0 if di == 0 else 1)
@@ -769,6 +844,7 @@ class Tacotron2(object):
         g = self.flat_g
         g.zero_()
         self.scal.zero_()
+        self._deferred = []
         B = self._bufs
         ops.F32_PASSES = self.passes_bwd
         Tx = self.Tx
@@ -801,7 +877,8 @@ class Tacotron2(object):
         Cx = hp.expand_conv_channels
         dx = self._buf("d_act_a", rows_o * 512, torch.float32)
         dx2 = self._buf("d_act_b", rows_o * 512, torch.float32)
-        self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx, D=Tx)
+        self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx, D=Tx,
+                         defer="head")
         self._tick("expand_lstm_bwd")
         cur, nxt = dx, dx2
         for i in range(hp.expand_conv_layers - 1, -1, -1):
@@ -809,10 +886,10 @@ class Tacotron2(object):
             cin = M if i == 0 else Cx
             if i == 0:   # gradient lands on mel_outputs, on top of the mel-loss gradient
                 self._conv_bwd("expand/conv_0", self._exp_in[0], cur, cin, Cx, hp.expand_conv_width, act, N, To, Po,
-                               "exp0", dmel, dx_accumulate=True, D=Tx)
+                               "exp0", dmel, dx_accumulate=True, D=Tx, defer="head")
             else:
                 self._conv_bwd("expand/conv_%d" % i, self._exp_in[i], cur, cin, Cx, hp.expand_conv_width, act, N, To,
-                               Po, "exp%d" % i, nxt, D=Tx)
+                               Po, "exp%d" % i, nxt, D=Tx, defer="head")
                 cur, nxt = nxt, cur
         self._tick("expand_conv_bwd")
         # ---- postnet: mel = dec + dense(postnet(dec))
@@ -830,10 +907,11 @@ class Tacotron2(object):
             cin = M if i == 0 else Cp
             if i == 0:   # accumulate into dmel: total gradient wrt decoder_outputs
                 self._conv_bwd("decoder_postnet/postnet_conv_0", self._post_in[0], cur, cin, Cp,
-                               hp.postnet_conv_width, act, N, To, Po, "post0", dmel, dx_accumulate=True)
+                               hp.postnet_conv_width, act, N, To, Po, "post0", dmel, dx_accumulate=True,
+                               defer="postnet")
             else:
                 self._conv_bwd("decoder_postnet/postnet_conv_%d" % i, self._post_in[i], cur, cin, Cp,
-                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, nxt)
+                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, nxt, defer="postnet")
                 cur, nxt = nxt, cur
         self._tick("postnet_bwd")
         # ---- decoder output projection (grad wrt decoder_outputs sits in dmel, padded layout)
@@ -868,7 +946,8 @@ class Tacotron2(object):
             ops.cast2d(src, rows, cols, cols, dst, cols, False)
             return dst
         h1b, h2b = b16("dec_h1_16", h1, D), b16("dec_h2_16", h2, D)
-        self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2, "decoder/lstm_2/bias")
+        self._defer("decoder", lambda: self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2,
+                                                         "decoder/lstm_2/bias"))
         dh1 = self._buf("d_h1", rows * D, torch.float32)
         if dg2b is not None:
             ops.gemm(dg2b, w16, dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
@@ -883,8 +962,9 @@ class Tacotron2(object):
                        dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
         self._tick("dec_lstm_bwd:loop1")
         dg1b = self._bufs.get("d_g1b") if w16 is not None else None
-        self._lstm_wgrads(b16("dec_hc_16", hc, A + E), A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1,
-                          "decoder/lstm_1/bias")
+        hcb = b16("dec_hc_16", hc, A + E)
+        self._defer("decoder", lambda: self._lstm_wgrads(hcb, A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1,
+                                                         "decoder/lstm_1/bias"))
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
         if dg1b is not None:
             ops.gemm(dg1b, w16, dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
@@ -938,23 +1018,26 @@ class Tacotron2(object):
         # hoisted weight gradients of the attention RNN
         p1, xa, fr = B["dec_p1"], B["dec_xa"], B["dec_fr"]
         sk = self._splitk
-        ops.gemm(fr, df1, g, M, 256, rows, M, 256, 256, a_mode=1, b_mode=1, c_off=w1, accumulate=2,
-                 split_k=sk(rows, M, 256))
-        # ctx part: ctx of slot s pairs with df1 of slot s+1
-        ops.gemm(hc, df1, g, E, 256, rows - 1, A + E, 256, 256, a_mode=1, b_mode=1, a_off=A, b_off=256,
-                 c_off=w1 + M * 256, accumulate=2, split_k=sk(rows, E, 256))
-        ops.colsum(df1, 256, rows, 256, g, out_off=self._o("decoder/decoder_prenet/dense_1/bias"))
-        ops.gemm(p1, dp2, g, 256, 128, rows, 256, 128, 128, a_mode=1, b_mode=1, c_off=w2, accumulate=2,
-                 split_k=sk(rows, 256, 128))
-        ops.colsum(dp2, 128, rows, 128, g, out_off=self._o("decoder/decoder_prenet/dense_2/bias"))
         XA = 128 + self.Dsp + A
-        ops.gemm(xa, dga, g, XA, 4 * A, rows, XA, 4 * A, 4 * A, a_mode=1, b_mode=1, c_off=wa, accumulate=2,
-                 split_k=sk(rows, XA, 4 * A))
-        ops.colsum(dga, 4 * A, rows, 4 * A, g, out_off=self._o("decoder/attention_lstm/bias"))
+
+        def attn_wgrads():      # operands: forward activations and the attention backward's own outputs, all left alone
+            ops.gemm(fr, df1, g, M, 256, rows, M, 256, 256, a_mode=1, b_mode=1, c_off=w1, accumulate=2,
+                     split_k=sk(rows, M, 256))
+            # ctx part: ctx of slot s pairs with df1 of slot s+1
+            ops.gemm(hc, df1, g, E, 256, rows - 1, A + E, 256, 256, a_mode=1, b_mode=1, a_off=A, b_off=256,
+                     c_off=w1 + M * 256, accumulate=2, split_k=sk(rows, E, 256))
+            ops.colsum(df1, 256, rows, 256, g, out_off=self._o("decoder/decoder_prenet/dense_1/bias"))
+            ops.gemm(p1, dp2, g, 256, 128, rows, 256, 128, 128, a_mode=1, b_mode=1, c_off=w2, accumulate=2,
+                     split_k=sk(rows, 256, 128))
+            ops.colsum(dp2, 128, rows, 128, g, out_off=self._o("decoder/decoder_prenet/dense_2/bias"))
+            ops.gemm(xa, dga, g, XA, 4 * A, rows, XA, 4 * A, 4 * A, a_mode=1, b_mode=1, c_off=wa, accumulate=2,
+                     split_k=sk(rows, XA, 4 * A))
+            ops.colsum(dga, 4 * A, rows, 4 * A, g, out_off=self._o("decoder/attention_lstm/bias"))
+            ops.gemm(hc, dq, g, A, A, rows, A + E, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2,
+                     split_k=sk(rows, A, A))
+        self._defer("decoder", attn_wgrads)
         if self.Dsp:
             self._speaker_bwd(dga, N, S1)
-        ops.gemm(hc, dq, g, A, A, rows, A + E, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2,
-                 split_k=sk(rows, A, A))
         # unfold dWcl[k,u] into location_conv [7,1,20] and location_layer [20,A]   (fp32, tiny)
         oc = self._o("decoder/attention/location_conv/kernel")
         ol = self._o("decoder/attention/location_layer/kernel")
@@ -969,24 +1052,28 @@ class Tacotron2(object):
                  split_k=sk(N * Pi, E, A))
         ops.gemm(dkeys_t, self._W(self.T), dvalues, N * Pi, E, A, A, A, E, a_mode=0, b_mode=0, b_off=om, accumulate=1)
         self._tick("attn_wgrad")
-        # ---- encoder
+        # ---- encoder; the queued weight gradients run beside it on the second stream
+        self._flush_deferred()
         He = hp.encoder_lstm_units
         Ce = hp.encoder_conv_channels
         rows_i = N * Pi
         ea = self._buf("d_enc_a", rows_i * max(Ce, hp.embedding_dim), torch.float32)
         eb = self._buf("d_enc_b", rows_i * max(Ce, hp.embedding_dim), torch.float32)
         self._bilstm_bwd("encoder/encoder_lstm", self._enc_in[-1], dvalues, Ce, He, N, Ti, Pi, self.input_lengths,
-                         "encl", ea)
+                         "encl", ea, defer="encoder")
         cur, nxt = ea, eb
         for i in range(hp.encoder_conv_layers - 1, -1, -1):
             act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
             cin = hp.embedding_dim if i == 0 else Ce
             self._conv_bwd("encoder/conv_%d" % i, self._enc_in[i], cur, cin, Ce, hp.encoder_conv_width, act, N, Ti, Pi,
-                           "enc%d" % i, nxt)
+                           "enc%d" % i, nxt, defer="encoder")
             cur, nxt = nxt, cur
         ops.embedding_bwd(self.inputs, cur, g, N, Ti, Pi, self.padl, hp.embedding_dim, self.vocab,
                           dtable_off=self._o("embedding/embedding"))
         self._tick("encoder_bwd")
+        self._join_deferred()
+        if self.timing is not None:
+            self._tick("wgrad_join")
 
     def _lstm_wgrads(self, x, ldx, h, H, dg, rows, koff, bias_name):
         """dWx += X^T dg, dWh += Hprev^T dg (slot layout: h_prev(row) = h(row-1)), db += colsum(dg)."""

@@ -367,8 +367,9 @@ class SimpleWaveNet(object):
         """wavenet_simple.py:436-453: float64 softmax of the last position's logits for one waveform of ids."""
         ids = torch.as_tensor(np.asarray(waveform_ids, np.int32)).to(self.device).view(1, -1).contiguous()
         logits, ow = self._forward(ids, 1, ids.shape[1], keep=False)
-        last = logits[(ow - 1) * self.Q: ow * self.Q].double()
-        return torch.softmax(last, dim=0).float()
+        probs = torch.empty(self.Q, dtype=torch.float32, device=self.device)
+        ops.wavenet_softmax(logits, self.Q, 1, self.Q, probs, logits_off=(ow - 1) * self.Q)
+        return probs
 
     def generate(self, seed_ids, n_samples, uniforms=None, seed=0, exact=None, fast=True, engine=None):
         """Incremental generation (generate_wavenet.py:56-142): seed_ids int [B, n_seed] (or [n_seed]) of mu-law codes,

@@ -376,6 +376,12 @@ def wavenet_softmax_ce(logits, ld, targets, rows, Q, scale, loss_acc, acc_off=0,
     L.call("ns_wavenet_softmax_ce", p, stream())
 
 
+def wavenet_softmax(logits, ld, rows, Q, probs, logits_off=0):
+    p = L.struct("ns_wavenet_softmax_params")
+    _fill(p, logits=ptr(logits, logits_off), ld=ld, rows=rows, Q=Q, probs=ptr(probs))
+    L.call("ns_wavenet_softmax", p, stream())
+
+
 def wavenet_generate(weights, offs, dilations, L_, R, Dc, S, Q, B, n_seed, total, queue_rows, ids, uniform, queues, probs=None,
                      fgT=None, deT=None, engine=0):
     p = L.struct("ns_wavenet_generate_params")

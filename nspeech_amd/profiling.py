@@ -54,12 +54,16 @@ def roofline(model, one_step):
         rec.append((2.0 * M * N * K * nb, e0, e1, passes,
                     (a_unique + float(K * N)) * esz * nb + float(M * N) * Cm.element_size() * nb, _last_kernel()))
 
+    # every product is timed running alone: the training step proper runs some weight gradients on a second stream
+    # beside the encoder BiLSTM (Tacotron2.overlap_wgrads), where a launch's duration is not the kernel's own
+    overlap, model.overlap_wgrads = getattr(model, "overlap_wgrads", False), False
     ops.gemm = timed
     try:
         one_step()
         torch.cuda.synchronize()
     finally:
         ops.gemm = orig
+        model.overlap_wgrads = overlap
     if not rec:
         return None
     flops = sum(r[0] for r in rec)                 # algorithmic (one product per multiply-add)

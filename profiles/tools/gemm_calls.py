@@ -18,6 +18,7 @@ def main():
     m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=1234)
     inputs, lengths, mel, lin = bench.synthetic_batch(hp, 32, 160, 1000, 1234)
     m.add_optimizer(0)
+    m.overlap_wgrads = False        # every product timed running alone
 
     def step():
         m.initialize(inputs, lengths, None, mel, lin)

@@ -306,6 +306,37 @@ def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
         assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
 
 
+@pytest.mark.parametrize("size", ["small", "full"])
+def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
+    """The decoder / attention / postnet weight gradients that run on a second stream beside the encoder BiLSTM
+    (Tacotron2.overlap_wgrads) equal the ones launched in line, up to the rounding of the split-K atomic sums - at the
+    benchmark shape too, where a buffer reused too early would show."""
+    from nspeech_amd import hparams as hparams_mod
+    if size == "small":
+        hp, (N, Ti, To) = small_hparams(), (6, 30, 60)
+    else:
+        hp, (N, Ti, To) = hparams_mod.load("taco2"), (32, 160, 1000)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=17)
+    m = _model(hp, "mixed", seed=7)
+    gs = []
+    for overlap in (False, True, True):
+        m.overlap_wgrads = overlap
+        m.initialize(inputs, lengths, None, mel, lin)
+        m.backward()
+        torch.cuda.synchronize()
+        assert not m._deferred
+        gs.append(m.flat_g.double().clone())
+    assert m._side is not None           # the second stream was really used
+    for g1 in gs[1:]:
+        for name, (off, shape) in m.layout.entries.items():
+            if name.endswith("conv1d/bias"):
+                continue
+            n = int(np.prod(shape))
+            d = (gs[0][off:off + n] - g1[off:off + n]).abs().max().item()
+            sc = gs[0][off:off + n].abs().max().item()
+            assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
+
+
 def test_model_audio_is_griffin_lim_of_the_linear_outputs(dev):
     """tacotron.py:107 / train.py:100-102: model.audio[0] is the in-graph Griffin-Lim of linear_outputs[0]."""
     from nspeech_amd.utils import audio as A
