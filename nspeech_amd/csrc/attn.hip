@@ -440,9 +440,17 @@ __global__ __launch_bounds__(ATHREADS) void attn_bwd_dq_kernel(AttnBwdStep<T> a)
 // Hoisted part of the attention backward: sums over all decoder steps that no recurrence needs.
 //   dkeys[t,u] = sum_s dpre_s[t,u],  dv[u] = sum_{s,t} de_s[t] th_s[t,u],
 //   dWcl[k,u]  = sum_{s,t} align_{s-1}[t+k-half] dpre_s[t,u]
-// One wave = 64 memory positions x PU units, looping over the S steps with everything in
-// registers (th is recomputed; nothing is read-modify-written in memory).
-constexpr int PU = 8;
+// One wave = 64 memory positions x PU units, looping over the S steps with everything in registers (th is recomputed;
+// nothing is read-modify-written in memory).  The per-step operands - a 64 + kw - 1 wide window of the previous
+// alignments and 64 energy gradients, shared by the four waves of the workgroup - come through LDS in blocks of
+// POST_SB steps: the next block's global loads are in flight while this block is computed (a register prefetch one
+// step ahead did not cover the load latency with three waves per SIMD: 515 us per call, 0.16 ms of arithmetic); the
+// query row (one address per wave) comes through scalar loads.
+constexpr int PU = 4;
+constexpr int POST_SB = 8;                       // steps per staged block
+constexpr int POST_AW = 64 + MAXKW;              // alignment window floats per step (64 + kw - 1 used)
+constexpr int POST_ROW = POST_AW + 64;           // + energy gradients
+constexpr int POST_PT = (POST_SB * POST_ROW + 255) / 256;   // staged values per thread
 struct AttnPost {
   int S, Ti, A, kw, Tia;
   const int* lengths;
@@ -454,28 +462,31 @@ struct AttnPost {
   float* dkeys_t;          // [N,A,Tia] out (plain store)
   float* dv; float* dwcl;  // +=
 };
+template <int KW>          // KW = the filter width when it is the usual 7 (straight-line step), 0 = a.kw at run time
 __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
   __shared__ __attribute__((aligned(8))) float wl[4][(1 + MAXKW) * PU];
+  __shared__ float stg[2][POST_SB][POST_ROW];
   const int n = blockIdx.z, tc = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int u0 = (blockIdx.y * 4 + wave) * PU;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int u0 = (blockIdx.y * 4 + wave) * PU;       // wave-uniform: the query row below comes through scalar loads
   const int t = tc * 64 + lane;
   const int Ti = a.Ti, A = a.A, Tia = a.Tia, S1 = a.S + 1;
   const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
-  const int half = (a.kw - 1) / 2;
-  if (u0 < A) {
+  const int kw = KW ? KW : a.kw;
+  const int half = (kw - 1) / 2;
+  const bool wave_on = u0 < A;                       // idle waves still stage and meet the barriers
+  if (wave_on) {
     for (int i = lane; i < (1 + MAXKW) * PU; i += 64) {
       const int j = i % PU, k = i / PU;   // k = 0: v, k >= 1: wcl[k-1]
       float val = 0.f;
       if (u0 + j < A) {
         if (k == 0) val = a.v[u0 + j];
-        else if (k - 1 < a.kw) val = a.wcl[(k - 1) * A + u0 + j];
+        else if (k - 1 < kw) val = a.wcl[(k - 1) * A + u0 + j];
       }
       wl[wave][i] = val;
     }
   }
-  __syncthreads();
-  if (u0 >= A) return;
   const bool act = t < L;
   // units in pairs: the multiply-adds of the location filter and of its gradient run as v_pk_fma_f32
   typedef float f2 __attribute__((ext_vector_type(2)));
@@ -483,62 +494,118 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
   f2 kv[PP], dk[PP], dvp[PP], dwp[MAXKW][PP];
 #pragma unroll
   for (int j = 0; j < PP; ++j) {
-    kv[j].x = (act && u0 + 2 * j < A) ? a.keys_t[((long)n * A + u0 + 2 * j) * Tia + t] : 0.f;
-    kv[j].y = (act && u0 + 2 * j + 1 < A) ? a.keys_t[((long)n * A + u0 + 2 * j + 1) * Tia + t] : 0.f;
+    kv[j].x = (wave_on && act && u0 + 2 * j < A) ? a.keys_t[((long)n * A + u0 + 2 * j) * Tia + t] : 0.f;
+    kv[j].y = (wave_on && act && u0 + 2 * j + 1 < A) ? a.keys_t[((long)n * A + u0 + 2 * j + 1) * Tia + t] : 0.f;
     dk[j] = (f2){0.f, 0.f}; dvp[j] = (f2){0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < MAXKW; ++k) dwp[k][j] = (f2){0.f, 0.f};
   }
   const float* alb = a.align + (long)n * S1 * Tia;
   const float* deb = a.de + (long)n * S1 * Tia;
-  const float* qb = a.q + (long)n * S1 * A + u0;
+  const float* qb = a.q + (long)n * S1 * A + (wave_on ? u0 : 0);
   const f2* wl2 = (const f2*)wl[wave];            // [(1 + MAXKW)][PP] pairs: row 0 = v, row 1 + k = wcl[k]
-  // one-step-ahead register prefetch of the per-step operands
-  float apn[MAXKW], den;
-  auto fetch = [&](int slot, float* apo, float& deo) {
+
+  // this thread's share of a staged block: POST_PT values, the same (step-in-block, column) every block
+  const float* src[POST_PT];
+  int sstep[POST_PT];
+  bool sok[POST_PT];
 #pragma unroll
-    for (int k = 0; k < MAXKW; ++k) {
-      const int tt = t + k - half;
-      apo[k] = (k < a.kw && tt >= 0 && tt < Ti) ? alb[(long)(slot - 1) * Tia + tt] : 0.f;
-    }
-    deo = act ? deb[(long)slot * Tia + t] : 0.f;
-  };
-  fetch(1, apn, den);
-  for (int slot = 1; slot <= a.S; ++slot) {
-    float apv[MAXKW], de = den;
-#pragma unroll
-    for (int k = 0; k < MAXKW; ++k) apv[k] = apn[k];
-    if (slot < a.S) fetch(slot + 1, apn, den);
-    const f2* qs = (const f2*)(qb + (long)slot * A);
-    const f2 de2 = (f2){de, de};
-#pragma unroll
-    for (int j = 0; j < PP; ++j) {
-      f2 x = kv[j] + qs[j];
-#pragma unroll
-      for (int k = 0; k < MAXKW; ++k)
-        if (k < a.kw) x = (f2){apv[k], apv[k]} * wl2[(1 + k) * PP + j] + x;
-      f2 th;
-      th.x = tanhf_(x.x);
-      th.y = tanhf_(x.y);
-      const f2 dpre = de2 * wl2[j] * ((f2){1.f, 1.f} - th * th);
-      dk[j] += dpre;
-      dvp[j] = de2 * th + dvp[j];
-#pragma unroll
-      for (int k = 0; k < MAXKW; ++k)
-        if (k < a.kw) dwp[k][j] = (f2){apv[k], apv[k]} * dpre + dwp[k][j];
+  for (int i = 0; i < POST_PT; ++i) {
+    const int idx = tid + 256 * i;
+    const int si = idx / POST_ROW, r = idx % POST_ROW;
+    sstep[i] = si;
+    if (r < POST_AW) {                      // align_{slot-1}[tc*64 - half + r]
+      const int tt = tc * 64 - half + r;
+      sok[i] = idx < POST_SB * POST_ROW && r < 64 + kw - 1 && tt >= 0 && tt < Ti;
+      src[i] = alb + (long)(si - 1) * Tia + min(max(tt, 0), Ti - 1);
+    } else {                                // de_slot[tc*64 + r - POST_AW]
+      const int t2 = tc * 64 + r - POST_AW;
+      sok[i] = idx < POST_SB * POST_ROW && t2 < L;
+      src[i] = deb + (long)si * Tia + min(t2, Tia - 1);
     }
   }
+  float sv[POST_PT];
+  auto gload = [&](int s0) {               // slots s0 .. s0 + POST_SB - 1
+#pragma unroll
+    for (int i = 0; i < POST_PT; ++i) {
+      const bool ok = sok[i] && s0 + sstep[i] <= a.S;
+      const float* pp = ok ? src[i] + (long)s0 * Tia : alb;        // never dereference an address outside the arrays
+      sv[i] = *pp;
+      sv[i] = ok ? sv[i] : 0.f;
+    }
+  };
+  auto sstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < POST_PT; ++i) {
+      const int idx = tid + 256 * i;
+      if (idx < POST_SB * POST_ROW) (&stg[buf][0][0])[idx] = sv[i];
+    }
+  };
+  // slot 1 is the first step; src[] was built for si - 1 / si relative to s0, and slot s0 + si - 1 >= 0 always holds
+  gload(1);
+  sstore(0);
+  __syncthreads();
+  f2 qn[PP];
+  {
+    const f2* qs = (const f2*)(qb + (long)1 * A);
+#pragma unroll
+    for (int j = 0; j < PP; ++j) qn[j] = qs[j];
+  }
+  int buf = 0;
+  for (int s0 = 1; s0 <= a.S; s0 += POST_SB, buf ^= 1) {
+    if (s0 + POST_SB <= a.S) gload(s0 + POST_SB);           // in flight during this block's arithmetic
+    if (wave_on) {
+#pragma unroll
+      for (int si = 0; si < POST_SB; ++si) {
+        const int slot = s0 + si;
+        if (slot <= a.S) {
+          float apv[MAXKW];
+#pragma unroll
+          for (int k = 0; k < MAXKW; ++k) apv[k] = (KW ? k < KW : k < kw) ? stg[buf][si][lane + k] : 0.f;
+          const float de = stg[buf][si][POST_AW + lane];
+          f2 qv[PP];
+#pragma unroll
+          for (int j = 0; j < PP; ++j) qv[j] = qn[j];
+          {
+            const f2* qs = (const f2*)(qb + (long)min(slot + 1, a.S) * A);
+#pragma unroll
+            for (int j = 0; j < PP; ++j) qn[j] = qs[j];
+          }
+          const f2 de2 = (f2){de, de};
+#pragma unroll
+          for (int j = 0; j < PP; ++j) {
+            f2 x = kv[j] + qv[j];
+#pragma unroll
+            for (int k = 0; k < MAXKW; ++k)
+              if (KW ? k < KW : k < kw) x = (f2){apv[k], apv[k]} * wl2[(1 + k) * PP + j] + x;
+            f2 th;
+            th.x = tanhf_(x.x);
+            th.y = tanhf_(x.y);
+            const f2 dpre = de2 * wl2[j] * ((f2){1.f, 1.f} - th * th);
+            dk[j] += dpre;
+            dvp[j] = de2 * th + dvp[j];
+#pragma unroll
+            for (int k = 0; k < MAXKW; ++k)
+              if (KW ? k < KW : k < kw) dwp[k][j] = (f2){apv[k], apv[k]} * dpre + dwp[k][j];
+          }
+        }
+      }
+    }
+    if (s0 + POST_SB <= a.S) sstore(buf ^ 1);
+    __syncthreads();
+  }
+  if (!wave_on) return;
 #pragma unroll
   for (int j = 0; j < PU; ++j) {
     if (u0 + j < A) {
       const float dkj = (j & 1) ? dk[j >> 1].y : dk[j >> 1].x;
       const float dvj = (j & 1) ? dvp[j >> 1].y : dvp[j >> 1].x;
       if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = dkj;
-      const float sv = wave_sum(dvj);
-      if (lane == 0) atomicAdd(a.dv + u0 + j, sv);
+      const float sv_ = wave_sum(dvj);
+      if (lane == 0) atomicAdd(a.dv + u0 + j, sv_);
 #pragma unroll
       for (int k = 0; k < MAXKW; ++k)
-        if (k < a.kw) {
+        if (k < kw) {
           const float sw = wave_sum((j & 1) ? dwp[k][j >> 1].y : dwp[k][j >> 1].x);
           if (lane == 0) atomicAdd(a.dwcl + k * A + u0 + j, sw);
         }
@@ -720,7 +787,8 @@ int ns_attn_bwd_post(const ns_taco2_attn_params& p, hipStream_t s) {
     q.keys_t = p.keys_t; q.q = p.q; q.align = p.align; q.de = p.de; q.wcl = p.wcl; q.v = p.v;
     q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl;
     dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
-    hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, s, q);
+    if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, s, q);
     NS_CHECK_LAUNCH("attn_post");
   }
   if (pvm) {
@@ -955,7 +1023,8 @@ extern "C" int ns_attention_post_bwd(const ns_attention_post_bwd_params* p, ns_s
   q.keys_t = p->keys_t; q.q = p->q; q.align = p->align; q.de = p->de; q.wcl = p->wcl; q.v = p->v;
   q.dkeys_t = p->dkeys_t; q.dv = p->dv; q.dwcl = p->dwcl;
   dim3 grid(ceil_div(p->Tia, 64), ceil_div(p->A, 4 * PU), p->N);
-  hipLaunchKernelGGL(attn_post_kernel, grid, dim3(256), 0, (hipStream_t)s, q);
+  if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, (hipStream_t)s, q);
+  else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, q);
   NS_CHECK_LAUNCH("attention_post_bwd");
   return NS_OK;
 }

@@ -502,7 +502,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(ns_colsum_params p) {
     for (int i = 0; i < 4; ++i) {
       float a = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
-      atomicAdd(p.out + 4 * q + i, a);
+      if (4 * q + i < p.C) atomicAdd(p.out + 4 * q + i, a);
     }
   }
 }
@@ -510,8 +510,9 @@ extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_colsum: null");
   if (p->rows <= 0 || p->C <= 0) return NS_OK;
   const int esz = p->dtype == NS_BF16 ? 2 : 4;
-  if (p->C % 4 == 0 && p->ld % 4 == 0 && ((uintptr_t)p->x % (4 * esz)) == 0) {
-    const dim3 grid(max(1, min(32, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
+  // a ragged last quad reads into the row's padding (C rounded up to 4 <= ld) and adds only its valid columns
+  if ((p->C + 3) / 4 * 4 <= p->ld && p->ld % 4 == 0 && ((uintptr_t)p->x % (4 * esz)) == 0) {
+    const dim3 grid(max(1, min(32, ceil_div(p->rows, 128))), ceil_div((p->C + 3) / 4, BN4_QUADS));
     if (p->dtype == NS_BF16) hipLaunchKernelGGL(colsum4_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, *p);
     else hipLaunchKernelGGL(colsum4_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, *p);
     NS_CHECK_LAUNCH("colsum");
@@ -523,24 +524,58 @@ extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
 }
 
 // ------------------------------------------------------------------ L1 loss + gradient
-__global__ void l1_loss_kernel(ns_l1_loss_params p) {
+// Wide rows (the linear spectrogram, F = 1025): one wave per row (n, t), rows strided over the grid; a lane walks the
+// row's F columns 64 apart (coalesced, no per-element division), eight loads in flight per operand.  Narrow rows (mel,
+// F = 80) would leave most of such a wave idle: they keep the flat element loop.
+__device__ __forceinline__ void l1_point(const ns_l1_loss_params& p, float pv, float tv, long prow, int f, float& s_all,
+                                         float& s_pr) {
+  const float d = pv - tv;
+  const float ab = fabsf(d);
+  s_all += ab;
+  const bool pr = f < p.n_prio;
+  if (pr) s_pr += ab;
+  if (p.dpred) {
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    st_dyn(p.dpred, p.dpred_dtype, prow * p.ldd + f, sg * (p.w_all + (pr ? p.w_prio : 0.f)));
+  }
+}
+template <bool WIDE>
+__global__ __launch_bounds__(256) void l1_loss_kernel(ns_l1_loss_params p) {
   __shared__ float red[32];
-  const long total = (long)p.N * p.T * p.F;
   float s_all = 0.f, s_pr = 0.f;
-  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    const int f = idx % p.F;
-    const long nt = idx / p.F;
-    const int t = nt % p.T;
-    const int n = nt / p.T;
-    const long prow = (long)n * p.P + p.padl + t;
-    const float d = p.pred[prow * p.ldp + f] - p.target[idx];
-    const float a = fabsf(d);
-    s_all += a;
-    const bool pr = f < p.n_prio;
-    if (pr) s_pr += a;
-    if (p.dpred) {
-      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-      st_dyn(p.dpred, p.dpred_dtype, prow * p.ldd + f, sg * (p.w_all + (pr ? p.w_prio : 0.f)));
+  if (WIDE) {
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)p.N * p.T;
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+      const int t = (int)(row % p.T);
+      const long n = row / p.T;
+      const long prow = n * p.P + p.padl + t;
+      const float* pr_ = p.pred + prow * p.ldp;
+      const float* tg_ = p.target + row * p.F;
+      for (int f0 = lane; f0 < p.F; f0 += 64 * 8) {
+        float a[8], b[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = f0 + 64 * j;
+          a[j] = f < p.F ? pr_[f] : 0.f;
+          b[j] = f < p.F ? tg_[f] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int f = f0 + 64 * j;
+          if (f < p.F) l1_point(p, a[j], b[j], prow, f, s_all, s_pr);
+        }
+      }
+    }
+  } else {
+    const long total = (long)p.N * p.T * p.F;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+      const int f = idx % p.F;
+      const long nt = idx / p.F;
+      const int t = nt % p.T;
+      const long n = nt / p.T;
+      const long prow = n * p.P + p.padl + t;
+      l1_point(p, p.pred[prow * p.ldp + f], p.target[idx], prow, f, s_all, s_pr);
     }
   }
   s_all = block_sum(s_all, red);
@@ -552,10 +587,13 @@ __global__ void l1_loss_kernel(ns_l1_loss_params p) {
 }
 extern "C" int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->pred && p->target && p->loss_acc, "ns_l1_loss: null");
-  const long total = (long)p->N * p->T * p->F;
+  const long rows = (long)p->N * p->T, total = rows * p->F;
   if (total <= 0) return NS_OK;
-  int grid = (int)min((long)2048, (total + 255) / 256);
-  hipLaunchKernelGGL(l1_loss_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
+  if (p->F >= 256) {
+    hipLaunchKernelGGL(l1_loss_kernel<true>, dim3((int)min((long)2048, (rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, *p);
+  } else {
+    hipLaunchKernelGGL(l1_loss_kernel<false>, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)s, *p);
+  }
   NS_CHECK_LAUNCH("l1_loss");
   return NS_OK;
 }
