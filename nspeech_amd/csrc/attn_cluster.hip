@@ -586,6 +586,12 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     if (tid >= 256 && tid < 256 + TSMAX) { acur[tid - 256] = h_a; da0s[tid - 256] = h_da0; }
     if (tid >= 320 && tid < 320 + GC) gts[tid - 320] = h_gt;
   };
+  // The images below are zeroed above by whichever threads the fill loops hand them to and written here by the
+  // threads that own the history values - other waves.  Without this barrier a wave that reaches store_history before
+  // the zero fill of another wave has run loses its values: acur / da0s (or the previous alignment) of the first
+  // backward step read as zero in one workgroup, once in 20 - 50 launches (found as a two-valued gradient of one
+  // utterance under profiles/tools/determinism_probe.py; the forward kernel fills every image from one place).
+  __syncthreads();
   load_history(p.S - 1, tid_);
   store_history((p.S - 1) & 1, tid_);
   float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;              // the cell owners' operands of the current step
@@ -861,6 +867,7 @@ static int launch_fwd(const ns_taco2_attn_params* p, void* work, hipStream_t s) 
   a.status = (int*)work;
   a.x2 = (u64*)((char*)work + 256);
   a.x3 = a.x2 + (size_t)p->N * CG * C::X2N;
+  a.x1 = nullptr;
   const size_t xbytes = sizeof(u64) * (size_t)p->N * CG * (C::X2N + C::X3N);
   a.trace = getenv("NS_ATTN_TRACE") ? (long long*)((char*)work + ns_taco2_attn_cluster_work_bytes(p) - TRACE_BYTES) : nullptr;
   { const int zrc = ns_zero_async(work, ((256 + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
