@@ -311,11 +311,16 @@ def main():
 
     # Two more steps outside the timed region, executed by EVERY rank (the step contains collectives):
     # one with per-phase events, one with an event pair around every large GEMM launch.
+    # The phase pass runs every launch on ONE stream (the timed steps put the weight gradients on a second one): a
+    # phase then holds all of its own work - the decoder-gate roofline below counts the weight-gradient products of
+    # the decoder LSTMs - and the phases add up to the single-stream step, a little more than ms_per_step.
+    overlap, model.overlap_wgrads = getattr(model, "overlap_wgrads", False), False
     model.timing = []
     one_step()
     torch.cuda.synchronize()
     tm = model.timing
     model.timing = None
+    model.overlap_wgrads = overlap
     phases = [(tm[i][0], tm[i - 1][1].elapsed_time(tm[i][1])) for i in range(1, len(tm))]
     if args.phases and rank == 0:
         for name, v in phases:
@@ -373,6 +378,8 @@ def main():
             "roofline": gate_roof,
             "roofline_gemm_family": roof,
             "phases_ms": {k: round(v, 3) for k, v in pd.items()},
+            "phases_note": "one extra step with every launch on one stream (sum = single-stream step); the timed steps "
+                           "run the weight-gradient products on a second stream",
         }
         if world == 1 and not args.train_only:
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
