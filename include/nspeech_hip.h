@@ -598,6 +598,16 @@ int ns_audio_pointwise(const ns_audio_pointwise_params* p, ns_stream_t stream);
 typedef struct { const float* x; float* y; int64_t n; float coef; int inverse; } ns_preemphasis_params;
 int ns_preemphasis(const ns_preemphasis_params* p, ns_stream_t stream);
 
+/* ---------------------------------------------------------------- FLAC input (host code, flac.hip)
+ * The reference reads LibriSpeech's .flac files through librosa.core.load (datasets/corpus/ljspeech.py:17,
+ * utils/audio.py:13-14).  data = the whole file in HOST memory.  ns_flac_info: stream parameters (total_samples per
+ * channel, 0 when the encoder left it out; md5_16 = STREAMINFO's MD5 of the decoded PCM, may be NULL).
+ * ns_flac_decode: out[sample * channels + channel] int32 in HOST memory, capacity / *decoded in samples per channel;
+ * every frame is checked against its CRC-8 and CRC-16. */
+int ns_flac_info(const uint8_t* data, size_t n, int* sample_rate, int* channels, int* bits_per_sample,
+                 int64_t* total_samples, uint8_t* md5_16);
+int ns_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64_t capacity, int64_t* decoded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -136,22 +136,57 @@ def resample(x, sr_orig, sr_new):
     return y.float().cpu().numpy()
 
 
+def _load_flac(path):
+    """FLAC file -> (float32 [samples, channels] in [-1, 1), sample rate): ns_flac_decode (csrc/flac.hip, host code),
+    checked against the MD5 of the decoded PCM that the encoder stored in STREAMINFO (all-zero = not stored)."""
+    import ctypes as C
+    import hashlib
+    data = open(path, "rb").read()
+    lib = L.lib()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    sr, ch, bps, total = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
+    md5 = (C.c_uint8 * 16)()
+    L.check(lib.ns_flac_info(buf, C.c_size_t(len(data)), C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total), md5), "ns_flac_info")
+    cap = total.value if total.value > 0 else len(data) * 8           # no total: a sample takes at least a bit per channel
+    out = np.empty((cap, ch.value), dtype=np.int32)
+    got = C.c_int64()
+    L.check(lib.ns_flac_decode(buf, C.c_size_t(len(data)), out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(cap), C.byref(got)),
+            "ns_flac_decode")
+    out = out[:got.value]
+    if total.value > 0 and got.value != total.value:
+        raise ValueError("%s: %d samples decoded, STREAMINFO announces %d" % (path, got.value, total.value))
+    if any(md5):
+        nb = (bps.value + 7) // 8
+        pcm = out.astype("<i4").view(np.uint8).reshape(-1, 4)[:, :nb].tobytes()
+        if hashlib.md5(pcm).digest() != bytes(md5):
+            raise ValueError("%s: decoded audio does not match the MD5 in STREAMINFO" % path)
+    return (out.astype(np.float32) / float(1 << (bps.value - 1))), sr.value
+
+
 def load_wav(path, offset=0.0, duration=None):
-    """PCM16 / float32 RIFF reader + mono mix-down + resampling to hparams.sample_rate, as librosa.core.load does for
-    the reference (audio.py:13-14; LJSpeech is 22 050 Hz, audio.yaml asks for 20 000 Hz)."""
-    try:
-        with wave.open(path, "rb") as f:
-            sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
-            raw = f.readframes(n)
-    except wave.Error as e:     # e.g. LibriSpeech FLAC: no decoder in this build
-        raise ValueError("%s: only RIFF/WAV input is supported (%s)" % (path, e))
+    """PCM16 / float32 RIFF or FLAC reader + mono mix-down + resampling to hparams.sample_rate, as librosa.core.load
+    does for the reference (audio.py:13-14; LJSpeech is 22 050 Hz WAV, LibriSpeech 16 000 Hz FLAC, audio.yaml asks for
+    20 000 Hz)."""
+    with open(path, "rb") as f:
+        magic = f.read(4)
     hp = get_hparams()
-    if width == 2:
-        x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
-    elif width == 4:
-        x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+    if magic == b"fLaC":                     # LibriSpeech (datasets/corpus/ljspeech.py:17)
+        x, sr = _load_flac(path)
+        ch = x.shape[1]
+        x = x.reshape(-1) if ch == 1 else x
     else:
-        raise ValueError("unsupported sample width %d" % width)
+        try:
+            with wave.open(path, "rb") as f:
+                sr, n, width, ch = f.getframerate(), f.getnframes(), f.getsampwidth(), f.getnchannels()
+                raw = f.readframes(n)
+        except wave.Error as e:
+            raise ValueError("%s: only RIFF/WAV and FLAC input is supported (%s)" % (path, e))
+        if width == 2:
+            x = np.frombuffer(raw, dtype="<i2").astype(np.float32) / 32768.0
+        elif width == 4:
+            x = np.frombuffer(raw, dtype="<f4").astype(np.float32)
+        else:
+            raise ValueError("unsupported sample width %d" % width)
     if ch > 1:
         x = x.reshape(-1, ch).mean(axis=1)
     s = int(offset * sr)                     # librosa seeks / truncates at the native rate, then resamples
