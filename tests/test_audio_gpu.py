@@ -184,3 +184,29 @@ def test_other_transform_sizes_take_the_generic_kernels(audio):
     finally:
         for k, v in keep.items():
             setattr(hp, k, v)
+
+
+def test_load_wav_reads_librispeech_flac_like_the_same_pcm_in_a_wav(audio, tmp_path):
+    """LibriSpeech: 16 kHz mono .flac, resampled to the model's 20 kHz like any other input (audio.py:13-14)."""
+    import os
+    import wave
+    import flac_writer as FW
+    from test_flac_cpu import _lpc
+    A, hp = audio
+    y = _speechlike(16000, 3)
+    pcm = np.round(y / np.abs(y).max() * 0.7 * 32767).astype(np.int64)[:, None]
+    frames, pos = [], 0
+    while pos < len(pcm):
+        size = min(4096, len(pcm) - pos)
+        spec = _lpc(pcm[pos:pos + size, 0], 8)
+        spec.update(porder=2 if size == 4096 else 0)
+        frames.append(dict(size=size, subframes=[spec]))
+        pos += size
+    pf, pw = os.path.join(str(tmp_path), "a.flac"), os.path.join(str(tmp_path), "a.wav")
+    with open(pf, "wb") as f:
+        f.write(FW.encode(pcm, 16, 16000, frames))
+    with wave.open(pw, "wb") as f:
+        f.setnchannels(1); f.setsampwidth(2); f.setframerate(16000)
+        f.writeframes(pcm[:, 0].astype("<i2").tobytes())
+    a, b = A.load_wav(pf), A.load_wav(pw)
+    assert a.shape == b.shape == (int(np.ceil(16000 * hp.sample_rate / 16000)),) and np.array_equal(a, b)
