@@ -205,11 +205,13 @@ int ns_adam(const ns_adam_params* p, ns_stream_t stream);
 typedef struct { const float* src; void* hi; void* lo; int64_t n; } ns_split_params;
 int ns_split_hi_lo(const ns_split_params* p, ns_stream_t stream);
 
-/* dst[c,r] = (T)src[r,c]  (k-contiguous shadow copies of recurrent weights). */
+/* dst[c,r] = (T)src[r,c]  (k-contiguous shadow copies of recurrent weights).  dst_hi / dst_lo (bf16, same layout as
+ * dst, both or neither): the pre-split pair of ns_split_hi_lo from the same pass; dst may then be NULL. */
 typedef struct {
   const float* src; int rows, cols; int64_t ld_src;
   void* dst; int dst_dtype; int64_t ld_dst;
   int transpose;
+  void* dst_hi; void* dst_lo;
 } ns_cast2d_params;
 int ns_cast2d(const ns_cast2d_params* p, ns_stream_t stream);
 

@@ -673,6 +673,14 @@ extern "C" int ns_adam(const ns_adam_params* p, ns_stream_t s) {
 }
 
 // ------------------------------------------------------------------ cast / transpose 2-D
+__device__ __forceinline__ void cast2d_put(const ns_cast2d_params& p, long i, float v) {
+  if (p.dst) st_dyn(p.dst, p.dst_dtype, i, v);
+  if (p.dst_hi) {
+    const bf16_t h = (bf16_t)v;
+    ((bf16_t*)p.dst_hi)[i] = h;
+    ((bf16_t*)p.dst_lo)[i] = (bf16_t)(v - (float)h);
+  }
+}
 __global__ void cast2d_kernel(ns_cast2d_params p) {
   __shared__ float tile[32][33];
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;  // bx over cols, by over rows of src
@@ -685,17 +693,18 @@ __global__ void cast2d_kernel(ns_cast2d_params p) {
   if (p.transpose) {
     for (int j = ty; j < 32; j += 8) {
       const int c = bx + j, r = by + tx;  // dst[c][r]
-      if (r < p.rows && c < p.cols) st_dyn(p.dst, p.dst_dtype, (long)c * p.ld_dst + r, tile[tx][j]);
+      if (r < p.rows && c < p.cols) cast2d_put(p, (long)c * p.ld_dst + r, tile[tx][j]);
     }
   } else {
     for (int j = ty; j < 32; j += 8) {
       const int r = by + j, c = bx + tx;
-      if (r < p.rows && c < p.cols) st_dyn(p.dst, p.dst_dtype, (long)r * p.ld_dst + c, tile[j][tx]);
+      if (r < p.rows && c < p.cols) cast2d_put(p, (long)r * p.ld_dst + c, tile[j][tx]);
     }
   }
 }
 extern "C" int ns_cast2d(const ns_cast2d_params* p, ns_stream_t s) {
-  NS_CHECK_ARG(p && p->src && p->dst, "ns_cast2d: null");
+  NS_CHECK_ARG(p && p->src && (p->dst || p->dst_hi), "ns_cast2d: null");
+  NS_CHECK_ARG(!p->dst_hi == !p->dst_lo, "ns_cast2d: dst_hi and dst_lo come as a pair");
   if (p->rows <= 0 || p->cols <= 0) return NS_OK;
   dim3 grid(ceil_div(p->cols, 32), ceil_div(p->rows, 32));
   hipLaunchKernelGGL(cast2d_kernel, grid, dim3(256), 0, (hipStream_t)s, *p);

@@ -185,16 +185,22 @@ class Tacotron2(object):
 
         split = self.passes_fwd > 0     # fp32 storage: also keep pre-split bf16 (hi, lo) copies
 
-        def tr(key, name, r0, rows, cols, D=None):
+        def tr(key, name, r0, rows, cols, D=None, pair_only=False):
+            """One pass per weight: the k-contiguous copy and, on fp32 storage, its pre-split (hi, lo) pair.
+            pair_only: nothing reads the fp32 copy (the 256-tile products take the pair) - it is not written."""
             D = D or T
-            if key not in self.tsh:
-                self.tsh[key] = torch.zeros(cols * rows, dtype=D, device=dev)
-            ops.cast2d(self.flat_p, rows, cols, cols, self.tsh[key], rows, True, src_off=self._o(name) + r0 * cols)
-            if split and D == torch.float32:
-                if key + "_hi" not in self.tsh:
-                    self.tsh[key + "_hi"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
-                    self.tsh[key + "_lo"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
-                ops.split_hi_lo(self.tsh[key], self.tsh[key + "_hi"], self.tsh[key + "_lo"], cols * rows)
+            want_pair = split and D == torch.float32
+            if want_pair and key + "_hi" not in self.tsh:
+                self.tsh[key + "_hi"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
+                self.tsh[key + "_lo"] = torch.zeros(cols * rows, dtype=torch.bfloat16, device=dev)
+            dst = None
+            if not (pair_only and want_pair):
+                if key not in self.tsh:
+                    self.tsh[key] = torch.zeros(cols * rows, dtype=D, device=dev)
+                dst = self.tsh[key]
+            ops.cast2d(self.flat_p, rows, cols, cols, dst, rows, True, src_off=self._o(name) + r0 * cols,
+                       dst_hi=self.tsh[key + "_hi"] if want_pair else None,
+                       dst_lo=self.tsh[key + "_lo"] if want_pair else None)
 
         M, E, A, D = hp.num_mels, 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
         He, Hx = hp.encoder_lstm_units, hp.expand_lstm_units
@@ -208,8 +214,8 @@ class Tacotron2(object):
         # the hoisted input products on the 256-tile kernel: k-contiguous [4H, C_in] shadows of the input rows of the
         # LSTM kernels (mixed: pre-split (hi, lo) pairs for the three-segment product; bf16 expand net: plain)
         if self.mode == "mixed" and (A + E) % 64 == 0 and D % 64 == 0 and (4 * D) % 128 == 0:
-            tr("l1_xT", "decoder/lstm_1/kernel", 0, A + E, 4 * D, torch.float32)
-            tr("l2_xT", "decoder/lstm_2/kernel", 0, D, 4 * D, torch.float32)
+            tr("l1_xT", "decoder/lstm_1/kernel", 0, A + E, 4 * D, torch.float32, pair_only=True)
+            tr("l2_xT", "decoder/lstm_2/kernel", 0, D, 4 * D, torch.float32, pair_only=True)
         if self.Tx == torch.bfloat16 and Cx % 64 == 0 and (4 * Hx) % 128 == 0:
             for d in ("fw", "bw"):
                 tr("exp_%s_xT" % d, "expand/encoder_lstm/%s/lstm_cell/kernel" % d, 0, Cx, 4 * Hx, self.Tx)
@@ -229,7 +235,8 @@ class Tacotron2(object):
             kp, Cp = hp.postnet_conv_width, hp.postnet_conv_channels
             for i in range(1, hp.postnet_conv_layers):
                 if (kp * Cp) % 64 == 0 and Cp % 128 == 0:
-                    tr("postT_%d" % i, "decoder_postnet/postnet_conv_%d/conv1d/kernel" % i, 0, kp * Cp, Cp, torch.float32)
+                    tr("postT_%d" % i, "decoder_postnet/postnet_conv_%d/conv1d/kernel" % i, 0, kp * Cp, Cp, torch.float32,
+                       pair_only=True)
         # folded location filter Wcl[k,u] = sum_j Wc[k,0,j] Wl[j,u]  (fp32)
         if "wcl" not in self.tsh:
             self.tsh["wcl"] = torch.zeros(7 * A, dtype=torch.float32, device=dev)
@@ -502,7 +509,7 @@ class Tacotron2(object):
         256-tile kernel: three segments over pre-split operands where the storage is fp32 (mixed), one where it is bf16."""
         D = D or self.T
         sh = self.tsh.get(key)
-        if sh is not None and self._x256_fits(rows, cout) and D == torch.float32 and key + "_hi" in self.tsh:
+        if self._x256_fits(rows, cout) and D == torch.float32 and key + "_hi" in self.tsh:
             xh = self._buf("xgs_hi_" + key, rows * cin, torch.bfloat16)
             xl = self._buf("xgs_lo_" + key, rows * cin, torch.bfloat16)
             ops.split_hi_lo(x, xh, xl, rows * cin)

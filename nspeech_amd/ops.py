@@ -168,10 +168,13 @@ def adam(pw, g, m, v, n, gnorm_sq, clip, grad_scale, lr_t, beta1, beta2, eps, sh
     L.call("ns_adam", p, stream())
 
 
-def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0):
+def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0, dst_hi=None, dst_lo=None):
+    """dst may be None when the pre-split pair (dst_hi, dst_lo) is all that is wanted."""
     p = L.struct("ns_cast2d_params")
-    _fill(p, src=ptr(src, src_off), rows=rows, cols=cols, ld_src=ld_src, dst=ptr(dst, dst_off),
-          dst_dtype=dt(dst), ld_dst=ld_dst, transpose=int(transpose))
+    _fill(p, src=ptr(src, src_off), rows=rows, cols=cols, ld_src=ld_src, dst=ptr(dst, dst_off) if dst is not None else None,
+          dst_dtype=dt(dst) if dst is not None else NS_F32, ld_dst=ld_dst, transpose=int(transpose))
+    if dst_hi is not None:
+        p.dst_hi, p.dst_lo = ptr(dst_hi, dst_off), ptr(dst_lo, dst_off)
     L.call("ns_cast2d", p, stream())
 
 
