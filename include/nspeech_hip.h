@@ -36,6 +36,17 @@ int ns_version(void);
 const char* ns_device_arch(void); /* "gfx950" */
 const char* ns_last_error(void);
 
+/* Diagnostics for the coexistence tests (tests/test_coexist_gpu.py); no reference counterpart, the reference
+ * is single-GPU (train.py:157).
+ * ns_occupy: `blocks` workgroups of `threads` threads, each with `lds_bytes` of LDS, that stay resident for about
+ *   `usec` microseconds and then exit - the footprint of a collective's channel kernel (RCCL launches a few dozen
+ *   256..512-thread workgroups that sit on their CUs until the peers have answered).  heavy != 0: 128 VGPRs per lane
+ *   instead of a handful.  `started` (nullable, device int, zeroed by the caller): every workgroup adds 1 once it runs.
+ * ns_wait_counter: one thread that returns once *counter >= target or after timeout_usec - put on the stream in front
+ *   of the kernel under test so that the occupier is resident when that kernel is dispatched. */
+int ns_occupy(int blocks, int threads, int lds_bytes, int heavy, double usec, int* started, ns_stream_t stream);
+int ns_wait_counter(const int* counter, int target, double timeout_usec, ns_stream_t stream);
+
 /* ------------------------------------------------------------------ GEMM / conv1d
  * C[M,N] (=|+=) alpha * act( A·B + bias ), fp32 accumulate.
  * Replaces tf.layers.dense / tf.layers.conv1d / the matmuls inside LSTMBlockCell and

@@ -37,7 +37,6 @@ constexpr int KWMAX = 8;
 constexpr int APAD = 8;            // zero margin around the alignment vector in LDS
 constexpr int KPAD = 4;            // row pad of the keys image: the energy pass reads keys[r][u] with r across 16 lanes and u
                                    // across 4 - a row stride of A floats puts all 16 rows on one bank (16-way conflict)
-constexpr unsigned SPIN_LIMIT = 2000000u;
 
 template <int A_, int D1_, int D2_>
 struct Cfg {
@@ -83,7 +82,7 @@ template <int PER>
 __device__ __forceinline__ void gather_granules(const u64* src, int total, unsigned tag, float* dst, int tid,
                                                 int* status, int code) {
   u64 v[PER];
-  unsigned spins = 0;
+  unsigned spins = 0, clk0 = 0;
   bool ok;
   do {
     ok = true;
@@ -95,9 +94,10 @@ __device__ __forceinline__ void gather_granules(const u64* src, int total, unsig
 #pragma unroll
     for (int j = 0; j < PER; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
     if (!ok) {
-      ++spins;
-      if (spins > SPIN_LIMIT) { atomicExch(status, code); ok = true; }
-      else if ((spins & 1023u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = true;
+      if ((++spins & 1023u) == 0) {        // every 1024 polls: has a peer given up, or is the wall-clock bound passed
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = true;
+        else if (ns_spin_timed_out(clk0)) { atomicExch(status, code); ok = true; }
+      }
     }
   } while (!ok);
 #pragma unroll

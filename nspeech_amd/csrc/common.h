@@ -138,4 +138,16 @@ __device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, 
 }
 
 
+// ---------------------------------------------------------------- bounded spins of the persistent kernels
+// Every wait of a persistent kernel is bounded in WALL-CLOCK time, not in iterations: a workgroup that cannot be placed
+// because a foreign kernel (a collective's channel kernel, a weight-gradient product on the second stream) holds its CU
+// keeps its peers polling for as long as that kernel lives, and an iteration count says nothing about how long that is.
+// The clock (s_memrealtime, 100 MHz) is read once per 1024 polls; 32 bits of it wrap after 42 s, far beyond the bound.
+constexpr unsigned NS_SPIN_TICKS = 200000000u;      // 2 s
+__device__ __forceinline__ bool ns_spin_timed_out(unsigned& t0) {
+  const unsigned now = (unsigned)wall_clock64() | 1u;
+  if (t0 == 0u) { t0 = now; return false; }
+  return now - t0 > NS_SPIN_TICKS;
+}
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

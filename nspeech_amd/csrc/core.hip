@@ -32,3 +32,53 @@ int ns_zero_async(void* p, size_t bytes, hipStream_t s) {
   NS_CHECK_LAUNCH("ns_zero");
   return NS_OK;
 }
+
+// ns_occupy / ns_wait_counter: hold CUs the way a collective's channel kernel does (see the header).  wall_clock64
+// ticks at 100 MHz.
+__global__ void ns_occupy_kernel(unsigned long long ticks, int* started) {
+  extern __shared__ char occupy_lds[];
+  if (threadIdx.x == 0) {
+    occupy_lds[0] = 1;      // the LDS allocation must be real
+    if (started) atomicAdd(started, 1);
+  }
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void ns_wait_counter_kernel(const int* counter, int target, unsigned long long ticks) {
+  const unsigned long long t0 = wall_clock64();
+  while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < ticks)
+    __builtin_amdgcn_s_sleep(8);
+}
+// The same with a register footprint: v127 is clobbered, so the kernel is allocated 128 VGPRs per lane (a collective's
+// channel kernel is register-heavy; beside 2 x 248 VGPRs of a persistent recurrence's waves there is no room for it).
+__global__ void ns_occupy_heavy_kernel(unsigned long long ticks, int* started) {
+  extern __shared__ char occupy_lds[];
+  if (threadIdx.x == 0) {
+    occupy_lds[0] = 1;
+    if (started) atomicAdd(started, 1);
+  }
+  asm volatile("v_mov_b32 v127, 0" ::: "v127");
+  const unsigned long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+extern "C" int ns_occupy(int blocks, int threads, int lds_bytes, int heavy, double usec, int* started, ns_stream_t stream) {
+  NS_CHECK_ARG(blocks >= 1 && blocks <= 4096 && threads >= 64 && threads <= 1024 && (threads & 63) == 0,
+               "ns_occupy: 1..4096 blocks of 64..1024 threads (a multiple of 64)");
+  NS_CHECK_ARG(lds_bytes >= 0 && lds_bytes <= 160 * 1024 && usec >= 0 && usec <= 1e6, "ns_occupy: lds <= 160 KB, usec <= 1e6");
+  if (lds_bytes > 64 * 1024)
+    (void)hipFuncSetAttribute(heavy ? (const void*)ns_occupy_heavy_kernel : (const void*)ns_occupy_kernel,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  const size_t lds = (size_t)(lds_bytes < 16 ? 16 : lds_bytes);
+  const unsigned long long ticks = (unsigned long long)(usec * 100.0);
+  if (heavy) hipLaunchKernelGGL(ns_occupy_heavy_kernel, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, ticks, started);
+  else hipLaunchKernelGGL(ns_occupy_kernel, dim3(blocks), dim3(threads), lds, (hipStream_t)stream, ticks, started);
+  NS_CHECK_LAUNCH("ns_occupy");
+  return NS_OK;
+}
+extern "C" int ns_wait_counter(const int* counter, int target, double timeout_usec, ns_stream_t stream) {
+  NS_CHECK_ARG(counter && timeout_usec >= 0 && timeout_usec <= 1e6, "ns_wait_counter: null counter or timeout > 1 s");
+  hipLaunchKernelGGL(ns_wait_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, target,
+                     (unsigned long long)(timeout_usec * 100.0));
+  NS_CHECK_LAUNCH("ns_wait_counter");
+  return NS_OK;
+}

@@ -19,7 +19,6 @@
 typedef unsigned long long u64;
 constexpr int CW = 8;            // waves per workgroup
 constexpr int CTHREADS = CW * 64;
-constexpr unsigned SPIN_LIMIT = 4000000u;
 
 struct LstmClusterArgs {
   int N, T, H, P, padl, CS;
@@ -113,7 +112,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_fwd_kernel(LstmClusterA
       const int total = 16 * GPR;
       for (int i0 = tid; i0 < total; i0 += CTHREADS * 4) {
         u64 v[4];
-        unsigned spins = 0;
+        unsigned spins = 0, clk0 = 0;
         bool ok;
         do {
           ok = true;
@@ -126,7 +125,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_fwd_kernel(LstmClusterA
 #pragma unroll
           for (int j = 0; j < 4; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)step);
           if (a.dbg & 4) ok = true;
-          if (!ok && ++spins > SPIN_LIMIT) { atomicExch(a.status, 1); ok = true; }
+          if (!ok && (++spins & 1023u) == 0 && ns_spin_timed_out(clk0)) { atomicExch(a.status, 1); ok = true; }
         } while (!ok);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_bwd_kernel(LstmClusterA
       const int total = 16 * GPR;
       for (int i0 = tid; i0 < total; i0 += CTHREADS * 8) {
         u64 v[8];
-        unsigned spins = 0;
+        unsigned spins = 0, clk0 = 0;
         bool okk;
         do {
           okk = true;
@@ -277,7 +276,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_bwd_kernel(LstmClusterA
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) okk = okk && ((unsigned)(v[j] >> 32) == (unsigned)bs);
-          if (!okk && ++spins > SPIN_LIMIT) { atomicExch(a.status, 2); okk = true; }
+          if (!okk && (++spins & 1023u) == 0 && ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); okk = true; }
         } while (!okk);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -373,6 +372,24 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_bwd_kernel(LstmClusterA
 //
 // Exchange layout (per chain and parity): a publishing lane's granules are contiguous, so one base
 // register + immediates address them; the poller decodes granule index -> (row, k) when it fills LDS.
+//
+// LDS hand-over audit (round 3; the class of the attention-backward race fixed in 844cc13 - an image filled by one
+// role and first read by another with no barrier in between).  Every image below is double-buffered by slot parity and
+// handed over by the ONE wg_barrier() per slot that every role joins (wg_barrier waits for lgkmcnt(0) first, so a
+// role's LDS writes AND reads of the slot have completed when it arrives):
+//   forward   hs[q&1]   pollers fill it in front of barrier q, compute waves read it behind barrier q; the pollers'
+//                       next fill of the same image is for slot q+2, behind barrier q+1, which the compute waves join
+//                       after their reads of slot q
+//             xgs[q&1]  prefetcher: slot 0 in front of barrier 0, slot q+1 behind barrier q; read behind barrier q+1
+//             svs[q&1]  compute waves write it in slot q, the saver reads it behind barrier q+1 and joins barrier q+2
+//                       (after its reads returned) before the compute waves write that image again in slot q+2
+//             abortf    zeroed by wave 0 in front of its first wg_barrier, read by every role behind that barrier
+//   backward  dgs[q&1], ops stage[q&1]: as hs / xgs;  c0: prefetcher in front of barrier 0, read in slot 0
+//             outs[q&1] compute waves write, then add to `ready` with release; the publisher acquires `ready` >= 4(q+1)
+//                       before it reads; its reads complete (the stores need the data) before it joins the next slot
+//                       barrier, two barriers before the compute waves write that image again
+//             ready     zeroed by wave 0 in front of barrier 0; the publisher joins barrier 0 before its first look
+// The single-role kernels above use one image and __syncthreads() on both sides of every use.
 constexpr int XW = 4;
 constexpr int FW_POLL = 2;               // poller waves (XW and XW + 3): half of the granules each, so a sweep is half as long
                                          // (expand BiLSTM forward 3.2 -> 3.0 ms)
@@ -515,7 +532,7 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
       if (step > 0) {
         const u64* cur = xb0 + ((size_t)rg * 2 + (step & 1)) * 16 * GPR;   // published by the peers with tag = step
         u64 v[PPG];
-        unsigned spins = 0;
+        unsigned spins = 0, clk0 = 0;
         bool ok;
         do {
           ok = true;
@@ -524,10 +541,9 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
 #pragma unroll
           for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)step);
           if (!ok) {
-            ++spins;
-            if (spins > SPIN_LIMIT) { atomicExch(a.status, 1); abortf[buf] = 1; ok = true; }
-            else if ((spins & 1023) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              abortf[buf] = 1; ok = true;
+            if ((++spins & 1023u) == 0) {
+              if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; ok = true; }
+              else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 1); abortf[buf] = 1; ok = true; }
             }
           }
         } while (!ok);
@@ -741,11 +757,13 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
       const int t = t_of(T - 1 - bs);
       const int n0 = (rg0 + rg) * 16;
       // wait for the XW compute waves of slot q (LDS counter)
-      unsigned spins = 0;
+      unsigned spins = 0, clk0 = 0;
       while (__hip_atomic_load(ready, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < XW * (q + 1)) {
         __builtin_amdgcn_s_sleep(1);
-        if (((++spins) & 255) == 0 && (abortf[0] | abortf[1])) return;
-        if (spins > SPIN_LIMIT) { atomicExch(a.status, 3); return; }
+        if (((++spins) & 255) == 0) {
+          if (abortf[0] | abortf[1]) return;
+          if ((spins & 1023u) == 0 && ns_spin_timed_out(clk0)) { atomicExch(a.status, 3); return; }
+        }
       }
       const char* so = (const char*)(outs + (size_t)(q & 1) * 16 * 4 * 64);
 #pragma unroll
@@ -776,13 +794,14 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
       if (bs > 0) {
         // every workgroup of the chain must have published backward step bs-1 (flag >= bs)
         const unsigned* fl = flags0 + rg * 8;
-        unsigned spins = 0;
+        unsigned spins = 0, clk0 = 0;
         for (;;) {
           const unsigned v = lane < CS ? __hip_atomic_load(fl + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
           if (__all(v >= (unsigned)bs)) break;
-          ++spins;
-          if (spins > SPIN_LIMIT) { atomicExch(a.status, 2); abortf[buf] = 1; break; }
-          if ((spins & 1023) == 0 && __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; break; }
+          if ((++spins & 1023u) == 0) {
+            if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; break; }
+            if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[buf] = 1; break; }
+          }
         }
         const int tn = t_of(T - bs);                   // time index of the step processed just before
         const int n0 = (rg0 + rg) * 16;

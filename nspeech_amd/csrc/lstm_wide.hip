@@ -39,7 +39,6 @@
 
 namespace {
 constexpr int WT = 512, WW = WT / 64;
-constexpr unsigned WSPIN = 1000000u;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr size_t WIDE_TRACE_BYTES = 256 * 8 * sizeof(long long);
 
@@ -100,7 +99,7 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
   const int nrec = __builtin_amdgcn_readfirstlane((int)bytes);
   const unsigned poff = lane < NP ? poff0 + (unsigned)lane * pstride : 0x80000000u;
   unsigned long long ready = 0ull;
-  unsigned done = 0u, spins = 0u;
+  unsigned done = 0u, spins = 0u, clk0 = 0u;
   for (;;) {
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, nrec, 0x00020000);
     if (ready != ALLP) {
@@ -132,11 +131,13 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
     }
     if (pmask) {              // the prober owns the time-out and the look at the status word
       if (*(volatile int*)abortf) return 0;
-      if (spins > 64u * WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
+      if ((spins & 0xffffu) == 0 && ns_spin_timed_out(clk0)) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
       continue;
     }
-    if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
-    if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return 0; }
+    if ((spins & 255u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return 0; }
+      if ((spins & 1023u) == 0 && ns_spin_timed_out(clk0)) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
+    }
   }
 }
 
@@ -153,7 +154,7 @@ __device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsign
   const unsigned long long all0 = np >= 64 ? ~0ull : ((1ull << np) - 1ull);
   const unsigned long long all1 = np > 64 ? (np >= 128 ? ~0ull : ((1ull << (np - 64)) - 1ull)) : 0ull;
   unsigned long long m0 = 0ull, m1 = 0ull;
-  unsigned spins = 0;
+  unsigned spins = 0, clk0 = 0;
   for (;;) {
     const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, o0, 0, 16);
     const u32x4 v1 = np > 64 ? __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 16) : (u32x4){0u, 0u, 0u, 0u};
@@ -162,8 +163,10 @@ __device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsign
     if (lane == 0) { pm[0] = m0; pm[1] = m1; }
     if (m0 == all0 && m1 == all1) return true;
     ++spins;
-    if (spins > WSPIN) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return false; }
-    if ((spins & 255u) == 0 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return false; }
+    if ((spins & 255u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { if (lane == 0) *abortf = 1; return false; }
+      if ((spins & 1023u) == 0 && ns_spin_timed_out(clk0)) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return false; }
+    }
   }
 }
 
@@ -178,7 +181,13 @@ constexpr bool FWD_PROBER = false;          // measured: 5.25 us per step with a
 constexpr int WTF = WT + 128 + (FWD_PROBER ? 64 : 0);
 template <typename T, int PASSES, int NCH>
 __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
-  __shared__ float red[WW][16][36];   // row stride = 4 mod 16 floats: conflict-free for the MFMA C layout's writes (+1 is not)
+  // Partial sums, sweepers -> cell waves.  Row stride = 4 mod 16 floats: conflict-free for the MFMA C layout's writes
+  // (+1 is not).  Two images by step parity (LDS hand-over audit, round 3): the barrier of step t orders the sweepers'
+  // writes before the cell waves' reads, but a sweeper whose K slice does not hold this workgroup's own units needs
+  // nothing from these cell waves to finish step t+1 - with ONE image its next write was kept behind their reads only by
+  // the two memory round trips every sweep takes.  With two, image (t & 1) is written again in step t+2, which a sweeper
+  // enters through the barrier of step t+1, and the cell waves reach that barrier after their reads of step t.
+  __shared__ float red[2][WW][16][36];
   __shared__ __attribute__((aligned(16))) T hst[16][8];
   __shared__ int abortf;
   __shared__ unsigned long long pmask[2][2];       // [step parity][producers 0..63, 64..127] published bits (prober wave)
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
   const int H = p.H, NUB = a.nub;
   const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
   const int n0 = rg * 16, u0 = ub * 8;
-  if (tid == 0) abortf = 0;
+  if (tid == 0) abortf = 0;                          // (audit) both initialised in front of the barrier below
   if (tid < 4) pmask[tid >> 1][tid & 1] = 0ull;
   const size_t hbytes = (size_t)p.N * p.P * p.ld_h * sizeof(T);
   constexpr int PPC = 8 * (int)sizeof(T) / 16;        // 16-byte pieces per 8-value fragment (2 for fp32, 1 for bf16)
@@ -254,7 +263,7 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][j * 16 + r16] = acc[j][q];
+        for (int q = 0; q < 4; ++q) red[t & 1][wave][g * 4 + q][j * 16 + r16] = acc[j][q];
       __syncthreads();
       if (abortf) return;
       wstamp(a, t, 2);
@@ -269,7 +278,10 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
         const unsigned prow = (unsigned)(((long)(n0 + prb) * p.P + p.padl + t - 1) * p.ld_h) * (unsigned)sizeof(T);
         probe_all<T>(p.h, hbytes, prow, 8u * (unsigned)sizeof(T), H / 8, &pmask[t & 1][0], lane, a.status, &abortf, 1);
       }
-      if (lane < 2) pmask[(t + 1) & 1][lane] = 0ull;  // nobody reads the other parity before the barrier
+      // (audit) pmask[parity]: filled by this prober, read by the sweepers of the same step.  The other parity is cleared
+      // here, after this step's probe and before this step's barrier: its last readers were the sweepers of step t-1,
+      // who passed the barrier of step t-1 before this iteration began; its next readers start after this barrier.
+      if (lane < 2) pmask[(t + 1) & 1][lane] = 0ull;
       __syncthreads();
       if (abortf) return;
     }
@@ -301,13 +313,15 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
     for (int j = 0; j < 4; ++j) {
       float s = pz[j];
 #pragma unroll
-      for (int w = 0; w < WW; ++w) s += red[w][er][(j >> 1) * 16 + (j & 1) * 8 + eu];
+      for (int w = 0; w < WW; ++w) s += red[t & 1][w][er][(j >> 1) * 16 + (j & 1) * 8 + eu];
       z[j] = s;
     }
     float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + p.forget_bias), go = sigmoidf_(z[3]);
     cst = gf * cst + gi * gj;
     float hv = go * tanhf_(cst);
     if (t >= elen) { cst = 0.f; hv = 0.f; gi = gj = gf = go = 0.f; }
+    // (audit) hst: written and read by the SAME cell wave (wave w owns rows 8w .. 8w+7 on both sides), so the release
+    // fence + wave barrier below is all the ordering it needs; no other role touches it
     hst[er][eu] = clean(hv, (T*)nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write -> read inside this wave (its own 8 rows)
     __builtin_amdgcn_wave_barrier();
@@ -344,7 +358,7 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
 constexpr int WTB = WT + 256;
 template <typename T, int NCH, int RPG>
 __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
-  __shared__ float red[WW][16][20];
+  __shared__ float red[2][WW][16][20];    // two images by step parity, as in the forward kernel
   __shared__ __attribute__((aligned(16))) bf16_t dst[16][4][16];      // this step's gate gradients (row, gate, unit)
   __shared__ int abortf;
   __shared__ unsigned long long pmask[2][2];
@@ -398,7 +412,7 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
         }
       }
 #pragma unroll
-      for (int q = 0; q < 4; ++q) red[wave][g * 4 + q][r16] = acc[q];
+      for (int q = 0; q < 4; ++q) red[bs & 1][wave][g * 4 + q][r16] = acc[q];
       __syncthreads();
       if (abortf) return;
       wstamp(a, bs, 2);
@@ -449,7 +463,7 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
     if (tr && bs < 256) a.trace[bs * 8 + 3] = wall_clock64();
     float dh = pdh;
 #pragma unroll
-    for (int w = 0; w < WW; ++w) dh += red[w][er][eu];
+    for (int w = 0; w < WW; ++w) dh += red[bs & 1][w][er][eu];
     const float gi = pg[0], gj = pg[1], gf = pg[2], go = pg[3];
     const float tc = tanhf_(pc);
     const float dc = dh * go * (1.f - tc * tc) + dcc;
@@ -461,6 +475,7 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
     dcc = dc * gf;
     if (t >= elen || !eok) { dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f; dcc = 0.f; }
 #pragma unroll
+    // (audit) dst: rows 4w .. 4w+3 are written (er = e >> 4) and published (row = 4w + lane / 8) by the same cell wave w
     for (int j = 0; j < 4; ++j) dst[er][j][eu] = clean(dgv[j], (bf16_t*)nullptr);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // LDS write -> read inside this wave (its own 4 rows)
     __builtin_amdgcn_wave_barrier();

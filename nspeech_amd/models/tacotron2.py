@@ -100,6 +100,10 @@ class Tacotron2(object):
         self._side_busy = False
         self.use_pv = True        # projected-memory form of the attention loop (ns_taco2_attn_params.pv)
         self._status_words = {}
+        # which kernel family ran each recurrence of the last pass: {"attn:fwd": "cluster" | "step",
+        # "dec1:bwd": "wide" | "step", "encl:fwd" / "expl:fwd": "cluster" | "step", ...}.  Tests assert on it; train.py
+        # logs it once, so a shape that falls off the persistent kernels is visible.
+        self.last_paths = {}
         pv, sv = P_.init_values(self.layout, self.stat_layout, seed)
         self.load_numpy(pv, sv)
         # attributes the reference exposes
@@ -549,8 +553,10 @@ class Tacotron2(object):
             w = self._buf("lstm_wide_work_%s_%s" % (tag, direction), ops.lstm_wide_work_floats(p), torch.float32)
             ops.lstm_wide(direction, p, w)
             self._status_words[(tag, direction)] = w
+            self.last_paths["%s:%s" % (tag, direction)] = "wide"
         else:
             ops.lstm_seq_call(direction, p)
+            self.last_paths["%s:%s" % (tag, direction)] = "step"
 
     use_cluster = True      # persistent whole-sequence BiLSTM kernels where the shape allows
     use_attn_cluster = True # persistent attention-RNN cluster kernels where the shape allows
@@ -561,8 +567,10 @@ class Tacotron2(object):
                              torch.float32)
             ops.lstm_cluster(direction, pair[0], pair[1], work)
             self._status_words[(tag, direction)] = work
+            self.last_paths["%s:%s" % (tag, direction)] = "cluster"
         else:
             ops.lstm_seq2(direction, pair[0], pair[1])
+            self.last_paths["%s:%s" % (tag, direction)] = "step"
 
     def check_status(self):
         """Raise if a persistent kernel reported an exchange timeout (host sync)."""
@@ -756,6 +764,7 @@ class Tacotron2(object):
             self._status_words[("attn", "fwd")] = cw
         else:
             ops.taco2_attn("fwd", **self._attn_args)
+        self.last_paths["attn:fwd"] = "cluster" if self._attn_cluster_fwd else "step"
         self._tick("attn_rnn")
 
         # ---- decoder LSTMs with hoisted inputs, then the projection (tacotron2.py:67-73)
@@ -1021,6 +1030,7 @@ class Tacotron2(object):
             self._status_words[("attn", "bwd")] = cw
         else:
             ops.taco2_attn("bwd", **args)
+        self.last_paths["attn:bwd"] = "cluster" if self._attn_cluster_fwd else "step"
         self._tick("attn_rnn_bwd")
         # hoisted weight gradients of the attention RNN
         p1, xa, fr = B["dec_p1"], B["dec_xa"], B["dec_fr"]

@@ -248,3 +248,25 @@ def test_speaker_projection_block():
     b = O.taco2_forward({**t(v1), **t(sv)}, hp1.values(), torch.tensor(inputs), torch.tensor(lengths),
                         torch.tensor(mel).double(), torch.tensor(lin).double())
     assert torch.allclose(a["mel_outputs"], b["mel_outputs"], atol=1e-12)
+
+
+def test_forced_relu_branches_reproduce_the_natural_pass_and_follow_the_given_masks():
+    """O.MASK_FORCE (the parity tests' same-branch aid): with the oracle's own masks the pass is unchanged bit for bit;
+    with one mask element flipped only the gradient through that unit changes."""
+    from util import oracle_relu_masks
+    from nspeech_amd.models import params as P_
+    from nspeech_amd.utils.text.symbols import symbols
+    hp = small_hparams()
+    layout, stat_layout = P_.taco2_layout(hp, len(symbols))
+    pv, sv = P_.init_values(layout, stat_layout, 3)
+    inputs, lengths, mel, lin = make_batch(hp, 2, 7, 10, seed=4)
+    masks = oracle_relu_masks(hp, pv, sv, inputs, lengths, mel, lin)
+    out0, loss0, g0 = oracle_run(hp, pv, sv, inputs, lengths, mel, lin)
+    out1, loss1, g1 = oracle_run(hp, pv, sv, inputs, lengths, mel, lin, force_masks=masks)
+    assert loss0 == loss1
+    for k in g0:
+        assert np.array_equal(g0[k], g1[k]), k
+    flipped = [m.copy() for m in masks]
+    flipped[0][0, 0, 0] = not flipped[0][0, 0, 0]
+    _, loss2, g2 = oracle_run(hp, pv, sv, inputs, lengths, mel, lin, force_masks=flipped)
+    assert any(not np.array_equal(g0[k], g2[k]) for k in g0)

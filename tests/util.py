@@ -37,10 +37,20 @@ def make_batch(hp, N, Ti, To, seed=0, vocab=149):
     return inputs, lengths, mel, lin
 
 
-def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64, need_grad=True, speaker_ids=None):
-    """Forward + loss + gradients with the CPU oracle.  Returns (out dict, loss tuple, grads dict)."""
+def oracle_run(hp, params, stats, inputs, lengths, mel, lin, dtype=torch.float64, need_grad=True, speaker_ids=None,
+               force_masks=None):
+    """Forward + loss + gradients with the CPU oracle.  Returns (out dict, loss tuple, grads dict).
+    force_masks: ReLU branch masks (model_relu_masks order) the oracle takes instead of its own (O.MASK_FORCE)."""
     sys.path.insert(0, os.path.join(ROOT))
     from oracle import taco2_oracle as O
+    O.MASK_FORCE = None if force_masks is None else [np.asarray(m) for m in force_masks]
+    try:
+        return _oracle_run(O, hp, params, stats, inputs, lengths, mel, lin, dtype, need_grad, speaker_ids)
+    finally:
+        O.MASK_FORCE = None
+
+
+def _oracle_run(O, hp, params, stats, inputs, lengths, mel, lin, dtype, need_grad, speaker_ids):
     p = {k: torch.tensor(v, dtype=dtype, requires_grad=need_grad) for k, v in params.items()}
     p.update({k: torch.tensor(v, dtype=dtype) for k, v in stats.items()})
     hpd = hp.values()
@@ -138,3 +148,49 @@ def same_branch_batch(m, hp, N, Ti, To, seed, tries=16, speaker_ids=None):
         if flips == 0:
             return inputs, lengths, mel, lin
     raise AssertionError("no batch without a ReLU branch difference within %d seeds" % tries)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64).ravel()
+    b = np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def rel_max(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def oracle_report(m, hp, inputs, lengths, mel, lin, speaker_ids=None, same_branch=True):
+    """One training pass of model `m` and of the float64 oracle on the same batch.  Returns {"out": {name: (rel L2,
+    rel max, mean L1)}, "grad": {name: (rel L2, rel max)}, "loss": (got, want), "flips": n ReLU branch differences,
+    "paths": m.last_paths}.  The caller sets the bounds; nothing is asserted here.
+    same_branch: the oracle takes every ReLU branch as the model took it (O.MASK_FORCE), so the gradients differ by
+    arithmetic only; `flips` still counts where the oracle's own pre-activations fell on the other side."""
+    params, stats = m.numpy_params(), m.numpy_stats()
+    want_masks = oracle_relu_masks(hp, params, stats, inputs, lengths, mel, lin, speaker_ids=speaker_ids)
+    m.initialize(inputs, lengths, speaker_ids, mel, lin)
+    got_masks = model_relu_masks(m)
+    assert len(got_masks) == len(want_masks)
+    flips = sum(int((a != b).sum()) for a, b in zip(got_masks, want_masks))
+    out, (loss, mel_loss, lin_loss), grads = oracle_run(hp, params, stats, inputs, lengths, mel, lin, speaker_ids=speaker_ids,
+                                                        force_masks=got_masks if same_branch else None)
+    m.backward()
+    m.read_losses()
+    rep = {"out": {}, "grad": {}, "loss": (m.loss, loss), "mel_loss": (m.mel_loss, mel_loss),
+           "linear_loss": (m.linear_loss, lin_loss), "flips": flips, "paths": dict(m.last_paths)}
+    for k in ("decoder_outputs", "mel_outputs", "linear_outputs", "alignments"):
+        a = getattr(m, k).float().cpu().numpy()
+        b = out[k].detach().numpy()
+        rep["out"][k] = (rel_l2(a, b), rel_max(a, b), float(np.abs(a - b).mean()))
+    got = m.numpy_grads()
+    gn = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in grads.values()))
+    for k in grads:
+        # a conv bias in front of BatchNorm has a zero true gradient (what is left is cancellation noise): compare it
+        # on the scale of the whole gradient instead of its own
+        if k.endswith("conv1d/bias") or np.linalg.norm(grads[k]) < 1e-9 * gn:
+            rep["grad"][k] = (float(np.linalg.norm(got[k] - grads[k]) / gn), float(np.abs(got[k] - grads[k]).max() / gn))
+        else:
+            rep["grad"][k] = (rel_l2(got[k], grads[k]), rel_max(got[k], grads[k]))
+    return rep
