@@ -315,6 +315,8 @@ def main():
     # phase then holds all of its own work - the decoder-gate roofline below counts the weight-gradient products of
     # the decoder LSTMs - and the phases add up to the single-stream step, a little more than ms_per_step.
     overlap, model.overlap_wgrads = getattr(model, "overlap_wgrads", False), False
+    one_step()                      # untimed: the one-stream form names some buffers differently (first-touch fills)
+    torch.cuda.synchronize()
     model.timing = []
     one_step()
     torch.cuda.synchronize()
@@ -357,12 +359,11 @@ def main():
                                                                    "TFLOPs": step_flop / (v / S * 1e-3) / 1e12 if v else None}
                            for k, v in loops.items()},
             "binding_bound": "weight-stationary: W_h never leaves the registers, so the HBM weight stream of the launch-per-step "
-                             "form (33.6 MB per step) is gone; each step is one store -> visible -> load hop of the state "
-                             "between the CUs (%.2f MB published, 64 KB fetched per CU = 16 MB chip-wide through the memory "
-                             "side) and costs 5.0 us forward / 5.9 us backward against a 3.4 / 4.6 us hop "
-                             "(profiles/r02_wide_trace.txt); MFMA time per step is ~0.1 us" % state_mb,
+                             "form is gone; each step is one store -> visible -> load hop of the state between the CUs "
+                             "(%.2f MB published per step); this run's per-step times are in `recurrence`, the split of a step "
+                             "into hop and arithmetic is traced in profiles/r02_wide_trace.txt" % state_mb,
             "traffic": _prof.pmc_traffic("lstm_wide"),
-            "traffic_note": "bytes per LAUNCH (= %d steps) at the L2's fabric side, profiles/r02_pmc_traffic.json" % S,
+            "traffic_note": "bytes per LAUNCH (= %d steps) at the L2's fabric side, %s" % (S, _prof.pmc_traffic_source()),
         }
         res = {
             "metric": "mel-frames/sec Tacotron-2 LJSpeech bs32 train step", "value": frames / (dt / args.steps),

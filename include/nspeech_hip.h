@@ -96,6 +96,14 @@ typedef struct {
   int batch; int64_t batch_stride_a, batch_stride_b, batch_stride_c;
   float* stat_part;  /* scratch for col_sum / col_sumsq (required with them), ns_gemm_stat_part_floats(M, N) floats */
   int stat_slots;    /* set by the library */
+  /* BatchNorm-BACKWARD statistics out of the product that forms dy (the data gradient of the layer above, or the
+   * BiLSTM's input gradient): with stat_z set - the saved BatchNorm input of the layer below, [M,N] in the layout of C -
+   * col_sumsq receives sum_m C[m,n] * (stat_z[m,n] - stat_mean[n]) * stat_istd[n] over the unmasked rows instead of the
+   * sum of squares, so col_sum / col_sumsq are the two column sums of modules.py:198's backward (sum dy, sum dy*xhat)
+   * and ns_bn_bwd needs no reduction pass of its own (ns_bn_bwd_params.sum_dy / sum_dyxh).  With accumulate = 1 the
+   * sums are taken on the accumulated value. */
+  const void* stat_z; int64_t ld_stat_z; int stat_z_dtype;
+  const float* stat_mean; const float* stat_istd;
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
 size_t ns_gemm_stat_part_floats(int M, int N);
@@ -157,8 +165,10 @@ int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t stream);
 /* BatchNorm + activation + bias backward of modules.py:194-198.
  * dy fp32 [rows,C] (grad wrt BN output), z = activated pre-BN value saved by forward.
  * Outputs: dpre (grad wrt conv output before the activation, operand dtype, pad rows 0),
- * dgamma/dbeta/dbias += .  work = fp32[64*C] scratch (per-row-block partial sums of dy and dy*xhat, added up in a
- * fixed order: the gradient that flows on is bitwise repeatable; no need to clear it). */
+ * dgamma/dbeta/dbias += .  work = fp32[200*C] scratch (per-row-block partial sums, added up in a fixed order: every
+ * output is bitwise repeatable; no need to clear it).
+ * sum_dy / sum_dyxh (both or neither, fp32[C]): the column sums of dy and dy*xhat over the unmasked rows, as left by
+ * the product that formed dy (ns_gemm_params.stat_z); without them a reduction pass over dy and z computes them. */
 typedef struct {
   const float* dy; const void* z; void* dpre; int dtype;
   int rows, C;
@@ -170,6 +180,7 @@ typedef struct {
   int row_period, row_lo, row_hi;
   int dpre_dtype;   /* 0: dpre has `dtype`; NS_BF16 with dtype NS_F32: dpre is written as bf16 (single-pass backward
                        products read it at half the bytes; the bias gradient is summed on the rounded values) */
+  const float* sum_dy; const float* sum_dyxh;
 } ns_bn_bwd_params;
 int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t stream);
 
@@ -209,8 +220,18 @@ typedef struct {
   const float* gnorm_sq; float clip; float grad_scale;
   float lr_t, beta1, beta2, eps;
   void* shadow_bf16;
+  /* status words of the step's persistent recurrences (ns_lstm_wide_* / ns_lstm_cluster_* / ns_taco2_attn_cluster_*:
+   * the first int of their work buffers; unused entries NULL).  If any is non-zero - an exchange timed out, that pass's
+   * outputs and therefore this gradient are invalid - NOTHING is updated and *skipped (nullable) is set to 1, on the
+   * device, without a host round trip in front of the optimiser. */
+  const int* status[12];
+  float* skipped;
 } ns_adam_params;
 int ns_adam(const ns_adam_params* p, ns_stream_t stream);
+
+/* Zero `bytes` (a multiple of 16, p 16-byte aligned) with a kernel on the stream.  Kernel, not hipMemsetAsync: a memset
+ * NODE of a captured HIP graph was seen to replay wrongly on ROCm 7.2 (see csrc/core.hip). */
+int ns_zero(void* p, size_t bytes, ns_stream_t stream);
 
 /* hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - hi[i]): pre-split operands for f32_passes = 3. */
 typedef struct { const float* src; void* hi; void* lo; int64_t n; } ns_split_params;

@@ -27,11 +27,12 @@ int ns_zero_async(void* p, size_t bytes, hipStream_t s) {
   if (bytes == 0) return NS_OK;
   NS_CHECK_ARG(p && (bytes & 15) == 0 && (((uintptr_t)p) & 15) == 0, "ns_zero_async: 16-byte granularity");
   const size_t n16 = bytes / 16;
-  const int grid = (int)((n16 + 255) / 256 < 1024 ? (n16 + 255) / 256 : 1024);
+  const int grid = (int)((n16 + 255) / 256 < 4096 ? (n16 + 255) / 256 : 4096);
   hipLaunchKernelGGL(ns_zero_kernel, dim3(grid), dim3(256), 0, s, (uint4*)p, n16);
   NS_CHECK_LAUNCH("ns_zero");
   return NS_OK;
 }
+extern "C" int ns_zero(void* p, size_t bytes, ns_stream_t stream) { return ns_zero_async(p, bytes, (hipStream_t)stream); }
 
 // ns_occupy / ns_wait_counter: hold CUs the way a collective's channel kernel does (see the header).  wall_clock64
 // ticks at 100 MHz.

@@ -274,7 +274,10 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 constexpr int BN4_QUADS = 16;      // channel quads per block (64 channels)
 constexpr int BN4_LANES = 16;      // row lanes per block: 16 x 16 = 256 threads
 constexpr int BN4_UNROLL = 4;
+constexpr int BN4_MAX_RB = 64;     // row blocks: 64 x (C / 64) workgroups = two per CU at C = 512, ~64 KB of loads in flight per CU
 
+// Fallback reduction (no producer statistics): per row block b, work[b*C + c] = sum dy, work[(RB + b)*C + c] = sum dy*xhat
+// over the block's valid rows; ns_stats_finalize adds the blocks in a fixed order.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p) {
   __shared__ float red[256][8];
@@ -282,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p)
   const int tid = threadIdx.x, ql = tid % BN4_QUADS, rl = tid / BN4_QUADS;
   const int q = blockIdx.y * BN4_QUADS + ql;
   const bool active = 4 * q < p.C;
-  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;      // rows per block: the host keeps ~32 adders per address
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   if (active) {
@@ -323,36 +326,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p)
     for (int i = 0; i < 4; ++i) {
       float a = 0.f, b = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) { a += red[r * BN4_QUADS + ql][i]; b += red[r * BN4_QUADS + ql][4 + i]; }
-      p.work[(long)(2 * blockIdx.x) * p.C + 4 * q + i] = a;
-      p.work[(long)(2 * blockIdx.x + 1) * p.C + 4 * q + i] = b;
+      p.work[(long)blockIdx.x * p.C + 4 * q + i] = a;
+      p.work[((long)gridDim.x + blockIdx.x) * p.C + 4 * q + i] = b;
     }
   }
 }
 
+// dz = gamma*istd*(dy - s1/M - xhat*s2/M); dpre = dz*act'(z) with s1 = sum dy, s2 = sum dy*xhat given per column (by the
+// product that formed dy, or by the reduction above).  Block = rows/RB rows x 64 channels; its column sums of dpre (the
+// bias gradient, taken on the values the weight-gradient product will read) go to part[blockIdx.x][C], added up in block
+// order by the finalize kernel: no float atomics, every output repeats bit for bit.
 template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) {
+__global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p, const float* sum_dy, const float* sum_dyxh,
+                                                            float* part) {
   __shared__ float red[256][4];
   const T* z = (const T*)p.z;
   const int tid = threadIdx.x, ql = tid % BN4_QUADS, rl = tid / BN4_QUADS;
   const int q = blockIdx.y * BN4_QUADS + ql;
   const bool active = 4 * q < p.C;
-  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;      // rows per block: the host keeps ~32 adders per address
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
   const bool d16 = sizeof(T) == 4 && p.dpre_dtype == NS_BF16;
   const float invM = 1.f / p.count;
   float sb[4] = {0.f, 0.f, 0.f, 0.f};
-  float4 tot1 = make_float4(0.f, 0.f, 0.f, 0.f), tot2 = tot1;
   if (active) {
     const float4 mean = *(const float4*)(p.mean + 4 * q), istd = *(const float4*)(p.istd + 4 * q);
     const float4 g = *(const float4*)(p.gamma + 4 * q);
-    float4 w1 = make_float4(0.f, 0.f, 0.f, 0.f), w2 = w1;      // the row blocks' partial sums, in block order
-    for (int b = 0; b < (int)gridDim.x; ++b) {
-      const float4 a1 = *(const float4*)(p.work + (long)(2 * b) * p.C + 4 * q);
-      const float4 a2 = *(const float4*)(p.work + (long)(2 * b + 1) * p.C + 4 * q);
-      w1.x += a1.x; w1.y += a1.y; w1.z += a1.z; w1.w += a1.w;
-      w2.x += a2.x; w2.y += a2.y; w2.z += a2.z; w2.w += a2.w;
-    }
-    tot1 = w1; tot2 = w2;
+    const float4 w1 = *(const float4*)(sum_dy + 4 * q), w2 = *(const float4*)(sum_dyxh + 4 * q);
     const float mu[4] = {mean.x, mean.y, mean.z, mean.w}, is[4] = {istd.x, istd.y, istd.z, istd.w};
     const float gi[4] = {g.x * istd.x, g.y * istd.y, g.z * istd.z, g.w * istd.w};
     const float m1[4] = {w1.x * invM, w1.y * invM, w1.z * invM, w1.w * invM};
@@ -394,7 +394,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) 
           }
         }
         const float4 ov = make_float4(o[0], o[1], o[2], o[3]);
-        // the bias gradient is taken on the values the weight-gradient GEMM will read
         if (d16) {
           st4((bf16_t*)p.dpre + idx, ov);
 #pragma unroll
@@ -415,32 +414,53 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p) 
     for (int i = 0; i < 4; ++i) {
       float a = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
-      if (p.dbias) atomicAdd(p.dbias + 4 * q + i, a);
-      if (blockIdx.x == 0) {
-        const float t1[4] = {tot1.x, tot1.y, tot1.z, tot1.w}, t2[4] = {tot2.x, tot2.y, tot2.z, tot2.w};
-        if (p.dgamma) p.dgamma[4 * q + i] += t2[i];
-        if (p.dbeta) p.dbeta[4 * q + i] += t1[i];
-      }
+      part[(long)blockIdx.x * p.C + 4 * q + i] = a;
     }
   }
+}
+__global__ void bn_bwd_finalize_kernel(ns_bn_bwd_params p, const float* sum_dy, const float* sum_dyxh, const float* part, int nb) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= p.C) return;
+  if (p.dbias) {
+    float a = 0.f;
+    for (int b = 0; b < nb; ++b) a += part[(long)b * p.C + c];
+    p.dbias[c] += a;
+  }
+  if (p.dgamma) p.dgamma[c] += sum_dyxh[c];
+  if (p.dbeta) p.dbeta[c] += sum_dy[c];
 }
 
 extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   NS_CHECK_ARG(p && p->dy && p->z && p->dpre && p->mean && p->istd && p->gamma && p->work, "ns_bn_bwd: null");
+  NS_CHECK_ARG(!p->sum_dy == !p->sum_dyxh, "ns_bn_bwd: sum_dy and sum_dyxh come together");
   const bool al16 = ((uintptr_t)p->dy % 16 == 0) && ((uintptr_t)p->z % 8 == 0) && ((uintptr_t)p->dpre % 8 == 0) &&
                     ((uintptr_t)p->mean % 16 == 0) && ((uintptr_t)p->istd % 16 == 0) && ((uintptr_t)p->gamma % 16 == 0) &&
                     ((uintptr_t)p->work % 16 == 0) && (p->dtype == NS_BF16 || ((uintptr_t)p->z % 16 == 0 &&
-                    (uintptr_t)p->dpre % (p->dpre_dtype == NS_BF16 ? 8 : 16) == 0));
+                    (uintptr_t)p->dpre % (p->dpre_dtype == NS_BF16 ? 8 : 16) == 0)) &&
+                    (!p->sum_dy || ((uintptr_t)p->sum_dy % 16 == 0 && (uintptr_t)p->sum_dyxh % 16 == 0));
   if (p->C % 4 == 0 && al16) {
-    const dim3 grid4(max(1, min(BN_MAX_BLOCKS, ceil_div(p->rows, 128))), ceil_div(p->C / 4, BN4_QUADS));
-    if (p->dtype == NS_BF16) {
-      hipLaunchKernelGGL(bn_bwd_reduce4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
-      hipLaunchKernelGGL(bn_bwd_apply4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p);
-    } else {
-      hipLaunchKernelGGL(bn_bwd_reduce4_kernel<float>, grid4, dim3(256), 0, s, *p);
-      hipLaunchKernelGGL(bn_bwd_apply4_kernel<float>, grid4, dim3(256), 0, s, *p);
+    // work: [0, C) sum dy | [C, 2C) sum dy*xhat (fallback only) | [2C, 2C + RB*C) bias-gradient partials |
+    //       [2C + 64C, 2C + 64C + 2*RB*C) the fallback reduction's partials
+    const int rb = max(1, min(BN4_MAX_RB, ceil_div(p->rows, 128)));
+    const dim3 grid4(rb, ceil_div(p->C / 4, BN4_QUADS));
+    const float* s1 = p->sum_dy;
+    const float* s2 = p->sum_dyxh;
+    float* part = p->work + 2L * p->C;
+    if (!s1) {
+      ns_bn_bwd_params q = *p;
+      q.work = p->work + (2L + BN4_MAX_RB) * p->C;
+      if (p->dtype == NS_BF16) hipLaunchKernelGGL(bn_bwd_reduce4_kernel<bf16_t>, grid4, dim3(256), 0, s, q);
+      else hipLaunchKernelGGL(bn_bwd_reduce4_kernel<float>, grid4, dim3(256), 0, s, q);
+      NS_CHECK_LAUNCH("bn_bwd_reduce");
+      const int rc = ns_stats_finalize(q.work, rb, p->C, p->work, p->work + p->C, s);
+      if (rc) return rc;
+      s1 = p->work;
+      s2 = p->work + p->C;
     }
+    if (p->dtype == NS_BF16) hipLaunchKernelGGL(bn_bwd_apply4_kernel<bf16_t>, grid4, dim3(256), 0, s, *p, s1, s2, part);
+    else hipLaunchKernelGGL(bn_bwd_apply4_kernel<float>, grid4, dim3(256), 0, s, *p, s1, s2, part);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(ceil_div(p->C, 256)), dim3(256), 0, s, *p, s1, s2, part, rb);
     NS_CHECK_LAUNCH("bn_bwd");
     return NS_OK;
   }
@@ -482,16 +502,17 @@ __global__ __launch_bounds__(256) void colsum4_kernel(ns_colsum_params p) {
   const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
   float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int CU = 8;          // rows in flight per thread (a bf16 row quad is only 8 bytes)
   if (active) {
-    for (int base = r0 + rl; base < r1; base += BN4_UNROLL * BN4_LANES) {
-      float4 v[BN4_UNROLL];
+    for (int base = r0 + rl; base < r1; base += CU * BN4_LANES) {
+      float4 v[CU];
 #pragma unroll
-      for (int u = 0; u < BN4_UNROLL; ++u) {
+      for (int u = 0; u < CU; ++u) {
         const int row = base + u * BN4_LANES;
         v[u] = row < r1 ? ld4(x + (long)row * p.ld + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
-      for (int u = 0; u < BN4_UNROLL; ++u) { s4[0] += v[u].x; s4[1] += v[u].y; s4[2] += v[u].z; s4[3] += v[u].w; }
+      for (int u = 0; u < CU; ++u) { s4[0] += v[u].x; s4[1] += v[u].y; s4[2] += v[u].z; s4[3] += v[u].w; }
     }
   }
 #pragma unroll
@@ -512,7 +533,7 @@ extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
   const int esz = p->dtype == NS_BF16 ? 2 : 4;
   // a ragged last quad reads into the row's padding (C rounded up to 4 <= ld) and adds only its valid columns
   if ((p->C + 3) / 4 * 4 <= p->ld && p->ld % 4 == 0 && ((uintptr_t)p->x % (4 * esz)) == 0) {
-    const dim3 grid(max(1, min(32, ceil_div(p->rows, 128))), ceil_div((p->C + 3) / 4, BN4_QUADS));
+    const dim3 grid(max(1, min(64, ceil_div(p->rows, 128))), ceil_div((p->C + 3) / 4, BN4_QUADS));
     if (p->dtype == NS_BF16) hipLaunchKernelGGL(colsum4_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, *p);
     else hipLaunchKernelGGL(colsum4_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, *p);
     NS_CHECK_LAUNCH("colsum");
@@ -605,9 +626,13 @@ __global__ void sumsq_kernel(ns_sumsq_params p) {
   float s = 0.f;
   const long n4 = p.n / 4;
   const float4* x4 = (const float4*)p.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-    const float4 v = x4[i];
-    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {      // four 16-byte loads in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = i + u * stride < n4 ? x4[i + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
   }
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x)
     s += p.x[i] * p.x[i];
@@ -646,6 +671,16 @@ extern "C" int ns_sumsq(const ns_sumsq_params* p, ns_stream_t s) {
 }
 
 __global__ void adam_kernel(ns_adam_params p) {
+  // a timed-out persistent recurrence left an invalid gradient: update nothing (uniform over the grid: every thread
+  // reads the same words, which no kernel of this step writes any more)
+  bool bad = false;
+#pragma unroll
+  for (int i = 0; i < 12; ++i)
+    if (p.status[i] && __hip_atomic_load(p.status[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) bad = true;
+  if (bad) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p.skipped) *p.skipped = 1.f;
+    return;
+  }
   float scale = p.grad_scale;
   if (p.gnorm_sq) {
     const float gn = sqrtf(p.gnorm_sq[0]) * p.grad_scale;
@@ -702,10 +737,76 @@ __global__ void cast2d_kernel(ns_cast2d_params p) {
     }
   }
 }
+// Vector form: 64 x 64 tiles, 16-byte loads, 4 destination elements per store (16 B fp32 / 8 B bf16).  The weight
+// shadows refreshed after every optimiser step are 28 M elements (tacotron2.py refresh_shadows); the scalar form above
+// moved them at a fraction of the HBM rate (0.27 ms per step).
+__device__ __forceinline__ void cast2d_put4(const ns_cast2d_params& p, long i, const float (&v)[4]) {
+  if (p.dst) {
+    if (p.dst_dtype == NS_BF16) {
+      bf16x4 o; o[0] = (bf16_t)v[0]; o[1] = (bf16_t)v[1]; o[2] = (bf16_t)v[2]; o[3] = (bf16_t)v[3];
+      *(bf16x4*)((bf16_t*)p.dst + i) = o;
+    } else {
+      *(float4*)((float*)p.dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  if (p.dst_hi) {
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (bf16_t)v[j]; lo[j] = (bf16_t)(v[j] - (float)hi[j]); }
+    *(bf16x4*)((bf16_t*)p.dst_hi + i) = hi;
+    *(bf16x4*)((bf16_t*)p.dst_lo + i) = lo;
+  }
+}
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(256) void cast2d_vec_kernel(ns_cast2d_params p) {
+  __shared__ float tile[TRANSPOSE ? 64 : 1][65];
+  const int bx = blockIdx.x * 64, by = blockIdx.y * 64;      // bx over cols, by over rows of src
+  const int q = threadIdx.x & 15, l = threadIdx.x >> 4;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = by + l + 16 * i, c = bx + q * 4;
+    v[i] = (r < p.rows && c < p.cols) ? *(const float4*)(p.src + (long)r * p.ld_src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!TRANSPOSE) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = by + l + 16 * i, c = bx + q * 4;
+      const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      if (r < p.rows && c < p.cols) cast2d_put4(p, (long)r * p.ld_dst + c, f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* t = &tile[l + 16 * i][q * 4];
+    t[0] = v[i].x; t[1] = v[i].y; t[2] = v[i].z; t[3] = v[i].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = l + 16 * i, r4 = q * 4;               // dst row bx + c holds src rows by + r4 .. + 3
+    const float f[4] = {tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]};
+    if (bx + c < p.cols && by + r4 < p.rows) cast2d_put4(p, (long)(bx + c) * p.ld_dst + by + r4, f);
+  }
+}
 extern "C" int ns_cast2d(const ns_cast2d_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->src && (p->dst || p->dst_hi), "ns_cast2d: null");
   NS_CHECK_ARG(!p->dst_hi == !p->dst_lo, "ns_cast2d: dst_hi and dst_lo come as a pair");
   if (p->rows <= 0 || p->cols <= 0) return NS_OK;
+  {
+    auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
+    const int dsz = p->dst_dtype == NS_BF16 ? 8 : 16;
+    const bool vec = p->cols % 4 == 0 && p->ld_src % 4 == 0 && p->ld_dst % 4 == 0 && (!p->transpose || p->rows % 4 == 0) &&
+                     al(p->src, 16) && al(p->dst, dsz) && al(p->dst_hi, 8) && al(p->dst_lo, 8) && (long)p->rows * p->cols >= 4096;
+    if (vec) {
+      const dim3 grid(ceil_div(p->cols, 64), ceil_div(p->rows, 64));
+      if (p->transpose) hipLaunchKernelGGL(cast2d_vec_kernel<true>, grid, dim3(256), 0, (hipStream_t)s, *p);
+      else hipLaunchKernelGGL(cast2d_vec_kernel<false>, grid, dim3(256), 0, (hipStream_t)s, *p);
+      NS_CHECK_LAUNCH("cast2d");
+      return NS_OK;
+    }
+  }
   dim3 grid(ceil_div(p->cols, 32), ceil_div(p->rows, 32));
   hipLaunchKernelGGL(cast2d_kernel, grid, dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("cast2d");

@@ -16,6 +16,7 @@ struct Epi {
   int M, N;
   const void* addend; long ld_add; int add_bf16;
   const void* gate; long ld_gate; int gate_dtype;
+  const void* sz; long ld_sz; int sz_bf16; const float* smean; const float* sistd;    // BatchNorm-backward statistics
 };
 
 __device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
@@ -26,6 +27,7 @@ __device__ __forceinline__ Epi make_epi(const ns_gemm_params& p) {
   e.M = p.M; e.N = p.N;
   e.addend = p.addend; e.ld_add = p.ld_add; e.add_bf16 = p.addend_dtype == NS_BF16;
   e.gate = p.gate; e.ld_gate = p.ld_gate; e.gate_dtype = p.dtype;
+  e.sz = p.stat_z; e.ld_sz = p.ld_stat_z; e.sz_bf16 = p.stat_z_dtype == NS_BF16; e.smean = p.stat_mean; e.sistd = p.stat_istd;
   return e;
 }
 
@@ -52,17 +54,30 @@ __device__ __forceinline__ float epi_value(const Epi& e, int m, int n, float acc
   return valid ? v : 0.f;
 }
 
-__device__ __forceinline__ void epi_store(const Epi& e, int m, int n, float v) {
+// returns the value now in C (what the statistics are taken on)
+__device__ __forceinline__ float epi_store(const Epi& e, int m, int n, float v) {
   long off = (long)m * e.ldc + n;
   if (e.accumulate == 2) {
     atomicAdd((float*)e.C + off, v);
   } else if (e.accumulate == 1) {
-    ((float*)e.C)[off] += v;
+    v += ((float*)e.C)[off];
+    ((float*)e.C)[off] = v;
   } else if (e.c_dtype == NS_BF16) {
-    ((bf16_t*)e.C)[off] = (bf16_t)v;
+    const bf16_t b = (bf16_t)v;
+    ((bf16_t*)e.C)[off] = b;
+    v = (float)b;
   } else {
     ((float*)e.C)[off] = v;
   }
+  return v;
+}
+// second statistic of a stored value: its square (BatchNorm forward: sum of squares), or, with stat_z, its product with
+// the normalised saved input of the BatchNorm below (BatchNorm backward: sum dy * xhat)
+__device__ __forceinline__ float stat_second(const Epi& e, int m, int n, float vs) {
+  if (!e.sz) return vs * vs;
+  const long o = (long)m * e.ld_sz + n;
+  const float zv = e.sz_bf16 ? (float)((const bf16_t*)e.sz)[o] : ((const float*)e.sz)[o];
+  return vs * ((zv - e.smean[n]) * e.sistd[n]);
 }
 
 // batched call: item z works on A + z*batch_stride_a, B + z*batch_stride_b, C + z*batch_stride_c (elements)
@@ -146,12 +161,10 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
       int n = n0 + tx * 4 + j;
       if (n >= p.N) continue;
       float v = epi_value(e, m, n, acc[i][j], add_bias, valid);
-      epi_store(e, m, n, v);
+      const float vs = epi_store(e, m, n, v);       // stats are taken on the value as the consumer will read it back
       if (valid) {
-        // stats are taken on the value as the consumer will read it back
-        float vs = (p.c_dtype == NS_BF16 && p.accumulate == 0) ? (float)(bf16_t)v : v;
         s1[j] += vs;
-        s2[j] += vs * vs;
+        s2[j] += stat_second(e, m, n, vs);
       }
     }
   }
@@ -280,7 +293,6 @@ __device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) 
 __device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&acc)[4][4], int m0, int n0, int wm,
                                               int wn, int lane, bool add_bias) {
   Epi e = make_epi(p);
-  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int n = n0 + wn * 64 + j * 16 + (lane & 15);
@@ -293,11 +305,10 @@ __device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&a
         if (m < p.M && n < p.N) {
           const bool valid = row_valid(e, m);
           float v = epi_value(e, m, n, acc[i][j][r], add_bias, valid);
-          epi_store(e, m, n, v);
+          const float vs = epi_store(e, m, n, v);
           if (valid) {
-            float vs = round_stats ? (float)(bf16_t)v : v;
             s1 += vs;
-            s2 += vs * vs;
+            s2 += stat_second(e, m, n, vs);
           }
         }
       }
@@ -430,38 +441,86 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
 // 838 (128^2 kernel: 662 / - / 610); three-segment product 344 algorithmic = 1032 issued (in-kernel split: 239).
 constexpr int XHALF = 16384, XBUF = 65536;
 
-// C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+// ---- vector epilogue.  The 256-tile kernel issues its MFMAs with the operands SWAPPED (a = the B fragment, b = the A
+// fragment), so a 16 x 16 accumulator holds the TRANSPOSED tile: lane l owns output row m = l & 15 and the four
+// consecutive columns n = (l >> 4) * 4 + r.  One 16-byte (fp32) / 8-byte (bf16) store per tile and lane instead of four
+// 4-byte ones, one row-mask test per row instead of per element, and bias / addend / gate / the BatchNorm-backward
+// operand (stat_z) come in as vectors.  Round 3: the scalar form cost ~10 us of a 60 us tile, and +60 us per launch
+// with the BatchNorm-backward statistics in it.
+__device__ __forceinline__ float4 ldv4(const void* base, bool bf16, long off) {
+  if (bf16) {
+    const bf16x4 v = *(const bf16x4*)((const bf16_t*)base + off);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *(const float4*)((const float*)base + off);
+}
 __device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&acc)[4][2], int mq, int nq, int lane) {
-  Epi e = make_epi(p);
-  const bool round_stats = (p.c_dtype == NS_BF16 && p.accumulate == 0);
+  const Epi e = make_epi(p);
+  const int li = lane & 15, c4 = (lane >> 4) * 4;
+  const bool want_stats = p.stat_part != nullptr;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int n = nq + j * 16 + (lane & 15);
-    float s1 = 0.f, s2 = 0.f;
+    const int n = nq + j * 16 + c4;               // this lane's four columns n .. n + 3: all inside or all outside N (N % 128 == 0)
+    if (n >= p.N) continue;                       // whole 16-lane rows take this branch together (row16_sum below)
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), smean = bias, sistd = bias;
+    if (e.bias) bias = *(const float4*)(e.bias + n);
+    if (e.sz) { smean = *(const float4*)(e.smean + n); sistd = *(const float4*)(e.sistd + n); }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int m = mq + i * 16 + li;
+      if (m >= p.M) continue;
+      const bool valid = row_valid(e, m);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+      float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.addend) ad = ldv4(e.addend, e.add_bf16, (long)m * e.ld_add + n);
+      const float aa[4] = {ad.x, ad.y, ad.z, ad.w};
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mq + i * 16 + (lane >> 4) * 4 + r;
-        if (m < p.M && n < p.N) {
-          const bool valid = row_valid(e, m);
-          const float v = epi_value(e, m, n, acc[i][j][r], true, valid);
-          epi_store(e, m, n, v);
-          if (valid) {
-            const float vs = round_stats ? (float)(bf16_t)v : v;
-            s1 += vs;
-            s2 += vs * vs;
-          }
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(e.alpha * v[r] + bb[r] + aa[r], e.act);
+      if (e.gate) {
+        const float4 gt = ldv4(e.gate, e.gate_dtype == NS_BF16, (long)m * e.ld_gate + n);
+        const float gg[4] = {gt.x, gt.y, gt.z, gt.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!(gg[r] > 0.f)) v[r] = 0.f;
+      }
+      if (!valid) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      const long off = (long)m * e.ldc + n;
+      if (e.accumulate == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd((float*)e.C + off + r, v[r]);
+      } else if (e.accumulate == 1) {
+        const float4 old = *(const float4*)((float*)e.C + off);
+        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (e.c_dtype == NS_BF16) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; v[r] = (float)o[r]; }    // statistics on the stored values
+        *(bf16x4*)((bf16_t*)e.C + off) = o;
+      } else {
+        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (want_stats && valid) {
+        if (e.sz) {
+          const float4 zz = ldv4(e.sz, e.sz_bf16, (long)m * e.ld_sz + n);
+          s2[0] += v[0] * ((zz.x - smean.x) * sistd.x); s2[1] += v[1] * ((zz.y - smean.y) * sistd.y);
+          s2[2] += v[2] * ((zz.z - smean.z) * sistd.z); s2[3] += v[3] * ((zz.w - smean.w) * sistd.w);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s2[r] += v[r] * v[r];
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[r] += v[r];
       }
     }
-    if (p.stat_part) {     // this quadrant's 64 rows = one statistics slot
-      s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
-      s2 += __shfl_xor(s2, 16, 64); s2 += __shfl_xor(s2, 32, 64);
-      if ((lane >> 4) == 0 && n < p.N) {
+    if (want_stats) {      // this quadrant's 64 rows = one statistics slot: add the 16 row lanes of each column group
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+      if (li == 0) {
         const long slot = mq >> 6;
-        p.stat_part[slot * p.N + n] = s1;
-        p.stat_part[(p.stat_slots + slot) * p.N + n] = s2;
+        *(float4*)(p.stat_part + slot * p.N + n) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *(float4*)(p.stat_part + (p.stat_slots + slot) * p.N + n) = make_float4(s2[0], s2[1], s2[2], s2[3]);
       }
     }
   }
@@ -560,7 +619,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
     _Pragma("unroll") for (int kk = 0; kk < 2; ++kk)                                                       \
       _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                        \
         _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                      \
-          acc[H][G][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][kk], BR[j][kk], acc[H][G][i][j], 0, 0, 0); \
+          acc[H][G][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BR[j][kk], fa[i][kk], acc[H][G][i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                         \
   } while (0)
 #define X_SYNC_LOADS()                              \
@@ -943,6 +1002,12 @@ static bool x256_ok(const ns_gemm_params& p) {
   if (p.K % 64 != 0 || p.K < 128 || p.M < 1024 || p.N % 128 != 0) return false;
   if ((p.A_lo != nullptr) != (p.B_lo != nullptr)) return false;
   if (p.A_lo && (!aligned16(p.A_lo) || !aligned16(p.B_lo))) return false;
+  {   // the vector epilogue: 16-byte (fp32) / 8-byte (bf16) accesses of C and of every per-element epilogue operand
+    auto al = [](const void* q, long ld, bool bf16) { return !q || ((((uintptr_t)q) & (bf16 ? 7 : 15)) == 0 && ld % 4 == 0); };
+    if (!al(p.C, p.ldc, p.c_dtype == NS_BF16) || !al(p.addend, p.ld_add, p.addend_dtype == NS_BF16) ||
+        !al(p.gate, p.ld_gate, true) || !al(p.stat_z, p.ld_stat_z, p.stat_z_dtype == NS_BF16) || !al(p.bias, 4, false) ||
+        !al(p.stat_mean, 4, false) || !al(p.stat_istd, 4, false) || !al(p.stat_part, 4, false)) return false;
+  }
   if ((double)p.M * (double)p.lda * 2.0 >= 4.0e9 || (double)p.N * (double)p.ldb * 2.0 >= 4.0e9) return false;
   if (getenv("NS_GEMM_NO256")) return false;
   // at least ~3/4 of the CUs busy, or the 128-tile kernel's finer grain wins
@@ -956,12 +1021,21 @@ extern "C" size_t ns_gemm_stat_part_floats(int M, int N) {
 
 static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream);
 
+// the fixed-order second stage on its own (ns_bn_bwd's fallback reduction and its bias-gradient partials use it too)
+int ns_stats_finalize(const float* part, int slots, int N, float* s1, float* s2, hipStream_t stream) {
+  hipLaunchKernelGGL(gemm_stats_finalize_kernel, dim3(ceil_div(N, 32)), dim3(1024), 0, stream, part, slots, N, s1, s2);
+  NS_CHECK_LAUNCH("gemm_stats_finalize");
+  return NS_OK;
+}
+
 extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NS_CHECK_ARG(pp != nullptr, "ns_gemm: null params");
   ns_gemm_params p = *pp;
   NS_CHECK_ARG(!p.col_sumsq || p.col_sum, "ns_gemm: col_sumsq needs col_sum");
   NS_CHECK_ARG(!p.col_sum || p.stat_part, "ns_gemm: col_sum needs the stat_part scratch (ns_gemm_stat_part_floats)");
+  NS_CHECK_ARG(!p.stat_z || (p.col_sum && p.col_sumsq && p.stat_mean && p.stat_istd && p.accumulate != 2 && p.split_k <= 1),
+               "ns_gemm: stat_z needs col_sum, col_sumsq, stat_mean, stat_istd and a non-atomic store");
   if (!p.col_sum) p.stat_part = nullptr;
   p.stat_slots = 0;
   int rc = gemm_dispatch(p, stream);

@@ -175,9 +175,12 @@ class DataFeeder(object):
             examples = group[self.rank::self.world]
         batches = [examples[i:i + n] for i in range(0, len(examples), n)]
         if self.world == 1:
-            self._order_rng.random()              # keeps the shared generator in step with the multi-rank walk
-            self._rng.shuffle(batches)
-            return [prepare_batch(b, r, self._rng) for b in batches]
+            # the batch order comes from the same generator and the same call as in the multi-rank walk below (one
+            # shuffle of the batch indices per group); the ITEMS of a group still differ between world sizes, since a
+            # group spans per_rank * world items
+            order = list(range(len(batches)))
+            self._order_rng.shuffle(order)
+            return [prepare_batch(batches[j], r, self._rng) for j in order]
         # global batch j = group[j*n*world : (j+1)*n*world]; every rank shuffles the batch order with the SHARED
         # generator (global step k is the same batch j on all ranks) and pads to the longest target of the whole
         # global batch, so T_out is equal across ranks and averaging the rank gradients is the global mean loss

@@ -100,6 +100,7 @@ class Tacotron2(object):
         self._side_busy = False
         self.use_pv = True        # projected-memory form of the attention loop (ns_taco2_attn_params.pv)
         self._status_words = {}
+        self._bwd_sums = {}       # conv tag -> (sum dy, sum dy*xhat) left by the product that formed that layer's dy
         # which kernel family ran each recurrence of the last pass: {"attn:fwd": "cluster" | "step",
         # "dec1:bwd": "wide" | "step", "encl:fwd" / "expl:fwd": "cluster" | "step", ...}.  Tests assert on it; train.py
         # logs it once, so a shape that falls off the persistent kernels is visible.
@@ -263,11 +264,21 @@ class Tacotron2(object):
             key = "%s_%s" % (name, str(dtype))
         b = self._bufs.get(key)
         if b is None or b.numel() < numel or b.dtype != dtype:
-            b = torch.zeros(numel, dtype=dtype, device=self.device)
+            b = torch.zeros(_round_up(numel, 8), dtype=dtype, device=self.device)      # whole 16-byte units (ops.zero)
             self._bufs[key] = b
         return b
 
-    _BUCKET_AFTER = {"expand_conv_bwd": "head", "postnet_bwd": "postnet", "attn_wgrad": "decoder",
+    # Where a gradient bucket is handed to the all-reduce (parallel.GradReducer).  Rule (measured with the
+    # occupier proxy of tests/test_coexist_gpu.py): never directly in front of a whole-chip persistent recurrence.  A
+    # collective's channel kernel that sits on a few dozen CUs keeps the last chains of lstm_wide_bwd / attn_cluster_bwd
+    # unplaced until it leaves or the placed chains have finished, so its time is added to the recurrence instead of
+    # hidden under it; beside GEMM-shaped phases (thousands of short workgroups) it shares the chip.  Hence:
+    #   head (30 MB)     after the expand convolutions' backward  -> runs beside the postnet backward (GEMMs, BatchNorm)
+    #   postnet (22 MB)  NOT after the postnet backward (the four decoder recurrences follow) but after the attention
+    #                    RNN's backward                            -> beside the attention weight gradients + encoder backward
+    #   decoder (68 MB)  after the attention weight gradients      -> beside the encoder backward
+    #   encoder (20 MB)  after the encoder backward                -> exposed (in front of clip + Adam)
+    _BUCKET_AFTER = {"expand_conv_bwd": "head", "attn_rnn_bwd": "postnet", "attn_wgrad": "decoder",
                      "encoder_bwd": "encoder"}
 
     # Weight gradients feed nothing before the optimiser, so they run on a second stream:
@@ -404,6 +415,28 @@ class Tacotron2(object):
             self._bufs["st_used"] = off + ((4 * cout + 63) // 64) * 64
         return m[tag]
 
+    def _bwd_stats_buf(self, tag, cout):
+        """[sum dy | sum dy*xhat] of one conv layer's BatchNorm backward, written by the product that forms its dy."""
+        m = self._bufs.setdefault("bst_map", {})
+        if tag not in m:
+            m[tag] = self._buf("bst_" + tag, 2 * cout, torch.float32)
+        return m[tag]
+
+    def _dy_stats_kw(self, stats_for, row0=0):
+        """ns_gemm keywords that make a product leave the BatchNorm-backward sums of its output for layer `stats_for`
+        (whose saved input and batch statistics it reads), or {}.  row0: the buffer row that output row 0 lands on (c_off)."""
+        if not stats_for or not self.fuse_bn_bwd_stats:
+            return {}
+        z = self._bufs[stats_for + "_z"]
+        st = self._bufs["st_map"][stats_for]
+        c = st.numel() // 4
+        bs = self._bwd_stats_buf(stats_for, c)
+        self._bwd_sums[stats_for] = (bs, bs[c:])
+        return dict(col_sum=bs, col_sumsq=bs[c:], stat_z=z, ld_stat_z=c, stat_z_off=row0 * c, stat_mean=st[2 * c:],
+                    stat_istd=st[3 * c:])
+
+    fuse_bn_bwd_stats = True    # BatchNorm-backward column sums out of the epilogue of the product that forms dy
+
     def _x256_split_ok(self, tag, rows, cin, cout, k):
         """A three-pass forward convolution that can run on the 256-tile kernel over pre-split operands."""
         return (self.mode == "mixed" and ("postT_" + tag[4:] + "_hi") in self.tsh and tag.startswith("post")
@@ -450,9 +483,10 @@ class Tacotron2(object):
         return (yh, yl) if emit_split else y
 
     def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False,
-                  D=None, defer=None):
+                  D=None, defer=None, stats_for=None):
         """Backward of _conv_fwd.  dy fp32 [rows,cout] -> grads in flat_g, dx fp32 [rows,cin].  defer = bucket name: the
-        weight gradient goes through _defer, on operand buffers of this layer's own."""
+        weight gradient goes through _defer, on operand buffers of this layer's own.  stats_for = tag of the conv layer
+        below: the data-gradient product leaves that layer's BatchNorm-backward sums (its dx is that layer's dy)."""
         kl = (k - 1) // 2
         kr = k - 1 - kl
         rows = N * Pp
@@ -472,10 +506,10 @@ class Tacotron2(object):
             x16 = self._buf("xin16_%d%s" % (cin, own), rows * cin, torch.bfloat16)
             ops.cast2d(xin, rows, cin, cin, x16, cin, False)
             xin = x16
-        work = self._buf("bn_work", 64 * max(2048, cout), torch.float32)
+        work = self._buf("bn_work", 200 * max(1024, cout), torch.float32)
         g = self.flat_g
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
-                   row_mask=(Pp, self.padl, self.padl + T),
+                   sums=self._bwd_sums.pop(tag, None), row_mask=(Pp, self.padl, self.padl + T),
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dgamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dbeta_off=self._o(scope + "/batch_normalization/beta"),
@@ -497,7 +531,7 @@ class Tacotron2(object):
             ops.gemm(dpre, w16 if w16 is not None else self._W(D), dx, Mg2, cin, k * cout, cout, cout, cin, a_mode=0, b_mode=0,
                      a_off=a2 * cout, b_off=self._o(scope + "/conv1d/kernel") + (k - 1) * cin * cout,
                      b_seg=(cout, -cin * cout), c_off=self.padl * cin, accumulate=1 if dx_accumulate else 0,
-                     row_mask=(Pp, self.padl, self.padl + T, self.padl))
+                     row_mask=(Pp, self.padl, self.padl + T, self.padl), **self._dy_stats_kw(stats_for, self.padl))
 
     @staticmethod
     def _splitk(K, M, N):
@@ -579,8 +613,10 @@ class Tacotron2(object):
             if v != 0:
                 raise RuntimeError("persistent LSTM kernel %s timed out (status %d)" % (key, v))
 
-    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None, defer=None):
-        """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients."""
+    def _bilstm_bwd(self, scope, x, dout, cin, H, N, T, Pp, lengths, tag, dx, D=None, defer=None, stats_for=None):
+        """dout fp32 [rows, 2H]; writes dx fp32 [rows, cin] and the kernel / bias gradients.  stats_for: the conv layer
+        whose output feeds this BiLSTM - the second (accumulating) input-gradient product leaves its BatchNorm-backward
+        sums."""
         rows = N * Pp
         D = D or self.T
         g = self.flat_g
@@ -624,7 +660,8 @@ class Tacotron2(object):
                 wgrads()
             # dx (+)= dgates . Wx^T
             ops.gemm(dg, self._W(D), dx, rows, cin, 4 * H, 4 * H, 4 * H, cin, a_mode=0, b_mode=0, b_off=ko,
-                     accumulate=0 if di == 0 else 1)
+                     accumulate=0 if di == 0 else 1, row_mask=(Pp, self.padl, self.padl + T, 0),
+                     **(self._dy_stats_kw(stats_for) if di == 1 else {}))
 
     # ------------------------------------------------------------------ multi-speaker (num_speakers > 1)
     def _speaker_fwd(self, N):
@@ -858,9 +895,10 @@ class Tacotron2(object):
         E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
         S1 = S + 1
         g = self.flat_g
-        g.zero_()
-        self.scal.zero_()
+        ops.zero(g)
+        ops.zero(self.scal)
         self._deferred = []
+        self._bwd_sums = {}
         B = self._bufs
         ops.F32_PASSES = self.passes_bwd
         Tx = self.Tx
@@ -881,7 +919,7 @@ class Tacotron2(object):
         ex = B["expl_h"]
         rows_o = N * Po
         dwl = self._buf("d_wl_pad", 2 * Hx * Fp, torch.float32)
-        dwl.zero_()
+        ops.zero(dwl)
         ops.gemm(ex, dlin, dwl, 2 * Hx, Fp, rows_o, 2 * Hx, Fp, Fp, a_mode=1, b_mode=1, accumulate=2,
                  split_k=self._splitk(rows_o, 2 * Hx, Fp))
         ops.copy3d(dwl, g, 1, 2 * Hx, F, (0, Fp), (0, F), dst_off=self._o("dense/kernel"), accumulate=1)
@@ -894,7 +932,7 @@ class Tacotron2(object):
         dx = self._buf("d_act_a", rows_o * 512, torch.float32)
         dx2 = self._buf("d_act_b", rows_o * 512, torch.float32)
         self._bilstm_bwd("expand/encoder_lstm", self._exp_in[-1], dex, Cx, Hx, N, To, Po, None, "expl", dx, D=Tx,
-                         defer="head")
+                         defer="head", stats_for="exp%d" % (hp.expand_conv_layers - 1))
         self._tick("expand_lstm_bwd")
         cur, nxt = dx, dx2
         for i in range(hp.expand_conv_layers - 1, -1, -1):
@@ -905,7 +943,7 @@ class Tacotron2(object):
                                "exp0", dmel, dx_accumulate=True, D=Tx, defer="head")
             else:
                 self._conv_bwd("expand/conv_%d" % i, self._exp_in[i], cur, cin, Cx, hp.expand_conv_width, act, N, To,
-                               Po, "exp%d" % i, nxt, D=Tx, defer="head")
+                               Po, "exp%d" % i, nxt, D=Tx, defer="head", stats_for="exp%d" % (i - 1))
                 cur, nxt = nxt, cur
         self._tick("expand_conv_bwd")
         # ---- postnet: mel = dec + dense(postnet(dec))
@@ -917,7 +955,8 @@ class Tacotron2(object):
                  split_k=self._splitk(rows_o, Cp, M))
         ops.colsum(dmel_t, M, rows_o, M, g, out_off=self._o("decoder_postnet/dense/bias"))
         cur, nxt = dx, dx2
-        ops.gemm(dmel_t, self._W(self.T), cur, rows_o, Cp, M, M, M, Cp, a_mode=0, b_mode=0, b_off=ko)
+        ops.gemm(dmel_t, self._W(self.T), cur, rows_o, Cp, M, M, M, Cp, a_mode=0, b_mode=0, b_off=ko,
+                 row_mask=(Po, self.padl, self.padl + To, 0), **self._dy_stats_kw("post%d" % (hp.postnet_conv_layers - 1)))
         for i in range(hp.postnet_conv_layers - 1, -1, -1):
             act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
             cin = M if i == 0 else Cp
@@ -927,7 +966,8 @@ class Tacotron2(object):
                                defer="postnet")
             else:
                 self._conv_bwd("decoder_postnet/postnet_conv_%d" % i, self._post_in[i], cur, cin, Cp,
-                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, nxt, defer="postnet")
+                               hp.postnet_conv_width, act, N, To, Po, "post%d" % i, nxt, defer="postnet",
+                               stats_for="post%d" % (i - 1))
                 cur, nxt = nxt, cur
         self._tick("postnet_bwd")
         # ---- decoder output projection (grad wrt decoder_outputs sits in dmel, padded layout)
@@ -994,10 +1034,10 @@ class Tacotron2(object):
         dq = self._buf("d_q", rows * A, T_)
         dkeys = self._buf("d_keys", N * Pi * A, torch.float32)
         dvalues = self._buf("d_values", N * Pi * E, torch.float32)
-        dkeys.zero_()
-        dvalues.zero_()
-        dwcl = self._buf("d_wcl", 7 * A, torch.float32)
-        dwcl.zero_()
+        ops.zero(dkeys)
+        ops.zero(dvalues)
+        dwcl = self._buf("d_wcl", _round_up(7 * A, 4), torch.float32)
+        ops.zero(dwcl)
         Tia = _round_up(Ti, 8)
         awork = self._buf("attn_work", N * (E + 9 * Tia + 2 * A + A * Tia) + 64, torch.float32)
         w1 = self._o("decoder/decoder_prenet/dense_1/kernel")
@@ -1077,13 +1117,13 @@ class Tacotron2(object):
         ea = self._buf("d_enc_a", rows_i * max(Ce, hp.embedding_dim), torch.float32)
         eb = self._buf("d_enc_b", rows_i * max(Ce, hp.embedding_dim), torch.float32)
         self._bilstm_bwd("encoder/encoder_lstm", self._enc_in[-1], dvalues, Ce, He, N, Ti, Pi, self.input_lengths,
-                         "encl", ea, defer="encoder")
+                         "encl", ea, defer="encoder", stats_for="enc%d" % (hp.encoder_conv_layers - 1))
         cur, nxt = ea, eb
         for i in range(hp.encoder_conv_layers - 1, -1, -1):
             act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
             cin = hp.embedding_dim if i == 0 else Ce
             self._conv_bwd("encoder/conv_%d" % i, self._enc_in[i], cur, cin, Ce, hp.encoder_conv_width, act, N, Ti, Pi,
-                           "enc%d" % i, nxt, defer="encoder")
+                           "enc%d" % i, nxt, defer="encoder", stats_for=("enc%d" % (i - 1)) if i > 0 else None)
             cur, nxt = nxt, cur
         ops.embedding_bwd(self.inputs, cur, g, N, Ti, Pi, self.padl, hp.embedding_dim, self.vocab,
                           dtable_off=self._o("embedding/embedding"))
@@ -1115,9 +1155,12 @@ class Tacotron2(object):
         n = self.layout.size
         # fixed summation order: every data-parallel rank must derive the same clip factor from the same gradient
         ops.sumsq(self.flat_g, n, self.scal, out_off=8, work=self._buf("sumsq_work", 1032, torch.float32))
+        # a persistent recurrence that timed out leaves an invalid gradient: the kernel then updates nothing and raises
+        # scal[9]; read_losses() reports it.  No host round trip in front of the optimiser.
         ops.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, n, self.scal[8:], self.gradient_clip,
                  1.0 / self.world_size, lr_t, b1, b2, 1e-8,
-                 shadow=self.flat_s if self.flat_s is not self.flat_p else None)
+                 shadow=self.flat_s if self.flat_s is not self.flat_p else None,
+                 status=list(self._status_words.values()), skipped=self.scal[9:])
         self.refresh_shadows()
         self.learning_rate = lr
         self.global_step += 1
@@ -1129,6 +1172,8 @@ class Tacotron2(object):
         d = self.dims
         s = self.scal.cpu().numpy()
         self.check_status()
+        if s[9] != 0:
+            raise RuntimeError("the optimiser step was skipped: a persistent recurrence reported a timeout")
         N, To = d["N"], d["To"]
         self.mel_loss = float(s[0]) / (N * To * hp.num_mels)
         self.linear_loss = 0.5 * float(s[2]) / (N * To * hp.num_freq) + 0.5 * float(s[3]) / (N * To * self._n_prio)

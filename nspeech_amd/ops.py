@@ -38,8 +38,12 @@ def ptr(t, off=0):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0, c_off=0,
          bias=None, bias_off=0, act=0, alpha=1.0, accumulate=0, row_mask=None, col_sum=None,
          col_sumsq=None, split_k=1, b_seg=None, addend=None, addend_off=0, ld_add=0, f32_passes=None,
-         gate=None, gate_off=0, ld_gate=0, a_lo=None, b_lo=None, batch=1, batch_strides=(0, 0, 0)):
-    """C = act(alpha * A.B + bias); see ns_gemm in include/nspeech_hip.h."""
+         gate=None, gate_off=0, ld_gate=0, a_lo=None, b_lo=None, batch=1, batch_strides=(0, 0, 0),
+         stat_z=None, ld_stat_z=0, stat_mean=None, stat_istd=None, stat_z_off=0):
+    """C = act(alpha * A.B + bias); see ns_gemm in include/nspeech_hip.h.
+    stat_z (+ ld_stat_z, stat_mean, stat_istd): col_sum / col_sumsq become the BatchNorm-backward sums of C as `dy`
+    against the saved BatchNorm input stat_z (sum dy, sum dy * xhat); stat_z_off: element offset of the row that pairs
+    with output row 0 (as c_off for C)."""
     assert A.dtype == B.dtype
     p = L.GemmParams()
     p.dtype = dt(A)
@@ -57,8 +61,11 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
         p.row_period, p.row_lo, p.row_hi, p.row_shift = row_mask
     p.col_sum = ptr(col_sum)
     p.col_sumsq = ptr(col_sumsq)
-    if col_sum is not None:      # scratch of the deterministic two-stage statistics (one per device, grown on demand)
+    if col_sum is not None:      # scratch of the deterministic two-stage statistics (one per device and stream)
         p.stat_part = ptr(_stat_part(col_sum.device, M, N))
+    if stat_z is not None:
+        p.stat_z, p.ld_stat_z, p.stat_z_dtype = ptr(stat_z, stat_z_off), ld_stat_z, dt(stat_z)
+        p.stat_mean, p.stat_istd = ptr(stat_mean), ptr(stat_istd)
     p.split_k = split_k
     if addend is not None:
         p.addend, p.ld_add, p.addend_dtype = ptr(addend, addend_off), ld_add, dt(addend)
@@ -77,12 +84,16 @@ _STAT_PART = {}
 
 
 def _stat_part(device, M, N):
+    """Partial-sum scratch of the GEMM statistics.  One per (device, stream): the producing product and its finalize
+    kernel run back to back on one stream, products on different streams (the weight-gradient stream, a feeder thread,
+    a second model) must not share it."""
     fn = L.lib().ns_gemm_stat_part_floats
     fn.restype = L.C.c_size_t
     need = int(fn(int(M), int(N)))
-    buf = _STAT_PART.get(device)
+    key = (device, stream())
+    buf = _STAT_PART.get(key)
     if buf is None or buf.numel() < need:
-        buf = _STAT_PART[device] = torch.empty(need, dtype=torch.float32, device=device)
+        buf = _STAT_PART[key] = torch.empty(need, dtype=torch.float32, device=device)
     return buf
 
 
@@ -129,8 +140,12 @@ def bn_fwd(z, y, rows, C, col_sum, col_sumsq, count, gamma, beta, moving_mean, m
 
 
 def bn_bwd(dy, z, dpre, rows, C, mean, istd, gamma, dgamma, dbeta, dbias, work, count, act, row_mask=None,
-           gamma_off=0, dgamma_off=0, dbeta_off=0, dbias_off=0):
+           gamma_off=0, dgamma_off=0, dbeta_off=0, dbias_off=0, sums=None):
+    """sums = (sum dy, sum dy * xhat) per column as left by the product that formed dy (gemm(..., stat_z=...))."""
     p = L.struct("ns_bn_bwd_params")
+    if sums is not None:
+        p.sum_dy, p.sum_dyxh = ptr(sums[0]), ptr(sums[1])
+    assert work.numel() >= 200 * C, "ns_bn_bwd: work needs 200 * C floats"
     _fill(p, dy=ptr(dy), z=ptr(z), dpre=ptr(dpre), dtype=dt(z), rows=rows, C=C, mean=ptr(mean), istd=ptr(istd),
           gamma=ptr(gamma, gamma_off), dgamma=ptr(dgamma, dgamma_off), dbeta=ptr(dbeta, dbeta_off),
           dbias=ptr(dbias, dbias_off), work=ptr(work), count=float(count), act=act)
@@ -161,11 +176,23 @@ def sumsq(x, n, out, out_off=0, work=None):
     L.call("ns_sumsq", p, stream())
 
 
-def adam(pw, g, m, v, n, gnorm_sq, clip, grad_scale, lr_t, beta1, beta2, eps, shadow=None):
+def adam(pw, g, m, v, n, gnorm_sq, clip, grad_scale, lr_t, beta1, beta2, eps, shadow=None, status=(), skipped=None):
+    """status: work buffers of this step's persistent recurrences (their first int is the status word); if one is
+    non-zero the kernel updates nothing and sets skipped[0] = 1."""
     p = L.struct("ns_adam_params")
     _fill(p, p=ptr(pw), g=ptr(g), m=ptr(m), v=ptr(v), n=n, gnorm_sq=ptr(gnorm_sq), clip=clip,
-          grad_scale=grad_scale, lr_t=lr_t, beta1=beta1, beta2=beta2, eps=eps, shadow_bf16=ptr(shadow))
+          grad_scale=grad_scale, lr_t=lr_t, beta1=beta1, beta2=beta2, eps=eps, shadow_bf16=ptr(shadow), skipped=ptr(skipped))
+    assert len(status) <= 12
+    for i, w in enumerate(status):
+        p.status[i] = ptr(w)
     L.call("ns_adam", p, stream())
+
+
+def zero(t):
+    """Clear a tensor with the library's fill kernel (16-byte granularity)."""
+    nbytes = t.numel() * t.element_size()
+    assert nbytes % 16 == 0 and t.data_ptr() % 16 == 0, "ops.zero: 16-byte granularity"
+    L.check(L.lib().ns_zero(C.c_void_p(ptr(t)), C.c_size_t(nbytes), C.c_void_p(stream())), "ns_zero")
 
 
 def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0, dst_hi=None, dst_lo=None):

@@ -31,6 +31,10 @@ def pmc_traffic(key):
         return None
 
 
+def pmc_traffic_source():
+    return "profiles/%s_pmc_traffic.json" % PROFILE_ROUND
+
+
 def roofline(model, one_step):
     rec = []
     orig = ops.gemm

@@ -110,9 +110,14 @@ def test_bucket_layout_matches_the_model_family():
     hp2 = hparams_mod.load("taco2")
     lay2, _ = P.taco2_layout(hp2, 149)
 
+    from nspeech_amd.models.tacotron2 import Tacotron2
+    # no bucket goes to the collective directly in front of the whole-chip decoder recurrences (the phases
+    # behind "postnet_bwd" and "dec_lstm_bwd"); the postnet bucket waits for the end of the attention RNN's backward
+    assert "postnet_bwd" not in Tacotron2._BUCKET_AFTER and "dec_lstm_bwd" not in Tacotron2._BUCKET_AFTER
+    assert Tacotron2._BUCKET_AFTER["attn_rnn_bwd"] == "postnet"
+
     class M2:
-        _BUCKET_AFTER = {"expand_conv_bwd": "head", "postnet_bwd": "postnet", "attn_wgrad": "decoder",
-                         "encoder_bwd": "encoder"}
+        _BUCKET_AFTER = Tacotron2._BUCKET_AFTER
         layout = lay2
         flat_g = torch.zeros(lay2.size)
     assert sorted(parallel.make_reducer(M2()).buckets) == ["decoder", "encoder", "head", "postnet"]

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from util import make_batch, oracle_run, same_branch_batch, small_hparams, stabilise_targets
+from util import make_batch, oracle_report, oracle_run, same_branch_batch, small_hparams, stabilise_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -64,29 +64,28 @@ def test_taco2_fp32_forward_backward_matches_oracle(dev, shape):
         assert np.abs(st[k] - v.numpy()).max() < 1e-4, k
 
 
+def _grad_summary(rep):
+    worst = sorted(rep["grad"].items(), key=lambda kv: -kv[1][0])
+    med = float(np.median([v[0] for v in rep["grad"].values()]))
+    return worst[0][0], worst[0][1][0], med
+
+
 def test_taco2_bf16_within_north_star_tolerance(dev):
     N, Ti, To = 4, 16, 40
     hp = small_hparams()
     m = _model(hp, "bf16")
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=7)
-    params, stats = m.numpy_params(), m.numpy_stats()
-    out, (loss, _, _), grads = oracle_run(hp, params, stats, inputs, lengths, mel, lin)
-    m.initialize(inputs, lengths, None, mel, lin)
-    m.backward()
-    m.read_losses()
-    l1 = np.abs(m.mel_outputs.float().cpu().numpy() - out["mel_outputs"].detach().numpy()).mean()
+    mel, lin = stabilise_targets(hp, m.numpy_params(), m.numpy_stats(), inputs, lengths, mel, lin)
+    rep = oracle_report(m, hp, inputs, lengths, mel, lin)
     # single-pass bf16 operands: ~1e-2 relative per O(1) output (measured 1.4e-2 here); the
     # north_star 1e-3 tolerance is met by the split-bf16 (3-pass) mode, tested separately
-    assert l1 < 3e-2, l1
-    assert abs(m.loss - loss) < 5e-3 * abs(loss)
-    got = m.numpy_grads()
-    # gradients: direction must agree (cosine) even though bf16 perturbs each element
-    for k in grads:
-        a, b = got[k].ravel().astype(np.float64), grads[k].ravel()
-        if np.linalg.norm(b) < 1e-6 or k.endswith("conv1d/bias"):
-            continue    # a bias in front of BatchNorm has a (near-)zero true gradient: pure cancellation
-        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-        assert cos > 0.9, (k, cos)
+    assert rep["out"]["mel_outputs"][2] < 3e-2, rep["out"]["mel_outputs"]
+    assert abs(rep["loss"][0] - rep["loss"][1]) < 5e-3 * abs(rep["loss"][1])
+    # every gradient tensor in relative L2 against the oracle on the same ReLU branches (round 2 held them to a cosine
+    # > 0.9 only); measured at this shape: worst tensor 0.17 (the attention query layer), median 0.083
+    name, worst, med = _grad_summary(rep)
+    print("bf16 small: worst gradient tensor %s rel L2 %.3e, median %.3e" % (name, worst, med))
+    assert worst < 0.35 and med < 0.15, (name, worst, med)
 
 
 def test_taco2_adam_step_matches_oracle(dev):
@@ -126,26 +125,19 @@ def test_taco2_split_bf16_meets_north_star_tolerance(dev, mode):
     hp = small_hparams()
     m = _model(hp, mode)
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=7)
-    params, stats = m.numpy_params(), m.numpy_stats()
-    mel, lin = stabilise_targets(hp, params, stats, inputs, lengths, mel, lin)
-    out, (loss, mel_loss, _), grads = oracle_run(hp, params, stats, inputs, lengths, mel, lin)
-    m.initialize(inputs, lengths, None, mel, lin)
-    m.backward()
-    m.read_losses()
-    l1 = np.abs(m.mel_outputs.float().cpu().numpy() - out["mel_outputs"].detach().numpy()).mean()
-    assert l1 < 1e-3, l1
-    assert np.abs(m.alignments.cpu().numpy() - out["alignments"].detach().numpy()).max() < 1e-3
-    assert abs(m.mel_loss - mel_loss) < 2e-3 * abs(mel_loss)
+    mel, lin = stabilise_targets(hp, m.numpy_params(), m.numpy_stats(), inputs, lengths, mel, lin)
+    rep = oracle_report(m, hp, inputs, lengths, mel, lin)
+    assert rep["out"]["mel_outputs"][2] < 1e-3, rep["out"]["mel_outputs"]
+    assert rep["out"]["alignments"][1] < 1e-3, rep["out"]["alignments"]
+    assert abs(rep["mel_loss"][0] - rep["mel_loss"][1]) < 2e-3 * abs(rep["mel_loss"][1])
     # in 'mixed' the mel->linear expand net runs single-pass bf16, so the linear loss moves by ~1e-2
-    assert abs(m.loss - loss) < (2e-3 if mode == "bf16x3" else 3e-2) * abs(loss)
-    got = m.numpy_grads()
-    for k in grads:
-        a, b = got[k].ravel().astype(np.float64), grads[k].ravel()
-        if np.linalg.norm(b) < 1e-6 or k.endswith("conv1d/bias"):
-            continue
-        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-        # 'mixed' back-propagates with single-pass bf16 products: direction only
-        assert cos > (0.999 if mode == "bf16x3" else 0.8), (k, cos)
+    assert abs(rep["loss"][0] - rep["loss"][1]) < (2e-3 if mode == "bf16x3" else 3e-2) * abs(rep["loss"][1])
+    # every gradient tensor in relative L2 on the oracle's side of the GPU's own ReLU branches (round 2: cosine > 0.999 /
+    # 0.8).  'mixed' back-propagates with single-pass bf16 products and runs the expand net in bf16.
+    name, worst, med = _grad_summary(rep)
+    print("%s small: worst gradient tensor %s rel L2 %.3e, median %.3e" % (mode, name, worst, med))
+    wb, mb = (6e-4, 2e-4) if mode == "bf16x3" else (0.15, 4e-2)     # measured 1.7e-4 / 6.9e-5 and 6.7e-2 / 1.7e-2
+    assert worst < wb and med < mb, (name, worst, med)
 
 
 def test_taco2_mixed_full_width_forward(dev):
@@ -264,17 +256,18 @@ def test_taco2_full_size_mixed_gradients_follow_split_bf16(dev):
     na = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in ga.values()))
     nb = np.sqrt(sum(float((v.astype(np.float64) ** 2).sum()) for v in gb.values()))
     assert abs(na - nb) < 0.1 * na, (na, nb)
-    bad = []
+    # per tensor, relative L2 (round 2: cosine > 0.7).  The two GPU passes take their own ReLU / L1-sign branches (the
+    # expand net runs in bf16 in `mixed`), so unlike the oracle tests at short lengths this bound includes kink flips.
+    rel = {}
     for k in ga:
         a, b = ga[k].ravel().astype(np.float64), gb[k].ravel().astype(np.float64)
         if np.linalg.norm(a) < 1e-7 * na or k.endswith("conv1d/bias"):
             continue        # a bias in front of BatchNorm has a (near-)zero true gradient
-        cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
-        # the expand net runs in bf16 in `mixed` (fp32 split in `bf16x3`) and its L1 sign pattern differs slightly,
-        # so its tensors and everything upstream of them agree in direction, not in value
-        if cos < 0.7:
-            bad.append((k, cos))
-    assert not bad, bad
+        rel[k] = float(np.linalg.norm(a - b) / np.linalg.norm(a))
+    worst = sorted(rel.items(), key=lambda kv: -kv[1])[:4]
+    med = float(np.median(list(rel.values())))
+    print("full size, mixed vs bf16x3: worst tensors %s, median %.3e, |g| %.4e vs %.4e" % (worst, med, nb, na))
+    assert worst[0][1] < 0.1 and med < 1.5e-2, (worst, med)        # measured 3.8e-2 (an encoder BatchNorm beta) / 5.0e-3
 
 
 @pytest.mark.parametrize("mode", ["fp32", "mixed"])
