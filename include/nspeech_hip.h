@@ -88,7 +88,8 @@ typedef struct {
   int addend_dtype; /* 0 / NS_F32: addend is fp32; NS_BF16: addend is bf16 */
   /* optional pre-split low parts of fp32 values (dtype NS_BF16, a_mode 0, b_mode 0, same strides as A / B): with
    * A = hi(a), A_lo = lo(a), B = hi(b), B_lo = lo(b) the call computes hi.hi + hi.lo + lo.hi on the matrix cores
-   * (the f32_passes = 3 product without the in-kernel split).  Both or neither. */
+   * (the f32_passes = 3 product without the in-kernel split).  Both or neither.  With f32_passes = 2 the hi.lo term
+   * is dropped (B, the weights, rounded to bf16; A exact to ~16 bits): two thirds of the matrix-core work. */
   const void* A_lo; const void* B_lo;
   /* batch > 1: `batch` independent products in one launch; item z uses A + z*batch_stride_a, B + z*batch_stride_b,
    * C + z*batch_stride_c (elements).  The per-utterance products of the attention loop (align[n] . memory[n],
@@ -278,6 +279,7 @@ typedef struct {
   const void* whT_hi; const void* whT_lo; const void* wh_bf16;
   void* dgates_bf16;                    /* optional [N*P, 4H] bf16 copy of dgates written and re-read by the
                                            backward recurrence (with wh_bf16: pure bf16 operand loads) */
+  void* h_bf16; int64_t ld_h_bf16;      /* optional bf16 copy of h, written by the fp32 form of ns_lstm_cluster_fwd */
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -291,8 +293,13 @@ int ns_lstm_seq2_bwd(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1,
 /* Persistent variant of ns_lstm_seq2_*: ONE launch for the whole sequence.  Each (direction,
  * 16-row group) recurrence runs on a cluster of H/64 workgroups that keep their W_h slice and the
  * cell state in registers and exchange h (backward: the gate gradients) through `work` with
- * tagged 8-byte granules.  bf16 only, H %% 64 == 0, H <= 512.  work[0] (int) is a status word:
- * non-zero after the call completes = an exchange timed out and the outputs are invalid. */
+ * tagged 8-byte granules.  bf16: H %% 64 == 0, H <= 512.  The forward call also takes dtype NS_F32 (H <= 256,
+ * f32_passes 3 with whT_hi / whT_lo): fp32 state, the recurrent product as three split-bf16 passes, h written as fp32
+ * (+ the optional h_bf16 copy), c as fp32 and the saved gates as BF16 - the backward pass of that arrangement is the
+ * bf16 call on wh = the bf16 weight copy.  ns_lstm_cluster_supported() says whether a pair of parameter blocks
+ * qualifies.  work[0] (int) is a status word: non-zero after the call completes = an exchange timed out and the
+ * outputs are invalid. */
+int ns_lstm_cluster_supported(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, int backward);
 size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p);
 int ns_lstm_cluster_fwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);
 int ns_lstm_cluster_bwd(const ns_lstm_seq_params* fw, const ns_lstm_seq_params* bw, void* work, ns_stream_t stream);

@@ -437,6 +437,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
 // later is behind a barrier both groups passed after their reads; the counted vmcnt sits in front of phase 4's first
 // barrier and the data is read from phase 1 of the next tile on, at least two barriers later for either group.
 // NSEG = 3: split-bf16 product of pre-split operands, K-tiles walk (A, B), (A, B_lo), (A_lo, B).
+// NSEG = 2 (f32_passes = 2 with pre-split operands): (A, B), (A_lo, B) - B (the weights) rounded to bf16, A exact to
+// ~16 bits; for products whose error budget allows it (the non-recurrent postnet convolutions).
 // Measured on MI355X (random operands): 4096^3 989 TFLOP/s, 8192^3 1010, conv data gradient 32124 x 512 x 2560
 // 838 (128^2 kernel: 662 / - / 610); three-segment product 344 algorithmic = 1032 issued (in-kernel split: 239).
 constexpr int XHALF = 16384, XBUF = 65536;
@@ -568,7 +570,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
     if (t_ < NT) {                                                                                       \
       const int sg_ = NSEG == 1 ? 0 : t_ / nk;                                                           \
       const int kt_ = NSEG == 1 ? t_ : t_ - sg_ * nk;                                                    \
-      const char* g_ = (ISA) ? (sg_ == 2 ? Alo : Ahi) : (sg_ == 1 ? Blo : Bhi);                          \
+      const char* g_ = (ISA) ? (sg_ == NSEG - 1 && NSEG > 1 ? Alo : Ahi) : (sg_ == 1 && NSEG == 3 ? Blo : Bhi); \
       if (!(ISA) && p.b_seg_len > 0) {      /* segment s of B's K range starts at B + s * b_seg_stride */ \
         const int bs_ = (kt_ * 64) / p.b_seg_len;                                                        \
         g_ += ((long)bs_ * p.b_seg_stride + (kt_ * 64 - bs_ * p.b_seg_len)) * 2;                         \
@@ -1089,11 +1091,14 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     if (!attr_set) {
       (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      (void)hipFuncSetAttribute((const void*)gemm_x256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_set = true;
     }
     p.stat_slots = 4 * ceil_div(p.M, 256);
-    g_last_kernel = p.A_lo ? "gemm_x256_kernel<3>" : "gemm_x256_kernel<1>";
-    if (p.A_lo) hipLaunchKernelGGL(gemm_x256_kernel<3>, dim3(tiles), dim3(512), lds, stream, p);
+    const bool two = p.A_lo && p.f32_passes == 2;
+    g_last_kernel = p.A_lo ? (two ? "gemm_x256_kernel<2>" : "gemm_x256_kernel<3>") : "gemm_x256_kernel<1>";
+    if (two) hipLaunchKernelGGL(gemm_x256_kernel<2>, dim3(tiles), dim3(512), lds, stream, p);
+    else if (p.A_lo) hipLaunchKernelGGL(gemm_x256_kernel<3>, dim3(tiles), dim3(512), lds, stream, p);
     else hipLaunchKernelGGL(gemm_x256_kernel<1>, dim3(tiles), dim3(512), lds, stream, p);
     NS_CHECK_LAUNCH("gemm_x256");
     return NS_OK;

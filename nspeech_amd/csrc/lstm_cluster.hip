@@ -29,6 +29,9 @@ struct LstmClusterArgs {
   bf16_t* h[2]; long ld_h;        // h[d] already offset to this direction's columns
   float* c[2];
   bf16_t* gates[2];
+  // fp32-state forward (lstm_cluster3_fwd_kernel): pre-split recurrent weights, fp32 h out, optional bf16 copy of h
+  const bf16_t* whT_hi[2]; const bf16_t* whT_lo[2];
+  float* hf[2]; bf16_t* hb[2]; long ld_hb;
   const float* dh[2]; long ld_dh; // backward: grad wrt h outputs (offset to direction's columns)
   bf16_t* dgates[2];
   const int* lengths;
@@ -632,6 +635,259 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
   }
 }
 
+
+// ==================================================================== fp32-state forward (round 3)
+// The encoder BiLSTM of the `mixed` / `bf16x3` modes keeps its state in fp32 and forms the recurrent product as three
+// split-bf16 MFMA passes (h = hi + lo, W = hi + lo: hi.hi + hi.lo + lo.hi); until round 3 that arrangement ran one
+// launch per time step (160 + 160 launches of 6 us).  Same roles and interleaving as lstm_cluster2_fwd_kernel, with what
+// the fp32 state changes:
+//   * a granule carries ONE unit: {step tag, fp32 h}; the pollers split it into the (hi, lo) LDS images;
+//   * the resident weights are twice the registers per unit (hi and lo planes), and a workgroup of 8 waves has 256 VGPRs
+//     per lane: a compute wave owns 8 units (two MFMA tiles [i | j], [f | o]: 128 VGPRs of weights), a workgroup 32
+//     units, a chain H / 32 workgroups; the cell update pairs lanes r16 and r16 + 8;
+//   * the saver writes h as fp32 (+ an optional bf16 copy for the weight gradients) and the gates as bf16: the backward
+//     pass of this arrangement is the bf16 kernel (single-pass products).
+constexpr int X3W = 4, X3_POLL = 2, X3_UPW = 32;
+constexpr int X3_WAVES = X3W + X3_POLL + 2;          // compute, pollers, prefetcher, saver: 8 waves, two per SIMD
+constexpr int XG3_LD = 4 * X3_UPW + 4;
+
+template <int HB, int R>        // HB = H / 64
+__global__ __launch_bounds__(X3_WAVES * 64) void lstm_cluster3_fwd_kernel(LstmClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = HB * 64, KS = H / 32, GPC = 16 * H;          // granules per chain and step
+  constexpr int CS = H / X3_UPW;                                   // workgroups per chain
+  constexpr int PPG = GPC / (X3_POLL * 64);                        // granules per poller lane (H / 8)
+  static_assert(GPC % (X3_POLL * 64) == 0, "poller coverage");
+  bf16_t* hsh = (bf16_t*)smem;                                    // [2][16][H] swizzled, high parts
+  bf16_t* hsl = hsh + 2 * 16 * H;                                 // [2][16][H] low parts
+  float* xgs = (float*)(hsl + 2 * 16 * H);                        // [2][16][XG3_LD]: row, gate * 32 + unit
+  // this slot's results for the saver: h f32 [16][32], c f32 [16][32], gates bf16 [16][4][32], h bf16 [16][32]
+  constexpr int SV_H = 16 * 32 * 4, SV_C = 16 * 32 * 4, SV_G = 16 * 4 * 32 * 2, SV_HB = 16 * 32 * 2;
+  constexpr int SV_BYTES = SV_H + SV_C + SV_G + SV_HB;           // 9216
+  char* svs = (char*)(xgs + 2 * 16 * XG3_LD);                     // [2][SV_BYTES]
+  int* abortf = (int*)(svs + 2 * SV_BYTES);                       // [2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsets = ((a.N + 15) / 16 + R - 1) / R;
+  const int set = blockIdx.x / CS, wgc = blockIdx.x % CS;
+  const int d = set / nsets, rg0 = (set % nsets) * R;
+  const int r16 = lane & 15, g = lane >> 4;
+  u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * GPC;   // + rg * 2*GPC + parity * GPC
+  const int u0 = wgc * X3_UPW;
+  const int T = a.T, Q = a.T * R;
+  if (tid < 2) abortf[tid] = 0;          // (audit) written by wave 0 in front of its first wg_barrier, read behind it
+
+  if (wave < X3W) {
+    // ================================================================ compute role
+    const int ul = wave * 8 + (r16 & 7);                     // unit inside the workgroup's 32
+    const bool cell_lane = r16 < 8;
+    const int pub0 = (((wgc * X3W + wave) * 32) + g * 8 + (r16 & 7)) * 4;    // this lane's 4 granules (rows g*4 .. g*4+3)
+    bf16x8 bwh[2][KS], bwl[2][KS];
+    {
+#pragma unroll
+      for (int tl = 0; tl < 2; ++tl) {
+        const int gate = tl * 2 + (r16 >> 3);
+        const long wrow = ((long)gate * H + u0 + ul) * H + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bwh[tl][ks] = *(const bf16x8*)(a.whT_hi[d] + wrow + ks * 32);
+          bwl[tl][ks] = *(const bf16x8*)(a.whT_lo[d] + wrow + ks * 32);
+        }
+      }
+    }
+    float cst[R][4];
+    int len[R][4];
+#pragma unroll
+    for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (rg0 + rg) * 16 + g * 4 + r;
+        cst[rg][r] = 0.f;
+        len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
+      }
+    for (int step = 0; step < T; ++step) {
+      const int t = d ? T - 1 - step : step;
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) {
+        const int q = step * R + rg, buf = q & 1;
+        wg_barrier();
+        if (abortf[buf]) return;
+        // tile 0 = [i | j], tile 1 = [f | o]: column r16 -> gate 2*tile + (r16 >> 3), unit ul
+        const float* xr = xgs + (size_t)buf * 16 * XG3_LD + (r16 >> 3) * X3_UPW + ul;
+        f32x4 accA, accB;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          accA[r] = xr[(g * 4 + r) * XG3_LD];
+          accB[r] = xr[(g * 4 + r) * XG3_LD + 2 * X3_UPW];
+        }
+        if (step > 0) {
+          const bf16_t* hbh = hsh + (size_t)buf * 16 * H;
+          const bf16_t* hbl = hsl + (size_t)buf * 16 * H;
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            const int so = swz_off(r16, ks * 32 + g * 8, H);
+            const bf16x8 ah = *(const bf16x8*)(hbh + so), al = *(const bf16x8*)(hbl + so);
+            accA = mfma_split<3>(ah, al, bwh[0][ks], bwl[0][ks], accA);
+            accB = mfma_split<3>(ah, al, bwh[1][ks], bwl[1][ks], accB);
+          }
+        }
+        float hv[4], sg[4][4], cn4[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float zj = __shfl_down(accA[r], 8, 64), zo = __shfl_down(accB[r], 8, 64);
+          const bool masked = t >= len[rg][r];
+          const float gi = sigmoidf_(accA[r]), gj = tanhf_(zj), gf = sigmoidf_(accB[r] + a.forget_bias), go = sigmoidf_(zo);
+          float cn = gf * cst[rg][r] + gi * gj;
+          float hn = go * tanhf_(cn);
+          if (masked) { cn = 0.f; hn = 0.f; }
+          cst[rg][r] = cn;
+          cn4[r] = cn;
+          hv[r] = hn;
+          sg[r][0] = masked ? 0.f : gi; sg[r][1] = masked ? 0.f : gj; sg[r][2] = masked ? 0.f : gf; sg[r][3] = masked ? 0.f : go;
+        }
+        // publish first (tag = step + 1): one granule per (row, unit), fp32
+        if (step + 1 < T && cell_lane) {
+          u64* nxt = xb0 + ((size_t)rg * 2 + ((step + 1) & 1)) * GPC + pub0;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            __hip_atomic_store(nxt + r, ((u64)(unsigned)(step + 1) << 32) | (u64)__float_as_uint(hv[r]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // results for the backward pass / the consumers of h go to LDS; the saver wave writes them out
+        if (cell_lane) {
+          char* sv = svs + (size_t)buf * SV_BYTES;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = g * 4 + r;
+            ((float*)sv)[row * X3_UPW + ul] = hv[r];
+            ((float*)(sv + SV_H))[row * X3_UPW + ul] = cn4[r];
+            bf16_t* gp = (bf16_t*)(sv + SV_H + SV_C) + row * 4 * X3_UPW + ul;
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) gp[gate * X3_UPW] = (bf16_t)sg[r][gate];
+            ((bf16_t*)(sv + SV_H + SV_C + SV_G))[row * X3_UPW + ul] = (bf16_t)hv[r];
+          }
+        }
+      }
+    }
+    wg_barrier();
+  } else if (wave < X3W + X3_POLL) {
+    // ================================================================ poller role: granule lane + 64 * jj of the chain
+    // decodes as r = lane & 3, unit in wave = (lane >> 2) & 7, g = ((jj & 1) << 1) | (lane >> 5), publishing wave =
+    // (jj >> 1) & 3, publishing workgroup = jj >> 3
+    const int j0 = (wave - X3W) * PPG;
+    const int pr_ = lane & 3, pu = (lane >> 2) & 7, pgl = lane >> 5;
+    for (int q = 0; q < Q; ++q) {
+      const int step = q / R, rg = q % R, buf = q & 1;
+      if (step > 0) {
+        const u64* cur = xb0 + ((size_t)rg * 2 + (step & 1)) * GPC;
+        u64 v[PPG];
+        unsigned spins = 0, clk0 = 0;
+        bool ok;
+        do {
+          ok = true;
+#pragma unroll
+          for (int j = 0; j < PPG; ++j) v[j] = __hip_atomic_load(cur + lane + (j0 + j) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+          for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)step);
+          if (!ok) {
+            if ((++spins & 1023u) == 0) {
+              if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; ok = true; }
+              else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 1); abortf[buf] = 1; ok = true; }
+            }
+          }
+        } while (!ok);
+        bf16_t* dh_ = hsh + (size_t)buf * 16 * H;
+        bf16_t* dl_ = hsl + (size_t)buf * 16 * H;
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) {
+          const int jj = j0 + j;
+          const int row = (((jj & 1) << 1) | pgl) * 4 + pr_;
+          const int k = (jj >> 3) * X3_UPW + ((jj >> 1) & 3) * 8 + pu;
+          const float x = __uint_as_float((unsigned)v[j]);
+          const bf16_t hi = (bf16_t)x;
+          const int so = swz_off(row, k, H);
+          dh_[so] = hi;
+          dl_[so] = (bf16_t)(x - (float)hi);
+        }
+      }
+      wg_barrier();
+      if (abortf[buf]) return;
+    }
+    wg_barrier();
+  } else if (wave == X3W + X3_POLL) {
+    // ================================================================ saver role (stores only), one slot behind
+    // per slot: h f32 128 chunks of 16 B, c 128, gates 256, h bf16 64 -> 9 per lane
+    auto save = [&](int q) {
+      const int step = q / R, rg = q % R;
+      const int t = d ? T - 1 - step : step;
+      const int n0 = (rg0 + rg) * 16;
+      const char* sv = svs + (size_t)(q & 1) * SV_BYTES;
+#pragma unroll
+      for (int j = 0; j < 9; ++j) {
+        const int idx = lane + 64 * j;
+        const f32x4 v = *(const f32x4*)(sv + idx * 16);
+        if (idx < 128) {
+          const int row = idx >> 3, cc = idx & 7;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.hf[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)a.ld_h + (unsigned)(u0 + cc * 4))) = v;
+        } else if (idx < 256) {
+          const int jj = idx - 128, row = jj >> 3, cc = jj & 7;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.c[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)H + (unsigned)(u0 + cc * 4))) = v;
+        } else if (idx < 512) {
+          const int jj = idx - 256, row = jj >> 4, gate = (jj >> 2) & 3, cc = jj & 3;
+          if (n0 + row < a.N)
+            *(f32x4*)(a.gates[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)(4 * H) + (unsigned)(gate * H + u0 + cc * 8))) = v;
+        } else {
+          const int jj = idx - 512, row = jj >> 2, cc = jj & 3;
+          if (a.hb[d] && n0 + row < a.N)
+            *(f32x4*)(a.hb[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)a.ld_hb + (unsigned)(u0 + cc * 8))) = v;
+        }
+      }
+    };
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q > 0) save(q - 1);
+    }
+    wg_barrier();
+    save(Q - 1);
+  } else {
+    // ================================================================ prefetcher role: 16 rows x 4 gates x 32 units = 512
+    // float4 per slot, 8 per lane: row 2j + (lane >> 5), gate (lane >> 3) & 3, 4 floats at (lane & 7) * 4
+    f32x4 pf[8];
+    const float* xg = a.xg[d];
+    const int prow = lane >> 5, pgate = (lane >> 3) & 3, pf4 = (lane & 7) * 4;
+    auto pf_load = [&](int q) {
+      const int step = q / R, rg = q % R;
+      const int t = d ? T - 1 - step : step;
+      const int n0 = (rg0 + rg) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int n = n0 + 2 * j + prow;
+        pf[j] = n < a.N ? *(const f32x4*)(xg + ((unsigned)(n * a.P + a.padl + t) * (unsigned)a.ld_xg + (unsigned)(pgate * H + u0 + pf4)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto pf_store = [&](int buf) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *(f32x4*)(xgs + ((size_t)buf * 16 + 2 * j + prow) * XG3_LD + pgate * X3_UPW + pf4) = pf[j];
+    };
+    pf_load(0);
+    pf_store(0);
+    if (Q > 1) pf_load(1);
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q + 1 < Q) {
+        pf_store((q + 1) & 1);
+        if (q + 2 < Q) pf_load(q + 2);
+      }
+    }
+    wg_barrier();
+  }
+}
+
 // Backward.  Compute wave w owns 16 units and the full K = 4H contraction for them (W_h rows as B
 // fragments, K/32 k-steps), so no cross-wave reduction is needed.
 //
@@ -894,11 +1150,35 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
 static int cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1) {
   return p0->dtype == NS_BF16 && p1->dtype == NS_BF16 && p0->H % 64 == 0 && p0->H <= 512 && p0->T >= 2;
 }
+// the fp32-state forward form: fp32 h, pre-split recurrent weights, three passes, H <= 256
+static int cluster3_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1) {
+  auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+  const ns_lstm_seq_params* pp[2] = {p0, p1};
+  if (p0->H % 64 != 0 || p0->H > 256 || p0->T < 2 || p0->N < 1) return 0;
+  if (2 * ((p0->N + 15) / 16 + 1) * 8 * sizeof(unsigned) > 4096) return 0;
+  for (int d = 0; d < 2; ++d) {
+    const ns_lstm_seq_params* p = pp[d];
+    if (p->dtype != NS_F32 || p->f32_passes != 3 || !p->whT_hi || !p->whT_lo || !p->xg || !p->h || !p->c || !p->gates) return 0;
+    if (!(al16(p->xg) && p->ld_xg % 4 == 0 && al16(p->h) && p->ld_h % 4 == 0 && al16(p->c) && al16(p->gates) &&
+          al16(p->whT_hi) && al16(p->whT_lo))) return 0;
+    if (p->h_bf16 && !(al16(p->h_bf16) && p->ld_h_bf16 % 8 == 0)) return 0;
+    const long widest = p->ld_xg > 4L * p->H ? p->ld_xg : 4L * p->H;
+    if ((long)p->N * p->P * widest >= (1L << 31)) return 0;
+  }
+  return 1;
+}
+extern "C" int ns_lstm_cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, int backward) {
+  if (!p0 || !p1) return 0;
+  if (!(p0->reverse == 0 && p1->reverse == 1 && p0->N == p1->N && p0->T == p1->T && p0->H == p1->H)) return 0;
+  if (cluster_supported(p0, p1)) return 1;
+  return !backward && cluster3_supported(p0, p1);
+}
 
 extern "C" size_t ns_lstm_cluster_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
   const size_t chains = 2 * (size_t)((p->N + 15) / 16 + 1);   // one spare row group per direction (pairs of interleaved chains)
-  // exchange buffers for the larger (backward) payload + status word + debug trace
+  // exchange buffers for the larger (backward) payload + status word + debug trace (the fp32 forward form's granules,
+  // one per unit, are half of that)
   return chains * 2 * 16 * (size_t)(4 * p->H / 2) * sizeof(u64) + 256 + 4096 + 512 * 8 * sizeof(long long);
 }
 
@@ -912,7 +1192,10 @@ static void fill(LstmClusterArgs& a, const ns_lstm_seq_params* p0, const ns_lstm
     a.xg[d] = pp[d]->xg; a.whT[d] = (const bf16_t*)pp[d]->whT; a.wh[d] = (const bf16_t*)pp[d]->wh;
     a.h[d] = (bf16_t*)pp[d]->h; a.c[d] = pp[d]->c; a.gates[d] = (bf16_t*)pp[d]->gates;
     a.dh[d] = pp[d]->dh; a.dgates[d] = (bf16_t*)pp[d]->dgates;
+    a.whT_hi[d] = (const bf16_t*)pp[d]->whT_hi; a.whT_lo[d] = (const bf16_t*)pp[d]->whT_lo;
+    a.hf[d] = (float*)pp[d]->h; a.hb[d] = (bf16_t*)pp[d]->h_bf16;
   }
+  a.ld_hb = p0->ld_h_bf16;
   a.status = (int*)work;
   a.flags = (unsigned*)((char*)work + 256);               // FLAG_BYTES, zeroed together with the status word
   a.xbuf = (u64*)((char*)work + 256 + FLAG_BYTES);
@@ -945,9 +1228,40 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
                                    ns_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   NS_CHECK_ARG(p0 && p1 && work, "ns_lstm_cluster_fwd: null");
-  NS_CHECK_ARG(cluster_supported(p0, p1), "ns_lstm_cluster_fwd: needs bf16, H %% 64 == 0, H <= 512, T >= 2");
   NS_CHECK_ARG(p0->reverse == 0 && p1->reverse == 1 && p0->N == p1->N && p0->T == p1->T && p0->H == p1->H,
                "ns_lstm_cluster_fwd: p0 forward / p1 reversed with equal shapes expected");
+  if (p0->dtype == NS_F32) {
+    NS_CHECK_ARG(cluster3_supported(p0, p1), "ns_lstm_cluster_fwd: the fp32 form needs H %% 64 == 0, H <= 256, T >= 2, "
+                 "f32_passes 3 with whT_hi / whT_lo, 16-byte aligned operands");
+    LstmClusterArgs a = {};
+    fill(a, p0, p1, work);
+    const int nrg = (a.N + 15) / 16, R = nrg >= 2 ? 2 : 1;
+    const size_t xbytes = (2 * (size_t)nrg + 2) * 2 * 16 * (size_t)a.H * sizeof(u64);
+    { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
+    const size_t lds3 = (size_t)2 * 2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG3_LD + 2 * 9216 + 32;
+    const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * (a.H / X3_UPW))), block(X3_WAVES * 64);
+#define NS_LAUNCH_F3(HB_) \
+    do { \
+      static bool attr3 = false; \
+      if (!attr3) { \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster3_fwd_kernel<HB_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster3_fwd_kernel<HB_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attr3 = true; \
+      } \
+      if (R == 2) hipLaunchKernelGGL((lstm_cluster3_fwd_kernel<HB_, 2>), grid, block, lds3, s, a); \
+      else hipLaunchKernelGGL((lstm_cluster3_fwd_kernel<HB_, 1>), grid, block, lds3, s, a); \
+    } while (0)
+    switch (a.H / 64) {
+      case 1: NS_LAUNCH_F3(1); break;
+      case 2: NS_LAUNCH_F3(2); break;
+      case 3: NS_LAUNCH_F3(3); break;
+      default: NS_LAUNCH_F3(4); break;
+    }
+#undef NS_LAUNCH_F3
+    NS_CHECK_LAUNCH("lstm_cluster3_fwd");
+    return NS_OK;
+  }
+  NS_CHECK_ARG(cluster_supported(p0, p1), "ns_lstm_cluster_fwd: needs bf16, H %% 64 == 0, H <= 512, T >= 2");
   LstmClusterArgs a = {};
   fill(a, p0, p1, work);
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);

@@ -93,6 +93,7 @@ class Tacotron2(object):
         self._bufs = {}
         self._sig = None
         self.timing = None
+        self.is_training_pass = True
         self.reducer = None       # parallel.GradReducer when data-parallel
         self._side = None         # second HIP stream for deferred weight gradients (created on first use)
         self._deferred = []
@@ -248,14 +249,23 @@ class Tacotron2(object):
         ops.gemm(self.flat_p, self.flat_p, self.tsh["wcl"], 7, A, 20, 20, A, A, b_mode=1,
                  a_off=self._o("decoder/attention/location_conv/kernel"),
                  b_off=self._o("decoder/attention/location_layer/kernel"))
-        # linear head padded to a multiple of 16 columns
+        # linear head padded to whole column tiles; bf16: to a multiple of 128 columns with a k-contiguous [Fp, 2H] copy
+        # beside it, so that the forward product and the data gradient (K = Fp) run on the 256-tile kernel
         F = hp.num_freq
-        Fp = _round_up(F, 16)
+        Fp = self._lin_pad(F)
         if "wl_pad" not in self.tsh:
             self.tsh["wl_pad"] = torch.zeros(2 * Hx * Fp, dtype=self.Tx, device=dev)
             self.tsh["bl_pad"] = torch.zeros(Fp, dtype=torch.float32, device=dev)
+            if self.Tx == torch.bfloat16 and Fp % 128 == 0 and (2 * Hx) % 64 == 0:
+                self.tsh["wl_padT"] = torch.zeros(Fp * 2 * Hx, dtype=self.Tx, device=dev)
         ops.cast2d(self.flat_p, 2 * Hx, F, F, self.tsh["wl_pad"], Fp, False, src_off=self._o("dense/kernel"))
         ops.cast2d(self.flat_p, 1, F, F, self.tsh["bl_pad"], Fp, False, src_off=self._o("dense/bias"))
+        if "wl_padT" in self.tsh:
+            ops.cast2d(self.flat_p, 2 * Hx, F, F, self.tsh["wl_padT"], 2 * Hx, True, src_off=self._o("dense/kernel"))
+
+    def _lin_pad(self, F):
+        """Padded column count of the linear head / linear_outputs buffer."""
+        return _round_up(F, 128) if (self.Tx == torch.bfloat16 and F >= 512) else _round_up(F, 16)
 
     # ------------------------------------------------------------------ buffers
     def _buf(self, name, numel, dtype, zero=True):
@@ -372,6 +382,7 @@ class Tacotron2(object):
         dev = self.device
         self._set_inputs(text_inputs, input_lengths, speaker_ids)
         self.is_training = linear_targets is not None
+        self.is_training_pass = self.is_training
         if self.is_training:
             self.mel_targets = torch.as_tensor(mel_targets).to(dev, torch.float32).contiguous()
             self.linear_targets = torch.as_tensor(linear_targets).to(dev, torch.float32).contiguous()
@@ -436,6 +447,12 @@ class Tacotron2(object):
                     stat_istd=st[3 * c:])
 
     fuse_bn_bwd_stats = True    # BatchNorm-backward column sums out of the epilogue of the product that forms dy
+    # split-bf16 passes of the postnet's 512 -> 512 forward convolutions in `mixed`: 3 = hi.hi + hi.lo + lo.hi.
+    # 2 (the weights rounded to bf16: lo.hi + hi.hi, gemm_x256_kernel<2>) was measured in round 3 as VERDICT r2 asked:
+    # 160 us per convolution against 203, but mel_outputs move by 4.1e-3 mean L1 at the benchmark shape (each rounded
+    # weight perturbs its term by 2^-9, and the sum of K such terms is no smaller relative to a sum that is itself a
+    # random walk over the same terms) - outside north_star's 1e-3.  Kept as a switch, not used.
+    postnet_passes = int(os.environ.get("NS_POSTNET_PASSES", "3"))
 
     def _x256_split_ok(self, tag, rows, cin, cout, k):
         """A three-pass forward convolution that can run on the 256-tile kernel over pre-split operands."""
@@ -462,7 +479,7 @@ class Tacotron2(object):
         if xsplit is not None:      # pre-split operands: (hi, hi), (hi, lo), (lo, hi) on the 256-tile kernel
             key = "postT_" + tag[4:]
             ops.gemm(xsplit[0], self.tsh[key + "_hi"], z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0,
-                     a_lo=xsplit[1], b_lo=self.tsh[key + "_lo"], **common)
+                     a_lo=xsplit[1], b_lo=self.tsh[key + "_lo"], f32_passes=self.postnet_passes, **common)
         elif wT is not None:        # k-contiguous weight shadow (refresh_shadows)
             ops.gemm(xin, wT, z, Mg, cout, k * cin, cin, k * cin, cout, a_mode=0, b_mode=0, **common)
         else:
@@ -537,7 +554,9 @@ class Tacotron2(object):
     def _splitk(K, M, N):
         tiles = ((M + 127) // 128) * ((N + 127) // 128)
         sk = max(1, min(32, 512 // max(tiles, 1)))
-        return max(1, min(sk, K // 512))
+        # products with a handful of output tiles (the attention RNN's and the encoder's weight gradients) are latency
+        # bound: a K slice of 256 per workgroup instead of 512 doubles the workgroups that share the operand stream
+        return max(1, min(sk, K // (256 if tiles <= 16 else 512)))
 
     def _x256_fits(self, rows, cout):
         return rows >= 1024 and ((rows + 255) // 256) * ((cout + 255) // 256) >= 96
@@ -562,6 +581,11 @@ class Tacotron2(object):
         rows = N * Pp
         D = D or self.T
         out = self._buf(tag + "_h", rows * 2 * H, D)
+        # fp32 storage with a single-pass bf16 backward (`mixed`): the persistent fp32-state forward kernel saves the
+        # gates as bf16 and a bf16 copy of h, and the backward pass is the bf16 cluster kernel (csrc/lstm_cluster.hip)
+        f32c = (D == torch.float32 and self.passes_fwd == 3 and self.use_cluster and H % 64 == 0 and H <= 256 and T >= 2
+                and (self.passes_bwd == 1 or not self.is_training_pass))
+        hb = self._buf(tag + "_h16", rows * 2 * H, torch.bfloat16) if f32c else None
         pair = []
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
@@ -569,12 +593,17 @@ class Tacotron2(object):
             self._xg_gemm(x, xg, rows, cin, 4 * H, "%s_%s_xT" % (key, d), self._o(kname),
                           self._o("%s/%s/lstm_cell/bias" % (scope, d)), D)
             c = self._buf("%s_c_%s" % (tag, d), rows * H, torch.float32)
-            gt = self._buf("%s_g_%s" % (tag, d), rows * 4 * H, D)
+            gt = self._buf("%s_g%s_%s" % (tag, "16" if f32c else "", d), rows * 4 * H, torch.bfloat16 if f32c else D)
             wk = "%s_%s_whT" % (key, d)
             pair.append(ops.lstm_seq_params(N, T, H, Pp, self.padl, xg, 4 * H, self.tsh[wk], None,
                                             lengths, d == "bw", out, 2 * H, c, gt, h_off=di * H,
                                             whT_hi=self.tsh.get(wk + "_hi") if D == torch.float32 else None,
-                                            whT_lo=self.tsh.get(wk + "_lo") if D == torch.float32 else None))
+                                            whT_lo=self.tsh.get(wk + "_lo") if D == torch.float32 else None,
+                                            h_bf16=hb, h_bf16_off=di * H, ld_h_bf16=2 * H))
+        if f32c and not ops.lstm_cluster_supported(pair[0], pair[1], False):
+            raise RuntimeError("BiLSTM %s: the fp32-state cluster kernel refused a shape its pre-check accepted" % tag)
+        self._bilstm_f32c = getattr(self, "_bilstm_f32c", {})
+        self._bilstm_f32c[tag] = f32c
         self._run_bilstm("fwd", pair, tag)
         return out
 
@@ -596,7 +625,11 @@ class Tacotron2(object):
     use_attn_cluster = True # persistent attention-RNN cluster kernels where the shape allows
 
     def _run_bilstm(self, direction, pair, tag):
-        if self.use_cluster and ops.lstm_cluster_supported(pair[0]):
+        from .._lib import NS_BF16
+        # fp32 parameter blocks take the persistent (fp32-state) kernel only where _bilstm_fwd arranged for it: that
+        # kernel saves the gates as bf16
+        ok = pair[0].dtype == NS_BF16 or getattr(self, "_bilstm_f32c", {}).get(tag, False)
+        if self.use_cluster and ok and ops.lstm_cluster_supported(pair[0], pair[1], direction == "bwd"):
             work = self._buf("lstm_cluster_work_%s_%s" % (tag, direction), ops.lstm_cluster_work_floats(pair[0]),
                              torch.float32)
             ops.lstm_cluster(direction, pair[0], pair[1], work)
@@ -621,13 +654,22 @@ class Tacotron2(object):
         D = D or self.T
         g = self.flat_g
         hbuf = self._bufs[tag + "_h"]
+        f32c = getattr(self, "_bilstm_f32c", {}).get(tag, False)
+        if f32c:
+            # the forward pass saved bf16 gates and a bf16 copy of h: everything below runs as in the bf16 mode, on the
+            # bf16 weight shadow (the single-pass backward of `mixed` rounds these operands to bf16 on load anyway)
+            hbuf = self._bufs[tag + "_h16"]
+            x16 = self._buf("%s_x16" % tag, rows * cin, torch.bfloat16)
+            ops.cast2d(x, rows, cin, cin, x16, cin, False)
+            x = x16
+            D = torch.bfloat16
         pair = []
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             ko = self._o(kname)
             c = self._bufs["%s_c_%s" % (tag, d)]
-            gt = self._bufs["%s_g_%s" % (tag, d)]
-            dg = self._buf("%s_dg_%s" % (tag, d), rows * 4 * H, D)
+            gt = self._bufs["%s_g%s_%s" % (tag, "16" if f32c else "", d)]
+            dg = self._buf("%s_dg%s_%s" % (tag, "16" if f32c else "", d), rows * 4 * H, D)
             work = self._buf("lstm_work_%s" % d, N * H + 64, torch.float32)
             pair.append(ops.lstm_seq_params(N, T, H, Pp, self.padl, self._bufs["%s_xg_%s" % (tag, d)], 4 * H, None,
                                             self._W(D), lengths, d == "bw", hbuf, 2 * H, c, gt, dh=dout,
@@ -639,7 +681,7 @@ class Tacotron2(object):
         for di, d in enumerate(("fw", "bw")):
             kname = "%s/%s/lstm_cell/kernel" % (scope, d)
             ko = self._o(kname)
-            dg = self._bufs["%s_dg_%s" % (tag, d)]
+            dg = self._bufs["%s_dg%s_%s" % (tag, "16" if f32c else "", d)]
 
             def wgrads(d=d, di=di, ko=ko, dg=dg):
                 # dWx += X^T dgates ; dWh += Hprev^T dgates ; db += colsum
@@ -715,7 +757,7 @@ class Tacotron2(object):
         S = To // r
         assert S <= hp.max_iters, "targets longer than max_iters*outputs_per_step"
         M, F = hp.num_mels, hp.num_freq
-        Fp = _round_up(F, 16)
+        Fp = self._lin_pad(F)
         E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
         Pi, Po = Ti + self.padl + self.padr, To + self.padl + self.padr
         S1 = S + 1
@@ -875,7 +917,10 @@ class Tacotron2(object):
         ex = self._bilstm_fwd("expand/encoder_lstm", x, cin, Hx, N, To, Po, None, "expl", "exp", D=Tx)
         self._tick("expand_lstm")
         lin = self._buf("lin_out", N * Po * Fp, torch.float32)
-        ops.gemm(ex, self.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=self.tsh["bl_pad"])
+        if "wl_padT" in self.tsh:
+            ops.gemm(ex, self.tsh["wl_padT"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, 2 * Hx, Fp, b_mode=0, bias=self.tsh["bl_pad"])
+        else:
+            ops.gemm(ex, self.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=self.tsh["bl_pad"])
         self._tick("linear")
 
         self.mel_outputs = mel[:N * Po * M].view(N, Po, M)[:, self.padl:self.padl + To]

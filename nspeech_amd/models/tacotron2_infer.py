@@ -83,7 +83,7 @@ def _infer_body(m):
     r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
     S = int(hp.max_iters)
     To = S * r
-    Fp = _round_up(F, 16)
+    Fp = m._lin_pad(F)
     E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
     Pi, Po = Ti + PADL + PADR, To + PADL + PADR
     S1 = S + 2
@@ -198,7 +198,10 @@ def _infer_body(m):
     Hx = hp.expand_lstm_units
     ex = m._bilstm_fwd("expand/encoder_lstm", x, cin, Hx, N, To, Po, None, "expl", "exp", D=Tx)
     lin = buf("lin_out", N * Po * Fp, torch.float32)
-    ops.gemm(ex, m.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=m.tsh["bl_pad"])
+    if "wl_padT" in m.tsh:
+        ops.gemm(ex, m.tsh["wl_padT"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, 2 * Hx, Fp, b_mode=0, bias=m.tsh["bl_pad"])
+    else:
+        ops.gemm(ex, m.tsh["wl_pad"], lin, N * Po, Fp, 2 * Hx, 2 * Hx, Fp, Fp, b_mode=1, bias=m.tsh["bl_pad"])
 
     m.dims = dict(N=N, Ti=Ti, To=To, S=S, Pi=Pi, Po=Po, Fp=Fp)
     m.mel_outputs = mel[:N * Po * M].view(N, Po, M)[:, PADL:PADL + To]

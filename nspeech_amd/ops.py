@@ -207,9 +207,12 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
 
 def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
                     dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
-                    forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0, dgates_bf16=None):
+                    forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0, dgates_bf16=None,
+                    h_bf16=None, h_bf16_off=0, ld_h_bf16=0, dtype=None):
     p = L.struct("ns_lstm_seq_params")
-    _fill(p, dtype=dt(h), N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
+    if h_bf16 is not None:
+        p.h_bf16, p.ld_h_bf16 = ptr(h_bf16, h_bf16_off), ld_h_bf16
+    _fill(p, dtype=dt(h) if dtype is None else dtype, N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
           dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES,
@@ -285,8 +288,11 @@ def taco2_attn_cluster(direction, cluster_work, **kw):
             "ns_taco2_attn_cluster_" + direction)
 
 
-def lstm_cluster_supported(p0):
-    return p0.dtype == NS_BF16 and p0.H % 64 == 0 and p0.H <= 512 and p0.T >= 2
+def lstm_cluster_supported(p0, p1=None, backward=False):
+    """Whether the persistent BiLSTM kernels take this pair of parameter blocks (bf16; forward also the fp32-state form)."""
+    if p1 is None:
+        return p0.dtype == NS_BF16 and p0.H % 64 == 0 and p0.H <= 512 and p0.T >= 2
+    return bool(L.lib().ns_lstm_cluster_supported(C.byref(p0), C.byref(p1), int(backward)))
 
 
 def lstm_cluster_work_floats(p0):
