@@ -510,6 +510,29 @@ int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* work, ns_stre
  * hoisted post-pass (dkeys, dv, dWcl, dctx_t, dvalues) as ns_taco2_attn_bwd. */
 int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stream_t stream);
 
+/* Free-running synthesis loop (tacotron2.py:78-83 with TacoTestHelper, helpers.py:7-38: the last predicted frame is
+ * the next step's input) as ONE persistent launch: the attention-RNN clusters of ns_taco2_attn_cluster_fwd plus
+ * workgroups that keep the two decoder LSTMs (tacotron2.py:67-70) register-resident as fp32, 12 units each, exchanging
+ * h_att / alignment / h1 / h2 / the next frame term as tagged 8-byte granules.  The frame feedback is folded:
+ * f1[s+1] = h2[s] . wpf + bpf with wpf = W_proj[:, last frame] . W_prenet1[frame rows] ([D, D1]) and
+ * bpf = b_proj[last frame] . W_prenet1[frame rows] + b_prenet1, so the output projection (tacotron2.py:73) leaves the
+ * loop: the caller forms decoder_outputs = h2 . W_proj + b_proj over the whole history afterwards.
+ * att: the attention block as for ns_taco2_attn_cluster_fwd with S = decoder steps; f1 slot 1 must hold the <GO>
+ * frame's term (= b_prenet1), later slots are not read.  Writes att.align / p1 / xa / q / ca / ga / hc[:, :, :A] and
+ * h2 fp32 [N, S+1, D] (step s in slot s+1).  N <= 2; (A, E, D) = (256, 512, 1024) or (64, 64, 64).
+ * work: ns_taco2_decode_work_bytes(); work[0] (int) is the status word (non-zero = an exchange timed out). */
+typedef struct {
+  ns_taco2_attn_params att;
+  int D;
+  const float* w_l1; const float* b_l1;   /* decoder/lstm_1 kernel [(A+E+D), 4D], bias [4D], fp32 */
+  const float* w_l2; const float* b_l2;   /* decoder/lstm_2 kernel [2D, 4D], bias */
+  const float* wpf; const float* bpf;     /* folded feedback [D, D1], [D1] */
+  float* h2;
+} ns_taco2_decode_params;
+int ns_taco2_decode_supported(const ns_taco2_decode_params* p);
+size_t ns_taco2_decode_work_bytes(const ns_taco2_decode_params* p);
+int ns_taco2_decode(const ns_taco2_decode_params* p, void* work, ns_stream_t stream);
+
 
 /* ------------------------------------------------------------------ simple WaveNet (models/wavenet_simple.py)
  * Row r of every series buffer is (n, t) = (r / T, r %% T) on ONE time grid of T = (clip length - 1) rows per item;

@@ -50,6 +50,8 @@ def _parse_header():
                 arr = re.match(r"(\w+)\[(\d+)\]$", nm)
                 if is_ptr:
                     ct = C.c_void_p
+                elif base in structs:           # a parameter block embedded in another one
+                    ct = structs[base]
                 else:
                     ct = _CTYPES[base]
                 if arr:

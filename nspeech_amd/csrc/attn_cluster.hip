@@ -61,6 +61,9 @@ struct ACArgs {
   u64* x1;                   // backward: [N][CG] dot-product shares
   int* status;
   long long* trace;          // NS_ATTN_TRACE=1: [step][16] timestamps (100 MHz) of workgroup 0, else null
+  // free-running decode (taco2_decode_kernel): the next step's frame term f1 arrives as granules from the decoder-LSTM
+  // workgroups ([N][D1], tag = consuming step + 1) and the alignment goes out to them ([N][Tia], tag = step + 1)
+  u64* f1x; u64* alx;
 };
 constexpr size_t TRACE_BYTES = 256 * 16 * sizeof(long long);
 __device__ __forceinline__ void stamp(const ACArgs& a, int st, int k) {
@@ -137,12 +140,27 @@ __device__ __forceinline__ float dot_regs(const float (&w)[NK], const float* x) 
 }
 
 // ===================================================================================== forward
-template <typename T, typename C>
-__global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
+// One granule, polled by its owner thread (the decode kernel's frame feedback).  Returns false on time-out / raised status.
+__device__ __forceinline__ bool poll_granule(const u64* g, unsigned tag, float& out, int* status, int code) {
+  unsigned spins = 0, clk0 = 0;
+  for (;;) {
+    const u64 v = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(v >> 32) == tag) { out = __uint_as_float((unsigned)v); return true; }
+    if ((++spins & 1023u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      if (ns_spin_timed_out(clk0)) { atomicExch(status, code); return false; }
+    }
+  }
+}
+
+// The forward recurrence of one workgroup (bid = utterance * CG + member).  INFER = free-running decode: the frame term
+// of the next step is not hoisted (it depends on this step's output through the two decoder LSTMs) but polled from
+// a.f1x, and the alignment is published to a.alx for the workgroups that run the first decoder LSTM.
+template <typename T, typename C, bool INFER>
+__device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const int bid) {
   constexpr int A = C::A, D1 = C::D1, D2 = C::D2, UPW = C::UPW, GC = C::GC, K = C::K;
   constexpr int GG = C::GG, GK = C::GK, P2G = C::P2G, P2K = C::P2K, QG = C::QG, QK = C::QK, CXG = C::CXG;
   constexpr int X2N = C::X2N, X3N = C::X3N;
-  extern __shared__ __attribute__((aligned(16))) float sm[];
   const ns_taco2_attn_params& p = a.p;
   float* xs = sm;                          // [K]      LSTM input: p2 | h(s-1)
   float* p1s = xs + K;                     // [D1]     prenet layer 1 of the current step
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   float* cst_s = wq_s + UPW * A;           // [KWMAX + 1][A]  folded location filter, attention_v
 
   const int tid_ = threadIdx.x;
-  const int n = blockIdx.x / CG, g = blockIdx.x % CG;
+  const int n = bid / CG, g = bid % CG;
   const long S1 = p.S + 1;
   const int Dsp = p.Dsp, XA = D2 + Dsp + A, HC = A + p.E;
   const int L = min(p.lengths ? p.lengths[n] : p.Ti, p.Ti);
@@ -169,6 +187,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
   const int half = (p.kw - 1) / 2;
   u64* x2 = a.x2 + (size_t)n * CG * X2N;
   u64* x3 = a.x3 + (size_t)n * CG * X3N;
+  if (INFER && tid_ == 0) sc[3] = 0.f;                    // set when the frame-feedback poll gave up
 
   // ---------------------------------------------------------------- resident weights (registers)
   const T* W2 = (const T*)p.w2;            // [D1][D2]
@@ -242,7 +261,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     const int p2q = tid / D2, gq = tid / GC, qu = tid % A, qq = tid / A;
     // next step's hoisted frame term, needed at the very end of this step
     float f1n = 0.f;
-    if (tid < D1 && st + 1 < p.S) f1n = p.f1[((long)n * S1 + slot + 1) * D1 + tid];
+    if (!INFER && tid < D1 && st + 1 < p.S) f1n = p.f1[((long)n * S1 + slot + 1) * D1 + tid];
 
     stamp(a, st, 0);
     // ---- (1) p2 = relu(p1 . W2 + b2): every workgroup computes all of it
@@ -401,14 +420,6 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
     }
     const float inv = 1.f / lsum;
     lds_barrier();                                   // al / p1s are rewritten below: everyone is done with step s
-    if (tid < D1) {
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < CG; ++q) s = fmaf(scl[q], gath[q * X3N + tid], s);
-      const float v = fmaxf(fmaf(s, inv, f1n), 0.f);
-      p1s[tid] = v;
-      if (st + 1 < p.S && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
-    }
     // the whole alignment (every workgroup needs its neighbours' positions for the location filter)
     for (int t = tid; t < p.Tia; t += CT) {
       float v = 0.f;
@@ -421,10 +432,29 @@ __global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
       if (mine) {
         p.align[((long)n * S1 + slot) * p.Tia + t] = v;
         if (p.align_t) stf((T*)p.align_t + ((long)n * S1 + slot) * p.Tia + t, v);
+        if (INFER) put_granule(a.alx + (size_t)n * p.Tia + t, tag, v);      // the first decoder LSTM waits for it
       }
     }
+    if (tid < D1) {
+      // free-running: the next frame term comes back through both decoder LSTMs (its tag = the consuming step + 1);
+      // the alignment above went out first - they cannot answer before they have it
+      if (INFER && st + 1 < p.S && !poll_granule(a.f1x + (size_t)n * D1 + tid, tag + 1, f1n, a.status, 3)) sc[3] = 1.f;
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < CG; ++q) s = fmaf(scl[q], gath[q * X3N + tid], s);
+      const float v = fmaxf(fmaf(s, inv, f1n), 0.f);
+      p1s[tid] = v;
+      if (st + 1 < p.S && tid / (D1 / CG) == g) stf((T*)p.p1 + ((long)n * S1 + slot + 1) * D1 + tid, v);
+    }
     lds_barrier();
+    if (INFER && sc[3] != 0.f) return;
   }
+}
+
+template <typename T, typename C>
+__global__ __launch_bounds__(CT) void attn_cluster_fwd_kernel(ACArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm_attn_fwd[];
+  attn_fwd_body<T, C, false>(a, sm_attn_fwd, blockIdx.x);
 }
 
 // ===================================================================================== backward
@@ -837,6 +867,275 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   }
 }
 
+
+// ===================================================================================== free-running decode (round 3)
+// Synthesis (tacotron2.py:78-83 with TacoTestHelper, helpers.py:7-38): the frame fed to step s+1 is the last frame
+// predicted at step s, so nothing can be hoisted out of the time loop and the launch-per-step form needs 9 dependent
+// launches per decoder step (80 us per step at batch 1).  Here the whole loop is ONE launch with three roles:
+//   workgroups [0, 8N)            the attention RNN clusters of attn_fwd_body<INFER> above
+//   the next NW workgroups        decoder LSTM 1, UPW = 12 units each (NW = ceil(D / 12))
+//   the last NW workgroups        decoder LSTM 2, 12 units each, plus the frame feedback
+// Every weight stays in registers as fp32 (matrix-VECTOR products at one or two utterances: exact fp32 FMAs, as in the
+// attention clusters); vectors travel as 8-byte {step tag, fp32} granules (the data is its own flag).  Per step:
+//   attention:  h_att(s) -> x2 (its own exchange), align(s) -> alx, then waits for f1(s+1)
+//   LSTM 1:     gathers h_att(s) + align(s); the context enters through the PROJECTED memory PM = memory . W_ctx of its
+//               own 48 gate columns (LDS, built once per call), so no 512-wide context is formed in the loop;
+//               adds the recurrent half W_h . h1(s-1) it computed in the shadow of the previous step; cell; h1(s) -> pub1
+//   LSTM 2:     gathers h1(s), adds its recurrent half, cell, h2(s) -> pub2 + history; then every LSTM-2 workgroup
+//               gathers h2(s) for its next recurrent half and for its columns of the FOLDED feedback
+//               f1(s+1) = h2(s) . (W_proj[:, last frame] . W_prenet1[frame rows]) + b  -> f1x   (the output projection
+//               itself is off the critical path: ONE product over the h2 history after the loop)
+// pub1 / pub2 are double-buffered by step parity (a producer may be a step ahead of a peer's second gather); x2, alx and
+// f1x need one buffer: their next writer sits behind a dependency chain through every reader.
+// Units per workgroup: 16 for LSTM 1 (K = A + D resident inputs: 160 weights per thread at the shipped widths), 8 for
+// LSTM 2 (K = 2D: 128 per thread) - with 12 + 12 the second cell's 192 weights per thread spilled.
+constexpr int DEC_UPW1 = 16, DEC_UPW2 = 8, DEC_KS = 32;
+
+struct DecArgs {
+  ACArgs att;
+  int N, S, E, D, NW1, NW2;
+  const float* w1; const float* b1;        // decoder/lstm_1 kernel [(A + E + D), 4D] fp32, bias [4D]
+  const float* w2; const float* b2;        // decoder/lstm_2 kernel [2D, 4D], bias
+  const float* wpf; const float* bpf;      // folded feedback [D, D1], [D1]
+  u64* pub1; u64* pub2;                    // [2][N][D]
+  float* h2hist;                           // [N][S + 1][D], slot s + 1
+};
+
+// PER granules per thread, all loads of a pass in flight together; at(i, src, dst) maps item i to its granule and its
+// LDS word.  Returns false on time-out / raised status.
+template <int PER, typename F>
+__device__ __forceinline__ bool dec_gather(int total, unsigned tag, int tid, int* status, int code, F at) {
+  const u64* src[PER];
+  float* dst[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int i = tid + j * CT;
+    src[j] = nullptr; dst[j] = nullptr;
+    if (i < total) at(i, src[j], dst[j]);
+  }
+  u64 v[PER];
+  unsigned spins = 0, clk0 = 0;
+  bool ok, good = true;
+  do {
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] = src[j] ? __hip_atomic_load(src[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((u64)tag << 32);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
+    if (!ok && (++spins & 1023u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { good = false; ok = true; }
+      else if (ns_spin_timed_out(clk0)) { atomicExch(status, code); good = false; ok = true; }
+    }
+  } while (!ok);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) if (dst[j]) *dst[j] = __uint_as_float((unsigned)v[j]);
+  return good;
+}
+
+// One decoder LSTM's workgroup w.  WHICH = 1: inputs h_att (A, registers) + context (through PM) + own h1; 2: h1 + own h2.
+// A workgroup owns UPW units = COLS = 4 UPW gate columns (column = gate * UPW + unit); thread (cg = tid & 15, ks = tid >> 4)
+// holds the CPT = COLS / 16 columns CPT cg .. of the k slice ks of each input.
+template <typename T, typename C, int E, int D, int NR, int WHICH>
+__device__ __forceinline__ void dec_lstm_role(const DecArgs& d, float* sm, const int w) {
+  constexpr int A = C::A, D1 = C::D1, X2N = C::X2N, UPWA = C::UPW;
+  constexpr int UPW = WHICH == 1 ? DEC_UPW1 : DEC_UPW2, COLS = 4 * UPW, CPT = COLS / 16, RS = COLS + 1;
+  constexpr int KX = WHICH == 1 ? A : D, KPX = KX / DEC_KS, KPH = D / DEC_KS;
+  static_assert(KX % DEC_KS == 0 && D % DEC_KS == 0 && COLS % 16 == 0, "slices");
+  const ns_taco2_attn_params& p = d.att.p;
+  const int tid = threadIdx.x, cg = tid & 15, ks = tid >> 4;
+  const int N = d.N, Tia = p.Tia, u0 = w * UPW;
+  const int NW = WHICH == 1 ? d.NW1 : d.NW2;
+  const int FPW = (D1 + NW - 1) / NW, f0 = w * FPW, fn = max(0, min(D1, f0 + FPW) - f0);      // own feedback columns (LSTM 2)
+  // ---- LDS
+  float* xv = sm;                               // [NR][KX]   gathered input of the x part
+  float* hv = xv + NR * KX;                     // [NR][D]    gathered own h of the previous step
+  float* red = hv + NR * D;                     // [32][COLS + 1] partial sums over the k slices
+  float* zr = red + DEC_KS * RS;                // [NR][COLS] recurrent half, computed a phase ahead
+  float* zs = zr + NR * COLS;                   // [COLS]     gate pre-activations of the row in work
+  float* flag = zs + COLS;                      // [4]        [0] abort
+  float* xtra = flag + 4;                       // WHICH 1: al_s [NR][Tia], PM [NR][Tia][COLS]; 2: wpf_s [FPW][D], red2 [32][64]
+  float* al_s = xtra;
+  float* PM = al_s + NR * Tia;
+  float* wpf_s = xtra;
+  float* red2 = wpf_s + (size_t)FPW * D;
+  // ---- resident weights
+  const float* W = WHICH == 1 ? d.w1 : d.w2;
+  const float* bias = WHICH == 1 ? d.b1 : d.b2;
+  const int rowh0 = WHICH == 1 ? A + E : D;
+  float wx[CPT][KPX], wh[CPT][KPH];
+#pragma unroll
+  for (int j = 0; j < CPT; ++j) {
+    const int col = CPT * cg + j, gate = col / UPW, ul = col % UPW;
+    const bool okc = u0 + ul < D;
+    const long wc = (long)gate * D + u0 + ul;
+#pragma unroll
+    for (int i = 0; i < KPX; ++i) wx[j][i] = okc ? W[(long)(ks * KPX + i) * 4 * D + wc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < KPH; ++i) wh[j][i] = okc ? W[(long)(rowh0 + ks * KPH + i) * 4 * D + wc] : 0.f;
+  }
+  if (tid < 4) flag[tid] = 0.f;
+  for (int i = tid; i < NR * COLS; i += CT) zr[i] = 0.f;
+  if (WHICH == 1) {
+    // projected memory of the own gate columns: PM[n][t][col] = sum_e memory[n][t][e] W[A + e][col]
+    const T* val = (const T*)p.values;
+    for (int o = tid; o < N * Tia * COLS; o += CT) {
+      const int col = o % COLS, t = (o / COLS) % Tia, n = o / (COLS * Tia);
+      const int gate = col / UPW, ul = col % UPW;
+      float s = 0.f;
+      if (t < p.Ti && u0 + ul < D) {
+        const T* vr = val + ((long)n * p.Pi + p.padl_i + t) * E;
+        const float* wc = W + (long)A * 4 * D + (long)gate * D + u0 + ul;
+        for (int e = 0; e < E; ++e) s = fmaf(ldf(vr + e), wc[(long)e * 4 * D], s);
+      }
+      PM[o] = s;
+    }
+  } else {
+    for (int o = tid; o < fn * D; o += CT) wpf_s[o] = d.wpf[(long)(o % D) * D1 + f0 + o / D];      // [j][k]
+  }
+  float cst[NR];
+#pragma unroll
+  for (int n = 0; n < NR; ++n) cst[n] = 0.f;
+  __syncthreads();
+
+  u64* mypub = WHICH == 1 ? d.pub1 : d.pub2;
+  for (int st = 0; st < d.S; ++st) {
+    const unsigned tag = (unsigned)(st + 1);
+    const size_t par = (size_t)(st & 1) * N * D;
+    // ---------------- phase a: the inputs of this step
+    bool good;
+    if (WHICH == 1) {
+      good = dec_gather<(NR * A + CT - 1) / CT>(N * A, tag, tid, d.att.status, 4, [&](int i, const u64*& src, float*& dst) {
+        const int n = i / A, u = i % A;
+        src = d.att.x2 + ((size_t)n * CG + u / UPWA) * X2N + A + u % UPWA;
+        dst = xv + n * KX + u;
+      });
+      good = dec_gather<(NR * 256 + CT - 1) / CT>(N * Tia, tag, tid, d.att.status, 4, [&](int i, const u64*& src, float*& dst) {
+        src = d.att.alx + i;
+        dst = al_s + i;
+      }) && good;
+    } else {
+      good = dec_gather<(NR * D + CT - 1) / CT>(N * D, tag, tid, d.att.status, 5, [&](int i, const u64*& src, float*& dst) {
+        src = d.pub1 + par + i;
+        dst = xv + i;
+      });
+    }
+    if (!good) flag[0] = 1.f;
+    lds_barrier();
+    if (flag[0] != 0.f) return;
+    for (int n = 0; n < N; ++n) {
+      float acc[CPT];
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+#pragma unroll
+      for (int i = 0; i < KPX; ++i) {
+        const float x = xv[n * KX + ks * KPX + i];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = fmaf(wx[j][i], x, acc[j]);
+      }
+      if (WHICH == 1) {
+        for (int t = ks; t < Tia; t += DEC_KS) {
+          const float av = al_s[n * Tia + t];
+          const float* pm = PM + ((size_t)n * Tia + t) * COLS + CPT * cg;
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[j] = fmaf(av, pm[j], acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CPT; ++j) red[ks * RS + CPT * cg + j] = acc[j];
+      lds_barrier();
+      if (tid < COLS) {
+        const int gate = tid / UPW, ul = tid % UPW;
+        float s = (u0 + ul < D ? bias[gate * D + u0 + ul] : 0.f) + zr[n * COLS + tid];
+#pragma unroll
+        for (int q = 0; q < DEC_KS; ++q) s += red[q * RS + tid];
+        zs[tid] = s;
+      }
+      lds_barrier();
+      if (tid < UPW && u0 + tid < D) {
+        const float gi = sigmoidf_(zs[tid]), gj = tanhf_(zs[UPW + tid]);
+        const float gf = sigmoidf_(zs[2 * UPW + tid] + 1.0f), go = sigmoidf_(zs[3 * UPW + tid]);
+        float c = cst[0];
+#pragma unroll
+        for (int q = 1; q < NR; ++q) c = n == q ? cst[q] : c;
+        c = gf * c + gi * gj;
+        const float h = go * tanhf_(c);
+#pragma unroll
+        for (int q = 0; q < NR; ++q) cst[q] = n == q ? c : cst[q];
+        put_granule(mypub + par + (size_t)n * D + u0 + tid, tag, h);
+        if (WHICH == 2) d.h2hist[((long)n * (d.S + 1) + st + 1) * D + u0 + tid] = h;
+      }
+      // red / zs are rewritten by the next row only behind the barrier that follows its partial sums
+      lds_barrier();
+    }
+    // ---------------- phase b: everybody's h of this step -> the recurrent half of the next step (and the feedback)
+    if (st + 1 < d.S) {
+      good = dec_gather<(NR * D + CT - 1) / CT>(N * D, tag, tid, d.att.status, 6, [&](int i, const u64*& src, float*& dst) {
+        src = mypub + par + i;
+        dst = hv + i;
+      });
+      if (!good) flag[0] = 1.f;
+      lds_barrier();
+      if (flag[0] != 0.f) return;
+      for (int n = 0; n < N; ++n) {
+        float acc[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KPH; ++i) {
+          const float x = hv[n * D + ks * KPH + i];
+#pragma unroll
+          for (int j = 0; j < CPT; ++j) acc[j] = fmaf(wh[j][i], x, acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) red[ks * RS + CPT * cg + j] = acc[j];
+        if (WHICH == 2) {
+          // the own columns of the folded feedback: (column j, k slice) pairs over the threads
+          for (int o = tid; o < fn * DEC_KS; o += CT) {
+            const int j = o / DEC_KS, q = o % DEC_KS;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < KPH; ++i) s = fmaf(wpf_s[j * D + q * KPH + i], hv[n * D + q * KPH + i], s);
+            red2[q * 64 + j] = s;
+          }
+        }
+        lds_barrier();
+        if (tid < COLS) {
+          float s = 0.f;
+#pragma unroll
+          for (int q = 0; q < DEC_KS; ++q) s += red[q * RS + tid];
+          zr[n * COLS + tid] = s;
+        } else if (WHICH == 2 && tid >= 64 && tid < 64 + fn) {
+          const int j = tid - 64;
+          float s = d.bpf[f0 + j];
+#pragma unroll
+          for (int q = 0; q < DEC_KS; ++q) s += red2[q * 64 + j];
+          put_granule(d.att.f1x + (size_t)n * D1 + f0 + j, tag + 1, s);
+        }
+        lds_barrier();
+      }
+    }
+  }
+}
+
+template <typename T, typename C, int E, int D, int NR>
+__global__ __launch_bounds__(CT) void taco2_decode_kernel(DecArgs d) {
+  extern __shared__ __attribute__((aligned(16))) float sm_dec[];
+  const int na = d.N * CG;
+  const int b = blockIdx.x;
+  if (b < na) attn_fwd_body<T, C, true>(d.att, sm_dec, b);
+  else if (b < na + d.NW1) dec_lstm_role<T, C, E, D, NR, 1>(d, sm_dec, b - na);
+  else dec_lstm_role<T, C, E, D, NR, 2>(d, sm_dec, b - na - d.NW1);
+}
+
+template <typename C, int E, int D, int NR>
+size_t dec_lds_bytes(int Tia, int NW2) {
+  const int FPW = (C::D1 + NW2 - 1) / NW2;
+  constexpr int C1 = 4 * DEC_UPW1, C2 = 4 * DEC_UPW2;
+  const size_t l1 = (size_t)NR * (C::A + D) + DEC_KS * (C1 + 1) + NR * C1 + C1 + 4 + (size_t)NR * Tia * (1 + C1);
+  const size_t l2 = (size_t)NR * (D + D) + DEC_KS * (C2 + 1) + NR * C2 + C2 + 4 + (size_t)FPW * D + DEC_KS * 64;
+  return sizeof(float) * (l1 > l2 ? l1 : l2);
+}
+
 template <typename C>
 size_t fwd_lds_bytes() {
   return sizeof(float) * (C::K + C::D1 + CT + C::A + 256 + 2 * APAD + TSMAX + (CT / 64) * TSMAX + C::UPW + 16 +
@@ -997,4 +1296,83 @@ extern "C" int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* wo
   }
   if (p->A == 256) return launch_bwd<float, BCfg<256, 256, 128>>(p, work, s);
   return launch_bwd<float, BCfg<64, 256, 128>>(p, work, s);
+}
+
+// ------------------------------------------------------------------ free-running decode, C ABI
+static bool decode_shape_ok(const ns_taco2_decode_params* q) {
+  if (!q) return false;
+  const ns_taco2_attn_params* p = &q->att;
+  if (!cluster_shape_ok(p)) return false;
+  if (!((p->A == 256 && p->E == 512 && q->D == 1024) || (p->A == 64 && p->E == 64 && q->D == 64))) return false;
+  if (p->N < 1 || p->N > 2 || p->Tia > 256 || p->Ti > p->Tia) return false;
+  const int NW1 = (q->D + DEC_UPW1 - 1) / DEC_UPW1, NW2 = (q->D + DEC_UPW2 - 1) / DEC_UPW2;
+  if (p->N * CG + NW1 + NW2 > 256) return false;       // every workgroup resident at once, one per CU
+  if ((256 + NW2 - 1) / NW2 > 64) return false;        // feedback columns per LSTM-2 workgroup (red2 rows)
+  return true;
+}
+extern "C" int ns_taco2_decode_supported(const ns_taco2_decode_params* q) { return decode_shape_ok(q) ? 1 : 0; }
+extern "C" size_t ns_taco2_decode_work_bytes(const ns_taco2_decode_params* q) {
+  if (!q) return 0;
+  const ns_taco2_attn_params* p = &q->att;
+  return ns_taco2_attn_cluster_work_bytes(p) + sizeof(u64) * ((size_t)p->N * (p->D1 + 256) + 4 * (size_t)p->N * q->D) + 256;
+}
+
+template <typename T, typename C, int E, int D>
+static int launch_decode(const ns_taco2_decode_params* q, void* work, hipStream_t s) {
+  const ns_taco2_attn_params* p = &q->att;
+  DecArgs d;
+  d.att.p = *p;
+  d.att.status = (int*)work;
+  d.att.x2 = (u64*)((char*)work + 256);
+  d.att.x3 = d.att.x2 + (size_t)p->N * CG * C::X2N;
+  d.att.x1 = nullptr;
+  d.att.f1x = d.att.x3 + (size_t)p->N * CG * C::X3N;
+  d.att.alx = d.att.f1x + (size_t)p->N * C::D1;
+  d.pub1 = d.att.alx + (size_t)p->N * 256;
+  d.pub2 = d.pub1 + 2 * (size_t)p->N * D;
+  const size_t xbytes = (size_t)((char*)(d.pub2 + 2 * (size_t)p->N * D) - (char*)work);
+  d.att.trace = nullptr;
+  d.N = p->N; d.S = p->S; d.E = E; d.D = D;
+  d.NW1 = (D + DEC_UPW1 - 1) / DEC_UPW1; d.NW2 = (D + DEC_UPW2 - 1) / DEC_UPW2;
+  d.w1 = q->w_l1; d.b1 = q->b_l1; d.w2 = q->w_l2; d.b2 = q->b_l2; d.wpf = q->wpf; d.bpf = q->bpf;
+  d.h2hist = q->h2;
+  { const int zrc = ns_zero_async(work, (xbytes + 15) & ~(size_t)15, s); if (zrc) return zrc; }
+  const int grid = p->N * CG + d.NW1 + d.NW2;
+#define NS_LAUNCH_DEC(NR_)                                                                                           \
+  do {                                                                                                               \
+    size_t lds = dec_lds_bytes<C, E, D, NR_>(p->Tia, d.NW2);                                                         \
+    const size_t la = fwd_lds_bytes<C>();                                                                            \
+    if (la > lds) lds = la;                                                                                          \
+    NS_CHECK_ARG(lds <= 160 * 1024, "ns_taco2_decode: %zu bytes of LDS needed", lds);                                \
+    static bool attr = false;                                                                                        \
+    if (!attr) {                                                                                                     \
+      (void)hipFuncSetAttribute((const void*)taco2_decode_kernel<T, C, E, D, NR_>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                             \
+      attr = true;                                                                                                   \
+    }                                                                                                                \
+    hipLaunchKernelGGL((taco2_decode_kernel<T, C, E, D, NR_>), dim3(grid), dim3(CT), lds, s, d);                     \
+  } while (0)
+  if (p->N == 1) NS_LAUNCH_DEC(1); else NS_LAUNCH_DEC(2);
+#undef NS_LAUNCH_DEC
+  NS_CHECK_LAUNCH("taco2_decode");
+  return NS_OK;
+}
+
+// The free-running decoder loop (attention RNN + both decoder LSTMs + the frame feedback) as ONE persistent launch,
+// see "free-running decode" above.  work: ns_taco2_decode_work_bytes(); work[0] (int) is the status word.
+extern "C" int ns_taco2_decode(const ns_taco2_decode_params* q, void* work, ns_stream_t s_) {
+  hipStream_t s = (hipStream_t)s_;
+  NS_CHECK_ARG(q && work, "ns_taco2_decode: null");
+  NS_CHECK_ARG(decode_shape_ok(q), "ns_taco2_decode: unsupported shape (needs the attention-cluster shapes, N <= 2, and "
+               "(A, E, D) = (256, 512, 1024) or (64, 64, 64))");
+  const ns_taco2_attn_params* p = &q->att;
+  NS_CHECK_ARG(p->keys && p->f1 && p->w2 && p->watt && p->wq && p->b2 && p->batt && p->wcl && p->v && p->p1 && p->xa &&
+                   p->hc && p->ca && p->ga && p->q && p->align && p->values && q->w_l1 && q->b_l1 && q->w_l2 && q->b_l2 &&
+                   q->wpf && q->bpf && q->h2, "ns_taco2_decode: null pointer");
+  if (p->dtype == NS_BF16) {
+    if (p->A == 256) return launch_decode<bf16_t, Cfg<256, 256, 128>, 512, 1024>(q, work, s);
+    return launch_decode<bf16_t, Cfg<64, 256, 128>, 64, 64>(q, work, s);
+  }
+  if (p->A == 256) return launch_decode<float, Cfg<256, 256, 128>, 512, 1024>(q, work, s);
+  return launch_decode<float, Cfg<64, 256, 128>, 64, 64>(q, work, s);
 }

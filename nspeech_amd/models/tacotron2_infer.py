@@ -47,75 +47,78 @@ def _lstm_step(m, a, a_off, a_sn, K, wT, bias_off, c_prev, c_prev_off, c_sn, h_o
     L.call("ns_lstm_step", p, ops.stream())
 
 
-def forward_infer(m):
-    """Runs the synthesis graph.  The first call with a given (N, T_in, max_iters) signature runs eagerly (it also
-    allocates every buffer); the second captures the whole pass - a few thousand dependent launches, host-bound when
-    issued one by one from Python - into a HIP graph over the now persistent buffers, and later calls replay it."""
-    hp = m._hparams
-    N, Ti = m.inputs.shape
-    sig = ("infer", N, Ti, int(hp.max_iters))
-    st = getattr(m, "_infer_graph", None)
-    if getattr(m, "use_graph", True) and st is not None and st["sig"] == sig and sig == m._sig:
-        st["inputs"].copy_(m.inputs)
-        st["lengths"].copy_(m.input_lengths)
-        m.inputs, m.input_lengths = st["inputs"], st["lengths"]
-        if m.speaker_ids is not None:
-            st["speakers"].copy_(m.speaker_ids)
-            m.speaker_ids = st["speakers"]
-        if st["graph"] is None:
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                _infer_body(m)
-            st["graph"] = g
-        st["graph"].replay()
-        return m
-    _infer_body(m)
-    m._infer_graph = dict(sig=sig, graph=None, inputs=m.inputs.clone(), lengths=m.input_lengths.clone(),
-                          speakers=m.speaker_ids.clone() if m.speaker_ids is not None else None)
-    return m
-
-
-def _infer_body(m):
+def _decode_persistent(m, N, Ti, Pi, Tia, S, enc, keys):
+    """The whole free-running decoder loop as ONE persistent launch (ns_taco2_decode, csrc/attn_cluster.hip "free-running
+    decode"): attention-RNN clusters + register-resident decoder LSTMs + folded frame feedback.  Returns (dec, al, S1)
+    in the [N, S+1, X] slot layout, or None when the shape is not covered (more than two utterances, other widths)."""
+    import ctypes as C
     hp = m._hparams
     T_ = m.T
-    N, Ti = m.inputs.shape
-    r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
-    S = int(hp.max_iters)
-    To = S * r
-    Fp = m._lin_pad(F)
+    r, M = hp.outputs_per_step, hp.num_mels
     E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
-    Pi, Po = Ti + PADL + PADR, To + PADL + PADR
-    S1 = S + 2
-    sig = ("infer", N, Ti, S)
-    if sig != m._sig:
-        m._bufs.clear()
-        m._sig = sig
-    ops.F32_PASSES = m.passes_fwd
-    _infer_shadows(m)
-    W = m._W(T_)
+    S1 = S + 1
+    buf, o, W = m._buf, m._o, m._W(T_)
+    Dsp = m.Dsp
+    XA = 128 + Dsp + A
+    # <GO> frame = zeros: the frame term of step 0 is the prenet bias (every slot gets it; only slot 1 is read)
+    fr = buf("dec_fr", N * S1 * M, T_)
+    f1 = buf("dec_f1", N * S1 * 256, torch.float32)
+    w1 = o("decoder/decoder_prenet/dense_1/kernel")
+    ops.gemm(fr, W, f1, N * S1, 256, M, M, 256, 256, b_mode=1, b_off=w1, bias=m.flat_p,
+             bias_off=o("decoder/decoder_prenet/dense_1/bias"))
+    pv = buf("dec_pv", N * Pi * 256, T_)
+    ops.gemm(enc, W, pv, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
+    xa = buf("dec_xa", N * S1 * XA, T_)
+    if Dsp:
+        ops.copy3d(m._speaker_fwd(N), xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
+    al = buf("dec_al", N * S1 * Tia, torch.float32)
+    args = dict(
+        pv=pv, Dsp=Dsp, dtype=ops.dt(xa), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=PADL, Tia=Tia, A=A, E=E, D1=256, D2=128, kw=7,
+        lengths=m.input_lengths, keys=keys, values=enc, f1=f1,
+        b2=(m.flat_p, o("decoder/decoder_prenet/dense_2/bias")), batt=(m.flat_p, o("decoder/attention_lstm/bias")),
+        wcl=m.tsh["wcl"], v=(m.flat_p, o("decoder/attention/attention_v")),
+        p1=buf("dec_p1", N * S1 * 256, T_), xa=xa, hc=buf("dec_hc", N * S1 * (A + E), T_),
+        ca=buf("dec_ca", N * S1 * A, torch.float32), ga=buf("dec_ga", N * S1 * 4 * A, T_),
+        q=buf("dec_q", N * S1 * A, torch.float32), align=al,
+        w2=(W, o("decoder/decoder_prenet/dense_2/kernel")), watt=(W, o("decoder/attention_lstm/kernel")),
+        wq=(W, o("decoder/attention/query_layer/kernel")))
+    q = L.struct("ns_taco2_decode_params")
+    q.att = ops._attn_params(args)
+    q.D = D
+    fp = m.flat_p
+    q.w_l1, q.b_l1 = ops.ptr(fp, o("decoder/lstm_1/kernel")), ops.ptr(fp, o("decoder/lstm_1/bias"))
+    q.w_l2, q.b_l2 = ops.ptr(fp, o("decoder/lstm_2/kernel")), ops.ptr(fp, o("decoder/lstm_2/bias"))
+    # folded feedback (exact fp32): wpf = W_proj[:, last frame] . W_prenet1[frame rows], bpf = b_proj[last frame] . same + b1
+    wpf = buf("dec_wpf", D * 256, torch.float32)
+    bpf = buf("dec_bpf", 256, torch.float32)
+    kp, bp = o("decoder/output_projection/kernel"), o("decoder/output_projection/bias")
+    ops.gemm(fp, fp, wpf, D, 256, M, M * r, 256, 256, b_mode=1, a_off=kp + (r - 1) * M, b_off=w1, f32_passes=0)
+    ops.gemm(fp, fp, bpf, 1, 256, M, M * r, 256, 256, b_mode=1, a_off=bp + (r - 1) * M, b_off=w1, bias=fp,
+             bias_off=o("decoder/decoder_prenet/dense_1/bias"), f32_passes=0)
+    q.wpf, q.bpf = ops.ptr(wpf), ops.ptr(bpf)
+    h2 = buf("dec_h2", N * S1 * D, torch.float32)
+    q.h2 = ops.ptr(h2)
+    lib = L.lib()
+    if not lib.ns_taco2_decode_supported(C.byref(q)):
+        return None
+    fn = lib.ns_taco2_decode_work_bytes
+    fn.restype = C.c_size_t
+    work = buf("decode_work", (int(fn(C.byref(q))) + 3) // 4, torch.float32)
+    L.check(lib.ns_taco2_decode(C.byref(q), C.c_void_p(ops.ptr(work)), C.c_void_p(ops.stream())), "ns_taco2_decode")
+    m._status_words[("decode", "fwd")] = work
+    # the output projection over the whole history (tacotron2.py:73), off the loop's critical path
+    dec = buf("dec_out", N * S1 * M * r, torch.float32)
+    ops.gemm(h2, fp, dec, N * S1, M * r, D, D, M * r, M * r, b_mode=1, b_off=kp, bias=fp, bias_off=bp)
+    return dec, al, S1
+
+
+def _decode_steps(m, N, Ti, Pi, Tia, S, S1, enc, keys_t):
+    """One decoder step = 9 dependent launches; step s lives in slot s+1 of every [N, S+2, X] buffer (slot 0 = zeros)."""
+    hp = m._hparams
+    T_ = m.T
+    r, M = hp.outputs_per_step, hp.num_mels
+    E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
     buf = m._buf
-
-    # ---- encoder with moving-average BatchNorm
-    emb = hp.embedding_dim
-    x = buf("enc_x0", N * Pi * emb, T_)
-    ops.embedding_fwd(m.inputs, m.flat_p, x, N, Ti, Pi, PADL, emb, m.vocab, table_off=m._o("embedding/embedding"))
-    cin = emb
-    for i in range(hp.encoder_conv_layers):
-        act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
-        x = m._conv_fwd("encoder/conv_%d" % i, x, cin, hp.encoder_conv_channels, hp.encoder_conv_width, act, N, Ti, Pi,
-                        "enc%d" % i, training=False)
-        cin = hp.encoder_conv_channels
-    enc = m._bilstm_fwd("encoder/encoder_lstm", x, cin, hp.encoder_lstm_units, N, Ti, Pi, m.input_lengths, "encl", "enc")
-    keys = buf("keys", N * Pi * A, torch.float32)
-    ops.gemm(enc, W, keys, N * Pi, A, E, E, A, A, b_mode=1, b_off=m._o("attention_decoder/memory_layer/kernel"))
-    Tia = _round_up(Ti, 8)
-    keys_t = buf("dec_keys_t", N * A * Tia, torch.float32)
-    L.check(L.lib().ns_taco2_keys_transpose(
-        L.C.c_void_p(ops.ptr(keys)), L.C.c_void_p(ops.ptr(keys_t)), N, Ti, Tia, Pi, PADL, A,
-        L.C.c_void_p(ops.stream())), "ns_taco2_keys_transpose")
-
-    # ---- decoder loop; step s lives in slot s+1 of every [N, S+2, X] buffer (slot 0 = zeros)
     Dsp = m.Dsp
     XP, XA, X1, X2 = M + E, 128 + Dsp + A, A + E + D, 2 * D
     xp = buf("inf_xp", N * S1 * XP, T_)      # [frame | ctx_prev]
@@ -170,6 +173,87 @@ def _infer_body(m):
                  bias=m.flat_p, bias_off=o("decoder/output_projection/bias"))
         # feed the last of the r frames back
         ops.copy3d(dec, xp, N, 1, M, (S1 * M * r, 0), (S1 * XP, 0), src_off=sl * M * r + (r - 1) * M, dst_off=nx * XP)
+
+    return dec, al
+
+
+def forward_infer(m):
+    """Runs the synthesis graph.  The first call with a given (N, T_in, max_iters) signature runs eagerly (it also
+    allocates every buffer); the second captures the whole pass - a few thousand dependent launches, host-bound when
+    issued one by one from Python - into a HIP graph over the now persistent buffers, and later calls replay it."""
+    hp = m._hparams
+    N, Ti = m.inputs.shape
+    sig = ("infer", N, Ti, int(hp.max_iters))
+    st = getattr(m, "_infer_graph", None)
+    if getattr(m, "use_graph", True) and st is not None and st["sig"] == sig and sig == m._sig:
+        st["inputs"].copy_(m.inputs)
+        st["lengths"].copy_(m.input_lengths)
+        m.inputs, m.input_lengths = st["inputs"], st["lengths"]
+        if m.speaker_ids is not None:
+            st["speakers"].copy_(m.speaker_ids)
+            m.speaker_ids = st["speakers"]
+        if st["graph"] is None:
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                _infer_body(m)
+            st["graph"] = g
+        st["graph"].replay()
+        return m
+    _infer_body(m)
+    m._infer_graph = dict(sig=sig, graph=None, inputs=m.inputs.clone(), lengths=m.input_lengths.clone(),
+                          speakers=m.speaker_ids.clone() if m.speaker_ids is not None else None)
+    return m
+
+
+def _infer_body(m):
+    hp = m._hparams
+    T_ = m.T
+    N, Ti = m.inputs.shape
+    r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq
+    S = int(hp.max_iters)
+    To = S * r
+    Fp = m._lin_pad(F)
+    E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
+    Pi, Po = Ti + PADL + PADR, To + PADL + PADR
+    S1 = S + 2
+    sig = ("infer", N, Ti, S)
+    if sig != m._sig:
+        m._bufs.clear()
+        m._sig = sig
+    ops.F32_PASSES = m.passes_fwd
+    _infer_shadows(m)
+    W = m._W(T_)
+    buf = m._buf
+    o = m._o
+
+    # ---- encoder with moving-average BatchNorm
+    emb = hp.embedding_dim
+    x = buf("enc_x0", N * Pi * emb, T_)
+    ops.embedding_fwd(m.inputs, m.flat_p, x, N, Ti, Pi, PADL, emb, m.vocab, table_off=m._o("embedding/embedding"))
+    cin = emb
+    for i in range(hp.encoder_conv_layers):
+        act = ACT_RELU if i < hp.encoder_conv_layers - 1 else ACT_NONE
+        x = m._conv_fwd("encoder/conv_%d" % i, x, cin, hp.encoder_conv_channels, hp.encoder_conv_width, act, N, Ti, Pi,
+                        "enc%d" % i, training=False)
+        cin = hp.encoder_conv_channels
+    enc = m._bilstm_fwd("encoder/encoder_lstm", x, cin, hp.encoder_lstm_units, N, Ti, Pi, m.input_lengths, "encl", "enc")
+    keys = buf("keys", N * Pi * A, torch.float32)
+    ops.gemm(enc, W, keys, N * Pi, A, E, E, A, A, b_mode=1, b_off=m._o("attention_decoder/memory_layer/kernel"))
+    Tia = _round_up(Ti, 8)
+    keys_t = buf("dec_keys_t", N * A * Tia, torch.float32)
+    L.check(L.lib().ns_taco2_keys_transpose(
+        L.C.c_void_p(ops.ptr(keys)), L.C.c_void_p(ops.ptr(keys_t)), N, Ti, Tia, Pi, PADL, A,
+        L.C.c_void_p(ops.stream())), "ns_taco2_keys_transpose")
+
+    # ---- decoder loop: one persistent launch where the shape allows (one or two utterances at the shipped or the test
+    # widths), else a chain of single-step launches
+    done = _decode_persistent(m, N, Ti, Pi, Tia, S, enc, keys) if getattr(m, "use_decode_kernel", True) else None
+    m.last_paths["decode"] = "persistent" if done is not None else "step"
+    if done is not None:
+        dec, al, S1 = done
+    else:
+        dec, al = _decode_steps(m, N, Ti, Pi, Tia, S, S1, enc, keys_t)
 
     # ---- postnet, residual, expand, linear head (inference BatchNorm)
     decp = buf("decp", N * Po * M, torch.float32)

@@ -29,6 +29,8 @@ def test_inference_matches_oracle(dev, trained):
     inputs, lengths, _, _ = make_batch(hp, 2, 12, 10, seed=4)
     out = _oracle_infer(hp, m, inputs, lengths)
     m.initialize(inputs, lengths)
+    m.check_status()
+    assert m.last_paths["decode"] == "persistent"          # two utterances: the one-launch decoder loop (ns_taco2_decode)
     assert tuple(m.mel_outputs.shape) == (2, 6 * hp.outputs_per_step, hp.num_mels)
     assert tuple(m.alignments.shape) == (2, 12, 6)
     for name in ("decoder_outputs", "mel_outputs", "linear_outputs", "alignments"):
@@ -37,7 +39,8 @@ def test_inference_matches_oracle(dev, trained):
         assert np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), name
 
 
-def test_inference_graph_replay_matches_eager(dev):
+@pytest.mark.parametrize("N", [3, 2, 1])          # 3: the launch-per-step loop; 2, 1: the persistent decoder loop
+def test_inference_graph_replay_matches_eager(dev, N):
     """Second call with one signature captures a HIP graph, later calls replay it: new inputs and lengths (same
     shapes) must give what a fresh eager pass gives, in the mode the bench uses."""
     from nspeech_amd.models import create_model
@@ -46,13 +49,46 @@ def test_inference_graph_replay_matches_eager(dev):
     e = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=3)
     e.use_graph = False
     for seed in (1, 2, 3, 4):           # eager, capture + replay, replay, replay
-        inputs, lengths, _, _ = make_batch(hp, 3, 11, 10, seed=seed)
+        inputs, lengths, _, _ = make_batch(hp, N, 11, 10, seed=seed)
         m.initialize(inputs, lengths)
         e.initialize(inputs, lengths)
         assert (m._infer_graph["graph"] is not None) == (seed > 1)
         for name in ("mel_outputs", "linear_outputs", "alignments"):
             got, ref = getattr(m, name).float(), getattr(e, name).float()
             assert torch.equal(got, ref), (seed, name, (got - ref).abs().max().item())
+    assert m.last_paths["decode"] == ("persistent" if N <= 2 else "step")
+
+
+@pytest.mark.parametrize("N,mode", [(1, "mixed"), (2, "mixed"), (1, "fp32"), (1, "bf16")])
+def test_persistent_decoder_loop_matches_the_step_launches_at_shipped_widths(dev, N, mode):
+    """ns_taco2_decode (attention clusters + register-resident decoder LSTMs + folded frame feedback in ONE launch) against
+    the launch-per-step loop on the same weights at the shipped widths (attention 256, LSTM(1024), 512-wide memory):
+    40 free-running steps.  The two differ in arithmetic (exact fp32 FMAs against three split-bf16 passes in `mixed`,
+    fp32 master weights against bf16 ones in `bf16`), and a free-running loop feeds its own rounding back."""
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models import create_model
+    hp = hparams_mod.load("taco2")
+    hp.max_iters = 40
+    inputs, lengths, _, _ = make_batch(hp, N, 37, 10, seed=5)
+    outs = []
+    for use in (True, False):
+        m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=4)
+        m.use_decode_kernel = use
+        m.use_graph = False
+        m.initialize(inputs, lengths)
+        torch.cuda.synchronize()
+        m.check_status()
+        assert m.last_paths["decode"] == ("persistent" if use else "step")
+        outs.append({k: getattr(m, k).float().clone() for k in ("decoder_outputs", "mel_outputs", "alignments")})
+        del m
+    tol = {"mixed": 2e-5, "fp32": 2e-5, "bf16": 1e-3}[mode]      # measured 7e-7, 6e-7, 1.4e-5
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+        print("%s N %d %s: persistent vs step launches max %.3e" % (mode, N, k, err))
+        assert err < tol, (k, err)
+    al = outs[0]["alignments"]
+    assert (al.sum(1) - 1.0).abs().max().item() < 1e-4
 
 
 def test_synthesizer_end_to_end(dev):
