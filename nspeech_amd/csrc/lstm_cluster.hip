@@ -1146,6 +1146,318 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
   }
 }
 
+
+// ==================================================================== backward, partial-sum exchange (round 3)
+// lstm_cluster2_bwd_kernel above sends every workgroup ALL 4H gate gradients of the step (16 x 4H bf16 = 32 KB per
+// chain at H = 256, 4x the forward payload) as dense rows behind drained stores and a flag: 4.2 us per step against
+// the forward kernel's 2.9.  The same product can be cut the other way: dh[t-1] = dgates[t] . Wh^T is a sum over the
+// gate columns, and a workgroup OWNS 256 of them (4 gates x its 64 units).  So it forms, from its own gate gradients
+// alone and straight after the cell update, its partial sum for EVERY unit of the layer - P[16, H] = dg_own[16, 256] .
+// Wh[:, own columns]^T, the same 128 MFMAs per step - and sends each peer only the 16 x 64 block of that peer's units:
+// (CS - 1) x 512 granules of {step tag, 2 x bf16} in and out per step (12 KB at H = 256, less than the forward
+// kernel's), the data is its own flag - no drain, no flag, no second round trip.  The receiver adds its own block (fp32,
+// LDS) and the peers' (bf16) in a fixed order.  Weights per workgroup: Wh[all H units][own 256 columns], the same
+// 128 VGPRs per lane.  Roles as in the forward kernel: 4 compute waves (wave w: the output tiles of units
+// [w * 16 HB, (w + 1) * 16 HB)), 2 pollers, prefetcher, saver (the gate gradients for the weight-gradient products).
+// Two workgroup barriers per slot: the slot hand-over, and one between the cell update (which writes the gate
+// gradients of all four compute waves into the LDS operand image) and the product that reads them.
+constexpr int BP_WAVES = XW + 2 + 2;     // compute, pollers, prefetcher, saver
+constexpr int DGI_LD = 256 + 8;          // bf16 per row of the operand image (row stride 4 banks mod 64: conflict-free 16-byte reads)
+
+template <int HB, int R>
+__global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmClusterArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int H = HB * 64, K4 = 4 * H, CS = HB;
+  constexpr int GPD = 16 * 32;                                        // granules per (destination, source) block
+  constexpr int NPG = (CS - 1) * GPD;                                 // granules a workgroup gathers per slot
+  constexpr int PPG = NPG / 128 > 0 ? NPG / 128 : 1;                  // per poller lane
+  // Everything a compute lane reads per slot is UNIT-major: lane (unit, rows g*4 .. g*4+3) fetches its four rows with ONE
+  // 16-byte read per array (two for the gates) instead of 4 - 16 scalar ones - the slot's critical path is this wave's
+  // dependent LDS latencies.  Unit strides are padded so that the 16 unit lanes of a read hit distinct banks.
+  constexpr int US = 20;                                              // floats per unit of an fp32 [unit][16 rows] image (16 + 4)
+  constexpr int GS = 72;                                              // bf16 per unit of the gates image [unit][16 rows][4 gates] (64 + 8)
+  bf16_t* dgi = (bf16_t*)smem;                                        // [2][16][DGI_LD] this slot's gate gradients (row, gate*64 + unit)
+  float* dps = (float*)(dgi + 2 * 16 * DGI_LD);                       // [2][CS - 1 (>= 1)][64][US] the peers' blocks, fp32
+  constexpr int DPS_BUF = (CS > 1 ? CS - 1 : 1) * 64 * US;
+  float* own = dps + 2 * DPS_BUF;                                     // [R][64][US] own block of the partial sums
+  char* ops = (char*)(own + R * 64 * US);                             // [2] stages of {gates bf16 [64][GS], dh f32 [64][US], cprev f32 [64][US]}
+  constexpr int OPS_G = 64 * GS * 2, OPS_F = 64 * US * 4;             // 9216, 5120
+  constexpr int OPS_STAGE = OPS_G + 2 * OPS_F;                        // 19456
+  float* c0 = (float*)(ops + 2 * OPS_STAGE);                          // [R][64][US] cell state at the first processed step
+  int* abortf = (int*)(c0 + R * 64 * US);                             // [2]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nsets = ((a.N + 15) / 16 + R - 1) / R;
+  const int set = blockIdx.x / CS, wgc = blockIdx.x % CS;
+  const int d = set / nsets, rg0 = (set % nsets) * R;
+  const int r16 = lane & 15, g = lane >> 4;
+  // exchange: [chain][parity][destination][source][16 rows][32 unit pairs]
+  u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * CS * CS * GPD;
+  const int u0 = wgc * 64;
+  const int T = a.T, Q = a.T * R;
+  if (tid < 2) abortf[tid] = 0;          // (audit) by wave 0 in front of its first wg_barrier, read behind it
+  auto t_of = [&](int step) { return d ? T - 1 - step : step; };
+
+  if (wave < XW) {
+    // ================================================================ compute role
+    const int wu = wave * 16 + r16;                    // unit inside the workgroup's 64 (cell update)
+    const int ut0 = wave * 16 * HB;                    // first output unit of this wave's HB tiles (product)
+    bf16x8 bw[HB][8];
+#pragma unroll
+    for (int j = 0; j < HB; ++j) {
+      const bf16_t* row = a.wh[d] + (long)(ut0 + 16 * j + r16) * K4 + u0 + g * 8;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) bw[j][ks] = *(const bf16x8*)(row + (ks >> 1) * H + (ks & 1) * 32);     // column gate*H + u0 + k%64
+    }
+    float dcc[R][4], pc[R][4];
+    int len[R][4];
+#pragma unroll
+    for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = (rg0 + rg) * 16 + g * 4 + r;
+        dcc[rg][r] = 0.f; pc[rg][r] = 0.f;
+        len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
+      }
+    for (int bs = 0; bs < T; ++bs) {                 // backward step index; forward step = T-1-bs
+      const int t = t_of(T - 1 - bs);
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg) {
+        const int q = bs * R + rg, buf = q & 1;
+        const int n0 = (rg0 + rg) * 16;
+        wg_barrier();
+        if (abortf[buf]) return;
+        const bool tr = (a.dbg & 16) && blockIdx.x == 0 && tid == 0 && q < 512;
+        if (tr) a.trace[q * 8 + 0] = wall_clock64();
+        // ---- dh of the step after, summed in a fixed order: own block, then the peers' in workgroup order
+        f32x4 rec = {0.f, 0.f, 0.f, 0.f};
+        if (bs > 0) {
+          rec = *(const f32x4*)(own + (rg * 64 + wu) * US + g * 4);
+#pragma unroll
+          for (int sx = 0; sx < CS - 1; ++sx) {
+            const f32x4 pv = *(const f32x4*)(dps + (size_t)buf * DPS_BUF + (sx * 64 + wu) * US + g * 4);
+            rec[0] += pv[0]; rec[1] += pv[1]; rec[2] += pv[2]; rec[3] += pv[3];
+          }
+        }
+        const char* st = ops + (size_t)buf * OPS_STAGE;
+        const bf16x8 gA = *(const bf16x8*)((const bf16_t*)st + wu * GS + g * 16);          // rows g*4, g*4+1: i j f o | i j f o
+        const bf16x8 gB = *(const bf16x8*)((const bf16_t*)st + wu * GS + g * 16 + 8);      // rows g*4+2, g*4+3
+        const f32x4 dh4 = *(const f32x4*)((const float*)(st + OPS_G) + wu * US + g * 4);
+        const f32x4 cp4 = *(const f32x4*)((const float*)(st + OPS_G + OPS_F) + wu * US + g * 4);
+        f32x4 c04 = {0.f, 0.f, 0.f, 0.f};
+        if (bs == 0) c04 = *(const f32x4*)(c0 + (rg * 64 + wu) * US + g * 4);
+        bf16_t* di = dgi + (size_t)buf * 16 * DGI_LD;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = g * 4 + r;
+          const int n = n0 + row;
+          const bf16x8& gq = r < 2 ? gA : gB;
+          const float gi = (float)gq[(r & 1) * 4 + 0], gj = (float)gq[(r & 1) * 4 + 1];
+          const float gf = (float)gq[(r & 1) * 4 + 2], go = (float)gq[(r & 1) * 4 + 3];
+          const float cprev = cp4[r];
+          const float ccur = bs == 0 ? c04[r] : pc[rg][r];
+          const float dh = dh4[r] + rec[r];
+          const float tc = tanhf_(ccur);
+          const float d_o = dh * tc * go * (1.f - go);
+          const float dc = dh * go * (1.f - tc * tc) + dcc[rg][r];
+          float dgv[4] = {dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj), dc * cprev * gf * (1.f - gf), d_o};
+          dcc[rg][r] = dc * gf;
+          if (t >= len[rg][r] || n >= a.N) {
+            dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f;
+            dcc[rg][r] = 0.f;
+          }
+          pc[rg][r] = cprev;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) di[row * DGI_LD + j * 64 + wu] = (bf16_t)dgv[j];
+        }
+        if (tr) a.trace[q * 8 + 1] = wall_clock64();
+        wg_barrier();            // the operand image is complete (all four compute waves), `own` has been read
+        if (tr) a.trace[q * 8 + 2] = wall_clock64();
+        // ---- partial sums of every unit's dh from the own 256 gate columns; wave w: units ut0 .. ut0 + 16 HB
+        if (bs + 1 < T) {
+          f32x4 acc[HB];
+#pragma unroll
+          for (int j = 0; j < HB; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 8; ++ks) {
+            const bf16x8 af = *(const bf16x8*)(di + r16 * DGI_LD + ks * 32 + g * 8);
+#pragma unroll
+            for (int j = 0; j < HB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bw[j][ks], acc[j], 0, 0, 0);
+          }
+          if (tr) a.trace[q * 8 + 3] = wall_clock64();
+          // D: column r16 = unit ut0 + 16 j + r16, rows g*4 + r.  Own units -> LDS (fp32); a peer's -> its granules
+          u64* nxt = xb0 + ((size_t)rg * 2 + ((bs + 1) & 1)) * CS * CS * GPD;
+#pragma unroll
+          for (int j = 0; j < HB; ++j) {
+            const int un = ut0 + 16 * j;                     // first unit of the tile
+            const int wd = un >> 6, uo = (un & 63) + r16;     // destination workgroup, unit inside its 64
+            if (wd == wgc) {
+              *(f32x4*)(own + (rg * 64 + uo) * US + g * 4) = acc[j];
+            } else {
+              u64* dst = nxt + ((size_t)(wd * CS + wgc) * 16 + g * 4) * 32 + (uo >> 1);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const unsigned pay = pack_bf16(acc[j][r], __shfl_down(acc[j][r], 1, 64));
+                if (!(r16 & 1))
+                  __hip_atomic_store(dst + r * 32, ((u64)(unsigned)(bs + 1) << 32) | pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+          if (tr) a.trace[q * 8 + 7] = wall_clock64();
+        }
+      }
+    }
+    wg_barrier();
+  } else if (wave < XW + 2) {
+    // ================================================================ poller role: the peers' blocks of the step before
+    // local granule li = lane + 64 * (j0 + j): source slot li / 512, row (li % 512) / 32, unit pair li % 32
+    const int j0 = (wave - XW) * PPG;
+    for (int q = 0; q < Q; ++q) {
+      const int bs = q / R, rg = q % R, buf = q & 1;
+      const bool trp = (a.dbg & 16) && blockIdx.x == 0 && tid == XW * 64 && q < 512;
+      if (trp) a.trace[q * 8 + 4] = wall_clock64();
+      if (bs > 0 && CS > 1) {
+        const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD;      // destination = this workgroup
+        u64 v[PPG];
+        unsigned spins = 0, clk0 = 0;
+        bool ok;
+        do {
+          ok = true;
+#pragma unroll
+          for (int j = 0; j < PPG; ++j) {
+            const int li = lane + 64 * (j0 + j), sx = li / GPD;
+            const int ws = sx < wgc ? sx : sx + 1;
+            v[j] = __hip_atomic_load(cur + (size_t)ws * GPD + (li % GPD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)bs);
+          if (!ok) {
+            if ((++spins & 1023u) == 0) {
+              if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; ok = true; }
+              else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[buf] = 1; ok = true; }
+            }
+          }
+        } while (!ok);
+        if (trp) { a.trace[q * 8 + 5] = wall_clock64(); a.trace[q * 8 + 6] = spins; }
+        float* dst = dps + (size_t)buf * DPS_BUF;
+#pragma unroll
+        for (int j = 0; j < PPG; ++j) {
+          const int li = lane + 64 * (j0 + j), sx = li / GPD, w_ = li % GPD;
+          const unsigned pay = (unsigned)v[j];
+          float2 f;
+          f.x = __uint_as_float(pay << 16);
+          f.y = __uint_as_float(pay & 0xffff0000u);
+          float* cell = dst + (sx * 64 + 2 * (w_ & 31)) * US + (w_ >> 5);      // [source][unit][row]
+          cell[0] = f.x;
+          cell[US] = f.y;
+        }
+      }
+      wg_barrier();
+      if (abortf[buf]) return;
+      wg_barrier();
+    }
+    wg_barrier();
+  } else if (wave == XW + 2) {
+    // ================================================================ saver role (stores only), one slot behind:
+    // the slot's gate gradients [16][4][64] bf16 = 512 chunks of 16 B, 8 per lane, out of the operand image
+    auto save = [&](int q) {
+      const int bs = q / R, rg = q % R;
+      const int t = t_of(T - 1 - bs);
+      const int n0 = (rg0 + rg) * 16;
+      const bf16_t* di = dgi + (size_t)(q & 1) * 16 * DGI_LD;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
+        const f32x4 v = *(const f32x4*)(di + row * DGI_LD + gate * 64 + c8 * 8);
+        if (n0 + row < a.N)
+          *(f32x4*)(a.dgates[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)K4 + (unsigned)(gate * H + u0 + c8 * 8))) = v;
+      }
+    };
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      if (q > 0) save(q - 1);
+      wg_barrier();
+    }
+    wg_barrier();
+    save(Q - 1);
+  } else {
+    // ================================================================ prefetcher role (loads only), as in lstm_cluster2_bwd_kernel
+    f32x4 pg[8], pd[4], pcp[4];
+    auto pf_load = [&](int q) {
+      const int bs = q / R, rg = q % R, step = T - 1 - bs;
+      const int t = t_of(step), tp = d ? t + 1 : t - 1;
+      const bool has_prev = step > 0;
+      const int n0 = (rg0 + rg) * 16;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
+        const int n = n0 + row;
+        pg[j] = n < a.N ? *(const f32x4*)(a.gates[d] + ((unsigned)(n * a.P + a.padl + t) * (unsigned)(4 * H) + (unsigned)(gate * H + u0 + c8 * 8)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
+        const int n = n0 + row;
+        pd[j] = n < a.N ? *(const f32x4*)(a.dh[d] + ((unsigned)(n * a.P + a.padl + t) * (unsigned)a.ld_dh + (unsigned)(u0 + c16 * 4)))
+                        : (f32x4){0.f, 0.f, 0.f, 0.f};
+        pcp[j] = (n < a.N && has_prev) ? *(const f32x4*)(a.c[d] + ((unsigned)(n * a.P + a.padl + tp) * (unsigned)H + (unsigned)(u0 + c16 * 4)))
+                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    auto pf_store = [&](int buf) {          // transposing stores (off the critical path): unit-major images
+      char* st = ops + (size_t)buf * OPS_STAGE;
+      bf16_t* sg = (bf16_t*)st;
+      float* sd = (float*)(st + OPS_G);
+      float* sc_ = (float*)(st + OPS_G + OPS_F);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
+        const bf16x8 v = __builtin_bit_cast(bf16x8, pg[j]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sg[(c8 * 8 + e) * GS + row * 4 + gate] = v[e];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          sd[(c16 * 4 + e) * US + row] = pd[j][e];
+          sc_[(c16 * 4 + e) * US + row] = pcp[j][e];
+        }
+      }
+    };
+    {
+      const int t0 = t_of(T - 1);
+#pragma unroll
+      for (int rg = 0; rg < R; ++rg)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
+          const int n = (rg0 + rg) * 16 + row;
+          const f32x4 v = n < a.N ? *(const f32x4*)(a.c[d] + ((unsigned)(n * a.P + a.padl + t0) * (unsigned)H + (unsigned)(u0 + c16 * 4)))
+                                  : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) c0[(rg * 64 + c16 * 4 + e) * US + row] = v[e];
+        }
+      pf_load(0);
+      pf_store(0);
+      if (Q > 1) pf_load(1);
+    }
+    for (int q = 0; q < Q; ++q) {
+      wg_barrier();
+      if (abortf[q & 1]) return;
+      wg_barrier();
+      if (q + 1 < Q) {
+        pf_store((q + 1) & 1);
+        if (q + 2 < Q) pf_load(q + 2);
+      }
+    }
+    wg_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ C ABI
 static int cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1) {
   return p0->dtype == NS_BF16 && p1->dtype == NS_BF16 && p0->H % 64 == 0 && p0->H <= 512 && p0->T >= 2;
@@ -1300,8 +1612,11 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   LstmClusterArgs a = {};
   fill(a, p0, p1, work);
   const size_t chains = 2 * (size_t)((a.N + 15) / 16);
-  // the role-split kernel exchanges through the dgates array + flags; only the single-role kernel needs the granule buffers
-  const size_t xbytes = role_split_ok(a, true) ? 0 : (chains + 2) * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64);
+  // dense-row role-split kernel: exchanges through the dgates array + flags; partial-sum kernel: [chain][2][CS][CS][512]
+  // granules; single-role kernel: [chain][2][16][2H]
+  const size_t xbytes = role_split_ok(a, true)
+                            ? ((a.dbg & 64) ? 0 : (chains + 2) * 2 * (size_t)a.CS * a.CS * 512 * sizeof(u64))
+                            : (chains + 2) * 2 * 16 * (size_t)(4 * a.H / 2) * sizeof(u64);
   { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   static bool attr = false;
   if (!attr) {
@@ -1312,6 +1627,37 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<3, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)lstm_cluster2_bwd_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
+  }
+  if (role_split_ok(a, true) && !(a.dbg & 64)) {
+    // partial-sum exchange (lstm_cluster2p_bwd_kernel); NS_CLUSTER_DBG bit 64: the dense-row exchange below; bit 32: no
+    // interleaving of row groups
+    // R = 2 (two row groups interleaved per workgroup) pays when the slot's compute chain is shorter than the hop;
+    // measured on the expand BiLSTM (T = 1000, H = 256, 2 row groups): R = 1 3.8 ms, R = 2 4.4 ms
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
+    const int CS = a.CS, peers = CS > 1 ? CS - 1 : 1;
+    const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + sizeof(float) * (2 * (size_t)peers * 64 * 20 + 2 * (size_t)R * 64 * 20) +
+                        2 * (64 * 72 * 2 + 2 * 64 * 20 * 4) + 32;
+    const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * CS)), block(BP_WAVES * 64);
+#define NS_LAUNCH_BP(HB_) \
+    do { \
+      static bool attrp = false; \
+      if (!attrp) { \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        attrp = true; \
+      } \
+      if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2>), grid, block, ldsp, s, a); \
+      else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1>), grid, block, ldsp, s, a); \
+    } while (0)
+    switch (a.H / 64) {
+      case 1: NS_LAUNCH_BP(1); break;
+      case 2: NS_LAUNCH_BP(2); break;
+      case 3: NS_LAUNCH_BP(3); break;
+      default: NS_LAUNCH_BP(4); break;
+    }
+#undef NS_LAUNCH_BP
+    NS_CHECK_LAUNCH("lstm_cluster2p_bwd");
+    return NS_OK;
   }
   if (role_split_ok(a, true)) {
     // two row groups: one set per group (R = 1, 16 workgroups) measured 4.33 ms against 4.55 ms for the interleaved
