@@ -1540,6 +1540,7 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
                                    ns_stream_t s_) {
   hipStream_t s = (hipStream_t)s_;
   NS_CHECK_ARG(p0 && p1 && work, "ns_lstm_cluster_fwd: null");
+  if (p0->dtype != NS_F32) NS_CHECK_ARG(cluster_supported(p0, p1), "ns_lstm_cluster_fwd: needs bf16, H %% 64 == 0, H <= 512, T >= 2");
   NS_CHECK_ARG(p0->reverse == 0 && p1->reverse == 1 && p0->N == p1->N && p0->T == p1->T && p0->H == p1->H,
                "ns_lstm_cluster_fwd: p0 forward / p1 reversed with equal shapes expected");
   if (p0->dtype == NS_F32) {
