@@ -131,6 +131,10 @@ int decode_subframe(BitReader& br, int64_t* out, int32_t* res, int blocksize, in
   if (br.bit()) wasted = (int)br.unary() + 1;
   bps -= wasted;
   if (bps <= 0) { ns_set_error("flac: wasted bits exceed the sample size"); return NS_ERR_BAD_ARG; }
+  // A well-formed stream never predicts a sample outside its size; a damaged one can make the predictor run away until
+  // the 64-bit sums overflow (found by the UBSan run of tests/test_sanitizer_cpu.py).  One bit of slack, then refuse.
+  const int64_t lim = (int64_t)1 << (bps + 1);
+  auto in_range = [&](int64_t v) { return v > -lim && v < lim; };
   if (type == 0) {
     const int64_t v = br.sbits(bps);
     for (int i = 0; i < blocksize; ++i) out[i] = v;
@@ -152,6 +156,7 @@ int decode_subframe(BitReader& br, int64_t* out, int32_t* res, int blocksize, in
         default: break;
       }
       out[i] = pred + res[i];
+      if (!in_range(out[i])) { ns_set_error("flac: predicted sample outside the sample size (damaged stream)"); return NS_ERR_BAD_ARG; }
     }
   } else if (type >= 32) {
     const int order = (type & 31) + 1;
@@ -169,6 +174,7 @@ int decode_subframe(BitReader& br, int64_t* out, int32_t* res, int blocksize, in
       int64_t s = 0;
       for (int j = 0; j < order; ++j) s += coef[j] * out[i - 1 - j];
       out[i] = (s >> shift) + res[i];
+      if (!in_range(out[i])) { ns_set_error("flac: predicted sample outside the sample size (damaged stream)"); return NS_ERR_BAD_ARG; }
     }
   } else {
     ns_set_error("flac: reserved subframe type %d", type);
@@ -251,7 +257,7 @@ extern "C" int ns_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64
     else if (chan == 9) { for (int i = 0; i < blocksize; ++i) ch[0][i] = ch[0][i] + ch[1][i]; }
     else if (chan == 10) {
       for (int i = 0; i < blocksize; ++i) {
-        const int64_t sd = ch[1][i], mid = (ch[0][i] << 1) | (sd & 1);
+        const int64_t sd = ch[1][i], mid = ch[0][i] * 2 + (sd & 1);      // not "<< 1": a negative mid is a sample, not a bit pattern
         ch[0][i] = (mid + sd) >> 1;
         ch[1][i] = (mid - sd) >> 1;
       }
