@@ -221,6 +221,9 @@ extern "C" int ns_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64
   while (off + 2 <= n && rc == NS_OK) {
     if (data[off] != 0xFF || (data[off + 1] & 0xFC) != 0xF8) {      // trailing padding / ID3 tags end the audio
       if (si.total && done >= si.total) break;
+      // no total in STREAMINFO: whatever follows the last whole frame (a tag, padding) ends the audio; the caller still
+      // has STREAMINFO's MD5 of the PCM to tell a cut stream from a complete one
+      if (!si.total && done > 0) break;
       ns_set_error("flac: lost frame sync at byte %zu", off); rc = NS_ERR_BAD_ARG; break;
     }
     BitReader br{data + off, n - off, 0, false};

@@ -136,22 +136,40 @@ def resample(x, sr_orig, sr_new):
     return y.float().cpu().numpy()
 
 
+def _strip_id3(data):
+    """Tags that taggers wrap around a FLAC stream: a leading ID3v2 block (10-byte header, sync-safe size, optional
+    footer) and a trailing 128-byte ID3v1 block."""
+    if data[:3] == b"ID3" and len(data) > 10:
+        size = ((data[6] & 0x7f) << 21) | ((data[7] & 0x7f) << 14) | ((data[8] & 0x7f) << 7) | (data[9] & 0x7f)
+        data = data[10 + size + (10 if data[5] & 0x10 else 0):]
+    if len(data) > 128 and data[-128:-125] == b"TAG":
+        data = data[:-128]
+    return data
+
+
 def _load_flac(path):
     """FLAC file -> (float32 [samples, channels] in [-1, 1), sample rate): ns_flac_decode (csrc/flac.hip, host code),
     checked against the MD5 of the decoded PCM that the encoder stored in STREAMINFO (all-zero = not stored)."""
     import ctypes as C
     import hashlib
-    data = open(path, "rb").read()
+    data = _strip_id3(open(path, "rb").read())
     lib = L.lib()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     sr, ch, bps, total = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
     md5 = (C.c_uint8 * 16)()
     L.check(lib.ns_flac_info(buf, C.c_size_t(len(data)), C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total), md5), "ns_flac_info")
-    cap = total.value if total.value > 0 else len(data) * 8           # no total: a sample takes at least a bit per channel
-    out = np.empty((cap, ch.value), dtype=np.int32)
+    # no total in STREAMINFO: start from a modest guess and double on "output buffer too small" (no bound follows from
+    # the file size: a CONSTANT subframe codes a whole block in a few bytes)
+    cap = total.value if total.value > 0 else max(1 << 16, len(data))
     got = C.c_int64()
-    L.check(lib.ns_flac_decode(buf, C.c_size_t(len(data)), out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(cap), C.byref(got)),
-            "ns_flac_decode")
+    while True:
+        out = np.empty((cap, ch.value), dtype=np.int32)
+        rc = lib.ns_flac_decode(buf, C.c_size_t(len(data)), out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(cap), C.byref(got))
+        if rc != 0 and total.value == 0 and b"output buffer too small" in lib.ns_last_error() and cap < (1 << 31):
+            cap *= 2
+            continue
+        L.check(rc, "ns_flac_decode")
+        break
     out = out[:got.value]
     if total.value > 0 and got.value != total.value:
         raise ValueError("%s: %d samples decoded, STREAMINFO announces %d" % (path, got.value, total.value))
@@ -169,6 +187,9 @@ def load_wav(path, offset=0.0, duration=None):
     20 000 Hz)."""
     with open(path, "rb") as f:
         magic = f.read(4)
+        if magic[:3] == b"ID3":              # an ID3v2 tag in front of the stream: look behind it
+            f.seek(0)
+            magic = _strip_id3(f.read())[:4]
     hp = get_hparams()
     if magic == b"fLaC":                     # LibriSpeech (datasets/corpus/ljspeech.py:17)
         x, sr = _load_flac(path)

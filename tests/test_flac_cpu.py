@@ -129,3 +129,19 @@ def test_load_wav_takes_flac_files(tmp_path):
     y = A.load_wav(p, offset=0.05, duration=0.1)
     s = int(0.05 * sr)
     assert np.allclose(y, want[s:s + int(0.1 * sr)], atol=1e-7)
+
+
+def test_id3_tags_and_a_missing_total(tmp_path):
+    """a leading ID3v2 block and a trailing ID3v1 block are skipped, and a stream whose STREAMINFO leaves the
+    total out is decoded into a buffer that grows on demand (a long CONSTANT-coded stream: far more than the first
+    guess of max(65536, file size) samples from a few hundred bytes)."""
+    n = 4096 * 40
+    pcm = np.full((n, 1), 1234, np.int64)
+    frames = [dict(size=4096, subframes=[dict(type="constant")]) for _ in range(40)]
+    blob = FW.encode(pcm, 16, 16000, frames, total_in_header=False)
+    assert len(blob) < 2000
+    tag2 = b"ID3" + bytes([3, 0, 0]) + bytes([0, 0, 1, 5]) + bytes(133)            # sync-safe size 1*128 + 5 = 133
+    tag1 = b"TAG" + bytes(125)
+    for name, data in (("plain.flac", blob), ("tagged.flac", tag2 + blob + tag1)):
+        x, sr = _decode(tmp_path, data, name)
+        assert sr == 16000 and x.shape == (n, 1) and np.all(np.round(x * 32768) == 1234), name

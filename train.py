@@ -116,6 +116,7 @@ def train(log_dir, args):
     model.add_stats()
     time_window, loss_window = ValueWindow(100), ValueWindow(100)
     saver = CheckpointSaver(log_dir)
+    paths_logged = None
     while args.max_steps is None or model.global_step < args.max_steps:
         t0 = time.time()
         inputs, lengths, mel, lin = feeder.next_batch()
@@ -125,6 +126,10 @@ def train(log_dir, args):
             torch.distributed.all_reduce(t)
             loss = float(t.item()) / world
         step = model.global_step
+        paths = getattr(model, "last_paths", None)
+        if paths and paths != paths_logged:         # which kernel family ran each recurrence (a batch shape that falls
+            paths_logged = dict(paths)              # off the persistent kernels runs ~2x slower: say so, once per change)
+            log("Recurrence kernels: %s" % ", ".join("%s=%s" % kv for kv in sorted(paths.items())), logf)
         time_window.append(time.time() - t0)
         loss_window.append(loss)
         frames = mel.shape[0] * mel.shape[1] * world
