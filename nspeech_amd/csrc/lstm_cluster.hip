@@ -1164,7 +1164,12 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
 constexpr int BP_WAVES = XW + 2 + 2;     // compute, pollers, prefetcher, saver
 constexpr int DGI_LD = 256 + 8;          // bf16 per row of the operand image (row stride 4 banks mod 64: conflict-free 16-byte reads)
 
-template <int HB, int R>
+// DIRECT: the compute lanes poll their own granules (a lane needs only the sums of ITS unit and rows: 4 rows x (CS - 1)
+// peers; the forward kernels cannot do this, every lane of theirs needs the whole gathered vector as an MFMA operand),
+// which removes the pollers' LDS image and its hand-over from the step's critical path; the poller waves then only keep
+// the barrier count.  The polls sit behind this wave's publish stores of the slot before in the memory queue - those
+// were issued a whole hop earlier and are acknowledged by now.
+template <int HB, int R, bool DIRECT>
 __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmClusterArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = HB * 64, K4 = 4 * H, CS = HB;
@@ -1233,10 +1238,42 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
         f32x4 rec = {0.f, 0.f, 0.f, 0.f};
         if (bs > 0) {
           rec = *(const f32x4*)(own + (rg * 64 + wu) * US + g * 4);
+          if (DIRECT && CS > 1) {
+            // granule (source ws, row, unit pair wu / 2) of this workgroup's block: {tag bs, units 2p | 2p + 1}
+            const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD + (g * 4) * 32 + (wu >> 1);
+            u64 v[CS > 1 ? CS - 1 : 1][4];
+            unsigned spins = 0, clk0 = 0;
+            bool ok;
+            do {
+              ok = true;
 #pragma unroll
-          for (int sx = 0; sx < CS - 1; ++sx) {
-            const f32x4 pv = *(const f32x4*)(dps + (size_t)buf * DPS_BUF + (sx * 64 + wu) * US + g * 4);
-            rec[0] += pv[0]; rec[1] += pv[1]; rec[2] += pv[2]; rec[3] += pv[3];
+              for (int sx = 0; sx < CS - 1; ++sx) {
+                const int ws = sx < wgc ? sx : sx + 1;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[sx][r] = __hip_atomic_load(cur + (size_t)ws * GPD + r * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+#pragma unroll
+              for (int sx = 0; sx < CS - 1; ++sx)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ok = ok && ((unsigned)(v[sx][r] >> 32) == (unsigned)bs);
+              if (!ok && (++spins & 1023u) == 0) {
+                if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[0] = abortf[1] = 1; ok = true; }
+                else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[0] = abortf[1] = 1; ok = true; }
+              }
+            } while (!ok);
+#pragma unroll
+            for (int sx = 0; sx < CS - 1; ++sx)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                const unsigned pay = (unsigned)v[sx][r];
+                rec[r] += __uint_as_float((wu & 1) ? (pay & 0xffff0000u) : (pay << 16));
+              }
+          } else {
+#pragma unroll
+            for (int sx = 0; sx < CS - 1; ++sx) {
+              const f32x4 pv = *(const f32x4*)(dps + (size_t)buf * DPS_BUF + (sx * 64 + wu) * US + g * 4);
+              rec[0] += pv[0]; rec[1] += pv[1]; rec[2] += pv[2]; rec[3] += pv[3];
+            }
           }
         }
         const char* st = ops + (size_t)buf * OPS_STAGE;
@@ -1272,6 +1309,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
         }
         if (tr) a.trace[q * 8 + 1] = wall_clock64();
         wg_barrier();            // the operand image is complete (all four compute waves), `own` has been read
+        if (DIRECT && abortf[buf]) return;
         if (tr) a.trace[q * 8 + 2] = wall_clock64();
         // ---- partial sums of every unit's dh from the own 256 gate columns; wave w: units ut0 .. ut0 + 16 HB
         if (bs + 1 < T) {
@@ -1316,7 +1354,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
       const int bs = q / R, rg = q % R, buf = q & 1;
       const bool trp = (a.dbg & 16) && blockIdx.x == 0 && tid == XW * 64 && q < 512;
       if (trp) a.trace[q * 8 + 4] = wall_clock64();
-      if (bs > 0 && CS > 1) {
+      if (!DIRECT && bs > 0 && CS > 1) {
         const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD;      // destination = this workgroup
         u64 v[PPG];
         unsigned spins = 0, clk0 = 0;
@@ -1355,6 +1393,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
       wg_barrier();
       if (abortf[buf]) return;
       wg_barrier();
+      if (DIRECT && abortf[buf]) return;
     }
     wg_barrier();
   } else if (wave == XW + 2) {
@@ -1378,6 +1417,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
       if (abortf[q & 1]) return;
       if (q > 0) save(q - 1);
       wg_barrier();
+      if (DIRECT && abortf[q & 1]) return;
     }
     wg_barrier();
     save(Q - 1);
@@ -1449,6 +1489,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
       wg_barrier();
       if (abortf[q & 1]) return;
       wg_barrier();
+      if (DIRECT && abortf[q & 1]) return;
       if (q + 1 < Q) {
         pf_store((q + 1) & 1);
         if (q + 2 < Q) pf_load(q + 2);
@@ -1548,7 +1589,8 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
                  "f32_passes 3 with whT_hi / whT_lo, 16-byte aligned operands");
     LstmClusterArgs a = {};
     fill(a, p0, p1, work);
-    const int nrg = (a.N + 15) / 16, R = nrg >= 2 ? 2 : 1;
+    // NS_CLUSTER_DBG bit 256: one row group per workgroup set (no interleaving), for A/B timing
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 256)) ? 2 : 1;        // encoder BiLSTM: 1.18 ms (R = 2) / 1.06 (R = 1)
     const size_t xbytes = (2 * (size_t)nrg + 2) * 2 * 16 * (size_t)a.H * sizeof(u64);
     { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
     const size_t lds3 = (size_t)2 * 2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG3_LD + 2 * 9216 + 32;
@@ -1582,7 +1624,9 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
   { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
   if (role_split_ok(a, false)) {
     const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 2 * (2048 + 4096 + 8192) + 32;
-    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && !(a.dbg & 32)) ? 2 : 1;
+    // two row groups interleaved per workgroup (R = 2) pay when a slot's compute chain is clearly shorter than the hop;
+    // round 3 (two forward pollers, shorter hop): expand BiLSTM 2.92 ms with R = 2, 2.75 ms with one set per row group
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * a.CS)), block(FW_WAVES * 64);
 #define NS_LAUNCH_F(HB_) \
     if (R == 2) hipLaunchKernelGGL((lstm_cluster2_fwd_kernel<HB_, 2>), grid, block, lds2, s, a); \
@@ -1643,12 +1687,17 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     do { \
       static bool attrp = false; \
       if (!attrp) { \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
         attrp = true; \
       } \
-      if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2>), grid, block, ldsp, s, a); \
-      else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1>), grid, block, ldsp, s, a); \
+      if (a.dbg & 128) { /* the poller-wave form, for A/B timing */ \
+        if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2, false>), grid, block, ldsp, s, a); \
+        else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1, false>), grid, block, ldsp, s, a); \
+      } else if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2, true>), grid, block, ldsp, s, a); \
+      else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1, true>), grid, block, ldsp, s, a); \
     } while (0)
     switch (a.H / 64) {
       case 1: NS_LAUNCH_BP(1); break;
