@@ -1180,16 +1180,18 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
   // 16-byte read per array (two for the gates) instead of 4 - 16 scalar ones - the slot's critical path is this wave's
   // dependent LDS latencies.  Unit strides are padded so that the 16 unit lanes of a read hit distinct banks.
   constexpr int US = 20;                                              // floats per unit of an fp32 [unit][16 rows] image (16 + 4)
-  constexpr int GS = 72;                                              // bf16 per unit of the gates image [unit][16 rows][4 gates] (64 + 8)
   bf16_t* dgi = (bf16_t*)smem;                                        // [2][16][DGI_LD] this slot's gate gradients (row, gate*64 + unit)
   float* dps = (float*)(dgi + 2 * 16 * DGI_LD);                       // [2][CS - 1 (>= 1)][64][US] the peers' blocks, fp32
   constexpr int DPS_BUF = (CS > 1 ? CS - 1 : 1) * 64 * US;
   float* own = dps + 2 * DPS_BUF;                                     // [R][64][US] own block of the partial sums
-  char* ops = (char*)(own + R * 64 * US);                             // [2] stages of {gates bf16 [64][GS], dh f32 [64][US], cprev f32 [64][US]}
-  constexpr int OPS_G = 64 * GS * 2, OPS_F = 64 * US * 4;             // 9216, 5120
-  constexpr int OPS_STAGE = OPS_G + 2 * OPS_F;                        // 19456
-  float* c0 = (float*)(ops + 2 * OPS_STAGE);                          // [R][64][US] cell state at the first processed step
-  int* abortf = (int*)(c0 + R * 64 * US);                             // [2]
+  // The operand stage keeps the row-major layout of the global arrays: the prefetcher's hand-over store is on the
+  // slot's critical path (the slot barrier waits for it) - a transposing store of 96 scattered LDS writes per lane cost
+  // 0.5 us per slot there, more than the compute lanes' scalar reads of a row-major stage do
+  char* ops = (char*)(own + R * 64 * US);                             // [2] stages of {gates bf16 [16][4][64], dh f32 [16][64], cprev f32 [16][64]}
+  constexpr int OPS_G = 16 * 4 * 64 * 2, OPS_F = 16 * 64 * 4;         // 8192, 4096
+  constexpr int OPS_STAGE = OPS_G + 2 * OPS_F;                        // 16384
+  float* c0 = (float*)(ops + 2 * OPS_STAGE);                          // [R][16][64] cell state at the first processed step
+  int* abortf = (int*)(c0 + R * 16 * 64);                             // [2]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nsets = ((a.N + 15) / 16 + R - 1) / R;
@@ -1277,23 +1279,19 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
           }
         }
         const char* st = ops + (size_t)buf * OPS_STAGE;
-        const bf16x8 gA = *(const bf16x8*)((const bf16_t*)st + wu * GS + g * 16);          // rows g*4, g*4+1: i j f o | i j f o
-        const bf16x8 gB = *(const bf16x8*)((const bf16_t*)st + wu * GS + g * 16 + 8);      // rows g*4+2, g*4+3
-        const f32x4 dh4 = *(const f32x4*)((const float*)(st + OPS_G) + wu * US + g * 4);
-        const f32x4 cp4 = *(const f32x4*)((const float*)(st + OPS_G + OPS_F) + wu * US + g * 4);
-        f32x4 c04 = {0.f, 0.f, 0.f, 0.f};
-        if (bs == 0) c04 = *(const f32x4*)(c0 + (rg * 64 + wu) * US + g * 4);
+        const bf16_t* sgt = (const bf16_t*)st;
+        const float* sdh = (const float*)(st + OPS_G);
+        const float* scp = (const float*)(st + OPS_G + OPS_F);
         bf16_t* di = dgi + (size_t)buf * 16 * DGI_LD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = g * 4 + r;
           const int n = n0 + row;
-          const bf16x8& gq = r < 2 ? gA : gB;
-          const float gi = (float)gq[(r & 1) * 4 + 0], gj = (float)gq[(r & 1) * 4 + 1];
-          const float gf = (float)gq[(r & 1) * 4 + 2], go = (float)gq[(r & 1) * 4 + 3];
-          const float cprev = cp4[r];
-          const float ccur = bs == 0 ? c04[r] : pc[rg][r];
-          const float dh = dh4[r] + rec[r];
+          const float gi = (float)sgt[(row * 4 + 0) * 64 + wu], gj = (float)sgt[(row * 4 + 1) * 64 + wu];
+          const float gf = (float)sgt[(row * 4 + 2) * 64 + wu], go = (float)sgt[(row * 4 + 3) * 64 + wu];
+          const float cprev = scp[row * 64 + wu];
+          const float ccur = bs == 0 ? c0[(rg * 16 + row) * 64 + wu] : pc[rg][r];
+          const float dh = sdh[row * 64 + wu] + rec[r];
           const float tc = tanhf_(ccur);
           const float d_o = dh * tc * go * (1.f - go);
           const float dc = dh * go * (1.f - tc * tc) + dcc[rg][r];
@@ -1446,26 +1444,14 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
                                        : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
     };
-    auto pf_store = [&](int buf) {          // transposing stores (off the critical path): unit-major images
+    auto pf_store = [&](int buf) {
       char* st = ops + (size_t)buf * OPS_STAGE;
-      bf16_t* sg = (bf16_t*)st;
-      float* sd = (float*)(st + OPS_G);
-      float* sc_ = (float*)(st + OPS_G + OPS_F);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
-        const bf16x8 v = __builtin_bit_cast(bf16x8, pg[j]);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) sg[(c8 * 8 + e) * GS + row * 4 + gate] = v[e];
-      }
+      for (int j = 0; j < 8; ++j) *(f32x4*)(st + (size_t)(lane + 64 * j) * 16) = pg[j];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int idx = lane + 64 * j, c16 = idx & 15, row = idx >> 4;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          sd[(c16 * 4 + e) * US + row] = pd[j][e];
-          sc_[(c16 * 4 + e) * US + row] = pcp[j][e];
-        }
+        *(f32x4*)(st + OPS_G + (size_t)(lane + 64 * j) * 16) = pd[j];
+        *(f32x4*)(st + OPS_G + OPS_F + (size_t)(lane + 64 * j) * 16) = pcp[j];
       }
     };
     {
@@ -1478,8 +1464,7 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
           const int n = (rg0 + rg) * 16 + row;
           const f32x4 v = n < a.N ? *(const f32x4*)(a.c[d] + ((unsigned)(n * a.P + a.padl + t0) * (unsigned)H + (unsigned)(u0 + c16 * 4)))
                                   : (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int e = 0; e < 4; ++e) c0[(rg * 64 + c16 * 4 + e) * US + row] = v[e];
+          *(f32x4*)(c0 + (rg * 16 * 64) + idx * 4) = v;
         }
       pf_load(0);
       pf_store(0);
@@ -1680,8 +1665,8 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     // measured on the expand BiLSTM (T = 1000, H = 256, 2 row groups): R = 1 3.8 ms, R = 2 4.4 ms
     const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
     const int CS = a.CS, peers = CS > 1 ? CS - 1 : 1;
-    const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + sizeof(float) * (2 * (size_t)peers * 64 * 20 + 2 * (size_t)R * 64 * 20) +
-                        2 * (64 * 72 * 2 + 2 * 64 * 20 * 4) + 32;
+    const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + sizeof(float) * (2 * (size_t)peers * 64 * 20 + (size_t)R * 64 * 20 + (size_t)R * 16 * 64) +
+                        2 * 16384 + 32;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * CS)), block(BP_WAVES * 64);
 #define NS_LAUNCH_BP(HB_) \
     do { \
