@@ -1161,37 +1161,39 @@ __global__ __launch_bounds__(BW_WAVES * 64) void lstm_cluster2_bwd_kernel(LstmCl
 // [w * 16 HB, (w + 1) * 16 HB)), 2 pollers, prefetcher, saver (the gate gradients for the weight-gradient products).
 // Two workgroup barriers per slot: the slot hand-over, and one between the cell update (which writes the gate
 // gradients of all four compute waves into the LDS operand image) and the product that reads them.
-constexpr int BP_WAVES = XW + 2 + 2;     // compute, pollers, prefetcher, saver
+constexpr int BP_WAVES = XW + 2;         // compute, saver, prefetcher
 constexpr int DGI_LD = 256 + 8;          // bf16 per row of the operand image (row stride 4 banks mod 64: conflict-free 16-byte reads)
 
-// DIRECT: the compute lanes poll their own granules (a lane needs only the sums of ITS unit and rows: 4 rows x (CS - 1)
-// peers; the forward kernels cannot do this, every lane of theirs needs the whole gathered vector as an MFMA operand),
-// which removes the pollers' LDS image and its hand-over from the step's critical path; the poller waves then only keep
-// the barrier count.  The polls sit behind this wave's publish stores of the slot before in the memory queue - those
-// were issued a whole hop earlier and are acknowledged by now.
-template <int HB, int R, bool DIRECT>
+// Who computes what is chosen so that NOTHING of the step's dependent chain crosses waves except the operand image:
+//   * compute wave w owns units [16 w, 16 w + 16) of the workgroup's 64 in the cell update, and in the product the HB
+//     output tiles {(destination workgroup wd, units 16 w .. 16 w + 16 of ITS 64)}: the tile for wd = this workgroup is
+//     the own block of exactly the units the wave updates next step, in exactly the accumulator layout the cell update
+//     uses (lane (r16, g): unit r16, rows 4 g .. 4 g + 3) - it stays in registers;
+//   * the peers' blocks are polled by the lane that consumes them (a lane needs only the sums of ITS unit and rows:
+//     4 rows x (CS - 1) peers; the forward kernels cannot do this, every lane of theirs needs the whole gathered vector
+//     as an MFMA operand): no poller waves, no LDS image of the gathered sums, no hand-over;
+//   * everything of the cell update that does not depend on the exchanged sums (operand reads, tanh, the gate
+//     derivatives) is done in front of the poll, inside the hop.
+// ONE workgroup barrier per slot is left - between the cell update (the four compute waves write the gate gradients
+// into the LDS operand image) and the product that reads it; the prefetcher's and the saver's hand-overs ride on it
+// (audit: stage[(q+1)&1] is stored between barrier(q-1) and barrier(q), last read in front of barrier(q-1), next read
+// behind barrier(q); dgi[q&1] is written in front of barrier(q), read by the product and - one slot behind - the saver
+// between barrier(q) and barrier(q+1), rewritten behind barrier(q+1)).
+// Slot timings (profiles/r03_cluster_bwd_trace.txt): poller-wave form 3.51 us, polling compute lanes 3.09, row-major
+// prefetcher hand-over 2.97, this form see the profile.
+template <int HB, int R>
 __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmClusterArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int H = HB * 64, K4 = 4 * H, CS = HB;
   constexpr int GPD = 16 * 32;                                        // granules per (destination, source) block
-  constexpr int NPG = (CS - 1) * GPD;                                 // granules a workgroup gathers per slot
-  constexpr int PPG = NPG / 128 > 0 ? NPG / 128 : 1;                  // per poller lane
-  // Everything a compute lane reads per slot is UNIT-major: lane (unit, rows g*4 .. g*4+3) fetches its four rows with ONE
-  // 16-byte read per array (two for the gates) instead of 4 - 16 scalar ones - the slot's critical path is this wave's
-  // dependent LDS latencies.  Unit strides are padded so that the 16 unit lanes of a read hit distinct banks.
-  constexpr int US = 20;                                              // floats per unit of an fp32 [unit][16 rows] image (16 + 4)
   bf16_t* dgi = (bf16_t*)smem;                                        // [2][16][DGI_LD] this slot's gate gradients (row, gate*64 + unit)
-  float* dps = (float*)(dgi + 2 * 16 * DGI_LD);                       // [2][CS - 1 (>= 1)][64][US] the peers' blocks, fp32
-  constexpr int DPS_BUF = (CS > 1 ? CS - 1 : 1) * 64 * US;
-  float* own = dps + 2 * DPS_BUF;                                     // [R][64][US] own block of the partial sums
-  // The operand stage keeps the row-major layout of the global arrays: the prefetcher's hand-over store is on the
-  // slot's critical path (the slot barrier waits for it) - a transposing store of 96 scattered LDS writes per lane cost
-  // 0.5 us per slot there, more than the compute lanes' scalar reads of a row-major stage do
-  char* ops = (char*)(own + R * 64 * US);                             // [2] stages of {gates bf16 [16][4][64], dh f32 [16][64], cprev f32 [16][64]}
+  // The operand stage keeps the row-major layout of the global arrays (a transposing prefetcher store was measured:
+  // 96 scattered LDS writes per lane, slower than the compute lanes' scalar reads of this layout)
+  char* ops = (char*)(dgi + 2 * 16 * DGI_LD);                         // [2] stages of {gates bf16 [16][4][64], dh f32 [16][64], cprev f32 [16][64]}
   constexpr int OPS_G = 16 * 4 * 64 * 2, OPS_F = 16 * 64 * 4;         // 8192, 4096
   constexpr int OPS_STAGE = OPS_G + 2 * OPS_F;                        // 16384
   float* c0 = (float*)(ops + 2 * OPS_STAGE);                          // [R][16][64] cell state at the first processed step
-  int* abortf = (int*)(c0 + R * 16 * 64);                             // [2]
+  int* abortf = (int*)(c0 + R * 16 * 64);                             // [1]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nsets = ((a.N + 15) / 16 + R - 1) / R;
@@ -1202,114 +1204,132 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
   u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * CS * CS * GPD;
   const int u0 = wgc * 64;
   const int T = a.T, Q = a.T * R;
-  if (tid < 2) abortf[tid] = 0;          // (audit) by wave 0 in front of its first wg_barrier, read behind it
+  if (tid == 0) abortf[0] = 0;           // (audit) by wave 0 in front of its first wg_barrier, read behind it
   auto t_of = [&](int step) { return d ? T - 1 - step : step; };
 
   if (wave < XW) {
     // ================================================================ compute role
-    const int wu = wave * 16 + r16;                    // unit inside the workgroup's 64 (cell update)
-    const int ut0 = wave * 16 * HB;                    // first output unit of this wave's HB tiles (product)
+    const int wu = wave * 16 + r16;                    // unit inside the workgroup's 64
+    // Wh[unit wu of workgroup j][own 256 gate columns], the columns in the operand image's order k = unit * 4 + gate
     bf16x8 bw[HB][8];
 #pragma unroll
     for (int j = 0; j < HB; ++j) {
-      const bf16_t* row = a.wh[d] + (long)(ut0 + 16 * j + r16) * K4 + u0 + g * 8;
+      const bf16_t* row = a.wh[d] + (long)(j * 64 + wu) * K4 + u0;
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) bw[j][ks] = *(const bf16x8*)(row + (ks >> 1) * H + (ks & 1) * 32);     // column gate*H + u0 + k%64
+      for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bw[j][ks][e] = row[(e & 3) * H + ks * 8 + g * 2 + (e >> 2)];
     }
     float dcc[R][4], pc[R][4];
+    f32x4 ownp[R];                                     // own block of the partial sums of the step before
     int len[R][4];
 #pragma unroll
-    for (int rg = 0; rg < R; ++rg)
+    for (int rg = 0; rg < R; ++rg) {
+      ownp[rg] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n = (rg0 + rg) * 16 + g * 4 + r;
         dcc[rg][r] = 0.f; pc[rg][r] = 0.f;
         len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
       }
+    }
+    // the part of a slot's cell update that does not need the exchanged sums; computed one slot ahead, under the
+    // product's MFMAs (the stage of slot q + 1 is complete behind barrier(q))
+    float kdo[4], kdc[4], ki[4], kj[4], kf[4], dhx[4], cpv[4], gfv[4];
+    auto indep = [&](int q) {
+      const int bs = q / R, rg = q % R;
+      const char* st = ops + (size_t)(q & 1) * OPS_STAGE;
+      const bf16_t* sgt = (const bf16_t*)st;
+      const float* sdh = (const float*)(st + OPS_G);
+      const float* scp = (const float*)(st + OPS_G + OPS_F);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = g * 4 + r;
+        const float gi = (float)sgt[(row * 4 + 0) * 64 + wu], gj = (float)sgt[(row * 4 + 1) * 64 + wu];
+        const float gf = (float)sgt[(row * 4 + 2) * 64 + wu], go = (float)sgt[(row * 4 + 3) * 64 + wu];
+        const float cprev = scp[row * 64 + wu];
+        float ccur = c0[(rg * 16 + row) * 64 + wu];
+        if (bs > 0) ccur = R == 1 ? pc[0][r] : (rg ? pc[R - 1][r] : pc[0][r]);
+        const float tc = tanhf_(ccur);
+        dhx[r] = sdh[row * 64 + wu];
+        kdo[r] = tc * go * (1.f - go);             // d_o = dh * kdo
+        kdc[r] = go * (1.f - tc * tc);             // dc = dh * kdc + dcc
+        ki[r] = gj * gi * (1.f - gi);
+        kj[r] = gi * (1.f - gj * gj);
+        kf[r] = cprev * gf * (1.f - gf);
+        cpv[r] = cprev; gfv[r] = gf;
+      }
+    };
+    wg_barrier();                                      // stage 0, c0 and abortf are in place
+    indep(0);
     for (int bs = 0; bs < T; ++bs) {                 // backward step index; forward step = T-1-bs
       const int t = t_of(T - 1 - bs);
 #pragma unroll
       for (int rg = 0; rg < R; ++rg) {
         const int q = bs * R + rg, buf = q & 1;
         const int n0 = (rg0 + rg) * 16;
-        wg_barrier();
-        if (abortf[buf]) return;
         const bool tr = (a.dbg & 16) && blockIdx.x == 0 && tid == 0 && q < 512;
         if (tr) a.trace[q * 8 + 0] = wall_clock64();
-        // ---- dh of the step after, summed in a fixed order: own block, then the peers' in workgroup order
-        f32x4 rec = {0.f, 0.f, 0.f, 0.f};
-        if (bs > 0) {
-          rec = *(const f32x4*)(own + (rg * 64 + wu) * US + g * 4);
-          if (DIRECT && CS > 1) {
-            // granule (source ws, row, unit pair wu / 2) of this workgroup's block: {tag bs, units 2p | 2p + 1}
-            const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD + (g * 4) * 32 + (wu >> 1);
-            u64 v[CS > 1 ? CS - 1 : 1][4];
-            unsigned spins = 0, clk0 = 0;
-            bool ok;
-            do {
-              ok = true;
+        // ---- dh of the step after, summed in a fixed order: own block, then the peers' in workgroup order.
+        // Granule (source ws, row pair 2 g + h, unit wu) of this workgroup's block: {tag bs, rows 2h | 2h + 1 of the lane}
+        f32x4 rec = ownp[rg];
+        if (bs > 0 && CS > 1) {
+          const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD + (g * 2) * 64 + wu;
+          u64 v[CS > 1 ? CS - 1 : 1][2];
+          unsigned spins = 0, clk0 = 0;
+          bool ok;
+          do {
+            ok = true;
 #pragma unroll
-              for (int sx = 0; sx < CS - 1; ++sx) {
-                const int ws = sx < wgc ? sx : sx + 1;
+            for (int sx = 0; sx < CS - 1; ++sx) {
+              const int ws = sx < wgc ? sx : sx + 1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[sx][r] = __hip_atomic_load(cur + (size_t)ws * GPD + r * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
-#pragma unroll
-              for (int sx = 0; sx < CS - 1; ++sx)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) ok = ok && ((unsigned)(v[sx][r] >> 32) == (unsigned)bs);
-              if (!ok && (++spins & 1023u) == 0) {
-                if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[0] = abortf[1] = 1; ok = true; }
-                else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[0] = abortf[1] = 1; ok = true; }
-              }
-            } while (!ok);
+              for (int h = 0; h < 2; ++h) v[sx][h] = __hip_atomic_load(cur + (size_t)ws * GPD + h * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
 #pragma unroll
             for (int sx = 0; sx < CS - 1; ++sx)
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const unsigned pay = (unsigned)v[sx][r];
-                rec[r] += __uint_as_float((wu & 1) ? (pay & 0xffff0000u) : (pay << 16));
-              }
-          } else {
-#pragma unroll
-            for (int sx = 0; sx < CS - 1; ++sx) {
-              const f32x4 pv = *(const f32x4*)(dps + (size_t)buf * DPS_BUF + (sx * 64 + wu) * US + g * 4);
-              rec[0] += pv[0]; rec[1] += pv[1]; rec[2] += pv[2]; rec[3] += pv[3];
+              for (int h = 0; h < 2; ++h) ok = ok && ((unsigned)(v[sx][h] >> 32) == (unsigned)bs);
+            if (!ok && (++spins & 1023u) == 0) {
+              if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[0] = 1; ok = true; }
+              else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[0] = 1; ok = true; }
             }
-          }
+          } while (!ok);
+          if (tr) { a.trace[q * 8 + 4] = wall_clock64(); a.trace[q * 8 + 6] = spins; }
+#pragma unroll
+          for (int sx = 0; sx < CS - 1; ++sx)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const unsigned pay = (unsigned)v[sx][h];
+              rec[2 * h] += __uint_as_float(pay << 16);
+              rec[2 * h + 1] += __uint_as_float(pay & 0xffff0000u);
+            }
         }
-        const char* st = ops + (size_t)buf * OPS_STAGE;
-        const bf16_t* sgt = (const bf16_t*)st;
-        const float* sdh = (const float*)(st + OPS_G);
-        const float* scp = (const float*)(st + OPS_G + OPS_F);
         bf16_t* di = dgi + (size_t)buf * 16 * DGI_LD;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = g * 4 + r;
           const int n = n0 + row;
-          const float gi = (float)sgt[(row * 4 + 0) * 64 + wu], gj = (float)sgt[(row * 4 + 1) * 64 + wu];
-          const float gf = (float)sgt[(row * 4 + 2) * 64 + wu], go = (float)sgt[(row * 4 + 3) * 64 + wu];
-          const float cprev = scp[row * 64 + wu];
-          const float ccur = bs == 0 ? c0[(rg * 16 + row) * 64 + wu] : pc[rg][r];
-          const float dh = sdh[row * 64 + wu] + rec[r];
-          const float tc = tanhf_(ccur);
-          const float d_o = dh * tc * go * (1.f - go);
-          const float dc = dh * go * (1.f - tc * tc) + dcc[rg][r];
-          float dgv[4] = {dc * gj * gi * (1.f - gi), dc * gi * (1.f - gj * gj), dc * cprev * gf * (1.f - gf), d_o};
-          dcc[rg][r] = dc * gf;
+          const float dh = dhx[r] + rec[r];
+          const float d_o = dh * kdo[r];
+          const float dc = dh * kdc[r] + dcc[rg][r];
+          float dgv[4] = {dc * ki[r], dc * kj[r], dc * kf[r], d_o};
+          dcc[rg][r] = dc * gfv[r];
           if (t >= len[rg][r] || n >= a.N) {
             dgv[0] = dgv[1] = dgv[2] = dgv[3] = 0.f;
             dcc[rg][r] = 0.f;
           }
-          pc[rg][r] = cprev;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) di[row * DGI_LD + j * 64 + wu] = (bf16_t)dgv[j];
+          pc[rg][r] = cpv[r];
+          uint2 pk;
+          pk.x = pack_bf16(dgv[0], dgv[1]);
+          pk.y = pack_bf16(dgv[2], dgv[3]);
+          *(uint2*)(di + row * DGI_LD + wu * 4) = pk;       // k = unit * 4 + gate
         }
         if (tr) a.trace[q * 8 + 1] = wall_clock64();
-        wg_barrier();            // the operand image is complete (all four compute waves), `own` has been read
-        if (DIRECT && abortf[buf]) return;
+        wg_barrier();            // the operand image is complete (all four compute waves)
+        if (abortf[0]) return;
         if (tr) a.trace[q * 8 + 2] = wall_clock64();
-        // ---- partial sums of every unit's dh from the own 256 gate columns; wave w: units ut0 .. ut0 + 16 HB
+        // ---- partial sums of dh from the own 256 gate columns; wave w: units 16 w .. 16 w + 16 of every workgroup
         if (bs + 1 < T) {
           f32x4 acc[HB];
 #pragma unroll
@@ -1320,107 +1340,67 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
 #pragma unroll
             for (int j = 0; j < HB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bw[j][ks], acc[j], 0, 0, 0);
           }
+          indep(q + 1);
           if (tr) a.trace[q * 8 + 3] = wall_clock64();
-          // D: column r16 = unit ut0 + 16 j + r16, rows g*4 + r.  Own units -> LDS (fp32); a peer's -> its granules
+          // D: column r16 = unit wu of workgroup j, rows g*4 + r.  A peer's tile -> its granules; the own tile stays here
           u64* nxt = xb0 + ((size_t)rg * 2 + ((bs + 1) & 1)) * CS * CS * GPD;
 #pragma unroll
           for (int j = 0; j < HB; ++j) {
-            const int un = ut0 + 16 * j;                     // first unit of the tile
-            const int wd = un >> 6, uo = (un & 63) + r16;     // destination workgroup, unit inside its 64
-            if (wd == wgc) {
-              *(f32x4*)(own + (rg * 64 + uo) * US + g * 4) = acc[j];
+            if (j == wgc) {
+              ownp[rg] = acc[j];
             } else {
-              u64* dst = nxt + ((size_t)(wd * CS + wgc) * 16 + g * 4) * 32 + (uo >> 1);
+              u64* dst = nxt + (size_t)(j * CS + wgc) * GPD + (g * 2) * 64 + wu;
 #pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                const unsigned pay = pack_bf16(acc[j][r], __shfl_down(acc[j][r], 1, 64));
-                if (!(r16 & 1))
-                  __hip_atomic_store(dst + r * 32, ((u64)(unsigned)(bs + 1) << 32) | pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              }
+              for (int h = 0; h < 2; ++h)
+                __hip_atomic_store(dst + h * 64, ((u64)(unsigned)(bs + 1) << 32) | pack_bf16(acc[j][2 * h], acc[j][2 * h + 1]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
           if (tr) a.trace[q * 8 + 7] = wall_clock64();
+        } else if (q + 1 < Q) {
+          indep(q + 1);
         }
       }
     }
-    wg_barrier();
-  } else if (wave < XW + 2) {
-    // ================================================================ poller role: the peers' blocks of the step before
-    // local granule li = lane + 64 * (j0 + j): source slot li / 512, row (li % 512) / 32, unit pair li % 32
-    const int j0 = (wave - XW) * PPG;
-    for (int q = 0; q < Q; ++q) {
-      const int bs = q / R, rg = q % R, buf = q & 1;
-      const bool trp = (a.dbg & 16) && blockIdx.x == 0 && tid == XW * 64 && q < 512;
-      if (trp) a.trace[q * 8 + 4] = wall_clock64();
-      if (!DIRECT && bs > 0 && CS > 1) {
-        const u64* cur = xb0 + ((size_t)rg * 2 + (bs & 1)) * CS * CS * GPD + (size_t)wgc * CS * GPD;      // destination = this workgroup
-        u64 v[PPG];
-        unsigned spins = 0, clk0 = 0;
-        bool ok;
-        do {
-          ok = true;
-#pragma unroll
-          for (int j = 0; j < PPG; ++j) {
-            const int li = lane + 64 * (j0 + j), sx = li / GPD;
-            const int ws = sx < wgc ? sx : sx + 1;
-            v[j] = __hip_atomic_load(cur + (size_t)ws * GPD + (li % GPD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-#pragma unroll
-          for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)bs);
-          if (!ok) {
-            if ((++spins & 1023u) == 0) {
-              if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { abortf[buf] = 1; ok = true; }
-              else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); abortf[buf] = 1; ok = true; }
-            }
-          }
-        } while (!ok);
-        if (trp) { a.trace[q * 8 + 5] = wall_clock64(); a.trace[q * 8 + 6] = spins; }
-        float* dst = dps + (size_t)buf * DPS_BUF;
-#pragma unroll
-        for (int j = 0; j < PPG; ++j) {
-          const int li = lane + 64 * (j0 + j), sx = li / GPD, w_ = li % GPD;
-          const unsigned pay = (unsigned)v[j];
-          float2 f;
-          f.x = __uint_as_float(pay << 16);
-          f.y = __uint_as_float(pay & 0xffff0000u);
-          float* cell = dst + (sx * 64 + 2 * (w_ & 31)) * US + (w_ >> 5);      // [source][unit][row]
-          cell[0] = f.x;
-          cell[US] = f.y;
-        }
-      }
-      wg_barrier();
-      if (abortf[buf]) return;
-      wg_barrier();
-      if (DIRECT && abortf[buf]) return;
-    }
-    wg_barrier();
-  } else if (wave == XW + 2) {
+  } else if (wave == XW) {
     // ================================================================ saver role (stores only), one slot behind:
-    // the slot's gate gradients [16][4][64] bf16 = 512 chunks of 16 B, 8 per lane, out of the operand image
+    // the slot's gate gradients out of the operand image [16 rows][unit * 4 + gate] into dgates[row][gate * H + unit]:
+    // a lane takes two (row, 8 units) blocks, reads their 8 x {4 gates} and writes one 16-byte chunk per gate
     auto save = [&](int q) {
       const int bs = q / R, rg = q % R;
       const int t = t_of(T - 1 - bs);
       const int n0 = (rg0 + rg) * 16;
       const bf16_t* di = dgi + (size_t)(q & 1) * 16 * DGI_LD;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int idx = lane + 64 * j, c8 = idx & 7, gate = (idx >> 3) & 3, row = idx >> 5;
-        const f32x4 v = *(const f32x4*)(di + row * DGI_LD + gate * 64 + c8 * 8);
-        if (n0 + row < a.N)
-          *(f32x4*)(a.dgates[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)K4 + (unsigned)(gate * H + u0 + c8 * 8))) = v;
+      for (int jj = 0; jj < 2; ++jj) {
+        const int idx = lane + 64 * jj, c8 = idx & 7, row = idx >> 3;
+        uint2 x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = *(const uint2*)(di + row * DGI_LD + (c8 * 8 + e) * 4);
+        if (n0 + row < a.N) {
+          bf16_t* out = a.dgates[d] + ((unsigned)((n0 + row) * a.P + a.padl + t) * (unsigned)K4 + (unsigned)(u0 + c8 * 8));
+#pragma unroll
+          for (int gate = 0; gate < 4; ++gate) {
+            unsigned w[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+              const unsigned lo = gate < 2 ? x[2 * e2].x : x[2 * e2].y, hi = gate < 2 ? x[2 * e2 + 1].x : x[2 * e2 + 1].y;
+              w[e2] = (gate & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            }
+            *(uint4*)(out + gate * H) = make_uint4(w[0], w[1], w[2], w[3]);
+          }
+        }
       }
     };
+    wg_barrier();
     for (int q = 0; q < Q; ++q) {
-      wg_barrier();
-      if (abortf[q & 1]) return;
       if (q > 0) save(q - 1);
       wg_barrier();
-      if (DIRECT && abortf[q & 1]) return;
+      if (abortf[0]) return;
     }
-    wg_barrier();
     save(Q - 1);
   } else {
-    // ================================================================ prefetcher role (loads only), as in lstm_cluster2_bwd_kernel
+    // ================================================================ prefetcher role (loads only)
     f32x4 pg[8], pd[4], pcp[4];
     auto pf_load = [&](int q) {
       const int bs = q / R, rg = q % R, step = T - 1 - bs;
@@ -1470,17 +1450,15 @@ __global__ __launch_bounds__(BP_WAVES * 64) void lstm_cluster2p_bwd_kernel(LstmC
       pf_store(0);
       if (Q > 1) pf_load(1);
     }
+    wg_barrier();
     for (int q = 0; q < Q; ++q) {
-      wg_barrier();
-      if (abortf[q & 1]) return;
-      wg_barrier();
-      if (DIRECT && abortf[q & 1]) return;
       if (q + 1 < Q) {
         pf_store((q + 1) & 1);
         if (q + 2 < Q) pf_load(q + 2);
       }
+      wg_barrier();
+      if (abortf[0]) return;
     }
-    wg_barrier();
   }
 }
 
@@ -1664,25 +1642,13 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     // R = 2 (two row groups interleaved per workgroup) pays when the slot's compute chain is shorter than the hop;
     // measured on the expand BiLSTM (T = 1000, H = 256, 2 row groups): R = 1 3.8 ms, R = 2 4.4 ms
     const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
-    const int CS = a.CS, peers = CS > 1 ? CS - 1 : 1;
-    const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + sizeof(float) * (2 * (size_t)peers * 64 * 20 + (size_t)R * 64 * 20 + (size_t)R * 16 * 64) +
-                        2 * 16384 + 32;
+    const int CS = a.CS;
+    const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + 2 * 16384 + sizeof(float) * (size_t)R * 16 * 64 + 32;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * CS)), block(BP_WAVES * 64);
 #define NS_LAUNCH_BP(HB_) \
     do { \
-      static bool attrp = false; \
-      if (!attrp) { \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        (void)hipFuncSetAttribute((const void*)lstm_cluster2p_bwd_kernel<HB_, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-        attrp = true; \
-      } \
-      if (a.dbg & 128) { /* the poller-wave form, for A/B timing */ \
-        if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2, false>), grid, block, ldsp, s, a); \
-        else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1, false>), grid, block, ldsp, s, a); \
-      } else if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2, true>), grid, block, ldsp, s, a); \
-      else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1, true>), grid, block, ldsp, s, a); \
+      if (R == 2) hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 2>), grid, block, ldsp, s, a); \
+      else hipLaunchKernelGGL((lstm_cluster2p_bwd_kernel<HB_, 1>), grid, block, ldsp, s, a); \
     } while (0)
     switch (a.H / 64) {
       case 1: NS_LAUNCH_BP(1); break;

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """In-kernel slot timings of lstm_cluster2p_bwd_kernel (the partial-sum backward BiLSTM) at the benchmark shape's expand
-BiLSTM: NS_CLUSTER_DBG=16 makes workgroup 0's compute wave 0 and first poller take 100 MHz stamps.
-Per slot: [0] compute start (behind the slot barrier), [1] cell update + operand image written, [2] behind the
-mid-slot barrier, [3] MFMAs issued and done (results needed by the next line), [7] partial sums published;
-poller: [4] starts waiting for the slot's blocks, [5] has them ([6] polls beyond the first)."""
+BiLSTM: NS_CLUSTER_DBG=16 makes workgroup 0's compute wave 0 take 100 MHz stamps.
+Per slot: [0] slot start (straight behind the publish of the slot before), [4] the peers' blocks of the step before
+have arrived ([6] poll passes beyond the first), [1] cell update done + operand image written, [2] behind the slot's
+barrier, [3] MFMAs issued and done, [7] partial sums published."""
 import os
 import sys
 
@@ -32,7 +32,7 @@ tr = w.view(torch.uint8)[off:off + 512 * 8 * 8].view(torch.int64).view(512, 8).c
 q0, q1 = 100, 500
 c = [tr[q0:q1, i] for i in range(8)]
 print("slots %d..%d: slot period %.2f us" % (q0, q1, (c[0][-1] - c[0][0]) / (q1 - q0 - 1)))
-print("compute wave: start -> cell update + image %.2f | mid barrier %.2f | MFMA %.2f | publish %.2f | publish -> next slot start %.2f"
-      % ((c[1] - c[0]).mean(), (c[2] - c[1]).mean(), (c[3] - c[2]).mean(), (c[7] - c[3]).mean(), (c[0][1:] - c[7][:-1]).mean()))
-print("poller: waits %.2f us for the slot's blocks (%.1f extra polls); blocks in -> compute start %.2f us; publish(q-1) -> blocks in(q) %.2f us"
-      % ((c[5] - c[4]).mean(), (c[6] * 100).mean(), (c[0] - c[5]).mean(), (c[5][1:] - c[7][:-1]).mean()))
+print("compute wave: start -> peers' sums in %.2f (%.1f extra poll passes) | -> cell update + image %.2f | barrier %.2f | MFMA %.2f | publish %.2f | -> next slot start %.2f"
+      % ((c[4] - c[0]).mean(), (c[6] * 100).mean(), (c[1] - c[4]).mean(), (c[2] - c[1]).mean(), (c[3] - c[2]).mean(), (c[7] - c[3]).mean(),
+         (c[0][1:] - c[7][:-1]).mean()))
+print("publish(q-1) -> peers' sums in(q): %.2f us" % (c[4][1:] - c[7][:-1]).mean())
