@@ -407,11 +407,22 @@ __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
   return (unsigned)(*(const unsigned short*)&b0) | ((unsigned)(*(const unsigned short*)&b1) << 16);
 }
 
+// Round 3 form.  The product is taken TRANSPOSED - the resident weights are the MFMA's A operand (M = the wave's 16
+// units), the gathered h its B operand (N = the 16 batch rows) - so a lane's accumulators are 4 consecutive UNITS of
+// one batch row: the new h packs into the exchange's {tag, 2 x bf16} unit-pair granules in the lane (two full-wave
+// stores, no cross-lane shuffle), the xg operands are one 16-byte LDS read per gate instead of 16 scalar ones, and the
+// saver's images take 6 vector writes instead of 24.  The workgroup's own h block goes into the next operand image
+// directly (LDS), only the peers' blocks are polled.  The xg operands of slot q + 1 are read at the end of slot q (the
+// prefetcher runs one interval ahead), so behind the slot barrier the chain starts with the MFMAs.
+// (audit) one barrier per slot, joined by every role: hs[q&1] is filled by the pollers (peers' blocks) and the compute
+// waves (own block: R = 1 in slot q-1 behind barrier(q-1), R = 2 behind barrier(q-1) of the slot after the producing
+// one) in front of barrier(q), read behind it, refilled behind barrier(q+1); xgs[(q+1)&1] is stored between
+// barrier(q-1) and barrier(q), read between barrier(q) and barrier(q+1); svs as before.
 template <int HB, int R>
 __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmClusterArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int H = HB * 64, FW_PG = 8 * HB, GPR = H / 2, KS = H / 32;
-  const int CS = HB;
+  constexpr int H = HB * 64, KS = H / 32, CS = HB;
+  constexpr int GPD = XW * 64 * 2;                              // granules per source workgroup and slot: [wave][lane][2]
   bf16_t* hs = (bf16_t*)smem;                                   // [2][16][H] swizzled
   float* xgs = (float*)(smem + (size_t)2 * 16 * H * 2);         // [2][16][XG_LD]: row, gate * 64 + unit
   // this slot's results for the saver wave: h bf16 [16][64], c f32 [16][64], gates bf16 [16][4][64]  (2 + 4 + 8 KB)
@@ -424,65 +435,68 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
   const int set = blockIdx.x / CS, wgc = blockIdx.x % CS;
   const int d = set / nsets, rg0 = (set % nsets) * R;           // this workgroup serves row groups rg0 .. rg0+R-1
   const int r16 = lane & 15, g = lane >> 4;
-  u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * 16 * GPR;   // + rg * 2*16*GPR + parity * 16*GPR
+  u64* xb0 = a.xbuf + (size_t)(d * nsets * R + rg0) * 2 * CS * GPD;   // + rg * 2*CS*GPD + parity * CS*GPD + source * GPD
   const int u0 = wgc * 64;
   const int T = a.T, Q = a.T * R;
   if (tid < 3) abortf[tid] = 0;
 
   if (wave < XW) {
-    // ================================================================ compute role
-    const int unit = u0 + wave * 16 + r16;
-    const int pub0 = (((wgc * XW + wave) * 32) + g * 8 + (r16 >> 1)) * 4;    // this lane's 4 granules (rows g*4 .. g*4+3)
-    bf16x8 bw[4][KS];
+    // ================================================================ compute role: batch row r16, units wq .. wq + 3
+    const int wq = wave * 16 + g * 4;                  // first of the lane's 4 units inside the workgroup's 64
+    bf16x8 bw[4][KS];                                  // A fragments: row (unit) wave * 16 + r16, k chunk g
     {
       const bf16_t* W = a.whT[d];
 #pragma unroll
       for (int gate = 0; gate < 4; ++gate) {
-        const bf16_t* row = W + ((long)gate * H + unit) * H;
+        const bf16_t* row = W + ((long)gate * H + u0 + wave * 16 + r16) * H;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) bw[gate][ks] = *(const bf16x8*)(row + ks * 32 + g * 8);
       }
     }
     float cst[R][4];
-    int len[R][4];
+    int len[R];
+    uint2 pend[R];                                     // R = 2: the own h block waits for the next slot's barrier
 #pragma unroll
-    for (int rg = 0; rg < R; ++rg)
+    for (int rg = 0; rg < R; ++rg) {
+      const int n = (rg0 + rg) * 16 + r16;
+      len[rg] = (a.lengths && n < a.N) ? a.lengths[n] : T;
+      pend[rg] = make_uint2(0u, 0u);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int n = (rg0 + rg) * 16 + g * 4 + r;
-        cst[rg][r] = 0.f;
-        len[rg][r] = (a.lengths && n < a.N) ? a.lengths[n] : T;
-      }
+      for (int r = 0; r < 4; ++r) cst[rg][r] = 0.f;
+    }
+    f32x4 acc[4];
+    auto load_xg = [&](int q) {
+      const float* xr = xgs + ((size_t)(q & 1) * 16 + r16) * XG_LD + wq;
+#pragma unroll
+      for (int gate = 0; gate < 4; ++gate) acc[gate] = *(const f32x4*)(xr + gate * 64);
+    };
+    wg_barrier();                                      // xg of slot 0 and abortf are in place
+    load_xg(0);
     for (int step = 0; step < T; ++step) {
       const int t = d ? T - 1 - step : step;
 #pragma unroll
       for (int rg = 0; rg < R; ++rg) {
         const int q = step * R + rg, buf = q & 1;
-        const int n0 = (rg0 + rg) * 16;
         wg_barrier();
         if (abortf[buf]) return;
         const bool tr = (a.dbg & 16) && blockIdx.x == 0 && tid == 0 && q < 512;
         if (tr) a.trace[q * 8 + 0] = wall_clock64();
-        const float* xr = xgs + (size_t)buf * 16 * XG_LD + (wave * 16 + r16);
-        f32x4 acc[4];
-#pragma unroll
-        for (int gate = 0; gate < 4; ++gate)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[gate][r] = xr[(g * 4 + r) * XG_LD + gate * 64];
+        if (R == 2 && q > 0)                           // the own block of slot q - 1, for slot q + 1
+          *(uint2*)(hs + (size_t)((q + 1) & 1) * 16 * H + swz_off(r16, u0 + wq, H)) = pend[(rg + 1) % R];
         if (step > 0) {
           const bf16_t* hb = hs + (size_t)buf * 16 * H;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8 af = *(const bf16x8*)(hb + swz_off(r16, ks * 32 + g * 8, H));
+            const bf16x8 hf = *(const bf16x8*)(hb + swz_off(r16, ks * 32 + g * 8, H));
 #pragma unroll
             for (int gate = 0; gate < 4; ++gate)
-              acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bw[gate][ks], acc[gate], 0, 0, 0);
+              acc[gate] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bw[gate][ks], hf, acc[gate], 0, 0, 0);
           }
         }
+        const bool masked = t >= len[rg];
         float hv[4], sg[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const bool masked = t >= len[rg][r];
           const float gi = sigmoidf_(acc[0][r]), gj = tanhf_(acc[1][r]);
           const float gf = sigmoidf_(acc[2][r] + a.forget_bias), go = sigmoidf_(acc[3][r]);
           float cn = gf * cst[rg][r] + gi * gj;
@@ -493,54 +507,62 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
           sg[r][0] = masked ? 0.f : gi; sg[r][1] = masked ? 0.f : gj; sg[r][2] = masked ? 0.f : gf; sg[r][3] = masked ? 0.f : go;
         }
         if (tr) a.trace[q * 8 + 1] = wall_clock64();
-        // publish first (tag = step + 1): even-unit lanes pack (h[u], h[u+1])
+        // publish first (tag = step + 1): units (wq, wq + 1) and (wq + 2, wq + 3) of row r16
+        uint2 hp;
+        hp.x = pack_bf16(hv[0], hv[1]);
+        hp.y = pack_bf16(hv[2], hv[3]);
         if (step + 1 < T) {
-          u64* nxt = xb0 + ((size_t)rg * 2 + ((step + 1) & 1)) * 16 * GPR + pub0;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const unsigned pay = pack_bf16(hv[r], __shfl_down(hv[r], 1, 64));
-            if (!(r16 & 1))
-              __hip_atomic_store(nxt + r, ((u64)(unsigned)(step + 1) << 32) | pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (CS > 1) {
+            u64* nxt = xb0 + ((size_t)rg * 2 + ((step + 1) & 1)) * CS * GPD + (size_t)wgc * GPD + (wave * 64 + lane) * 2;
+            __hip_atomic_store(nxt, ((u64)(unsigned)(step + 1) << 32) | hp.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(nxt + 1, ((u64)(unsigned)(step + 1) << 32) | hp.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
+          if (R == 1) *(uint2*)(hs + (size_t)((q + 1) & 1) * 16 * H + swz_off(r16, u0 + wq, H)) = hp;
+          else pend[rg] = hp;
         }
         if (tr) a.trace[q * 8 + 2] = wall_clock64();
         // results for the backward pass / the consumers of h go to LDS; the saver wave writes them out
         {
           char* sv = svs + (size_t)buf * SV_BYTES;
-          const int wu = wave * 16 + r16;
+          *(uint2*)((bf16_t*)sv + r16 * 64 + wq) = hp;
+          *(f32x4*)((float*)(sv + SV_H) + r16 * 64 + wq) = (f32x4){cst[rg][0], cst[rg][1], cst[rg][2], cst[rg][3]};
+          bf16_t* gp = (bf16_t*)(sv + SV_H + SV_C) + r16 * 4 * 64 + wq;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = g * 4 + r;
-            ((bf16_t*)sv)[row * 64 + wu] = (bf16_t)hv[r];
-            ((float*)(sv + SV_H))[row * 64 + wu] = cst[rg][r];
-            bf16_t* gp = (bf16_t*)(sv + SV_H + SV_C) + row * 4 * 64 + wu;
-#pragma unroll
-            for (int gate = 0; gate < 4; ++gate) gp[gate * 64] = (bf16_t)sg[r][gate];
+          for (int gate = 0; gate < 4; ++gate) {
+            uint2 pk;
+            pk.x = pack_bf16(sg[0][gate], sg[1][gate]);
+            pk.y = pack_bf16(sg[2][gate], sg[3][gate]);
+            *(uint2*)(gp + gate * 64) = pk;
           }
         }
+        if (q + 1 < Q) load_xg(q + 1);
       }
     }
     wg_barrier();
   } else if (wave == XW || wave == XW + 3) {
-    // ================================================================ poller role
-    static_assert(16 * GPR == FW_PG * 64 && FW_PG % FW_POLL == 0, "poller coverage");
-    constexpr int PPG = FW_PG / FW_POLL;              // granule columns of this poller
+    // ================================================================ poller role: the peers' h blocks
+    constexpr int NPG = (CS - 1) * GPD;                // granules to gather per slot
+    constexpr int PPG = NPG / (FW_POLL * 64) > 0 ? NPG / (FW_POLL * 64) : 1;
+    static_assert(CS == 1 || NPG == PPG * FW_POLL * 64, "poller coverage");
     const int j0 = (wave == XW ? 0 : 1) * PPG;
-    // granule lane + 64*jj: r = lane & 3, unit pair = (lane >> 2) & 7, g = ((jj & 1) << 1) | (lane >> 5), wave slot = jj >> 1
-    const int pr_ = lane & 3, pp = (lane >> 2) & 7, pgl = lane >> 5;
+    wg_barrier();
     for (int q = 0; q < Q; ++q) {
       const int step = q / R, rg = q % R, buf = q & 1;
-      const bool tr = (a.dbg & 16) && blockIdx.x == 0 && lane == 0 && q < 512;
+      const bool tr = (a.dbg & 16) && blockIdx.x == 0 && lane == 0 && wave == XW && q < 512;
       if (tr) a.trace[q * 8 + 4] = wall_clock64();
-      if (step > 0) {
-        const u64* cur = xb0 + ((size_t)rg * 2 + (step & 1)) * 16 * GPR;   // published by the peers with tag = step
+      if (step > 0 && CS > 1) {
+        const u64* cur = xb0 + ((size_t)rg * 2 + (step & 1)) * CS * GPD;   // published by the peers with tag = step
         u64 v[PPG];
         unsigned spins = 0, clk0 = 0;
         bool ok;
         do {
           ok = true;
 #pragma unroll
-          for (int j = 0; j < PPG; ++j) v[j] = __hip_atomic_load(cur + lane + (j0 + j) * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int j = 0; j < PPG; ++j) {
+            const int li = lane + 64 * (j0 + j), sx = li / GPD;
+            const int ws = sx < wgc ? sx : sx + 1;
+            v[j] = __hip_atomic_load(cur + (size_t)ws * GPD + (li % GPD), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
 #pragma unroll
           for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == (unsigned)step);
           if (!ok) {
@@ -554,10 +576,12 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
         bf16_t* dst = hs + (size_t)buf * 16 * H;
 #pragma unroll
         for (int j = 0; j < PPG; ++j) {
-          const int jj = j0 + j;
-          const int row = (((jj & 1) << 1) | pgl) * 4 + pr_;
-          const int k = (jj >> 1) * 16 + pp * 2;
-          *(unsigned*)(dst + swz_off(row, k, H)) = (unsigned)v[j];
+          // granule li of source ws: wave (li / 128) % 4, lane' = (li / 2) % 64 -> row lane' % 16, units 4 (lane' / 16) + 2 (li % 2)
+          const int li = lane + 64 * (j0 + j), sx = li / GPD, lw = li % GPD;
+          const int ws = sx < wgc ? sx : sx + 1;
+          const int lp = (lw >> 1) & 63;
+          const int k = ws * 64 + (lw >> 7) * 16 + (lp >> 4) * 4 + (lw & 1) * 2;
+          *(unsigned*)(dst + swz_off(lp & 15, k, H)) = (unsigned)v[j];
         }
       }
       wg_barrier();
@@ -592,6 +616,7 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
         }
       }
     };
+    wg_barrier();
     for (int q = 0; q < Q; ++q) {
       wg_barrier();
       if (abortf[q & 1]) return;
@@ -600,8 +625,8 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
     wg_barrier();
     save(Q - 1);
   } else {
-    // ================================================================ prefetcher role
-    // stage row j, gate = lane / 16, 4 floats at (lane % 16) * 4
+    // ================================================================ prefetcher role, one interval ahead:
+    // xg of slot q + 1 is in LDS before barrier(q).  Stage row j, gate = lane / 16, 4 floats at (lane % 16) * 4
     f32x4 pf[16];
     const float* xg = a.xg[d];
     const int pgate = lane >> 4, pf4 = (lane & 15) * 4;
@@ -623,13 +648,14 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
     pf_load(0);
     pf_store(0);
     if (Q > 1) pf_load(1);
+    wg_barrier();
     for (int q = 0; q < Q; ++q) {
-      wg_barrier();
-      if (abortf[q & 1]) return;
       if (q + 1 < Q) {
         pf_store((q + 1) & 1);
         if (q + 2 < Q) pf_load(q + 2);
       }
+      wg_barrier();
+      if (abortf[q & 1]) return;
     }
     wg_barrier();
   }
