@@ -353,103 +353,14 @@ __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* 
 // (k2lo, k3): k = k1 + 64 k2hi + 16 k2lo + 256 k3) and the readers of the bins 64 n1 + lane both stay (nearly) conflict free
 __device__ __forceinline__ int gw_nat(int k) { return k + 16 * (k >> 6); }
 
+constexpr int GL_NP = 9;                    // pairs (k, M - k) per lane: k = 64 n1 + lane, n1 < 8; n1 = 8 is lane 0's (512, 512)
+// The pairs (k, M - k), k = 64 n1 + lane: split -> unit phase x magnitude -> merge, ONCE per pair for both bins; the two
+// results replace Z[k] and Z[M - k] in the wave's natural-order image (no other lane touches those two cells).
+// With t1 = Xn[k] + conj Xn[M-k], c1 = conj(w) (Xn[k] - conj Xn[M-k]):  conj Zt[k] = conj(t1 + i c1), conj Zt[M-k] = t1 - i c1.
 template <bool INIT>
-__global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const ns_griffin_lim_params& p = g.p;
-  constexpr int M = 1024, N = 2048, F = M + 1;
-  v2f* tw = (v2f*)sm;                                          // [1024] W_1024^j
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  v2f* buf = tw + M + wave * GW_PAD;
-  // the W_1024 table is built AFTER this wave's operand loads are in flight (one latency instead of two); a wave
-  // beyond the last frame walks the last frame's loads up to the barrier and leaves
-  auto build_table = [&]() {
-    for (int j = tid; j < M; j += 256) {
-      const v2f v = ((const v2f*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
-      tw[j] = j < 512 ? v : -v;
-    }
-    __syncthreads();
-  };
-  const int traw = blockIdx.x * 4 + wave, n = blockIdx.y;
-  const int t = min(traw, p.T - 1);
-  float* mag = g.mag + ((long)n * p.T + t) * F;
-  v2f z[16];
-  constexpr int NP = 9;                                        // pairs (k, M - k) per lane: k = 64 n1 + lane, n1 < 8; n1 = 8 is lane 0's (512, 512)
-  float mkv[NP], mpv[NP];
-  v2f wv[NP];
-  // per-lane base pointers: every access below is base[constant]
-  const v2f* tw2l = (const v2f*)p.twiddle + lane;              // exp(-2 pi i k / 2048), k = 64 n1 + lane
-  const float* magk = mag + lane;                              // mag[64 n1 + lane]
-  const float* magp = mag + (M - lane);                        // mag[M - k] = magp[-64 n1]
-  const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
+__device__ __forceinline__ void gl_pairs(v2f* buf, int lane, const float (&mkv)[GL_NP], const float (&mpv)[GL_NP], const v2f (&wv)[GL_NP]) {
 #pragma unroll
-  for (int n1 = 0; n1 < NP; ++n1) wv[n1] = tw2l[64 * n1];
-  if constexpr (!INIT) {
-    // ---- overlap-add gather (the previous iteration's windowed frames) -> window -> z[m] = (x[2m], x[2m+1]).
-    //      Sample j of frame t lies in frames t + q0, t + q0 - 1, ... (at most 4: the host checks win <= 4 hop) at
-    //      offsets o0, o0 + hop, ...: element index e0 + dq (hop - win) of this clip's frames.  Range-checked buffer
-    //      loads (an out-of-range lane reads 0) and every load in flight before the first is used.
-    const int hop = p.hop, win = p.win;
-    const float inv_hop = 1.f / hop;
-    const auto frs = __builtin_amdgcn_make_buffer_rsrc((void*)(g.fprev + (long)n * p.T * win), 0, p.T * win * 4, 0x00020000);
-    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
-    u32x2_t xs[8][4];
-#pragma unroll
-    for (int n1 = 0; n1 < 8; ++n1) {
-      const int j = 2 * (64 * n1 + lane);
-      int q0 = (int)((j + 0.5f) * inv_hop);       // the quotient of two small integers through a float reciprocal: exact
-      q0 = min(q0, p.T - 1 - t);
-      const int o0 = j - q0 * hop;
-      const int e0 = (t + q0) * win + o0;
-#pragma unroll
-      for (int dq = 0; dq < 4; ++dq) {
-        const bool ok = j < win && t + q0 - dq >= 0 && o0 + dq * hop < win;
-        xs[n1][dq] = __builtin_amdgcn_raw_buffer_load_b64(frs, ok ? (unsigned)(e0 + dq * (hop - win)) * 4u : 0x80000000u, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int n1 = 0; n1 < NP; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
-    build_table();
-    if (traw >= p.T) return;
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) {
-      v2f v = {0.f, 0.f};
-      if (n1 < 8) {
-        const v2f wd = 2 * (64 * n1 + lane) < win ? winl[64 * n1] : (v2f){0.f, 0.f};
-        const v2f a0 = {__uint_as_float(xs[n1 & 7][0][0]), __uint_as_float(xs[n1 & 7][0][1])};
-        const v2f a1 = {__uint_as_float(xs[n1 & 7][1][0]), __uint_as_float(xs[n1 & 7][1][1])};
-        const v2f a2 = {__uint_as_float(xs[n1 & 7][2][0]), __uint_as_float(xs[n1 & 7][2][1])};
-        const v2f a3 = {__uint_as_float(xs[n1 & 7][3][0]), __uint_as_float(xs[n1 & 7][3][1])};
-        v = ((a0 + a1) + (a2 + a3)) * wd;
-      }
-      z[n1] = v;
-    }
-    fft1024_wave(z, buf, tw, lane);
-    v2f* nat = buf + ((lane >> 2) + 80 * (lane & 3));          // gw_nat(k1 + 64 k2hi + 16 k2lo + 256 k3)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) nat[16 * (q >> 2) + 320 * (q & 3)] = z[q];
-    wave_lds_fence();
-  } else {
-    build_table();
-    if (traw >= p.T) return;
-    // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
-    const float* sp = p.spec + ((long)n * p.T + t) * F;
-#pragma unroll
-    for (int n1 = 0; n1 < NP; ++n1) {
-      const int k = 64 * n1 + lane;
-      const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
-      mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-      mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-      if (n1 < 8 || lane == 0) { mag[k] = mkv[n1]; mag[M - k] = mpv[n1]; }
-    }
-  }
-  // ---- the pairs (k, M - k), k = 64 n1 + lane (n1 < 8; lane 0 also takes (512, 512)): split -> unit phase x magnitude
-  //      -> merge, ONCE per pair for both bins; the two results replace Z[k] and Z[M - k] in the natural-order image
-  //      (no other lane touches those two cells), then every lane reads its pass-1 inputs conj(Zt[64 n1 + lane]).
-  //      With t1 = Xn[k] + conj Xn[M-k], c1 = conj(w) (Xn[k] - conj Xn[M-k]):  conj Zt[k] = conj(t1 + i c1),
-  //      conj Zt[M-k] = t1 - i c1.
-#pragma unroll
-  for (int n1 = 0; n1 < NP; ++n1) {
+  for (int n1 = 0; n1 < GL_NP; ++n1) {
     const float mk = mkv[n1], mp = mpv[n1];
     const v2f w = wv[n1];
     // natural-order cells of the two bins: gw_nat(k) = 80 n1 + lane; the partner (M - k) & 1023 (bin 0 for k = 0)
@@ -483,6 +394,113 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
       buf[ik] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};
     }
   }
+}
+
+// Overlap-add gather of one frame's samples from the previous iteration's windowed frames (at most 4 cover a sample:
+// the host checks win <= 4 hop): sample j of frame t lies in frames t + q0, t + q0 - 1, ... at offsets o0, o0 + hop, ...
+// = element index e0 + dq (hop - win) of this clip's frames.  Range-checked buffer loads (an out-of-range lane reads 0);
+// the caller issues all of them before the first is used.  AUX 16 = sc1: frames written by other CUs inside this launch.
+typedef unsigned int gl_u32x2 __attribute__((ext_vector_type(2)));
+template <int AUX>
+__device__ __forceinline__ void gl_issue_gather(const float* frames_of_clip, int T, int t, int hop, int win, int lane, gl_u32x2 (&xs)[8][4]) {
+  const float inv_hop = 1.f / hop;
+  const auto frs = __builtin_amdgcn_make_buffer_rsrc((void*)frames_of_clip, 0, T * win * 4, 0x00020000);
+#pragma unroll
+  for (int n1 = 0; n1 < 8; ++n1) {
+    const int j = 2 * (64 * n1 + lane);
+    int q0 = (int)((j + 0.5f) * inv_hop);       // the quotient of two small integers through a float reciprocal: exact
+    q0 = min(q0, T - 1 - t);
+    const int o0 = j - q0 * hop;
+    const int e0 = (t + q0) * win + o0;
+#pragma unroll
+    for (int dq = 0; dq < 4; ++dq) {
+      const bool ok = j < win && t + q0 - dq >= 0 && o0 + dq * hop < win;
+      xs[n1][dq] = __builtin_amdgcn_raw_buffer_load_b64(frs, ok ? (unsigned)(e0 + dq * (hop - win)) * 4u : 0x80000000u, 0, AUX);
+    }
+  }
+}
+__device__ __forceinline__ void gl_window_gathered(const gl_u32x2 (&xs)[8][4], const v2f* winl, int win, int lane, v2f (&z)[16]) {
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    v2f v = {0.f, 0.f};
+    if (n1 < 8) {
+      const v2f wd = 2 * (64 * n1 + lane) < win ? winl[64 * n1] : (v2f){0.f, 0.f};
+      const v2f a0 = {__uint_as_float(xs[n1 & 7][0][0]), __uint_as_float(xs[n1 & 7][0][1])};
+      const v2f a1 = {__uint_as_float(xs[n1 & 7][1][0]), __uint_as_float(xs[n1 & 7][1][1])};
+      const v2f a2 = {__uint_as_float(xs[n1 & 7][2][0]), __uint_as_float(xs[n1 & 7][2][1])};
+      const v2f a3 = {__uint_as_float(xs[n1 & 7][3][0]), __uint_as_float(xs[n1 & 7][3][1])};
+      v = ((a0 + a1) + (a2 + a3)) * wd;
+    }
+    z[n1] = v;
+  }
+}
+
+template <bool INIT>
+__global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const ns_griffin_lim_params& p = g.p;
+  constexpr int M = 1024, N = 2048, F = M + 1;
+  v2f* tw = (v2f*)sm;                                          // [1024] W_1024^j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v2f* buf = tw + M + wave * GW_PAD;
+  // the W_1024 table is built AFTER this wave's operand loads are in flight (one latency instead of two); a wave
+  // beyond the last frame walks the last frame's loads up to the barrier and leaves
+  auto build_table = [&]() {
+    for (int j = tid; j < M; j += 256) {
+      const v2f v = ((const v2f*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
+      tw[j] = j < 512 ? v : -v;
+    }
+    __syncthreads();
+  };
+  const int traw = blockIdx.x * 4 + wave, n = blockIdx.y;
+  const int t = min(traw, p.T - 1);
+  float* mag = g.mag + ((long)n * p.T + t) * F;
+  v2f z[16];
+  constexpr int NP = GL_NP;
+  float mkv[NP], mpv[NP];
+  v2f wv[NP];
+  // per-lane base pointers: every access below is base[constant]
+  const v2f* tw2l = (const v2f*)p.twiddle + lane;              // exp(-2 pi i k / 2048), k = 64 n1 + lane
+  const float* magk = mag + lane;                              // mag[64 n1 + lane]
+  const float* magp = mag + (M - lane);                        // mag[M - k] = magp[-64 n1]
+  const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
+#pragma unroll
+  for (int n1 = 0; n1 < NP; ++n1) wv[n1] = tw2l[64 * n1];
+  if constexpr (!INIT) {
+    // ---- overlap-add gather (the previous iteration's windowed frames) -> window -> z[m] = (x[2m], x[2m+1]).
+    //      Sample j of frame t lies in frames t + q0, t + q0 - 1, ... (at most 4: the host checks win <= 4 hop) at
+    //      offsets o0, o0 + hop, ...: element index e0 + dq (hop - win) of this clip's frames.  Range-checked buffer
+    //      loads (an out-of-range lane reads 0) and every load in flight before the first is used.
+    const int win = p.win;
+    gl_u32x2 xs[8][4];
+    gl_issue_gather<0>(g.fprev + (long)n * p.T * win, p.T, t, p.hop, win, lane, xs);
+#pragma unroll
+    for (int n1 = 0; n1 < NP; ++n1) { mkv[n1] = magk[64 * n1]; mpv[n1] = magp[-64 * n1]; }
+    build_table();
+    if (traw >= p.T) return;
+    gl_window_gathered(xs, winl, win, lane, z);
+    fft1024_wave(z, buf, tw, lane);
+    v2f* nat = buf + ((lane >> 2) + 80 * (lane & 3));          // gw_nat(k1 + 64 k2hi + 16 k2lo + 256 k3)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) nat[16 * (q >> 2) + 320 * (q & 3)] = z[q];
+    wave_lds_fence();
+  } else {
+    build_table();
+    if (traw >= p.T) return;
+    // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
+    const float* sp = p.spec + ((long)n * p.T + t) * F;
+#pragma unroll
+    for (int n1 = 0; n1 < NP; ++n1) {
+      const int k = 64 * n1 + lane;
+      const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
+      mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      if (n1 < 8 || lane == 0) { mag[k] = mkv[n1]; mag[M - k] = mpv[n1]; }
+    }
+  }
+  // ---- the pairs (k, M - k): split -> unit phase x magnitude -> merge; then every lane reads its pass-1 inputs
+  //      conj(Zt[64 n1 + lane])
+  gl_pairs<INIT>(buf, lane, mkv, mpv, wv);
   wave_lds_fence();
 #pragma unroll
   for (int n1 = 0; n1 < 16; ++n1) z[n1] = buf[80 * n1 + lane];
@@ -501,6 +519,131 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   }
 }
 
+// ------------------------------------------------------------------ Griffin-Lim, one launch for a whole clip (round 3)
+// A single 10 s clip is 797 frames = 200 workgroups of four waves: with a launch per iteration (61 of them) each launch
+// is ~12 us of which the iteration itself is a few - the rest is launch boundary.  Here every wave KEEPS its frame for
+// all iterations (magnitudes and twiddles stay in registers, the W_1024 table in LDS) and the overlap-add dependency
+// is carried by one counter per frame: frame t's iteration i reads the iteration i-1 frames t-3 .. t+3 (win <= 4 hop),
+// so it waits for their counters, gathers them with sc1 loads (bypassing this XCD's L2) and publishes its own frame
+// with write-through stores, drains them and raises its counter.  Two frame buffers suffice: frame t' overwrites its
+// iteration i-1 output in iteration i+1, which it enters only after every neighbour has raised counter i - that is,
+// after they have read it.  The final overlap-add runs in the same launch (frame t writes samples [t hop, (t+1) hop),
+// the last frame the tail).  The grid must be co-resident (the host checks <= 256 workgroups); every wait is bounded by
+// wall clock and raises the status word, and an aborted frame writes NaN over its samples.
+__global__ __launch_bounds__(256) void gl_persist_kernel(GlArgs g, float* fa, float* fb, unsigned* flags, int* status, int Lout) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const ns_griffin_lim_params& p = g.p;
+  constexpr int M = 1024, N = 2048, F = M + 1;
+  v2f* tw = (v2f*)sm;                                          // [1024] W_1024^j
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  v2f* buf = tw + M + wave * GW_PAD;
+  for (int j = tid; j < M; j += 256) {
+    const v2f v = ((const v2f*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
+    tw[j] = j < 512 ? v : -v;
+  }
+  __syncthreads();                                             // the only workgroup barrier: the waves run on their own from here
+  const int t = blockIdx.x * 4 + wave, n = blockIdx.y;
+  if (t >= p.T) return;
+  const int T = p.T, hop = p.hop, win = p.win;
+  v2f z[16];
+  float mkv[GL_NP], mpv[GL_NP];
+  v2f wv[GL_NP];
+  const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
+  {
+    const v2f* tw2l = (const v2f*)p.twiddle + lane;            // exp(-2 pi i k / 2048), k = 64 n1 + lane
+    const float* sp = p.spec + ((long)n * T + t) * F;
+#pragma unroll
+    for (int n1 = 0; n1 < GL_NP; ++n1) {
+      const int k = 64 * n1 + lane;
+      wv[n1] = tw2l[64 * n1];
+      // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
+      const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
+      mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+      mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
+    }
+  }
+  unsigned* fl = flags + (long)n * T;
+  const float invN = 1.f / N;
+  const int m0 = (lane >> 2) + 64 * (lane & 3);                // m = k1 + 64 k2hi + 16 k2lo + 256 k3
+  const v2f* wo = (const v2f*)p.window + m0;
+  const v2f sc = {invN, -invN};
+  // second half of an iteration: pass-1 inputs out of the natural-order image -> transform -> windowed frame out
+  // (write-through), drained, counter raised to `done`
+  auto finish = [&](float* frames, unsigned done) {
+    wave_lds_fence();
+#pragma unroll
+    for (int n1 = 0; n1 < 16; ++n1) z[n1] = buf[80 * n1 + lane];
+    wave_lds_fence();                                           // every lane has read Z before the buffer is reused
+    fft1024_wave(z, buf, tw, lane);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(frames + ((long)n * T + t) * win), 0, win * 4, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int dm = 16 * (q >> 2) + 256 * (q & 3);
+      if (2 * (m0 + dm) < win) {
+        const v2f y = z[q] * sc * wo[dm];
+        const gl_u32x2 yb = {__float_as_uint(y.x), __float_as_uint(y.y)};
+        __builtin_amdgcn_raw_buffer_store_b64(yb, rs, (unsigned)(m0 + dm) * 8u, 0, 16);      // aux 16 = sc1 (write-through)
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // drain before the counter
+    if (lane == 0) __hip_atomic_store(fl + t, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // waits until the frames t + lo .. t + hi (those that exist) have raised their counters to `need`
+  auto wait_frames = [&](int lo, int hi, unsigned need) -> bool {
+    const int f = t + lo + lane;
+    const bool mine = lane <= hi - lo && f >= 0 && f < T && f != t;
+    unsigned spins = 0, clk0 = 0;
+    for (;;) {
+      const unsigned v = mine ? __hip_atomic_load(fl + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
+      if (!__any((int)(v - need) < 0)) break;
+      if ((++spins & 1023u) == 0) {
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+        if (ns_spin_timed_out(clk0)) { if (lane == 0) atomicExch(status, 1); return false; }
+      }
+    }
+    asm volatile("" ::: "memory");                              // the gather loads stay behind the poll (a wave's loads are in order)
+    return true;
+  };
+  const int pos0 = t * hop, pos1 = t == T - 1 ? Lout : pos0 + hop;
+  auto poison = [&]() {
+    for (int pos = pos0 + lane; pos < pos1; pos += 64) p.wav[(long)n * Lout + pos] = __uint_as_float(0x7fc00000u);
+  };
+  // ---- iteration "init": zero phase
+  gl_pairs<true>(buf, lane, mkv, mpv, wv);
+  finish(fa, 1u);
+  float* cur = fa;
+  float* nxt = fb;
+  for (int it = 0; it < p.iters; ++it) {
+    if (!wait_frames(-3, 3, (unsigned)(it + 1))) { poison(); return; }
+    gl_u32x2 xs[8][4];
+    gl_issue_gather<16>(cur + (long)n * T * win, T, t, hop, win, lane, xs);
+    gl_window_gathered(xs, winl, win, lane, z);
+    fft1024_wave(z, buf, tw, lane);
+    v2f* nat = buf + ((lane >> 2) + 80 * (lane & 3));          // gw_nat(k1 + 64 k2hi + 16 k2lo + 256 k3)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) nat[16 * (q >> 2) + 320 * (q & 3)] = z[q];
+    wave_lds_fence();
+    gl_pairs<false>(buf, lane, mkv, mpv, wv);
+    finish(nxt, (unsigned)(it + 2));
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  // ---- overlap-add of the last iteration's frames: samples [t hop, (t+1) hop) (+ the tail for the last frame) are
+  //      covered by frames t-3 .. t only
+  if (!wait_frames(-3, 0, (unsigned)(p.iters + 1))) { poison(); return; }
+  {
+    const float* fr = cur + (long)n * T * win;
+    for (int pos = pos0 + lane; pos < pos1; pos += 64) {
+      float sum = 0.f;
+      for (int f = t; f >= 0; --f) {
+        const int off = pos - f * hop;
+        if (off >= win) break;
+        sum += __hip_atomic_load(fr + (long)f * win + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      p.wav[(long)n * Lout + pos] = sum;
+    }
+  }
+}
+
 __global__ void gl_ola_kernel(GlArgs g, int Lout) {
   const ns_griffin_lim_params& p = g.p;
   const int n = blockIdx.y;
@@ -512,7 +655,8 @@ __global__ void gl_ola_kernel(GlArgs g, int Lout) {
 extern "C" size_t ns_griffin_lim_work_bytes(const ns_griffin_lim_params* p) {
   if (!p) return 0;
   const size_t F = p->n_fft / 2 + 1;
-  return sizeof(float) * ((((size_t)p->N * p->T * F + 1) & ~(size_t)1) + 2 * (size_t)p->N * p->T * p->win) + 256;
+  // magnitudes, two frame buffers, one counter per frame (the single-launch kernel), status word
+  return sizeof(float) * ((((size_t)p->N * p->T * F + 1) & ~(size_t)1) + 2 * (size_t)p->N * p->T * p->win + (size_t)p->N * p->T) + 256 + 32;
 }
 
 extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
@@ -543,6 +687,24 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
                      (((uintptr_t)p->work) & 7) == 0;
   const size_t lds_w = sizeof(float2) * (1024 + 4 * GW_PAD);
   dim3 grid(p->T, p->N), grid_w(ceil_div(p->T, 4), p->N);
+  const int Lout = (p->T - 1) * p->hop + p->win;
+  // a clip (or a few) whose frames fit the chip at once: the whole call as ONE launch; NS_GL_PERSIST=0 keeps the
+  // launch-per-iteration form (A/B timing, and what the tests compare it with)
+  const char* gp_env = getenv("NS_GL_PERSIST");
+  const bool allow_persist = !(gp_env && atoi(gp_env) == 0);
+  if (wavek && allow_persist && (size_t)grid_w.x * grid_w.y <= 256 && (double)p->T * p->win * 4 < 2.0e9) {
+    static bool attrp = false;
+    if (!attrp) {
+      (void)hipFuncSetAttribute((const void*)gl_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attrp = true;
+    }
+    unsigned* flags = (unsigned*)(((uintptr_t)(fb + (size_t)p->N * p->T * p->win) + 15) & ~(uintptr_t)15);
+    int* status = (int*)(flags + (size_t)p->N * p->T);
+    { const int zrc = ns_zero_async(flags, (((size_t)p->N * p->T * 4 + 64) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
+    hipLaunchKernelGGL(gl_persist_kernel, grid_w, dim3(256), lds_w, s, g, fa, fb, flags, status, Lout);
+    NS_CHECK_LAUNCH("griffin_lim_persist");
+    return NS_OK;
+  }
   auto launch = [&]() {
     if (wavek && g.init) hipLaunchKernelGGL(gl_wave_kernel<true>, grid_w, dim3(256), lds_w, s, g);
     else if (wavek) hipLaunchKernelGGL(gl_wave_kernel<false>, grid_w, dim3(256), lds_w, s, g);
@@ -556,7 +718,6 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
     launch();
     float* tmp = cur; cur = nxt; nxt = tmp;
   }
-  const int Lout = (p->T - 1) * p->hop + p->win;
   g.fprev = cur;
   hipLaunchKernelGGL(gl_ola_kernel, dim3(ceil_div(Lout, 256), p->N), dim3(256), 0, s, g, Lout);
   NS_CHECK_LAUNCH("griffin_lim");
