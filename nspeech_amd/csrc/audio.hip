@@ -519,130 +519,19 @@ __global__ __launch_bounds__(256) void gl_wave_kernel(GlArgs g) {
   }
 }
 
-// ------------------------------------------------------------------ Griffin-Lim, one launch for a whole clip (round 3)
-// A single 10 s clip is 797 frames = 200 workgroups of four waves: with a launch per iteration (61 of them) each launch
-// is ~12 us of which the iteration itself is a few - the rest is launch boundary.  Here every wave KEEPS its frame for
-// all iterations (magnitudes and twiddles stay in registers, the W_1024 table in LDS) and the overlap-add dependency
-// is carried by one counter per frame: frame t's iteration i reads the iteration i-1 frames t-3 .. t+3 (win <= 4 hop),
-// so it waits for their counters, gathers them with sc1 loads (bypassing this XCD's L2) and publishes its own frame
-// with write-through stores, drains them and raises its counter.  Two frame buffers suffice: frame t' overwrites its
-// iteration i-1 output in iteration i+1, which it enters only after every neighbour has raised counter i - that is,
-// after they have read it.  The final overlap-add runs in the same launch (frame t writes samples [t hop, (t+1) hop),
-// the last frame the tail).  The grid must be co-resident (the host checks <= 256 workgroups); every wait is bounded by
-// wall clock and raises the status word, and an aborted frame writes NaN over its samples.
-__global__ __launch_bounds__(256) void gl_persist_kernel(GlArgs g, float* fa, float* fb, unsigned* flags, int* status, int Lout) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  const ns_griffin_lim_params& p = g.p;
-  constexpr int M = 1024, N = 2048, F = M + 1;
-  v2f* tw = (v2f*)sm;                                          // [1024] W_1024^j
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  v2f* buf = tw + M + wave * GW_PAD;
-  for (int j = tid; j < M; j += 256) {
-    const v2f v = ((const v2f*)p.twiddle)[j < 512 ? 2 * j : 2 * j - M];
-    tw[j] = j < 512 ? v : -v;
-  }
-  __syncthreads();                                             // the only workgroup barrier: the waves run on their own from here
-  const int t = blockIdx.x * 4 + wave, n = blockIdx.y;
-  if (t >= p.T) return;
-  const int T = p.T, hop = p.hop, win = p.win;
-  v2f z[16];
-  float mkv[GL_NP], mpv[GL_NP];
-  v2f wv[GL_NP];
-  const v2f* winl = (const v2f*)p.window + lane;               // window[2 (64 n1 + lane)], [.. + 1]
-  {
-    const v2f* tw2l = (const v2f*)p.twiddle + lane;            // exp(-2 pi i k / 2048), k = 64 n1 + lane
-    const float* sp = p.spec + ((long)n * T + t) * F;
-#pragma unroll
-    for (int n1 = 0; n1 < GL_NP; ++n1) {
-      const int k = 64 * n1 + lane;
-      wv[n1] = tw2l[64 * n1];
-      // S = (10^((clip(x)*(-min) + min + ref)/20))^power, zero phase
-      const float x0 = fminf(1.f, fmaxf(0.f, sp[k])), x1 = fminf(1.f, fmaxf(0.f, sp[M - k]));
-      mkv[n1] = p.raw_magnitude ? sp[k] : __powf(__powf(10.f, (x0 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-      mpv[n1] = p.raw_magnitude ? sp[M - k] : __powf(__powf(10.f, (x1 * -p.min_level_db + p.min_level_db + p.ref_level_db) * 0.05f), p.power);
-    }
-  }
-  unsigned* fl = flags + (long)n * T;
-  const float invN = 1.f / N;
-  const int m0 = (lane >> 2) + 64 * (lane & 3);                // m = k1 + 64 k2hi + 16 k2lo + 256 k3
-  const v2f* wo = (const v2f*)p.window + m0;
-  const v2f sc = {invN, -invN};
-  // second half of an iteration: pass-1 inputs out of the natural-order image -> transform -> windowed frame out
-  // (write-through), drained, counter raised to `done`
-  auto finish = [&](float* frames, unsigned done) {
-    wave_lds_fence();
-#pragma unroll
-    for (int n1 = 0; n1 < 16; ++n1) z[n1] = buf[80 * n1 + lane];
-    wave_lds_fence();                                           // every lane has read Z before the buffer is reused
-    fft1024_wave(z, buf, tw, lane);
-    const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(frames + ((long)n * T + t) * win), 0, win * 4, 0x00020000);
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int dm = 16 * (q >> 2) + 256 * (q & 3);
-      if (2 * (m0 + dm) < win) {
-        const v2f y = z[q] * sc * wo[dm];
-        const gl_u32x2 yb = {__float_as_uint(y.x), __float_as_uint(y.y)};
-        __builtin_amdgcn_raw_buffer_store_b64(yb, rs, (unsigned)(m0 + dm) * 8u, 0, 16);      // aux 16 = sc1 (write-through)
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // drain before the counter
-    if (lane == 0) __hip_atomic_store(fl + t, done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // waits until the frames t + lo .. t + hi (those that exist) have raised their counters to `need`
-  auto wait_frames = [&](int lo, int hi, unsigned need) -> bool {
-    const int f = t + lo + lane;
-    const bool mine = lane <= hi - lo && f >= 0 && f < T && f != t;
-    unsigned spins = 0, clk0 = 0;
-    for (;;) {
-      const unsigned v = mine ? __hip_atomic_load(fl + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : need;
-      if (!__any((int)(v - need) < 0)) break;
-      if ((++spins & 1023u) == 0) {
-        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
-        if (ns_spin_timed_out(clk0)) { if (lane == 0) atomicExch(status, 1); return false; }
-      }
-    }
-    asm volatile("" ::: "memory");                              // the gather loads stay behind the poll (a wave's loads are in order)
-    return true;
-  };
-  const int pos0 = t * hop, pos1 = t == T - 1 ? Lout : pos0 + hop;
-  auto poison = [&]() {
-    for (int pos = pos0 + lane; pos < pos1; pos += 64) p.wav[(long)n * Lout + pos] = __uint_as_float(0x7fc00000u);
-  };
-  // ---- iteration "init": zero phase
-  gl_pairs<true>(buf, lane, mkv, mpv, wv);
-  finish(fa, 1u);
-  float* cur = fa;
-  float* nxt = fb;
-  for (int it = 0; it < p.iters; ++it) {
-    if (!wait_frames(-3, 3, (unsigned)(it + 1))) { poison(); return; }
-    gl_u32x2 xs[8][4];
-    gl_issue_gather<16>(cur + (long)n * T * win, T, t, hop, win, lane, xs);
-    gl_window_gathered(xs, winl, win, lane, z);
-    fft1024_wave(z, buf, tw, lane);
-    v2f* nat = buf + ((lane >> 2) + 80 * (lane & 3));          // gw_nat(k1 + 64 k2hi + 16 k2lo + 256 k3)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) nat[16 * (q >> 2) + 320 * (q & 3)] = z[q];
-    wave_lds_fence();
-    gl_pairs<false>(buf, lane, mkv, mpv, wv);
-    finish(nxt, (unsigned)(it + 2));
-    float* tmp = cur; cur = nxt; nxt = tmp;
-  }
-  // ---- overlap-add of the last iteration's frames: samples [t hop, (t+1) hop) (+ the tail for the last frame) are
-  //      covered by frames t-3 .. t only
-  if (!wait_frames(-3, 0, (unsigned)(p.iters + 1))) { poison(); return; }
-  {
-    const float* fr = cur + (long)n * T * win;
-    for (int pos = pos0 + lane; pos < pos1; pos += 64) {
-      float sum = 0.f;
-      for (int f = t; f >= 0; --f) {
-        const int off = pos - f * hop;
-        if (off >= win) break;
-        sum += __hip_atomic_load(fr + (long)f * win + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      p.wav[(long)n * Lout + pos] = sum;
-    }
-  }
-}
+// ------------------------------------------------------------------ one launch for a whole clip: measured and dropped (round 3)
+// A 10 s clip is 797 frames = 200 workgroups of four waves, 61 dependent launches of ~12 us.  A persistent form - every
+// wave keeps its frame for all iterations, the overlap-add dependency (frames t-3 .. t+3) carried across the chip
+// inside the launch - was built twice and timed with in-kernel stamps (profiles/r03_griffin_lim_trace.txt):
+//   per-frame counters behind drained write-through stores: 12.6 us per iteration (0.75 ms per call, as the 61 launches):
+//       transforms 1.5 + 2.0, pair pass 1.65, gather 1.1, frame stores + drain + counter 4.4, counter wait 1.9;
+//   frames as {iteration tag, sample} granules, the gather's loads repeated until every tag is new (no drain, no
+//       counter): 15.3 us (0.95 ms): the 8 write-through store instructions alone take 4.3 us to issue, and a gather
+//       pass is 26 MB of sc1 loads chip-wide (2.8 us, bound by the fabric; the samples are read four times over).
+// The iteration is NOT launch bound: a lone wave per SIMD spends 5.1 us in its two transforms and the pair pass with
+// nothing to hide the LDS round trips, and what crosses CUs inside a launch must bypass the L2s, which costs as much
+// as the launch boundary it replaces.  The launch-per-iteration form stays; the next step for a single clip is more
+// lanes per frame (two waves, 8 points per lane), not fewer launches.
 
 __global__ void gl_ola_kernel(GlArgs g, int Lout) {
   const ns_griffin_lim_params& p = g.p;
@@ -652,11 +541,15 @@ __global__ void gl_ola_kernel(GlArgs g, int Lout) {
     p.wav[(long)n * Lout + pos] = ola_gather(fr, p.T, p.hop, p.win, pos);
 }
 
+// n_fft 2048 with even hop / window (the shipped hparams): the wave-per-frame kernels
+static bool gl_wave_ok(const ns_griffin_lim_params* p) {
+  return p->n_fft == 2048 && (p->hop & 1) == 0 && (p->win & 1) == 0 && p->win <= 4 * p->hop && p->win <= 1024 &&
+         (((uintptr_t)p->window) & 7) == 0;
+}
 extern "C" size_t ns_griffin_lim_work_bytes(const ns_griffin_lim_params* p) {
   if (!p) return 0;
   const size_t F = p->n_fft / 2 + 1;
-  // magnitudes, two frame buffers, one counter per frame (the single-launch kernel), status word
-  return sizeof(float) * ((((size_t)p->N * p->T * F + 1) & ~(size_t)1) + 2 * (size_t)p->N * p->T * p->win + (size_t)p->N * p->T) + 256 + 32;
+  return sizeof(float) * ((((size_t)p->N * p->T * F + 1) & ~(size_t)1) + 2 * (size_t)p->N * p->T * p->win) + 256;
 }
 
 extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
@@ -682,29 +575,10 @@ extern "C" int ns_griffin_lim(const ns_griffin_lim_params* p, ns_stream_t s_) {
   }
   // n_fft 2048 with even hop / window (the shipped hparams): the wave-per-frame kernel; anything else: one workgroup
   // per frame with the transforms in LDS
-  const bool wavek = p->n_fft == 2048 && (p->hop & 1) == 0 && (p->win & 1) == 0 && p->win <= 4 * p->hop && p->win <= 1024 &&
-                     (((uintptr_t)p->window) & 7) == 0 &&
-                     (((uintptr_t)p->work) & 7) == 0;
+  const bool wavek = gl_wave_ok(p) && (((uintptr_t)p->work) & 7) == 0;
   const size_t lds_w = sizeof(float2) * (1024 + 4 * GW_PAD);
   dim3 grid(p->T, p->N), grid_w(ceil_div(p->T, 4), p->N);
   const int Lout = (p->T - 1) * p->hop + p->win;
-  // a clip (or a few) whose frames fit the chip at once: the whole call as ONE launch; NS_GL_PERSIST=0 keeps the
-  // launch-per-iteration form (A/B timing, and what the tests compare it with)
-  const char* gp_env = getenv("NS_GL_PERSIST");
-  const bool allow_persist = !(gp_env && atoi(gp_env) == 0);
-  if (wavek && allow_persist && (size_t)grid_w.x * grid_w.y <= 256 && (double)p->T * p->win * 4 < 2.0e9) {
-    static bool attrp = false;
-    if (!attrp) {
-      (void)hipFuncSetAttribute((const void*)gl_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attrp = true;
-    }
-    unsigned* flags = (unsigned*)(((uintptr_t)(fb + (size_t)p->N * p->T * p->win) + 15) & ~(uintptr_t)15);
-    int* status = (int*)(flags + (size_t)p->N * p->T);
-    { const int zrc = ns_zero_async(flags, (((size_t)p->N * p->T * 4 + 64) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
-    hipLaunchKernelGGL(gl_persist_kernel, grid_w, dim3(256), lds_w, s, g, fa, fb, flags, status, Lout);
-    NS_CHECK_LAUNCH("griffin_lim_persist");
-    return NS_OK;
-  }
   auto launch = [&]() {
     if (wavek && g.init) hipLaunchKernelGGL(gl_wave_kernel<true>, grid_w, dim3(256), lds_w, s, g);
     else if (wavek) hipLaunchKernelGGL(gl_wave_kernel<false>, grid_w, dim3(256), lds_w, s, g);

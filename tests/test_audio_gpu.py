@@ -108,26 +108,6 @@ def test_griffin_lim_at_the_benchmarked_size(audio):
     assert rel < 1e-3, rel
 
 
-def test_griffin_lim_single_launch_equals_the_launch_per_iteration_form(audio, monkeypatch):
-    """gl_persist_kernel (one launch per call: every wave keeps its frame for all iterations, frame counters carry the
-    overlap-add dependency) runs the arithmetic of gl_wave_kernel + gl_ola_kernel in the same order: equal bit for bit,
-    for one clip at the benchmarked size, a short clip (frames without all six neighbours), two clips in one call and
-    0 iterations; and it repeats."""
-    A, hp = audio
-    y = _speechlike(200000, 77)
-    big = AO.spectrogram(y, dict(HP, min_level_db=-100)).T[:797].copy()
-    cases = [(big, 60), (big[:5], 7), (big[:1], 3), (np.stack([big[:300], big[300:600]]), 4), (big[:123], 0)]
-    for spec, iters in cases:
-        monkeypatch.setenv("NS_GL_PERSIST", "0")
-        ref = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
-        monkeypatch.setenv("NS_GL_PERSIST", "1")
-        got = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
-        again = A.griffin_lim_gpu(spec, iters=iters).cpu().numpy()
-        assert np.isfinite(got).all() and np.abs(got).max() > 0
-        assert np.array_equal(got, ref), (spec.shape, iters, np.abs(got - ref).max())
-        assert np.array_equal(got, again)
-
-
 def test_private_helpers_of_the_reference_module(audio):
     """audio.py:77-171: every `_`-helper the reference's callers could reach, against the float64 oracle."""
     A, hp = audio
