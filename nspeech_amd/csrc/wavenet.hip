@@ -520,14 +520,28 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_fast_kernel(ns_wavene
 
 // ---- MFMA variant (R == Dc == 32): the residual chain of a sample on the matrix cores of ONE wavefront, the skip
 // products of the same sample on the other seven waves while the chain is still running.
-//   chain wave : z = [x[t-d] | x[t]] . W (64 x 64) as 2 k-steps x 4 column tiles of v_mfma_f32_16x16x32_bf16 with the
-//                input vector in row 0 of the A fragment (lanes 0, 16, 32, 48 hold 8 values each), gate + 1x1 dense
-//                (2 more MFMAs) per layer; operands are gathered through a 32-float LDS line; weights (transposed bf16
-//                shadows, 10 sixteen-byte loads per lane per layer) and the ring line are fetched THREE layers ahead.
-//   skip waves : wave w owns rows k = w (mod 8) of every layer's [32, S] skip kernel (wave 1 also k = 0 mod 8), a lane
+//   chain wave : the products are taken TRANSPOSED - the layer's weights are the A operand of
+//                v_mfma_f32_16x16x32_bf16 (M = 16 output channels per tile), the activation vector its B operand in
+//                column 0 (lanes 0, 16, 32, 48 hold 8 channels each) - so the result comes back in the SAME four lanes
+//                (column 0 of D: lane 16 g holds rows 4 g .. 4 g + 3 of every tile).  With the K axis of the weight
+//                shadows stored in the order k-slot (g, j) <-> channel 4 g + (j & 3) + 16 (j >> 2) (the host permutes
+//                the transposed shadows once), a lane's 8 results of the two tiles of a product ARE its 8 operand
+//                slots of the next product: z = [x[t-d] | x[t]] . W (2 k-steps x 4 tiles), gate, 1x1 dense (2 tiles)
+//                and the residual run from registers to registers - no LDS round trip in the 50-layer dependency
+//                chain (round 2 gathered the operand through an LDS line twice per layer: 1.1 us per layer); the only
+//                cross-lane moves are DPP row shifts that deal the 8 gate inputs of a lane to 8 lanes of its row and back,
+//                so the transcendental-rate gate math is issued once per layer instead of 8 times.  Weights (10 sixteen-byte loads per lane per layer) and the ring line are fetched two
+//                layers ahead; the gated outputs go to LDS for the skip waves as fire-and-forget writes.
+//   skip waves : the 32 rows of every layer's [32, S] skip kernel are dealt 5 5 5 5 4 4 4 over the seven waves, a lane
 //                owns 8 adjacent columns; they follow the chain through an LDS progress counter and keep three layers
 //                of weights in flight, so the skip sum is finished when the chain is.
 constexpr int MF_AHEAD = 2;
+// DPP moves inside a row of 16 lanes: row_shr:n = 0x110 + n (lane i takes lane i - n; a lane without a source keeps
+// `old`), row_shl:n = 0x100 + n (lane i takes lane i + n; without a source: 0)
+#define MF_DPP_KEEP(old_, src_, ctrl_) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old_)), __builtin_bit_cast(int, (float)(src_)), (ctrl_), 0xF, 0xF, false))
+#define MF_DPP_ZERO(src_, ctrl_) \
+  __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(src_)), (ctrl_), 0xF, 0xF, true))
 struct GenMf { uint4 fg[8]; uint4 de[2]; float4 r0, r1; };
 
 __device__ __forceinline__ bf16x8 mf_pack(float4 a, float4 b) {
@@ -645,14 +659,24 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
       if (tid == 0) chain_pos = 0;
       __syncthreads();
       // ================================================================ chain wave
-      float xa = 0.f, xb = 0.f;            // pair layout: lanes < 16 hold x[lane] and x[16 + lane]
-      if (lane < 16) {
+      // ring rows of this sample for every layer, one modulo per lane instead of two scalar division sequences (+ two LDS
+      // reads and their waits) per layer inside the chain: lane i holds the row of layers i and i + 64
+      const int rr0 = lane < L ? (int)qoff[lane] + t % dil[lane] : 0;
+      const int rr1 = lane + 64 < L ? (int)qoff[(lane + 64) & 127] + t % dil[(lane + 64) & 127] : 0;
+#define MF_RROW(l_) ((l_) < 64 ? __builtin_amdgcn_readlane(rr0, (l_)) : __builtin_amdgcn_readlane(rr1, (l_) - 64))
+      // lane 16 g (the only lanes that carry data; the others hold zeros throughout) keeps channels
+      // 4 g + (j & 3) + 16 (j >> 2), j < 8, of the layer input
+      float xv[8];
+      {
         const int a = ids[t - 1], c = ids[t];
         const bf16_t* w0 = wb + p.off_causal + (long)a * C, *w1 = wb + p.off_causal + ((long)Q + c) * C;
-        xa = (float)w0[lane] + (float)w1[lane];
-        xb = (float)w0[16 + lane] + (float)w1[16 + lane];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int ch = 4 * kq + (j & 3) + 16 * (j >> 2);
+          xv[j] = afl ? (float)w0[ch] + (float)w1[ch] : 0.f;
+        }
       }
-      // (macros, not lambdas over struct references: the four weight sets must stay in named registers - an address
+      // (macros, not lambdas over struct references: the weight sets must stay in named registers - an address
       // taken struct goes to scratch memory, and every scratch access drags a vmcnt(0) wait behind the prefetches)
 #define MF_LOAD(W_, l_)                                                                                                  \
   do {                                                                                                                   \
@@ -662,7 +686,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
         W_##_fg[sidx * 4 + tt] = *(const uint4*)(fgT + (((long)ll_ * 2 * C + 16 * tt + l15) * 2 * C + 32 * sidx + 8 * kq)); \
     _Pragma("unroll") for (int tt = 0; tt < 2; ++tt)                                                                      \
       W_##_de[tt] = *(const uint4*)(deT + (((long)ll_ * C + 16 * tt + l15) * C + 8 * kq));                                 \
-    const float* ring_ = queues + (qoff[ll_] + (t % dil[ll_])) * C + 8 * kq;                                              \
+    const float* ring_ = queues + (long)MF_RROW(ll_) * C + 8 * kq;                                                        \
     W_##_r0 = afl ? *(const float4*)ring_ : make_float4(0.f, 0.f, 0.f, 0.f);                                              \
     W_##_r1 = afl ? *(const float4*)(ring_ + 4) : make_float4(0.f, 0.f, 0.f, 0.f);                                        \
   } while (0)
@@ -670,43 +694,50 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
       MF_DECL(w0); MF_DECL(w1);
       MF_LOAD(w0, 0);
       if (L > 1) MF_LOAD(w1, 1);
-      const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #define MF_LAYER(l_, W_)                                                                                                 \
   do {                                                                                                                   \
     const int l = (l_);                                                                                                  \
-    if (lane < 16) { xg[lane] = xa; xg[16 + lane] = xb; }                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
-    bf16x8 a_cur = zero8, a_old = zero8;                                                                                  \
-    if (afl) {                                                                                                            \
-      a_cur = mf_pack(*(const float4*)(xg + 8 * kq), *(const float4*)(xg + 8 * kq + 4));                                   \
-      a_old = mf_pack(W_##_r0, W_##_r1);                                                                                  \
-    }                                                                                                                     \
+    const bf16x8 b_cur = mf_pack(make_float4(xv[0], xv[1], xv[2], xv[3]), make_float4(xv[4], xv[5], xv[6], xv[7]));        \
+    const bf16x8 b_old = mf_pack(W_##_r0, W_##_r1);                                                                       \
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;                                             \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[0]), acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[1]), acc1, 0, 0, 0);                            \
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[2]), acc2, 0, 0, 0);                            \
-    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_old, mf_bits(W_##_fg[3]), acc3, 0, 0, 0);                            \
-    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[4]), acc0, 0, 0, 0);                            \
-    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[5]), acc1, 0, 0, 0);                            \
-    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[6]), acc2, 0, 0, 0);                            \
-    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur, mf_bits(W_##_fg[7]), acc3, 0, 0, 0);                            \
-    /* row 0 of the result: lanes < 16, register 0 -> columns 16*tile + lane (filter 0..31 | gate 32..63) */              \
-    const float oa = tanhf_(acc0[0]) * sigmoidf_(acc2[0]);                                                                \
-    const float ob = tanhf_(acc1[0]) * sigmoidf_(acc3[0]);                                                                \
-    float* ol = outs + l * C;                                                                                             \
-    if (lane < 16) { ol[lane] = oa; ol[16 + lane] = ob; }                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[0]), b_old, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[1]), b_old, acc1, 0, 0, 0);                            \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[2]), b_old, acc2, 0, 0, 0);                            \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[3]), b_old, acc3, 0, 0, 0);                            \
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[4]), b_cur, acc0, 0, 0, 0);                            \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[5]), b_cur, acc1, 0, 0, 0);                            \
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[6]), b_cur, acc2, 0, 0, 0);                            \
+    acc3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_fg[7]), b_cur, acc3, 0, 0, 0);                            \
+    /* column 0 of the results: lane 16 g, register r = row 4 g + r of the tile (tiles: filter 0..15, 16..31, gate ..): */  \
+    /* its 8 (filter, gate) pairs are dealt to lanes 16 g + s, s < 8, of the DPP row (row_shr:s reaches exactly lane s */    \
+    /* from lane 0; a lane below s keeps what it has), so the transcendental-rate gate math runs ONCE per layer on    */    \
+    /* 32 lanes instead of 8 times on 4, and row_shl:j brings the 8 results back to lane 16 g                         */    \
+    float zf = acc0[0], zg = acc2[0];                                                                                     \
+    zf = MF_DPP_KEEP(zf, acc0[1], 0x111); zg = MF_DPP_KEEP(zg, acc2[1], 0x111);                                           \
+    zf = MF_DPP_KEEP(zf, acc0[2], 0x112); zg = MF_DPP_KEEP(zg, acc2[2], 0x112);                                           \
+    zf = MF_DPP_KEEP(zf, acc0[3], 0x113); zg = MF_DPP_KEEP(zg, acc2[3], 0x113);                                           \
+    zf = MF_DPP_KEEP(zf, acc1[0], 0x114); zg = MF_DPP_KEEP(zg, acc3[0], 0x114);                                           \
+    zf = MF_DPP_KEEP(zf, acc1[1], 0x115); zg = MF_DPP_KEEP(zg, acc3[1], 0x115);                                           \
+    zf = MF_DPP_KEEP(zf, acc1[2], 0x116); zg = MF_DPP_KEEP(zg, acc3[2], 0x116);                                           \
+    zf = MF_DPP_KEEP(zf, acc1[3], 0x117); zg = MF_DPP_KEEP(zg, acc3[3], 0x117);                                           \
+    const float og = tanhf_(zf) * sigmoidf_(zg);          /* lane 16 g + s: slot s = channel 4 g + (s & 3) + 16 (s >> 2) */ \
+    /* for the skip waves (natural channel order); LDS is in order inside a wave: the counter lands behind the data */    \
+    if (emit && l15 < 8) outs[l * C + 4 * kq + (l15 & 3) + 16 * (l15 >> 2)] = og;                                         \
     if (emit && lane == 0) *(volatile int*)&chain_pos = l + 1; /* the skip waves may take layer l */                      \
-    bf16x8 a_out = zero8;                                                                                                 \
-    if (afl) a_out = mf_pack(*(const float4*)(ol + 8 * kq), *(const float4*)(ol + 8 * kq + 4));                            \
+    float4 oa, ob;                                                                                                        \
+    oa.x = og;                       oa.y = MF_DPP_ZERO(og, 0x101); oa.z = MF_DPP_ZERO(og, 0x102); oa.w = MF_DPP_ZERO(og, 0x103); \
+    ob.x = MF_DPP_ZERO(og, 0x104); ob.y = MF_DPP_ZERO(og, 0x105); ob.z = MF_DPP_ZERO(og, 0x106); ob.w = MF_DPP_ZERO(og, 0x107); \
+    const bf16x8 b_out = mf_pack(oa, ob);                                                                                 \
     f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = d0;                                                                             \
-    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_out, mf_bits(W_##_de[0]), d0, 0, 0, 0);                                \
-    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_out, mf_bits(W_##_de[1]), d1, 0, 0, 0);                                \
-    if (lane < 16) { /* the current input replaces the one just used */                                                   \
-      float* ringw = queues + (qoff[l] + (t % dil[l])) * C;                                                               \
-      ringw[lane] = xa; ringw[16 + lane] = xb;                                                                            \
+    d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_de[0]), b_out, d0, 0, 0, 0);                                \
+    d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(mf_bits(W_##_de[1]), b_out, d1, 0, 0, 0);                                \
+    if (afl) { /* the current input replaces the one just used (in this lane's slot order) */                             \
+      float* ringw = queues + (long)MF_RROW(l) * C + 8 * kq;                                                              \
+      *(float4*)ringw = make_float4(xv[0], xv[1], xv[2], xv[3]);                                                          \
+      *(float4*)(ringw + 4) = make_float4(xv[4], xv[5], xv[6], xv[7]);                                                    \
     }                                                                                                                     \
-    xa += d0[0]; xb += d1[0];                                                                                             \
+    xv[0] += d0[0]; xv[1] += d0[1]; xv[2] += d0[2]; xv[3] += d0[3];                                                       \
+    xv[4] += d1[0]; xv[5] += d1[1]; xv[6] += d1[2]; xv[7] += d1[3];                                                       \
     if (l + MF_AHEAD < L) MF_LOAD(W_, l + MF_AHEAD);                                                                      \
   } while (0)
       for (int l4 = 0; l4 < L; l4 += MF_AHEAD) {
@@ -716,6 +747,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
 #undef MF_LAYER
 #undef MF_LOAD
 #undef MF_DECL
+#undef MF_RROW
       __syncthreads();
       if (!emit) continue;
       gen_post(t);
@@ -726,14 +758,16 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
       __syncthreads();
       if (emit) {
       // ================================================================ skip waves
-      // wave w: rows k = w (mod 8); wave 1 also k = 0 (mod 8); a lane owns columns 8*lane .. 8*lane+7
-      const int nr = wave == 1 ? 8 : 4;
+      // the 32 rows of a layer's skip kernel over the seven waves: waves 1 - 4 take 5 consecutive rows, waves 5 - 7 take 4
+      // (the slowest skip wave bounds a drawn sample once the chain runs from registers: with 8 rows on wave 1 the skip
+      // waves took 0.75 us per layer); a lane owns columns 8*lane .. 8*lane+7
+      const int nr = wave <= 4 ? 5 : 4;
+      const int row0 = wave <= 4 ? 5 * (wave - 1) : 20 + 4 * (wave - 5);
       const bool colok = 8 * lane < S;
-      // row i of this wave: wave 1 takes k = 0, 8, 16, 24, 1, 9, 17, 25; wave w > 1 takes k = w, w + 8, w + 16, w + 24
-#define SK_ROW(i_) (wave == 1 ? ((i_) < 4 ? 8 * (i_) : 8 * ((i_) - 4) + 1) : 8 * (i_) + wave)
+#define SK_ROW(i_) (row0 + (i_))
 #define SK_LOAD(W_, l_)                                                                                              \
   do {                                                                                                               \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i)                                                                     \
       W_[i] = (i < nr && colok) ? *(const uint4*)(wb + p.off_skip + ((long)(l_) * C + SK_ROW(i)) * S + 8 * lane)      \
                                 : make_uint4(0u, 0u, 0u, 0u);                                                        \
   } while (0)
@@ -746,7 +780,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
       if (++spins > (1u << 26)) break;                                                                                \
     }                                                                                                                 \
     const float* ol = outs + l * C;                                                                                   \
-    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 5; ++i) {                                                                   \
       if (i < nr) {                                                                                                   \
         const float xv = ol[SK_ROW(i)];                                                                               \
         a0 = fmaf(xv, pk_lo(W_[i].x), a0); a1 = fmaf(xv, pk_hi(W_[i].x), a1);                                         \
@@ -758,7 +792,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
     if (l + 3 < L) SK_LOAD(W_, l + 3);                                                                                \
   } while (0)
       float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f, a4 = 0.f, a5 = 0.f, a6 = 0.f, a7 = 0.f;
-      uint4 s0[8], s1[8], s2[8];
+      uint4 s0[5], s1[5], s2[5];
       SK_LOAD(s0, 0);
       if (L > 1) SK_LOAD(s1, 1);
       if (L > 2) SK_LOAD(s2, 2);

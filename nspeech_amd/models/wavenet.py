@@ -410,6 +410,12 @@ class SimpleWaveNet(object):
             fgT, deT = fg.contiguous().to(torch.bfloat16), de.contiguous().to(torch.bfloat16)
         if engine is None:          # MFMA chain + concurrent skip waves at the shipped widths, else the single-wave VALU chain
             engine = 2 if (fgT is not None and self.R == 32 and self.S <= 512) else 1
+        if engine == 2:
+            # the MFMA chain keeps the activations in fragment layout between layers: operand slot 8 g + j of a
+            # 32-wide K block holds channel 4 g + (j & 3) + 16 (j >> 2) (wavenet.hip, wn_generate_mfma_kernel)
+            perm = torch.tensor([4 * (i // 8) + (i % 4) + 16 * ((i % 8) // 4) for i in range(32)], device=dev)
+            fgT = torch.cat([fgT[:, :, :32][:, :, perm], fgT[:, :, 32:][:, :, perm]], dim=2).contiguous()
+            deT = deT[:, :, perm].contiguous()
         ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
                              probs=self.last_probs, fgT=fgT, deT=deT, engine=engine)
         self._gen_keep = (fgT, deT, un, queues, dil)        # keep the operands alive until the stream has used them
