@@ -146,6 +146,16 @@ __device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, 
 // keeps its peers polling for as long as that kernel lives, and an iteration count says nothing about how long that is.
 // The clock (s_memrealtime, 100 MHz) is read once per 1024 polls; 32 bits of it wrap after 42 s, far beyond the bound.
 constexpr unsigned NS_SPIN_TICKS = 200000000u;      // 2 s
+// Volatile accesses to LDS words that another wave of the workgroup polls / raises.  Through a GENERIC pointer a volatile
+// access compiles to flat_load / flat_store ... sc0 sc1, and its s_waitcnt vmcnt(0) also waits for every vector-memory
+// load the wave has in flight (the sweep of lstm_wide, the weight prefetches of the WaveNet chain); with the LDS address
+// space spelled out it is a ds_read / ds_write that only touches lgkmcnt.
+template <typename T> __device__ __forceinline__ T ns_lds_peek(const T* p) {
+  return *(const volatile __attribute__((address_space(3))) T*)p;
+}
+template <typename T> __device__ __forceinline__ void ns_lds_poke(T* p, T v) {
+  *(volatile __attribute__((address_space(3))) T*)p = v;
+}
 __device__ __forceinline__ bool ns_spin_timed_out(unsigned& t0) {
   const unsigned now = (unsigned)wall_clock64() | 1u;
   if (t0 == 0u) { t0 = now; return false; }

@@ -91,7 +91,7 @@ template <typename T, int NL, int LPC, int PPCH>
 __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t bytes, unsigned poff0, unsigned pstride,
                                                       unsigned off0, unsigned in_grp, unsigned per_grp, u32x4 (&v)[NL], int lane,
                                                       int* status, int* abortf, int code, long long* tslot,
-                                                      const volatile unsigned long long* pmask = nullptr, int pbit0 = 0) {
+                                                      const unsigned long long* pmask = nullptr, int pbit0 = 0) {
   constexpr int NP = (NL / LPC) * PPCH;                       // producers of this wave's K slice
   constexpr unsigned long long ALLP = NP >= 64 ? ~0ull : ((1ull << NP) - 1ull);
   constexpr unsigned ALLL = (1u << NL) - 1u;
@@ -104,7 +104,7 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
     const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, nrec, 0x00020000);
     if (ready != ALLP) {
       if (pmask) {            // a prober wave polls for the whole workgroup and keeps the producers' bits in LDS
-        ready = (pmask[pbit0 >> 6] >> (pbit0 & 63)) & ALLP;
+        ready = (ns_lds_peek(pmask + (pbit0 >> 6)) >> (pbit0 & 63)) & ALLP;      // an LDS read: does not wait for the sweep's loads
       } else {
         const u32x4 pv = __builtin_amdgcn_raw_buffer_load_b128(rs, poff, 0, 16);
         ready |= __builtin_amdgcn_ballot_w64(lane < NP && !has_sentinel<T>(pv));
@@ -130,7 +130,7 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
       done &= ~stale;
     }
     if (pmask) {              // the prober owns the time-out and the look at the status word
-      if (*(volatile int*)abortf) return 0;
+      if (ns_lds_peek(abortf)) return 0;
       if ((spins & 0xffffu) == 0 && ns_spin_timed_out(clk0)) { if (lane == 0) { atomicExch(status, code); *abortf = 1; } return 0; }
       continue;
     }
@@ -146,7 +146,7 @@ __device__ __forceinline__ unsigned sweep_progressive(const void* base, size_t b
 // producers that have published in pm[0..1] (LDS) for the sweepers.  Returns false on time-out / raised status.
 template <typename T>
 __device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsigned poff0, unsigned pstride, int np,
-                                          volatile unsigned long long* pm, int lane, int* status, int* abortf, int code) {
+                                          unsigned long long* pm, int lane, int* status, int* abortf, int code) {
   const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)((uintptr_t)base >> 32));
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
   const unsigned o0 = lane < np ? poff0 + (unsigned)lane * pstride : 0x80000000u;
@@ -160,7 +160,7 @@ __device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsign
     const u32x4 v1 = np > 64 ? __builtin_amdgcn_raw_buffer_load_b128(rs, o1, 0, 16) : (u32x4){0u, 0u, 0u, 0u};
     m0 |= __builtin_amdgcn_ballot_w64(lane < np && !has_sentinel<T>(v0));
     m1 |= __builtin_amdgcn_ballot_w64(lane + 64 < np && !has_sentinel<T>(v1));
-    if (lane == 0) { pm[0] = m0; pm[1] = m1; }
+    if (lane == 0) { ns_lds_poke(pm, m0); ns_lds_poke(pm + 1, m1); }
     if (m0 == all0 && m1 == all1) return true;
     ++spins;
     if ((spins & 255u) == 0) {
@@ -178,6 +178,7 @@ __device__ __forceinline__ bool probe_all(const void* base, size_t bytes, unsign
 // version measured 3.7 us for a sweep that succeeded at its first pass).
 // NCH = 32-wide K chunks per sweeper (H / 256); PASSES = 3: fp32 state, hi / lo weight planes; 1: bf16 everywhere
 constexpr bool FWD_PROBER = false;          // measured: 5.25 us per step with a prober wave, 5.04 with the sweepers' own probes
+                                            // (round 3, the mask polled as a plain LDS read instead of a flat load: 5.2 against 5.08)
 constexpr int WTF = WT + 128 + (FWD_PROBER ? 64 : 0);
 template <typename T, int PASSES, int NCH>
 __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
