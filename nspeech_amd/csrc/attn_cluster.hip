@@ -76,17 +76,22 @@ __device__ __forceinline__ void stamp(const ACArgs& a, int st, int k) {
 // through global memory is either tag-polled (the exchanges) or read by later kernels.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void put_granule(u64* g, unsigned tag, float v) {
+__device__ __forceinline__ void put_granule(u64* g_, unsigned tag, float v) {
+  NS_GLOBAL u64* g = (NS_GLOBAL u64*)g_;
   __hip_atomic_store(g, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Every thread waits for its own granules (PER per thread, stride CT) and drops the values into LDS.
+// Returns false when this thread gave up (a peer raised the status word, or the wall-clock bound passed): the caller
+// raises the workgroup's LDS abort word then - no thread reads the status word from memory on the step's critical path
+// (round 2 had thread 0 load it behind every gather: one more memory round trip in front of the barrier, 2 per step).
 template <int PER>
-__device__ __forceinline__ void gather_granules(const u64* src, int total, unsigned tag, float* dst, int tid,
+__device__ __forceinline__ bool gather_granules(const u64* src_, int total, unsigned tag, float* dst, int tid,
                                                 int* status, int code) {
+  const NS_GLOBAL u64* src = (const NS_GLOBAL u64*)src_;      // global_load, not flat_load: the poll leaves lgkmcnt alone
   u64 v[PER];
   unsigned spins = 0, clk0 = 0;
-  bool ok;
+  bool ok, gave_up = false;
   do {
     ok = true;
 #pragma unroll
@@ -98,8 +103,8 @@ __device__ __forceinline__ void gather_granules(const u64* src, int total, unsig
     for (int j = 0; j < PER; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
     if (!ok) {
       if ((++spins & 1023u) == 0) {        // every 1024 polls: has a peer given up, or is the wall-clock bound passed
-        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = true;
-        else if (ns_spin_timed_out(clk0)) { atomicExch(status, code); ok = true; }
+        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = gave_up = true;
+        else if (ns_spin_timed_out(clk0)) { atomicExch(status, code); ok = gave_up = true; }
       }
     }
   } while (!ok);
@@ -108,6 +113,7 @@ __device__ __forceinline__ void gather_granules(const u64* src, int total, unsig
     const int i = tid + j * CT;
     if (i < total) dst[i] = __uint_as_float((unsigned)v[j]);
   }
+  return !gave_up;
 }
 
 template <typename T> __device__ __forceinline__ float ldw(const T* p, long i) { return ldf(p + i); }
@@ -187,7 +193,8 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
   const int half = (p.kw - 1) / 2;
   u64* x2 = a.x2 + (size_t)n * CG * X2N;
   u64* x3 = a.x3 + (size_t)n * CG * X3N;
-  if (INFER && tid_ == 0) sc[3] = 0.f;                    // set when the frame-feedback poll gave up
+  if (tid_ == 0) { sc[2] = 0.f; sc[3] = 0.f; }            // [2] set by a thread whose gather gave up, [3] by the frame-feedback poll
+                                                          // (both in front of the __syncthreads() below)
 
   // ---------------------------------------------------------------- resident weights (registers)
   const T* W2 = (const T*)p.w2;            // [D1][D2]
@@ -315,8 +322,7 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
     }
     stamp(a, st, 3);
     // ---- (4) gather X2: q = sum of the partials (fixed order), h of every unit
-    gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1);
-    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    if (!gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
     if (sc[2] != 0.f) return;                 // uniform: every thread reads the same LDS word
     stamp(a, st, 4);
@@ -403,8 +409,7 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
     }
     stamp(a, st, 8);
     // ---- (7) gather X3, combine
-    gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2);
-    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    if (!gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, st, 9);
@@ -704,7 +709,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     }
     // ---- exchange 1 has been under way all along: the dot product, then the energy gradients
     if (wave == 7) {
-      gather_granules<1>(e1, CG, tag, gath, lane < CG ? lane : CG, a.status, 5);      // lanes >= CG read nothing
+      if (!gather_granules<1>(e1, CG, tag, gath, lane < CG ? lane : CG, a.status, 5)) sc[2] = 1.f;      // lanes >= CG read nothing
       float d = lane < CG ? gath[lane] : 0.f;
       d = wave_sum(d);
       if (lane == 0) sc[0] = d;
@@ -751,8 +756,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     }
     stamp(a, p.S - 1 - st, 4);
     // ---- gather E2: dq = sum of the partials
-    gather_granules<(CG * A + CT - 1) / CT>(e2, CG * A, tag, gath, tid, a.status, 3);
-    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    if (!gather_granules<(CG * A + CT - 1) / CT>(e2, CG * A, tag, gath, tid, a.status, 3)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, p.S - 1 - st, 5);
@@ -818,8 +822,7 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     }
     if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, ccv);
     stamp(a, p.S - 1 - st, 7);
-    gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4);
-    if (tid == 0) sc[2] = __hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1.f : 0.f;
+    if (!gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
     if (sc[2] != 0.f) return;
     stamp(a, p.S - 1 - st, 8);

@@ -150,6 +150,8 @@ constexpr unsigned NS_SPIN_TICKS = 200000000u;      // 2 s
 // access compiles to flat_load / flat_store ... sc0 sc1, and its s_waitcnt vmcnt(0) also waits for every vector-memory
 // load the wave has in flight (the sweep of lstm_wide, the weight prefetches of the WaveNet chain); with the LDS address
 // space spelled out it is a ds_read / ds_write that only touches lgkmcnt.
+#define NS_GLOBAL __attribute__((address_space(1)))      // a pointer known to be global memory (pointers out of by-value
+                                                        // argument structs are generic: flat_load / flat_store)
 template <typename T> __device__ __forceinline__ T ns_lds_peek(const T* p) {
   return *(const volatile __attribute__((address_space(3))) T*)p;
 }
