@@ -686,36 +686,46 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       if (lane == 0) put_granule(e1 + g, tag, d);
     }
     stamp(a, p.S - 1 - st, 2);
-    // ---- P3: energy pass in the A-operand layout of v_mfma_f32_16x16x4_f32: row = position, k = unit.  Needs no dot
-    //      product yet: g1 = v (1 - tanh^2) stays in registers, Z = g1 . Wcl^T comes out of the matrix core
-    float g1v[16];
+    // ---- P3: energy pass.  x^T[u][t] = (keys[t][u] + q[u]) + sum_k Wcl[k][u] align[t + k - half] is taken on the matrix
+    //      core TRANSPOSED (A = the folded filter: row = unit, k = tap; B = the alignment window: col = position; C = keys
+    //      + q as one 16-byte LDS read each), so a lane holds 4 UNITS of one position - exactly the B operand of the next
+    //      product Z^T[k][t] = sum_u Wcl[k][u] g1[t][u] when its k-steps are taken as the unit sets {4 g4 + q}: g1 =
+    //      v (1 - tanh^2) goes from the accumulators of the first product straight into the second (round 2 formed x
+    //      with 128 FMAs per lane from 112 scalar LDS reads: 2.5 us per step for this block).  Needs no dot product yet.
+    float g1v[16];                           // [unit tile][position tile][q]: position 16 rt + c, unit ub + 16 ut + 4 g4 + q
     const int r = lane & 15, kq = lane >> 4;
     if (wave < A / 32) {
-      f32x4 acc[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-      float ap0[KWMAX], ap1[KWMAX];
+      const int ub = wave * 32;
+      f32x4 accz[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // Z^T: rows = taps 4 kq + q', col = position r
 #pragma unroll
-      for (int k = 0; k < KWMAX; ++k) { ap0[k] = al[APAD + t0 + r - half + k]; ap1[k] = al[APAD + t0 + r + 16 - half + k]; }
+      for (int ut = 0; ut < 2; ++ut) {
+        const int u4 = ub + ut * 16 + 4 * kq;
+        const f32x4 q4 = *(const f32x4*)(qs + u4), v4 = *(const f32x4*)(cst_s + KWMAX * (A + KPAD) + u4);
+        const float wa0 = cst_s[kq * (A + KPAD) + ub + ut * 16 + r], wa1 = cst_s[(4 + kq) * (A + KPAD) + ub + ut * 16 + r];
+        f32x4 wz = {0.f, 0.f, 0.f, 0.f};                                  // Wcl[tap r][units u4 .. u4 + 3]; rows past kw are zero
+        if (r < KWMAX) wz = *(const f32x4*)(cst_s + r * (A + KPAD) + u4);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int u = wave * 32 + j * 4 + kq;
-        const float qv = qs[u], vv = cst_s[KWMAX * (A + KPAD) + u];
-        float x0 = keys_s[r * (A + KPAD) + u] + qv, x1 = keys_s[(r + 16) * (A + KPAD) + u] + qv;
+        for (int rt = 0; rt < 2; ++rt) {
+          const f32x4 k4 = *(const f32x4*)(keys_s + (rt * 16 + r) * (A + KPAD) + u4);
+          f32x4 acc = {k4[0] + q4[0], k4[1] + q4[1], k4[2] + q4[2], k4[3] + q4[3]};
+          const float* aw = al + APAD + t0 + rt * 16 + r - half + kq;
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0, aw[0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1, aw[4], acc, 0, 0, 0);
+          const bool live = rt * 16 + r < tn;
 #pragma unroll
-        for (int k = 0; k < KWMAX; ++k) { const float w = cst_s[k * (A + KPAD) + u]; x0 = fmaf(ap0[k], w, x0); x1 = fmaf(ap1[k], w, x1); }
-        const float th0 = tanhf_(x0), th1 = tanhf_(x1);
-        g1v[2 * j] = r < tn ? vv * (1.f - th0 * th0) : 0.f;
-        g1v[2 * j + 1] = r + 16 < tn ? vv * (1.f - th1 * th1) : 0.f;
-        const float b = r < KWMAX ? cst_s[r * (A + KPAD) + u] : 0.f;          // Wcl[k = r][u]; rows past kw are zero
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j], b, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(g1v[2 * j + 1], b, acc[1], 0, 0, 0);
-        if ((j & 3) == 3) asm volatile("" ::: "memory");
+          for (int q = 0; q < 4; ++q) {
+            const float th = tanhf_(acc[q]);
+            const float gq = live ? v4[q] * (1.f - th * th) : 0.f;
+            g1v[ut * 8 + rt * 4 + q] = gq;
+            accz[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[q], gq, accz[rt], 0, 0, 0);
+          }
+        }
       }
-      // D: col = lane & 15 (filter tap), row = (lane >> 4) * 4 + reg (position inside the 16-row tile)
-      if (r < 8) {
+      if (kq < 2) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + mt * 16 + kq * 4 + q) * 8 + r] = acc[mt][q];
+          for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + rt * 16 + r) * 8 + 4 * kq + q] = accz[rt][q];
       }
     }
     // ---- exchange 1 has been under way all along: the dot product, then the energy gradients
@@ -741,10 +751,10 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
     if (wave < A / 32) {
       const float de0 = dev[r], de1 = dev[r + 16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) g1v[j] = row16_sum(fmaf(de0, g1v[2 * j], de1 * g1v[2 * j + 1]));
-      if (r == 0) {
+      for (int j = 0; j < 8; ++j) g1v[j] = row16_sum(fmaf(de0, g1v[(j >> 2) * 8 + (j & 3)], de1 * g1v[(j >> 2) * 8 + 4 + (j & 3)]));
+      if (r == 0) {        // j = 4 ut + q: unit ub + 16 ut + 4 kq + q
 #pragma unroll
-        for (int j = 0; j < 8; ++j) put_granule(e2 + (size_t)g * A + wave * 32 + j * 4 + kq, tag, g1v[j]);
+        for (int j = 0; j < 8; ++j) put_granule(e2 + (size_t)g * A + wave * 32 + (j >> 2) * 16 + 4 * kq + (j & 3), tag, g1v[j]);
       }
     }
     if (tid < TSMAX * 8) {
