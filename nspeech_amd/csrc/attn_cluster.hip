@@ -210,15 +210,21 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
   }
   const int gc = tid % GC, gq0 = tid / GC;
   const int gcol = (gc / UPW) * A + g * UPW + (gc % UPW);          // column of the [.., 4A] kernel
-  float wgr[GK];
+  // every k group takes a share of the prenet rows AND a share of the h rows: the h half of next step's gates is formed in
+  // the shadow of exchange 3 (h(s) is final since exchange 2), so only D2 / GG FMAs per thread sit on the step's chain
+  constexpr int GKP = D2 / GG, GKH = A / GG;
+  static_assert(D2 % GG == 0 && A % GG == 0 && GKP + GKH == GK, "gate row split");
+  float wgp[GKP], wgh[GKH];
   {
     // rows behind the prenet part skip the speaker rows (their product is folded into the bias)
-    const int k0 = gq0 * GK;
-    const T* blo = Watt + (long)k0 * 4 * A + gcol;
-    const T* bhi = blo + (long)Dsp * 4 * A;
+    const T* bp = Watt + (long)(gq0 * GKP) * 4 * A + gcol;
+    const T* bh = Watt + (long)(D2 + Dsp + gq0 * GKH) * 4 * A + gcol;
 #pragma unroll
-    for (int i = 0; i < GK; ++i) wgr[i] = ldf((k0 + i < D2 ? blo : bhi) + i * 4 * A);
+    for (int i = 0; i < GKP; ++i) wgp[i] = ldf(bp + i * 4 * A);
+#pragma unroll
+    for (int i = 0; i < GKH; ++i) wgh[i] = ldf(bh + i * 4 * A);
   }
+  float hpart = 0.f;                         // h(s-1) . W[h rows of this group]: h(-1) = 0
   // W_query rows of this workgroup's units and the per-unit constants of the energy pass live in LDS (the register
   // file is taken by the two big weight slices): wq_s[UPW][A], cst_s[KWMAX + 1][A] = folded location filter | v
   for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
@@ -286,7 +292,7 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
     stamp(a, st, 1);
     // ---- (2) gates of this workgroup's units, cell update
     float sv[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    red[tid] = dot_regs<GK>(wgr, xs + gq * GK);
+    red[tid] = hpart + dot_regs<GKP>(wgp, xs + gq * GKP);
     lds_barrier();
     if (tid < UPW) {
       float z[4];
@@ -321,6 +327,28 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
       put_granule(x2 + (size_t)g * X2N + tid, tag, s);
     }
     stamp(a, st, 3);
+    // ---- (5a) in the shadow of exchange 2: the part of the energies that does not need the query.  The location term
+    //      loc[t][u] = sum_k align[t + k - half] w[k][u] is a matrix product with K = 8 taps: two k-steps of
+    //      v_mfma_f32_16x16x4_f32 (exact fp32) per 16 positions x 16 units, accumulated onto C = keys[t][u].  A = the
+    //      alignment window (row = position), B = the folded filter, D: lane = unit, registers = 4 positions.
+    f32x4 eacc[2][2];                        // [unit tile][position tile]
+    if (wave < A / 32) {
+      const int c = lane & 15, g4 = lane >> 4;
+#pragma unroll
+      for (int ut = 0; ut < 2; ++ut) {
+        const int u = wave * 32 + ut * 16 + c;
+        const float w0 = cst_s[g4 * (A + KPAD) + u], w1 = cst_s[(4 + g4) * (A + KPAD) + u];       // B[k = g4 (+ 4)][col = u]
+#pragma unroll
+        for (int rt = 0; rt < 2; ++rt) {
+          f32x4 acc;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[q] = keys_s[(rt * 16 + g4 * 4 + q) * (A + KPAD) + u];
+          const float* aw = al + APAD + t0 + rt * 16 + c - half + g4;                               // A[row = c][k = g4 (+ 4)]
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[0], w0, acc, 0, 0, 0);
+          eacc[ut][rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[4], w1, acc, 0, 0, 0);
+        }
+      }
+    }
     // ---- (4) gather X2: q = sum of the partials (fixed order), h of every unit
     if (!gather_granules<(CG * X2N + CT - 1) / CT>(x2, CG * X2N, tag, gath, tid, a.status, 1)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
@@ -346,33 +374,21 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
     }
     lds_barrier();
     stamp(a, st, 5);
-    // ---- (5) energies of the own positions.  The location term loc[t][u] = sum_k align[t + k - half] w[k][u] is itself a
-    //      matrix product with K = 8 taps: two k-steps of v_mfma_f32_16x16x4_f32 (exact fp32) per 16 positions x 16 units,
-    //      accumulated onto C = keys[t][u] + q[u].  A = the alignment window (row = position, one LDS read per k-step),
-    //      B = the folded filter (constants of the lane: 4 registers), so per step a lane reads 16 keys + 2 query values
-    //      + 4 alignment values from LDS where the scalar form read 112 values and issued 128 FMAs; tanh, the product
-    //      with attention_v and the sum over the wave's 32 units (a DPP row reduction over the 16 unit lanes) follow in
-    //      the D layout (lane = unit, registers = 4 positions).  Round 2 measured 2.0 us per step for this block.
+    // ---- (5b) energies of the own positions: x = (keys + location term, formed in the shadow of exchange 2) + q; tanh,
+    //      the product with attention_v and the sum over the wave's 32 units (a DPP row reduction over the 16 unit
+    //      lanes) in the D layout.  Round 2 formed x with 128 FMAs per lane out of 112 scalar LDS reads behind the
+    //      exchange: 2.0 us per step for this block; with the location term on the matrix core 1.3; see the trace.
     if (wave < A / 32) {
       const int c = lane & 15, g4 = lane >> 4;
-      const int ub = wave * 32;
       float part[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
       for (int ut = 0; ut < 2; ++ut) {
-        const int u = ub + ut * 16 + c;
+        const int u = wave * 32 + ut * 16 + c;
         const float qv = qs[u], vv = cst_s[KWMAX * (A + KPAD) + u];
-        const float w0 = cst_s[g4 * (A + KPAD) + u], w1 = cst_s[(4 + g4) * (A + KPAD) + u];       // B[k = g4 (+ 4)][col = u]
 #pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          f32x4 acc;
+        for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
-          for (int q = 0; q < 4; ++q) acc[q] = keys_s[(rt * 16 + g4 * 4 + q) * (A + KPAD) + u] + qv;
-          const float* aw = al + APAD + t0 + rt * 16 + c - half + g4;                               // A[row = c][k = g4 (+ 4)]
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[0], w0, acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[4], w1, acc, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) part[rt][q] = fmaf(vv, tanhf_(acc[q]), part[rt][q]);
-        }
+          for (int q = 0; q < 4; ++q) part[rt][q] = fmaf(vv, tanhf_(eacc[ut][rt][q] + qv), part[rt][q]);
       }
 #pragma unroll
       for (int rt = 0; rt < 2; ++rt)
@@ -419,6 +435,8 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
       put_granule(x3 + (size_t)g * X3N + tid, tag, es[tid - D1 - 2]);
     }
     stamp(a, st, 8);
+    // ---- in the shadow of exchange 3: the h half of the NEXT step's gates (xs[D2 ..] = h(s) since (4))
+    hpart = dot_regs<GKH>(wgh, xs + D2 + gq * GKH);
     // ---- (7) gather X3, combine
     if (!gather_granules<(CG * X3N + CT - 1) / CT>(x3, CG * X3N, tag, gath, tid, a.status, 2)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
