@@ -660,6 +660,51 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
   store_history((p.S - 1) & 1, tid_);
   float o_dhc = h_dhc, o_c = h_c, o_cp = h_cp;              // the cell owners' operands of the current step
   __syncthreads();
+  // The energy pass of a step needs only that step's HISTORY (query, previous alignment) - nothing of the backward
+  // chain - so it runs one step ahead, in the shadow of exchange 3 of the step before (its history images are in LDS
+  // since the middle of that step); g1 stays in registers until P4 of its step, Z^T waits in zred.
+  float g1v[16];                             // [unit tile][position tile][q]: position 16 rt + c, unit ub + 16 ut + 4 g4 + q
+  auto energy_pass = [&](const float* qs, const float* al, int lane, int wave) {
+    const int r = lane & 15, kq = lane >> 4;
+    if (wave < A / 32) {
+    const int ub = wave * 32;
+    f32x4 accz[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // Z^T: rows = taps 4 kq + q', col = position r
+#pragma unroll
+    for (int ut = 0; ut < 2; ++ut) {
+      const int u4 = ub + ut * 16 + 4 * kq;
+      const f32x4 q4 = *(const f32x4*)(qs + u4), v4 = *(const f32x4*)(cst_s + KWMAX * (A + KPAD) + u4);
+      const float wa0 = cst_s[kq * (A + KPAD) + ub + ut * 16 + r], wa1 = cst_s[(4 + kq) * (A + KPAD) + ub + ut * 16 + r];
+      f32x4 wz = {0.f, 0.f, 0.f, 0.f};                                  // Wcl[tap r][units u4 .. u4 + 3]; rows past kw are zero
+      if (r < KWMAX) wz = *(const f32x4*)(cst_s + r * (A + KPAD) + u4);
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const f32x4 k4 = *(const f32x4*)(keys_s + (rt * 16 + r) * (A + KPAD) + u4);
+        f32x4 acc = {k4[0] + q4[0], k4[1] + q4[1], k4[2] + q4[2], k4[3] + q4[3]};
+        const float* aw = al + APAD + t0 + rt * 16 + r - half + kq;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0, aw[0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1, aw[4], acc, 0, 0, 0);
+        const bool live = rt * 16 + r < tn;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float th = tanhf_(acc[q]);
+          const float gq = live ? v4[q] * (1.f - th * th) : 0.f;
+          g1v[ut * 8 + rt * 4 + q] = gq;
+          accz[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[q], gq, accz[rt], 0, 0, 0);
+        }
+      }
+    }
+    if (kq < 2) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + rt * 16 + r) * 8 + 4 * kq + q] = accz[rt][q];
+    }
+  }
+  };
+  {
+    const int par0 = (p.S - 1) & 1;
+    energy_pass(par0 ? qs1 : qs0, par0 ? al1 : al0, tid_ & 63, tid_ >> 6);      // the first step's own pass
+  }
 
   for (int st = p.S - 1; st >= 0; --st) {
     const long slot = st + 1;
@@ -704,48 +749,13 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       if (lane == 0) put_granule(e1 + g, tag, d);
     }
     stamp(a, p.S - 1 - st, 2);
-    // ---- P3: energy pass.  x^T[u][t] = (keys[t][u] + q[u]) + sum_k Wcl[k][u] align[t + k - half] is taken on the matrix
+    // ---- P3 (runs one step AHEAD, see energy_pass above): energy pass.  x^T[u][t] = (keys[t][u] + q[u]) + sum_k Wcl[k][u] align[t + k - half] is taken on the matrix
     //      core TRANSPOSED (A = the folded filter: row = unit, k = tap; B = the alignment window: col = position; C = keys
     //      + q as one 16-byte LDS read each), so a lane holds 4 UNITS of one position - exactly the B operand of the next
     //      product Z^T[k][t] = sum_u Wcl[k][u] g1[t][u] when its k-steps are taken as the unit sets {4 g4 + q}: g1 =
     //      v (1 - tanh^2) goes from the accumulators of the first product straight into the second (round 2 formed x
     //      with 128 FMAs per lane from 112 scalar LDS reads: 2.5 us per step for this block).  Needs no dot product yet.
-    float g1v[16];                           // [unit tile][position tile][q]: position 16 rt + c, unit ub + 16 ut + 4 g4 + q
     const int r = lane & 15, kq = lane >> 4;
-    if (wave < A / 32) {
-      const int ub = wave * 32;
-      f32x4 accz[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};     // Z^T: rows = taps 4 kq + q', col = position r
-#pragma unroll
-      for (int ut = 0; ut < 2; ++ut) {
-        const int u4 = ub + ut * 16 + 4 * kq;
-        const f32x4 q4 = *(const f32x4*)(qs + u4), v4 = *(const f32x4*)(cst_s + KWMAX * (A + KPAD) + u4);
-        const float wa0 = cst_s[kq * (A + KPAD) + ub + ut * 16 + r], wa1 = cst_s[(4 + kq) * (A + KPAD) + ub + ut * 16 + r];
-        f32x4 wz = {0.f, 0.f, 0.f, 0.f};                                  // Wcl[tap r][units u4 .. u4 + 3]; rows past kw are zero
-        if (r < KWMAX) wz = *(const f32x4*)(cst_s + r * (A + KPAD) + u4);
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          const f32x4 k4 = *(const f32x4*)(keys_s + (rt * 16 + r) * (A + KPAD) + u4);
-          f32x4 acc = {k4[0] + q4[0], k4[1] + q4[1], k4[2] + q4[2], k4[3] + q4[3]};
-          const float* aw = al + APAD + t0 + rt * 16 + r - half + kq;
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa0, aw[0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa1, aw[4], acc, 0, 0, 0);
-          const bool live = rt * 16 + r < tn;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const float th = tanhf_(acc[q]);
-            const float gq = live ? v4[q] * (1.f - th * th) : 0.f;
-            g1v[ut * 8 + rt * 4 + q] = gq;
-            accz[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wz[q], gq, accz[rt], 0, 0, 0);
-          }
-        }
-      }
-      if (kq < 2) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) zred[(wave * TSMAX + rt * 16 + r) * 8 + 4 * kq + q] = accz[rt][q];
-      }
-    }
     // ---- exchange 1 has been under way all along: the dot product, then the energy gradients
     if (wave == 7) {
       if (!gather_granules<1>(e1, CG, tag, gath, lane < CG ? lane : CG, a.status, 5)) sc[2] = 1.f;      // lanes >= CG read nothing
@@ -860,6 +870,8 @@ __global__ __launch_bounds__(CT) void attn_cluster_bwd_kernel(ACArgs a) {
       put_granule(e3 + (size_t)g * E3N + tid, tag, s);
     }
     if (tid < CCN) put_granule(e3 + (size_t)g * E3N + K + tid, tag, ccv);
+    // in the shadow of exchange 3: the energy pass of step s-1 (history images of parity par ^ 1, filled behind E2)
+    if (st > 0) energy_pass(par ? qs0 : qs1, par ? al0 : al1, lane, wave);
     stamp(a, p.S - 1 - st, 7);
     if (!gather_granules<(CG * E3N + CT - 1) / CT>(e3, CG * E3N, tag, gath, tid, a.status, 4)) sc[2] = 1.f;        // the abort word: zero since the kernel's start
     lds_barrier();
