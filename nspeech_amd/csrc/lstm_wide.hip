@@ -500,6 +500,247 @@ __global__ __launch_bounds__(WTB) void lstm_wide_bwd_kernel(WideArgs a) {
   }
 }
 
+// ===================================================================================== backward, partial sums (round 3)
+// The backward kernel above gathers, per workgroup and step, ALL 4H gate gradients of its 8 rows (64 KB at H = 1024)
+// behind a probe: two dependent memory round trips, 5.9 us per step.  dh[t-1] = dgates[t] . Wh^T is a sum over the gate
+// columns, and a workgroup OWNS 64 of them (4 gates x its 16 units): as in lstm_cluster2p_bwd_kernel it forms, from its
+// own gate gradients alone and straight after the cell update, its partial sum for EVERY unit of the layer - P[8, H] =
+// dg_own[8, 64] . Wh[:, own columns]^T, H / 16 MFMA tiles of K = 64 - and sends each peer only the 8 x 16 block of that
+// peer's units, as {step tag, 2 x bf16} granules (two rows of one unit): 64 granules per (destination, source), the data
+// is its own flag - no probe, no second round trip, and half the bytes (32 KB in and out per workgroup and step).
+// The receiver adds the blocks in a fixed order (own block fp32 first, then sources in the polling order below).
+//   8 product waves  : resident Wh[units of their H/128 destination tiles][own 64 columns] (64 VGPRs per lane at
+//                      H = 1024); per step: poll the granules of 1/8 of the sources (lane = one (unit, row pair) item),
+//                      sum them, LDS -> barrier A -> (cell waves) -> barrier B -> MFMA over the operand image ->
+//                      publish (the own tile goes to LDS as fp32)
+//   2 cell waves     : thread = (row, unit); behind barrier A add the eight partial sums, own block and dh_out, update
+//                      the cell, write the bf16 operand image, barrier B; then the stores only later kernels read and
+//                      the next step's operand loads.
+// Exchange buffer (work): [row group][step parity][destination][source][64 items] of 8 bytes, zeroed per launch.
+constexpr int PSW = 8;                       // product waves
+constexpr int PST = PSW * 64 + 128;          // + two cell waves
+typedef unsigned long long ps_u64;
+// orders LDS only: __syncthreads() would also drain the vector-memory queue (the publish stores' acknowledgements)
+__device__ __forceinline__ void ps_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// UPB = units per workgroup (16 or 32).  What a step costs is the write-through traffic: every (row, destination unit)
+// gets one partial sum from every SOURCE block, rows x H x (H / UPB) values per step chip-wide - 8 MB of granules at
+// UPB = 16, and the fabric takes write-through stores at ~3.3 TB/s (2.4 us per step just to issue them, measured); 32-unit
+// blocks halve the sources and with them every byte written and polled (the resident weights double: Wh[H units][own
+// 128 columns] = 256 KB per workgroup, three quarters in registers, the last k-step in LDS), on half the workgroups.
+template <typename T, int NT, int UPB>       // NT = destination tiles per product wave = H / 128
+__global__ __launch_bounds__(PST) void lstm_wide_bwd_ps_kernel(WideArgs a, ps_u64* xbuf) {
+  constexpr int TB = UPB / 16;               // 16-unit tiles per block
+  constexpr int KO = 4 * UPB, KS = KO / 32;  // own gate columns, k-steps of the product
+  constexpr int ITEMS = UPB * 4;             // (unit, row pair) items per (destination, source) block
+  constexpr int IPL = ITEMS / 64;            // items per polling lane
+  constexpr int LDW = KO + 8;                // bf16 per row of the operand image
+  constexpr int KSR = UPB == 32 ? KS - 1 : KS;          // k-steps of the weights kept in registers (the rest: LDS)
+  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+  bf16_t* dgi = (bf16_t*)ps_smem;                               // [16][LDW], rows 8 .. 15 stay zero
+  float* red = (float*)(dgi + 16 * LDW);                        // [PSW][ITEMS][2]
+  float* ownp = red + PSW * ITEMS * 2;                          // [ITEMS][2]
+  int* abortf = (int*)(ownp + ITEMS * 2);                       // [4]
+  bf16x8* wl = (bf16x8*)(abortf + 4);                           // [PSW * NT tiles][64 lanes] the last k-step's fragments (UPB = 32)
+  const ns_lstm_seq_params& p = a.p;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, K = 4 * H, NUB = H / UPB;
+  const int rg = blockIdx.x / NUB, ub = blockIdx.x % NUB;
+  const int n0 = rg * 8, u0 = ub * UPB;
+  ps_u64* xb0 = xbuf + (size_t)rg * 2 * NUB * NUB * ITEMS;
+  if (tid == 0) abortf[0] = 0;
+  for (int i = tid; i < 16 * LDW; i += PST) dgi[i] = (bf16_t)0.f;
+  for (int i = tid; i < ITEMS * 2; i += PST) ownp[i] = 0.f;
+  for (int i = tid; i < PSW * ITEMS * 2; i += PST) red[i] = 0.f;
+
+  if (wave < PSW) {
+    // ------------------------------------------------------------------ product / polling waves
+    const int r16 = lane & 15, g = lane >> 4;
+    const bf16_t* W = sizeof(T) == 2 ? (const bf16_t*)p.wh : (const bf16_t*)p.wh_bf16;
+    // B fragments: tile j -> destination units (wave * NT + j) * 16 ..; lane (n = r16, k chunk g): own column k = 32 ks +
+    // 8 g + e -> gate k / UPB, own unit k % UPB (8 consecutive units: one 16-byte load)
+    bf16x8 bw[NT][KSR];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 32 * ks + 8 * g;
+        const bf16x8 w = *(const bf16x8*)(W + (long)((wave * NT + j) * 16 + r16) * K + (long)(k / UPB) * H + u0 + (k % UPB));
+        if (ks < KSR) bw[j][ks] = w;
+        else wl[(wave * NT + j) * 64 + lane] = w;
+      }
+    __syncthreads();
+    for (int bs = 0; bs < p.T; ++bs) {
+      // ---- the peers' blocks of the step before: lane = items lane, lane + 64 ..; sources wave + 8 j (fixed order)
+      float s0[IPL], s1[IPL];
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+      wstamp(a, bs, 0);
+      unsigned passes = 0;
+      if (bs > 0) {
+        const ps_u64* cur = xb0 + ((size_t)(bs & 1) * NUB + ub) * NUB * ITEMS + lane;
+        constexpr int NSRC = NT * 16 / UPB;            // sources per wave = NUB / PSW
+        ps_u64 v[NSRC][IPL];
+        unsigned spins = 0, clk0 = 0;
+        bool ok;
+        do {
+          ok = true;
+#pragma unroll
+          for (int j = 0; j < NSRC; ++j) {
+            const int src = wave + PSW * j;
+#pragma unroll
+            for (int i = 0; i < IPL; ++i)
+              v[j][i] = src == ub ? ((ps_u64)(unsigned)bs << 32)
+                                  : __hip_atomic_load((const NS_GLOBAL ps_u64*)(cur + (size_t)src * ITEMS + 64 * i), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT);
+          }
+#pragma unroll
+          for (int j = 0; j < NSRC; ++j)
+#pragma unroll
+            for (int i = 0; i < IPL; ++i) ok = ok && ((unsigned)(v[j][i] >> 32) == (unsigned)bs);
+          if (!ok && (++spins & 1023u) == 0) {   /* spins = polling passes beyond the first */
+            if (__hip_atomic_load(a.status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { ns_lds_poke(abortf, 1); ok = true; }
+            else if (ns_spin_timed_out(clk0)) { atomicExch(a.status, 2); ns_lds_poke(abortf, 1); ok = true; }
+          }
+        } while (!ok);
+        passes = spins;
+#pragma unroll
+        for (int j = 0; j < NSRC; ++j)
+#pragma unroll
+          for (int i = 0; i < IPL; ++i) {
+            const unsigned pay = (unsigned)v[j][i];
+            s0[i] += __uint_as_float(pay << 16);
+            s1[i] += __uint_as_float(pay & 0xffff0000u);
+          }
+      }
+      wstamp(a, bs, 1);
+      if (a.trace && blockIdx.x == 0 && tid == 0 && bs < 256) a.trace[bs * 8 + 5] = passes;
+#pragma unroll
+      for (int i = 0; i < IPL; ++i) {
+        red[((wave * ITEMS) + lane + 64 * i) * 2] = s0[i];
+        red[((wave * ITEMS) + lane + 64 * i) * 2 + 1] = s1[i];
+      }
+      ps_barrier();                          // A: the partial sums are in LDS
+      wstamp(a, bs, 2);
+      if (abortf[0]) return;
+      ps_barrier();                          // B: the operand image of this step is complete
+      wstamp(a, bs, 3);
+      if (bs + 1 < p.T) {
+        bf16x8 af[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = *(const bf16x8*)(dgi + r16 * LDW + 32 * ks + 8 * g);
+        ps_u64* nxt = xb0 + (size_t)((bs + 1) & 1) * NUB * NUB * ITEMS;
+        // four tiles at a time, k-step outermost: four independent accumulator chains keep the matrix pipe issuing
+        // (one tile after the other is a chain of KS dependent MFMAs each), and the first group's stores go out under
+        // the second group's products
+        constexpr int TG = NT < 4 ? NT : 4;
+#pragma unroll
+        for (int j0 = 0; j0 < NT; j0 += TG) {
+          f32x4 acc[TG];
+#pragma unroll
+          for (int jj = 0; jj < TG; ++jj) acc[jj] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < TG; ++jj)
+              acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ks], ks < KSR ? bw[j0 + jj][ks < KSR ? ks : 0] : wl[(wave * NT + j0 + jj) * 64 + lane],
+                                                                acc[jj], 0, 0, 0);
+#pragma unroll
+          for (int jj = 0; jj < TG; ++jj) {
+            // D: column r16 = unit of the destination tile, rows 4 g + q (rows 0 .. 7 are this workgroup's):
+            // item = unit in the destination block + UPB * (row pair)
+            const int tile = wave * NT + j0 + jj, dest = tile / TB, ui = (tile % TB) * 16 + r16;
+            if (g < 2) {
+              if (dest == ub) {
+                ownp[(ui + UPB * (2 * g)) * 2] = acc[jj][0]; ownp[(ui + UPB * (2 * g)) * 2 + 1] = acc[jj][1];
+                ownp[(ui + UPB * (2 * g + 1)) * 2] = acc[jj][2]; ownp[(ui + UPB * (2 * g + 1)) * 2 + 1] = acc[jj][3];
+              } else {
+                NS_GLOBAL ps_u64* dst = (NS_GLOBAL ps_u64*)(nxt + ((size_t)dest * NUB + ub) * ITEMS + ui + 2 * UPB * g);
+                const ps_u64 tg = (ps_u64)(unsigned)(bs + 1) << 32;
+                const bf16_t b0 = (bf16_t)acc[jj][0], b1 = (bf16_t)acc[jj][1], b2 = (bf16_t)acc[jj][2], b3 = (bf16_t)acc[jj][3];
+                const unsigned p01 = (unsigned)__builtin_bit_cast(unsigned short, b0) | ((unsigned)__builtin_bit_cast(unsigned short, b1) << 16);
+                const unsigned p23 = (unsigned)__builtin_bit_cast(unsigned short, b2) | ((unsigned)__builtin_bit_cast(unsigned short, b3) << 16);
+                __hip_atomic_store(dst, tg | p01, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + UPB, tg | p23, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
+            }
+          }
+        }
+      }
+      wstamp(a, bs, 4);
+    }
+    return;
+  }
+  // -------------------------------------------------------------------- cell waves: thread = (row er, units eu + 16 c)
+  __syncthreads();                           // pairs with the product waves' barrier behind their weight loads
+  const int e = tid - PSW * 64, er = e >> 4, eu = e & 15;
+  const int en = n0 + er;
+  const bool eok = en < p.N;
+  const int elen = (eok && p.lengths) ? p.lengths[en] : p.T;
+  const int half = er & 1;
+  float dcc[TB];
+  float pg[TB][4], pdh[TB], pc[TB], pcp[TB];
+#pragma unroll
+  for (int c = 0; c < TB; ++c) { dcc[c] = 0.f; pdh[c] = 0.f; pc[c] = 0.f; pcp[c] = 0.f; pg[c][0] = pg[c][1] = pg[c][2] = pg[c][3] = 0.f; }
+  auto load_ops = [&](int t) {
+    if (eok) {
+      const long rowi = (long)en * p.P + p.padl + t;
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {
+        const int u = u0 + eu + 16 * c;
+        const T* gp = (const T*)p.gates + rowi * 4 * H + u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pg[c][j] = ldf(gp + (long)j * H);
+        pdh[c] = p.dh[rowi * p.ld_dh + u];
+        pc[c] = p.c[rowi * H + u];
+        pcp[c] = t > 0 ? p.c[(rowi - 1) * H + u] : 0.f;
+      }
+    }
+  };
+  load_ops(p.T - 1);
+  for (int t = p.T - 1; t >= 0; --t) {
+    ps_barrier();                            // A
+    if (abortf[0]) return;
+    float dgv[TB][4];
+#pragma unroll
+    for (int c = 0; c < TB; ++c) {
+      const int item = eu + 16 * c + UPB * (er >> 1);
+      float dh = pdh[c] + ownp[item * 2 + half];
+#pragma unroll
+      for (int w = 0; w < PSW; ++w) dh += red[(w * ITEMS + item) * 2 + half];
+      const float gi = pg[c][0], gj = pg[c][1], gf = pg[c][2], go = pg[c][3];
+      const float tc = tanhf_(pc[c]);
+      const float dc = dh * go * (1.f - tc * tc) + dcc[c];
+      dgv[c][0] = dc * gj * gi * (1.f - gi);
+      dgv[c][1] = dc * gi * (1.f - gj * gj);
+      dgv[c][2] = dc * pcp[c] * gf * (1.f - gf);
+      dgv[c][3] = dh * tc * go * (1.f - go);
+      dcc[c] = dc * gf;
+      if (t >= elen || !eok) { dgv[c][0] = dgv[c][1] = dgv[c][2] = dgv[c][3] = 0.f; dcc[c] = 0.f; }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) dgi[er * LDW + j * UPB + eu + 16 * c] = (bf16_t)dgv[c][j];
+    }
+    ps_barrier();                            // B
+    // ---- what only later kernels read: the gate gradients (bf16 copy and, for fp32 storage, fp32), next operands
+    if (eok) {
+      const long rowi = (long)en * p.P + p.padl + t;
+      bf16_t* xb = sizeof(T) == 2 ? (bf16_t*)p.dgates : (bf16_t*)p.dgates_bf16;
+#pragma unroll
+      for (int c = 0; c < TB; ++c) {
+        bf16_t* db = xb + rowi * K + u0 + eu + 16 * c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) db[(long)j * H] = (bf16_t)dgv[c][j];
+        if (sizeof(T) == 4) {
+          float* dg = (float*)p.dgates + rowi * K + u0 + eu + 16 * c;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) dg[(long)j * H] = dgv[c][j];
+        }
+      }
+    }
+    if (t > 0) load_ops(t - 1);
+  }
+}
+
 bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
   if (!p || p->reverse || p->T < 2) return false;
   const int H = p->H;
@@ -529,7 +770,11 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
 extern "C" int ns_lstm_wide_supported(const ns_lstm_seq_params* p, int backward) { return wide_shape_ok(p, backward, nullptr) ? 1 : 0; }
 extern "C" size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
-  return 256 + WIDE_TRACE_BYTES;       // status word (+ the NS_WIDE_TRACE timestamps)
+  // status word, the NS_WIDE_TRACE timestamps, the partial-sum backward kernel's exchange buffer
+  size_t ex = 0;
+  if (p->H % 128 == 0 && p->H >= 256 && p->H <= 1024 && ((p->N + 7) / 8) * (p->H / 16) <= 256)
+    ex = (size_t)((p->N + 7) / 8) * 2 * (p->H / 16) * (p->H / 16) * 64 * sizeof(ps_u64);      // the 16-unit form's (the 32-unit form needs half)
+  return 256 + WIDE_TRACE_BYTES + ex + 64;
 }
 
 template <typename T, int PASSES>
@@ -591,6 +836,41 @@ extern "C" int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stre
   int rc = ns_zero_async(work, 256, s);
   if (rc) return rc;
   const bool r8 = ((p->N + 7) / 8) * nub <= 256;
+  // the partial-sum exchange (lstm_wide_bwd_ps_kernel): 8-row groups, H a multiple of 128; NS_WIDE_PS=0 keeps the sweep
+  // form, 16 the 16-unit blocks
+  {
+    const char* ps_env = getenv("NS_WIDE_PS");
+    const int ps_mode = ps_env ? atoi(ps_env) : 32;
+    if (r8 && p->H % 128 == 0 && ps_mode != 0) {
+      const int nrg = (p->N + 7) / 8;
+      const int upb = ps_mode == 16 ? 16 : 32, nb = p->H / upb, items = upb * 4;
+      ps_u64* xbuf = (ps_u64*)(((uintptr_t)work + 256 + WIDE_TRACE_BYTES + 15) & ~(uintptr_t)15);
+      const size_t xbytes = (size_t)nrg * 2 * nb * nb * items * sizeof(ps_u64);
+      rc = ns_zero_async(xbuf, xbytes, s);
+      if (rc) return rc;
+      const int grid = nrg * nb;
+      const int nt = p->H / 128;
+      const size_t ldsb = (size_t)16 * (4 * upb + 8) * 2 + sizeof(float) * (PSW * items * 2 + items * 2) + 16 +
+                          (upb == 32 ? (size_t)PSW * nt * 64 * 16 : 0);
+#define NS_LAUNCH_PS2(T_, NT_, UPB_) \
+      do { \
+        static bool attr_ = false; \
+        if (!attr_) { (void)hipFuncSetAttribute((const void*)lstm_wide_bwd_ps_kernel<T_, NT_, UPB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_ = true; } \
+        hipLaunchKernelGGL((lstm_wide_bwd_ps_kernel<T_, NT_, UPB_>), dim3(grid), dim3(PST), ldsb, s, a, xbuf); \
+      } while (0)
+#define NS_LAUNCH_PS(T_) \
+      if (upb == 16) { \
+        switch (nt) { case 2: NS_LAUNCH_PS2(T_, 2, 16); break; case 4: NS_LAUNCH_PS2(T_, 4, 16); break; default: NS_LAUNCH_PS2(T_, 8, 16); break; } \
+      } else { \
+        switch (nt) { case 2: NS_LAUNCH_PS2(T_, 2, 32); break; case 4: NS_LAUNCH_PS2(T_, 4, 32); break; default: NS_LAUNCH_PS2(T_, 8, 32); break; } \
+      }
+      if (p->dtype == NS_BF16) { NS_LAUNCH_PS(bf16_t) } else { NS_LAUNCH_PS(float) }
+#undef NS_LAUNCH_PS
+#undef NS_LAUNCH_PS2
+      NS_CHECK_LAUNCH("lstm_wide_bwd_ps");
+      return NS_OK;
+    }
+  }
   const int grid = (r8 ? (p->N + 7) / 8 : (p->N + 15) / 16) * nub;
   bf16_t* xb = p->dtype == NS_BF16 ? (bf16_t*)p->dgates : (bf16_t*)p->dgates_bf16;
   hipLaunchKernelGGL(wide_fill_kernel<bf16_t>, dim3(1024), dim3(256), 0, s, xb, p->N, (long)p->P, p->padl, p->T, 4L * p->H, 4 * p->H);

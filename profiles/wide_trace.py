@@ -28,6 +28,21 @@ def report(name, work, S):
     print("    publish -> wave 0 has seen all its producers       %6.2f us" % us(nx[:, 6] - r[:, 4]))
     print("    -> its last pieces loaded and checked              %6.2f us" % us(nx[:, 1] - nx[:, 6]))
 
+def report_ps(name, work, S):
+    """lstm_wide_bwd_ps_kernel (partial-sum exchange): [0] step start, [1] every polled granule carries this step's tag
+    ([5] passes beyond the first), [2] behind barrier A, [3] behind barrier B (cell update done), [4] products done and
+    published."""
+    tr = work[64:64 + 256 * 8 * 2].view(torch.int64).view(256, 8).cpu().numpy().astype(np.float64)
+    r, nx = tr[4:min(S, 256) - 1], tr[5:min(S, 256)]
+    us = lambda x: x.mean() * 1e-2
+    print("%s (partial-sum exchange): %.2f us per step" % (name, us(nx[:, 0] - r[:, 0])))
+    print("  product wave 0: polls until its granules are new     %6.2f us  (%.2f extra passes)" % (us(r[:, 1] - r[:, 0]), r[:, 5].mean()))
+    print("  sums to LDS + barrier A                              %6.2f us" % us(r[:, 2] - r[:, 1]))
+    print("  cell update (cell waves) + barrier B                 %6.2f us" % us(r[:, 3] - r[:, 2]))
+    print("  MFMA + publish                                       %6.2f us" % us(r[:, 4] - r[:, 3]))
+    print("  publish -> the NEXT step's granules all in           %6.2f us" % us(nx[:, 1] - r[:, 4]))
+
+
 def main():
     hp = hparams_mod.load("taco2")
     m = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=1234)
@@ -40,7 +55,10 @@ def main():
     m.check_status()
     for k in sorted(m._bufs):
         if k.startswith("lstm_wide_work_"):
-            report(k[len("lstm_wide_work_"):], m._bufs[k], 200)
+            if k.endswith("_bwd") and os.environ.get("NS_WIDE_PS", "1") != "0":
+                report_ps(k[len("lstm_wide_work_"):], m._bufs[k], 200)
+            else:
+                report(k[len("lstm_wide_work_"):], m._bufs[k], 200)
 
 
 if __name__ == "__main__":
