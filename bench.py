@@ -349,7 +349,7 @@ def main():
         from nspeech_amd import profiling as _prof
         state_mb = args.batch * D * 4 / 1e6
         gate_roof = {
-            "bound": "mfma", "kernel": "decoder LSTM(1024) x 2 gate GEMMs: lstm_wide_fwd_kernel / lstm_wide_bwd_kernel (ONE "
+            "bound": "mfma", "kernel": "decoder LSTM(1024) x 2 gate GEMMs: lstm_wide_fwd_kernel / lstm_wide_bwd_ps_kernel (ONE "
                                        "persistent launch per LSTM and direction, W_h register-resident, %d steps each) + the "
                                        "hoisted input and weight-gradient GEMMs" % S,
             "achieved": gate_flop / (gate_ms * 1e-3) / 1e12 if gate_ms else None, "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -360,8 +360,10 @@ def main():
                            for k, v in loops.items()},
             "binding_bound": "weight-stationary: W_h never leaves the registers, so the HBM weight stream of the launch-per-step "
                              "form is gone; each step is one store -> visible -> load hop of the state between the CUs "
-                             "(%.2f MB published per step); this run's per-step times are in `recurrence`, the split of a step "
-                             "into hop and arithmetic is traced in profiles/r02_wide_trace.txt" % state_mb,
+                             "(forward: %.2f MB of state published and gathered by every workgroup per step; backward: "
+                             "partial dh sums as self-flagging granules, one hop); this run's per-step times are in "
+                             "`recurrence`, the split of a step into hop and arithmetic is traced in "
+                             "profiles/r03_wide_trace.txt" % state_mb,
             "traffic": _prof.pmc_traffic("lstm_wide"),
             "traffic_note": "bytes per LAUNCH (= %d steps) at the L2's fabric side, %s" % (S, _prof.pmc_traffic_source()),
         }

@@ -51,10 +51,10 @@ def main():
                 "traffic including Infinity-Cache hits; per launch, averaged over the launches of the pass",
         "gemm_family": family("gemm", lambda k: "gemm_mfma" in k or "gemm_x256" in k,
                               "gemm_mfma_kernel + gemm_mfma_f32_kernel + gemm_x256_kernel"),
-        "lstm_wide": family("wide", lambda k: "lstm_wide_fwd_kernel" in k or "lstm_wide_bwd_kernel" in k,
-                            "lstm_wide_fwd_kernel + lstm_wide_bwd_kernel (one launch = all decoder steps of one LSTM)"),
+        "lstm_wide": family("wide", lambda k: "lstm_wide_fwd_kernel" in k or "lstm_wide_bwd" in k,
+                            "lstm_wide_fwd_kernel + lstm_wide_bwd[_ps]_kernel (one launch = all decoder steps of one LSTM)"),
         "lstm_wide_fwd": family("widef", lambda k: "lstm_wide_fwd_kernel" in k, "lstm_wide_fwd_kernel"),
-        "lstm_wide_bwd": family("wideb", lambda k: "lstm_wide_bwd_kernel" in k, "lstm_wide_bwd_kernel"),
+        "lstm_wide_bwd": family("wideb", lambda k: "lstm_wide_bwd" in k, "lstm_wide_bwd_kernel / lstm_wide_bwd_ps_kernel"),
         "attn_cluster": family("attn", lambda k: "attn_cluster_fwd_kernel" in k or "attn_cluster_bwd_kernel" in k,
                                "attn_cluster_fwd_kernel + attn_cluster_bwd_kernel"),
         "lstm_cluster": family("clu", lambda k: "lstm_cluster" in k, "lstm_cluster2_fwd_kernel + lstm_cluster2_bwd_kernel"),
