@@ -300,6 +300,13 @@ class Tacotron2(object):
     #    kernels' workgroups hold the whole register file of every CU (494 - 504 of 512 VGPRs per SIMD lane), a GEMM
     #    workgroup cannot sit beside them.
     overlap_wgrads = os.environ.get("NS_OVERLAP_WGRADS", "1") != "0"
+    # Groups whose (otherwise eager) weight gradients are QUEUED and released in front of the decoder LSTMs' backward
+    # recurrences: those run on 128 of the 256 CUs since round 3 (lstm_wide_bwd_ps_kernel) - 1.6 ms with half the chip
+    # idle, where the eager products shared the chip with the main stream's own GEMMs.  Measured (step, ms): none queued
+    # 20.98, postnet 20.77, head 20.56, postnet + head 20.50; also LSTM 2's own weight gradients under LSTM 1's
+    # recurrence 20.64, also the encoder's 20.67 (both worse: the queue then outlasts the window and delays the
+    # whole-chip attention recurrence behind it).  NS_WGRAD_QUEUE="" restores the eager form.
+    queue_groups = tuple(g for g in os.environ.get("NS_WGRAD_QUEUE", "postnet,head").split(",") if g)
 
     def _side_stream(self):
         """The second stream, made to wait for everything enqueued on the main stream so far."""
@@ -317,7 +324,7 @@ class Tacotron2(object):
         onto that stream.  The caller guarantees that nothing overwrites fn's operands before _join_deferred."""
         if not (self.overlap_wgrads and self.device.type == "cuda"):
             fn()
-        elif eager:
+        elif eager and group not in self.queue_groups:
             self._side_groups.add(group)
             with torch.cuda.stream(self._side_stream()):
                 fn()
@@ -328,6 +335,7 @@ class Tacotron2(object):
         if not self._deferred:
             return
         calls, self._deferred = self._deferred, []
+        self._side_groups.update(grp for grp, _ in calls)        # a later bucket release follows them onto that stream
         with torch.cuda.stream(self._side_stream()):
             for _, fn in calls:
                 fn()
@@ -1032,6 +1040,8 @@ class Tacotron2(object):
         dg2 = self._buf("d_g2", rows * 4 * D, T_)
         self._dgb("d_g2b", rows * 4 * D, T_)
         self._tick("dec_lstm_bwd:proj")
+        if self.queue_groups:
+            self._flush_deferred()
         self._run_lstm("bwd", "dec2", N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D,
                        B["dec_c2"], B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
                        wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D,
@@ -1049,6 +1059,8 @@ class Tacotron2(object):
         h1b, h2b = b16("dec_h1_16", h1, D), b16("dec_h2_16", h2, D)
         self._defer("decoder", lambda: self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2,
                                                          "decoder/lstm_2/bias"))
+        if "decoder2" in self.queue_groups:      # LSTM 2's weight gradients under LSTM 1's recurrence (measured: worse)
+            self._flush_deferred()
         dh1 = self._buf("d_h1", rows * D, torch.float32)
         if dg2b is not None:
             ops.gemm(dg2b, w16, dh1, rows, D, 4 * D, 4 * D, 4 * D, D, a_mode=0, b_mode=0, b_off=k2)
