@@ -129,6 +129,22 @@ class Tacotron2(object):
             self.flat_stats.copy_(torch.from_numpy(hs))
         self.refresh_shadows(full=True)
 
+    def load_adam_slots(self, m, v):
+        """Adam first / second moments by variable name (a TF checkpoint's `<variable>/Adam`, `/Adam_1` slots)."""
+        hm, hv = np.zeros(self.layout.size, np.float32), np.zeros(self.layout.size, np.float32)
+        for name, (off, shape) in self.layout.entries.items():
+            n = int(np.prod(shape))
+            hm[off:off + n] = np.asarray(m[name], np.float32).reshape(-1)
+            hv[off:off + n] = np.asarray(v[name], np.float32).reshape(-1)
+        self.flat_m[:self.layout.size].copy_(torch.from_numpy(hm))
+        self.flat_v[:self.layout.size].copy_(torch.from_numpy(hv))
+
+    def numpy_adam_slots(self):
+        hm, hv = self.flat_m.cpu().numpy(), self.flat_v.cpu().numpy()
+        ent = self.layout.entries.items()
+        return ({k: hm[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in ent},
+                {k: hv[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in ent})
+
     def numpy_params(self):
         host = self.flat_p.cpu().numpy()
         return {k: host[o:o + int(np.prod(s))].reshape(s).copy() for k, (o, s) in self.layout.entries.items()}

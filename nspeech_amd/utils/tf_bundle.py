@@ -326,7 +326,7 @@ def name_candidates(name):
 def map_checkpoint(tensors, layout, stat_layout, name_map=None):
     """-> (params dict, stats dict, report).  `name_map`: this build's name -> checkpoint name overrides."""
     name_map = name_map or {}
-    found, missing, used = {}, [], set()
+    found, missing, used, hits = {}, [], set(), {}
     for lay in (layout, stat_layout):
         for name, (_, shape) in lay.entries.items():
             cands = [name_map[name]] if name in name_map else name_candidates(name)
@@ -339,10 +339,25 @@ def map_checkpoint(tensors, layout, stat_layout, name_map=None):
                 raise ValueError("%s: checkpoint tensor %s has shape %s, the model needs %s" % (name, hit, a.shape, shape))
             found[name] = a.astype(np.float32)
             used.add(hit)
+            hits[name] = hit
     extra = sorted(k for k in tensors if k not in used and "/Adam" not in k and not k.endswith("_power") and k != "global_step")
     report = dict(missing=missing, unused=extra, global_step=int(tensors["global_step"]) if "global_step" in tensors else None)
     params = {k: found[k] for k in layout.entries if k in found}
     stats = {k: found[k] for k in stat_layout.entries if k in found}
+    # tf.train.AdamOptimizer keeps its moments as slot variables beside each trainable, `<variable>/Adam` (m) and
+    # `<variable>/Adam_1` (v) (the reference saves them with the model, train.py:60 - tf.train.Saver over all variables);
+    # the bias-correction powers beta1_power / beta2_power are functions of the update count, which global_step carries.
+    # They are taken only as a complete set: report["adam_slots"] = (m, v) dicts by this build's names, or None.
+    m, v = {}, {}
+    for name in layout.entries:
+        hit = hits.get(name)
+        if hit is None or hit + "/Adam" not in tensors or hit + "/Adam_1" not in tensors:
+            break
+        am, av = np.asarray(tensors[hit + "/Adam"]), np.asarray(tensors[hit + "/Adam_1"])
+        if tuple(am.shape) != tuple(params[name].shape) or tuple(av.shape) != tuple(params[name].shape):
+            raise ValueError("%s: Adam slots of %s have shapes %s / %s, the variable %s" % (name, hit, am.shape, av.shape, params[name].shape))
+        m[name], v[name] = am.astype(np.float32), av.astype(np.float32)
+    report["adam_slots"] = (m, v) if len(m) == len(layout.entries) and not missing else None
     return params, stats, report
 
 
@@ -355,15 +370,25 @@ def load_into_model(model, prefix, name_map=None):
     model.load_numpy(params, stats)
     if report["global_step"] is not None:
         model.global_step = report["global_step"]
+    if report.get("adam_slots") is not None and hasattr(model, "load_adam_slots"):
+        model.load_adam_slots(*report["adam_slots"])       # resume with the reference's optimizer state (train.py:67-71)
     return report
 
 
-def export_model(model, prefix):
+def export_model(model, prefix, with_adam_slots=False):
     """Writes the model's trainables, BatchNorm moving statistics and global_step as a TF bundle under this build's
-    names ('model/inference/...')."""
+    names ('model/inference/...'); with_adam_slots: also the Adam moments as `<variable>/Adam`, `/Adam_1` slot variables
+    and beta1_power / beta2_power, the way tf.train.Saver writes a training checkpoint."""
     t = {"model/inference/" + k: v for k, v in model.numpy_params().items()}
     t.update({"model/inference/" + k: v for k, v in model.numpy_stats().items()})
     t["global_step"] = np.asarray(model.global_step, np.int64)
+    if with_adam_slots and hasattr(model, "numpy_adam_slots"):
+        m, v = model.numpy_adam_slots()
+        t.update({"model/inference/" + k + "/Adam": a for k, a in m.items()})
+        t.update({"model/inference/" + k + "/Adam_1": a for k, a in v.items()})
+        lr_t = max(1, model.global_step)
+        t["beta1_power"] = np.asarray(getattr(model, "adam_beta1", 0.9) ** lr_t, np.float32)
+        t["beta2_power"] = np.asarray(getattr(model, "adam_beta2", 0.999) ** lr_t, np.float32)
     save_tf_checkpoint(prefix, t)
 
 

@@ -96,6 +96,25 @@ def test_name_mapping_onto_the_tacotron2_layout(tmp_path):
     bad["model/inference/embedding/embedding"] = np.zeros((3, 3), np.float32)
     with pytest.raises(ValueError):
         B.map_checkpoint(bad, lay, st)
+    # Adam slots (tf.train.Saver writes `<variable>/Adam`, `/Adam_1` beside every trainable, train.py:60): taken only as
+    # a complete set, under this build's names; one slot above (embedding only) is not a set
+    assert rep["adam_slots"] is None
+    full = dict(tensors)
+    rng = np.random.default_rng(5)
+    for name in pv:
+        full[tf_names[name] + "/Adam"] = rng.standard_normal(pv[name].shape).astype(np.float32)
+        full[tf_names[name] + "/Adam_1"] = rng.random(pv[name].shape).astype(np.float32)
+    full["beta1_power"] = np.asarray(0.9 ** 77, np.float32)
+    prefix2 = str(tmp_path / "model.ckpt-78")
+    B.save_tf_checkpoint(prefix2, full)
+    _, _, rep4 = B.map_checkpoint(B.load_tf_checkpoint(prefix2), lay, st)
+    m, v = rep4["adam_slots"]
+    assert rep4["unused"] == ["model/inference/something/else"] and set(m) == set(pv) == set(v)
+    assert all(np.array_equal(m[k], full[tf_names[k] + "/Adam"]) and np.array_equal(v[k], full[tf_names[k] + "/Adam_1"]) for k in pv)
+    wrong = dict(full)
+    wrong[tf_names["embedding/embedding"] + "/Adam_1"] = np.zeros((2, 2), np.float32)
+    with pytest.raises(ValueError):
+        B.map_checkpoint(wrong, lay, st)
 
 
 def test_reader_against_hand_assembled_bundle(tmp_path):

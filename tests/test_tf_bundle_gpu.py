@@ -35,3 +35,31 @@ def test_export_import_round_trip_and_synthesis(dev, tmp_path):
     c = create_model("taco2", small_hparams(max_iters=5), device="cuda:0", dtype="fp32", seed=1)
     with pytest.raises(ValueError):
         B.load_into_model(c, prefix)
+
+
+def test_training_checkpoint_with_adam_slots_resumes_the_same_trajectory(dev, tmp_path):
+    """train.py:60,67-71: the reference saves and restores its optimizer slots with the model.  A bundle written with the
+    Adam moments (`<variable>/Adam`, `/Adam_1`, beta powers) restores them: the next training step from the restored
+    model equals the next step of the original bit for bit; without the slots the moments start afresh and it does not."""
+    from nspeech_amd.models import create_model
+    from nspeech_amd.utils import tf_bundle as B
+    hp = small_hparams(max_iters=5)
+    inputs, lengths, mel, lin = make_batch(hp, 2, 7, 10, seed=4)
+    a = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=21)
+    a.add_optimizer(0)
+    for _ in range(3):
+        a.step(inputs, lengths, mel, lin)
+    full, bare = str(tmp_path / "model.ckpt-3"), str(tmp_path / "bare.ckpt-3")
+    B.export_model(a, full, with_adam_slots=True)
+    B.export_model(a, bare)
+    a.step(inputs, lengths, mel, lin)
+    outs = []
+    for prefix in (full, bare):
+        b = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=99)
+        rep = B.load_into_model(b, prefix)
+        assert (rep["adam_slots"] is not None) == (prefix == full) and b.global_step == 3
+        b.add_optimizer(b.global_step)
+        b.step(inputs, lengths, mel, lin)
+        outs.append(b.flat_p.clone())
+    assert torch.equal(outs[0], a.flat_p)
+    assert not torch.equal(outs[1], a.flat_p)

@@ -102,7 +102,7 @@ def train(log_dir, args):
     if args.restore_step:
         path = "%s-%d" % (os.path.join(log_dir, "model.ckpt"), args.restore_step)
         from nspeech_amd.utils import tf_bundle
-        if tf_bundle.is_bundle(path):          # a TensorFlow checkpoint of the reference (Adam slots start afresh)
+        if tf_bundle.is_bundle(path):          # a TensorFlow checkpoint of the reference (Adam slots taken when complete)
             tf_bundle.load_into_model(model, path)
         else:
             model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
