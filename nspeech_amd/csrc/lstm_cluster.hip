@@ -1579,7 +1579,7 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     LstmClusterArgs a = {};
     fill(a, p0, p1, work);
     // NS_CLUSTER_DBG bit 256: one row group per workgroup set (no interleaving), for A/B timing
-    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 256)) ? 2 : 1;        // encoder BiLSTM: 1.18 ms (R = 2) / 1.06 (R = 1)
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && (a.dbg & 1024)) ? 2 : 1;        // see the bf16 forward kernel's launch: one set per row group
     const size_t xbytes = (2 * (size_t)nrg + 2) * 2 * 16 * (size_t)a.H * sizeof(u64);
     { const int zrc = ns_zero_async(work, ((256 + FLAG_BYTES + xbytes) + 15) & ~(size_t)15, s); if (zrc) return zrc; }
     const size_t lds3 = (size_t)2 * 2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG3_LD + 2 * 9216 + 32;
@@ -1615,7 +1615,12 @@ extern "C" int ns_lstm_cluster_fwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     const size_t lds2 = (size_t)2 * 16 * a.H * 2 + sizeof(float) * 2 * 16 * XG_LD + 2 * (2048 + 4096 + 8192) + 32;
     // two row groups interleaved per workgroup (R = 2) pay when a slot's compute chain is clearly shorter than the hop;
     // round 3 (two forward pollers, shorter hop): expand BiLSTM 2.92 ms with R = 2, 2.75 ms with one set per row group
-    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
+    // Re-measured at the end of round 3 (transposed product: the compute chain of a slot is 0.7 us against a hop of 1.5):
+    // expand BiLSTM forward 2.38 ms with one set per row group, 3.56 ms with two row groups interleaved per workgroup; the
+    // backward kernel 2.63 against 4.36, the fp32 forward 1.08 against 1.17 (encoder).  Interleaving only doubles the
+    // slots a workgroup walks through: every row group gets its own set of workgroups (2 x 4 x row groups <= 256 CUs up
+    // to batch 512); NS_CLUSTER_DBG bits 512 / 1024 / 2048 force R = 2 (bf16 forward / fp32 forward / backward).
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && (a.dbg & 512)) ? 2 : 1;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * a.CS)), block(FW_WAVES * 64);
 #define NS_LAUNCH_F(HB_) \
     if (R == 2) hipLaunchKernelGGL((lstm_cluster2_fwd_kernel<HB_, 2>), grid, block, lds2, s, a); \
@@ -1667,7 +1672,7 @@ extern "C" int ns_lstm_cluster_bwd(const ns_lstm_seq_params* p0, const ns_lstm_s
     // interleaving of row groups
     // R = 2 (two row groups interleaved per workgroup) pays when the slot's compute chain is shorter than the hop;
     // measured on the expand BiLSTM (T = 1000, H = 256, 2 row groups): R = 1 3.8 ms, R = 2 4.4 ms
-    const int nrg = (a.N + 15) / 16, R = (nrg >= 3 && !(a.dbg & 32)) ? 2 : 1;
+    const int nrg = (a.N + 15) / 16, R = (nrg >= 2 && (a.dbg & 2048)) ? 2 : 1;
     const int CS = a.CS;
     const size_t ldsp = (size_t)2 * 16 * DGI_LD * 2 + 2 * 16384 + sizeof(float) * (size_t)R * 16 * 64 + 32;
     const dim3 grid((unsigned)(2 * ((nrg + R - 1) / R) * CS)), block(BP_WAVES * 64);
