@@ -772,7 +772,7 @@ extern "C" size_t ns_lstm_wide_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
   // status word, the NS_WIDE_TRACE timestamps, the partial-sum backward kernel's exchange buffer
   size_t ex = 0;
-  if (p->H % 128 == 0 && p->H >= 256 && p->H <= 1024 && ((p->N + 7) / 8) * (p->H / 16) <= 256)
+  if (p->H % 128 == 0 && p->H >= 256 && p->H <= 1024 && ((p->N + 7) / 8) * (p->H / 32) <= 256)
     ex = (size_t)((p->N + 7) / 8) * 2 * (p->H / 16) * (p->H / 16) * 64 * sizeof(ps_u64);      // the 16-unit form's (the 32-unit form needs half)
   return 256 + WIDE_TRACE_BYTES + ex + 64;
 }
@@ -841,9 +841,9 @@ extern "C" int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stre
   {
     const char* ps_env = getenv("NS_WIDE_PS");
     const int ps_mode = ps_env ? atoi(ps_env) : 32;
-    if (r8 && p->H % 128 == 0 && ps_mode != 0) {
-      const int nrg = (p->N + 7) / 8;
-      const int upb = ps_mode == 16 ? 16 : 32, nb = p->H / upb, items = upb * 4;
+    const int nrg = (p->N + 7) / 8;
+    const int upb = ps_mode == 16 ? 16 : 32, nb = p->H / upb, items = upb * 4;
+    if (p->H % 128 == 0 && ps_mode != 0 && nrg * nb <= 256) {      // 8-row groups x unit blocks, one workgroup per CU
       ps_u64* xbuf = (ps_u64*)(((uintptr_t)work + 256 + WIDE_TRACE_BYTES + 15) & ~(uintptr_t)15);
       const size_t xbytes = (size_t)nrg * 2 * nb * nb * items * sizeof(ps_u64);
       rc = ns_zero_async(xbuf, xbytes, s);
