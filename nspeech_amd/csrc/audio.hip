@@ -292,12 +292,52 @@ constexpr int GW_PAD = 1280;                 // float2 per wave: 16 rows of 68 (
 // complex values as packed pairs (re, im): an add is one v_pk_add_f32, a product two packed operations
 typedef float v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v2f mul_neg_i(v2f v) { return (v2f){v.y, -v.x}; }
-__device__ __forceinline__ v2f cmulv(v2f x, float a, float b) {          // x * (a + i b)
-  return x * (v2f){a, a} + (v2f){-x.y, x.x} * (v2f){b, b};
+// Complex arithmetic on packed (re, im) pairs with the swaps, conjugations and sign flips carried by the packed
+// instructions' own operand selects (op_sel / op_sel_hi / neg_lo / neg_hi): written from the vector types the compiler
+// spends a v_xor (sign), a v_mov (swap) and a wait state per product - 5 issue slots where 2 - 3 do (round 3: 2 426 ->
+// ~2 000 instructions per frame and iteration; the results are the same IEEE operations, bit for bit).
+//   x * (w.x + i w.y):  t = (-x.y w.y, x.x w.y);  r = (x.x w.x, x.y w.x) + t
+__device__ __forceinline__ v2f cmulw(v2f x, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\ts_nop 0\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+      : "=&v"(t), "=&v"(r) : "v"(x), "v"(w));
+  return r;
+}
+//   x * conj(w) = x * (w.x - i w.y):  t = (x.y w.y, -x.x w.y)
+__device__ __forceinline__ v2f cmulw_conj(v2f x, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\ts_nop 0\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+      : "=&v"(t), "=&v"(r) : "v"(x), "v"(w));
+  return r;
+}
+__device__ __forceinline__ v2f cmulv(v2f x, float a, float b) { return cmulw(x, (v2f){a, b}); }        // x * (a + i b)
+//   a + (u.y, -u.x) = a - i u   and   a - (u.y, -u.x) = a + i u
+__device__ __forceinline__ v2f add_mi(v2f a, v2f u) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(u));
+  return r;
+}
+__device__ __forceinline__ v2f add_pi(v2f a, v2f u) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(u));
+  return r;
+}
+//   a + conj(b)   and   a - conj(b)
+__device__ __forceinline__ v2f add_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f sub_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 __device__ __forceinline__ void fft4(v2f& a, v2f& b, v2f& c, v2f& d) {   // in place: X0..X3 of x0..x3
-  const v2f t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
-  a = t0 + t2; c = t0 - t2; b = t1 + t3; d = t1 - t3;
+  const v2f t0 = a + c, t1 = a - c, t2 = b + d, u = b - d;
+  a = t0 + t2; c = t0 - t2; b = add_mi(t1, u); d = add_pi(t1, u);
 }
 // 16-point forward DFT in registers, natural order in and out (4 x 4, the digit reversal is register renaming)
 __device__ __forceinline__ void fft16(v2f (&x)[16]) {
@@ -326,7 +366,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* tw, int lane) {
   fft16(x);
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) { const v2f w = tw[lane * k1]; x[k1] = cmulv(x[k1], w.x, w.y); }
+  for (int k1 = 1; k1 < 16; ++k1) x[k1] = cmulw(x[k1], tw[lane * k1]);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = x[k1];
   wave_lds_fence();
@@ -336,7 +376,7 @@ __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* 
   wave_lds_fence();                                             // the buffer is free again
   fft16(x);
 #pragma unroll
-  for (int k2 = 1; k2 < 16; ++k2) { const v2f w = tw[16 * n3 * k2]; x[k2] = cmulv(x[k2], w.x, w.y); }
+  for (int k2 = 1; k2 < 16; ++k2) x[k2] = cmulw(x[k2], tw[16 * n3 * k2]);
   // second exchange: the four n3 of a (k1, k2) come together in one lane - lane (k1 = lane >> 2, k2hi = lane & 3) takes
   // k2 = 4 k2hi + k2lo - and the last radix-4 runs in registers (a DPP quad version of this pass cost 290 VALU
   // instructions per transform where this costs 40 and two dozen LDS instructions)
@@ -374,9 +414,8 @@ __device__ __forceinline__ void gl_pairs(v2f* buf, int lane, const float (&mkv)[
       // X[k] = ((A + conj B) - i w (A - conj B)) / 2 ;  X[M-k] = ((B + conj A) + i conj(w) (B - conj A)) / 2
       // (the factor 1/2 drops out of the unit phase).  With s1 = A + conj B, d1 = A - conj B, wd = w d1:
       //   2 X[k] = s1 - i wd = (s1.x + wd.y, s1.y - wd.x);   2 X[M-k] = (s1.x - wd.y, -s1.y - wd.x)
-      const v2f cB = {B.x, -B.y};
-      const v2f s1 = A + cB, d1 = A - cB;
-      const v2f wd = cmulv(d1, w.x, w.y);
+      const v2f s1 = add_conj(A, B), d1 = sub_conj(A, B);
+      const v2f wd = cmulw(d1, w);
       const v2f ea = {s1.x + wd.y, s1.y - wd.x};
       const v2f eb = {s1.x - wd.y, -s1.y - wd.x};
       // m e / max(1e-8, |e|) with e = ea / 2
@@ -386,9 +425,8 @@ __device__ __forceinline__ void gl_pairs(v2f* buf, int lane, const float (&mkv)[
       xa = ea * (v2f){sa, sa};
       xb = eb * (v2f){sb, sb};
     }
-    const v2f cxb = {xb.x, -xb.y};
-    const v2f t1 = xa + cxb, u1 = xa - cxb;
-    const v2f c1 = cmulv(u1, w.x, -w.y);                        // conj(w) u1
+    const v2f t1 = add_conj(xa, xb), u1 = sub_conj(xa, xb);
+    const v2f c1 = cmulw_conj(u1, w);                           // conj(w) u1
     if (n1 < 8 || lane == 0) {
       if (!(n1 == 0 && lane == 0)) buf[ip] = (v2f){t1.x + c1.y, t1.y - c1.x};     // bin M - k (bin M itself does not exist)
       buf[ik] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};

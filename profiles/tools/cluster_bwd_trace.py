@@ -24,12 +24,12 @@ for _ in range(2):
     m.initialize(inputs, lengths, None, mel, lin)
     m.backward()
 torch.cuda.synchronize()
-w = m._bufs["lstm_cluster_work_expl_bwd"]
-N, H = 32, hp.expand_lstm_units
+w = m._bufs["lstm_cluster_work_%s_bwd" % os.environ.get("NS_TRACE_TAG", "expl")]
+N, H = 32, (hp.expand_lstm_units if os.environ.get("NS_TRACE_TAG", "expl") == "expl" else hp.encoder_lstm_units)
 chains = 2 * ((N + 15) // 16 + 1)
 off = 256 + 4096 + chains * 2 * 16 * (4 * H // 2) * 8
 tr = w.view(torch.uint8)[off:off + 512 * 8 * 8].view(torch.int64).view(512, 8).cpu().numpy().astype(np.float64) * 0.01   # us
-q0, q1 = 100, 500
+q0, q1 = (100, 500) if os.environ.get("NS_TRACE_TAG", "expl") == "expl" else (20, 150)
 c = [tr[q0:q1, i] for i in range(8)]
 print("slots %d..%d: slot period %.2f us" % (q0, q1, (c[0][-1] - c[0][0]) / (q1 - q0 - 1)))
 print("compute wave: start -> peers' sums in %.2f (%.1f extra poll passes) | -> cell update + image %.2f | barrier %.2f | MFMA %.2f | publish %.2f | -> next slot start %.2f"
