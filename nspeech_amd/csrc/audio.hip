@@ -313,6 +313,17 @@ __device__ __forceinline__ v2f cmulw_conj(v2f x, v2f w) {
   return r;
 }
 __device__ __forceinline__ v2f cmulv(v2f x, float a, float b) { return cmulw(x, (v2f){a, b}); }        // x * (a + i b)
+// two independent products interleaved: the packed product with operand selects needs one wait state before its result is
+// read, and the other product's instruction fills it
+__device__ __forceinline__ void cmulw2(v2f& x0, v2f w0, v2f& x1, v2f w1) {
+  v2f t0, t1, r0, r1;
+  asm("v_pk_mul_f32 %0, %4, %5 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\t"
+      "v_pk_mul_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\t"
+      "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+      : "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(w0), "v"(x1), "v"(w1));
+  x0 = r0; x1 = r1;
+}
 //   a + (u.y, -u.x) = a - i u   and   a - (u.y, -u.x) = a + i u
 __device__ __forceinline__ v2f add_mi(v2f a, v2f u) {
   v2f r;
@@ -345,9 +356,11 @@ __device__ __forceinline__ void fft16(v2f (&x)[16]) {
 #pragma unroll
   for (int n2 = 0; n2 < 4; ++n2) fft4(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
   // element 4 k1 + n2 times W_16^(n2 k1)
-  x[5] = cmulv(x[5], C1, -S1);   x[6] = cmulv(x[6], HH, -HH);    x[7] = cmulv(x[7], S1, -C1);
-  x[9] = cmulv(x[9], HH, -HH);   x[10] = mul_neg_i(x[10]);       x[11] = cmulv(x[11], -HH, -HH);
-  x[13] = cmulv(x[13], S1, -C1); x[14] = cmulv(x[14], -HH, -HH); x[15] = cmulv(x[15], -C1, S1);
+  cmulw2(x[5], (v2f){C1, -S1}, x[6], (v2f){HH, -HH});
+  cmulw2(x[7], (v2f){S1, -C1}, x[9], (v2f){HH, -HH});
+  x[10] = mul_neg_i(x[10]);
+  cmulw2(x[11], (v2f){-HH, -HH}, x[13], (v2f){S1, -C1});
+  cmulw2(x[14], (v2f){-HH, -HH}, x[15], (v2f){-C1, S1});
 #pragma unroll
   for (int k1 = 0; k1 < 4; ++k1) fft4(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
   // position 4 k1 + k2 holds X[k1 + 4 k2]
@@ -365,8 +378,9 @@ __device__ __forceinline__ void wave_lds_fence() {
 // Z[k1 + 16 (4 k2hi + k2lo) + 256 k3] in x[4 k2lo + k3].  tw[j] = exp(-2 pi i j / 1024) (LDS), buf = this wave's GW_PAD complex values.
 __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* tw, int lane) {
   fft16(x);
+  x[1] = cmulw(x[1], tw[lane]);
 #pragma unroll
-  for (int k1 = 1; k1 < 16; ++k1) x[k1] = cmulw(x[k1], tw[lane * k1]);
+  for (int k1 = 2; k1 < 16; k1 += 2) cmulw2(x[k1], tw[lane * k1], x[k1 + 1], tw[lane * (k1 + 1)]);
 #pragma unroll
   for (int k1 = 0; k1 < 16; ++k1) buf[k1 * 68 + lane] = x[k1];
   wave_lds_fence();
@@ -375,8 +389,9 @@ __device__ __forceinline__ void fft1024_wave(v2f (&x)[16], v2f* buf, const v2f* 
   for (int n2 = 0; n2 < 16; ++n2) x[n2] = buf[k1l * 68 + 4 * n2 + n3];
   wave_lds_fence();                                             // the buffer is free again
   fft16(x);
+  x[1] = cmulw(x[1], tw[16 * n3]);
 #pragma unroll
-  for (int k2 = 1; k2 < 16; ++k2) x[k2] = cmulw(x[k2], tw[16 * n3 * k2]);
+  for (int k2 = 2; k2 < 16; k2 += 2) cmulw2(x[k2], tw[16 * n3 * k2], x[k2 + 1], tw[16 * n3 * (k2 + 1)]);
   // second exchange: the four n3 of a (k1, k2) come together in one lane - lane (k1 = lane >> 2, k2hi = lane & 3) takes
   // k2 = 4 k2hi + k2lo - and the last radix-4 runs in registers (a DPP quad version of this pass cost 290 VALU
   // instructions per transform where this costs 40 and two dozen LDS instructions)
