@@ -322,7 +322,17 @@ class Tacotron2(object):
     # 20.98, postnet 20.77, head 20.56, postnet + head 20.50; also LSTM 2's own weight gradients under LSTM 1's
     # recurrence 20.64, also the encoder's 20.67 (both worse: the queue then outlasts the window and delays the
     # whole-chip attention recurrence behind it).  NS_WGRAD_QUEUE="" restores the eager form.
-    queue_groups = tuple(g for g in os.environ.get("NS_WGRAD_QUEUE", "postnet,head").split(",") if g)
+    # Data parallel: a queued group's bucket is released BEHIND its products; for `head` that would start its all-reduce at
+    # the end of the window, under the whole-chip attention recurrence (the case _BUCKET_AFTER avoids), so with a reducer
+    # only the postnet group is queued (its bucket goes out behind the attention recurrence either way) and `head` keeps
+    # its eager products and its release beside the postnet backward.
+    _queue_env = os.environ.get("NS_WGRAD_QUEUE")
+
+    @property
+    def queue_groups(self):
+        if self._queue_env is not None:
+            return tuple(g for g in self._queue_env.split(",") if g)
+        return ("postnet",) if self.reducer is not None else ("postnet", "head")
 
     def _side_stream(self):
         """The second stream, made to wait for everything enqueued on the main stream so far."""
