@@ -358,21 +358,11 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < CG; ++q) s += gath[q * X2N + tid];
-      qs[tid] = s;
-      if (tid / UPW == g) p.q[((long)n * S1 + slot) * A + tid] = s;
+      if (tid / UPW == g) p.q[((long)n * S1 + slot) * A + tid] = s;       // (the energy lanes below form the same sum themselves)
       xs[D2 + tid] = gath[(tid / UPW) * X2N + A + (tid % UPW)];          // h(s) for the next step's gates
     }
-    if (tid < UPW) {
-      // what the backward pass / the hoisted products read of this step's cell: stored only now, so that these
-      // stores did not sit in front of this wave's polling loads (one vmcnt queue for loads and stores)
-      const int u = g * UPW + tid;
-      p.ca[((long)n * S1 + slot) * A + u] = cstate;
-      T* gp = (T*)p.ga + ((long)n * S1 + slot) * 4 * A;
-      stf(gp + u, sv[0]); stf(gp + A + u, sv[1]); stf(gp + 2 * A + u, sv[2]); stf(gp + 3 * A + u, sv[3]);
-      stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, sv[4]);
-      if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, sv[4]);
-    }
-    lds_barrier();
+    // no barrier here: the energy lanes read the gathered partial queries (complete since the barrier above) and add them
+    // in the same order; xs[D2 ..] is next read behind the barriers that follow the energy pass
     stamp(a, st, 5);
     // ---- (5b) energies of the own positions: x = (keys + location term, formed in the shadow of exchange 2) + q; tanh,
     //      the product with attention_v and the sum over the wave's 32 units (a DPP row reduction over the 16 unit
@@ -384,7 +374,10 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
 #pragma unroll
       for (int ut = 0; ut < 2; ++ut) {
         const int u = wave * 32 + ut * 16 + c;
-        const float qv = qs[u], vv = cst_s[KWMAX * (A + KPAD) + u];
+        const float vv = cst_s[KWMAX * (A + KPAD) + u];
+        float qv = 0.f;
+#pragma unroll
+        for (int q = 0; q < CG; ++q) qv += gath[q * X2N + u];
 #pragma unroll
         for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
@@ -400,7 +393,17 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
     }
     lds_barrier();
     stamp(a, st, 6);
-    if (wave == 0) {
+    if (tid < UPW) {
+      // what the backward pass / the hoisted products read of this step's cell: stored only now (behind the energy pass, while wave 1 takes the softmax), so that these
+      // stores did not sit in front of this wave's polling loads (one vmcnt queue for loads and stores)
+      const int u = g * UPW + tid;
+      p.ca[((long)n * S1 + slot) * A + u] = cstate;
+      T* gp = (T*)p.ga + ((long)n * S1 + slot) * 4 * A;
+      stf(gp + u, sv[0]); stf(gp + A + u, sv[1]); stf(gp + 2 * A + u, sv[2]); stf(gp + 3 * A + u, sv[3]);
+      stf((T*)p.hc + ((long)n * S1 + slot) * HC + u, sv[4]);
+      if (st + 1 < p.S) stf((T*)p.xa + ((long)n * S1 + slot + 1) * XA + D2 + Dsp + u, sv[4]);
+    }
+    if (wave == 1) {
       // local softmax: lane = local position
       float e = -INFINITY;
       if (lane < tn) {
