@@ -30,6 +30,9 @@
 // What is left is
 // the hop itself: store -> visible + one probe round trip (1.9 us) + one data round trip (1.5 us; 2.2 us for the
 // backward pass's 64 KB per CU), then ~1.5 us of MFMA, barrier and cell update.
+// Round 3: the BACKWARD recurrence runs on lstm_wide_bwd_ps_kernel (further down) - partial sums of dh as self-flagging
+// granules, one hop, 4.1 us per step; the sweep-form backward kernel below stays for NS_WIDE_PS=0 and the shapes the new
+// one does not take (H not a multiple of 128, more than 256 workgroups).
 // Every spin is bounded; a timeout raises the status word and all waves of the workgroup leave together.  The grid
 // (row groups x unit blocks <= 256 workgroups, one per CU) must be resident at once: ns_lstm_wide_supported() refuses
 // shapes that do not fit.
