@@ -1055,9 +1055,11 @@ class Tacotron2(object):
         ops.copy3d(dmel, ddec, N, To, M, (Po * M, M), (S1 * M * r, M), src_off=self.padl * M, dst_off=M * r)
         h2, h1, hc = B["dec_h2"], B["dec_h1"], B["dec_hc"]
         kp = self._o("decoder/output_projection/kernel")
-        ops.gemm(h2, ddec, g, D, M * r, rows, D, M * r, M * r, a_mode=1, b_mode=1, c_off=kp, accumulate=2,
-                 split_k=self._splitk(rows, D, M * r))
-        ops.colsum(ddec, M * r, rows, M * r, g, out_off=self._o("decoder/output_projection/bias"))
+        def proj_wgrad():      # feeds nothing before the optimiser: with the decoder group's queued products (h2, ddec stay)
+            ops.gemm(h2, ddec, g, D, M * r, rows, D, M * r, M * r, a_mode=1, b_mode=1, c_off=kp, accumulate=2,
+                     split_k=self._splitk(rows, D, M * r))
+            ops.colsum(ddec, M * r, rows, M * r, g, out_off=self._o("decoder/output_projection/bias"))
+        self._defer("decoder", proj_wgrad)
         dh2 = self._buf("d_h2", rows * D, torch.float32)
         ops.gemm(ddec, self._W(self.T), dh2, rows, D, M * r, M * r, M * r, D, a_mode=0, b_mode=0, b_off=kp)
         # ---- LSTM2, LSTM1 through time
@@ -1076,15 +1078,19 @@ class Tacotron2(object):
         w16 = self._bf16_w(T_)
         dg2b = self._bufs.get("d_g2b") if w16 is not None else None
 
-        def b16(name, src, cols):       # bf16 copy of a forward activation for the single-pass weight gradients
-            if dg2b is None:
-                return src
-            dst = self._buf(name, rows * cols, torch.bfloat16)
-            ops.cast2d(src, rows, cols, cols, dst, cols, False)
-            return dst
+        def b16(name, src, cols):       # bf16 copy of a forward activation for the single-pass weight gradients:
+            return src if dg2b is None else self._buf(name, rows * cols, torch.bfloat16)      # the buffer now,
+
+        def cast16(dst, src, cols):                                                            # the copy with its consumer
+            if dst is not src:
+                ops.cast2d(src, rows, cols, cols, dst, cols, False)
         h1b, h2b = b16("dec_h1_16", h1, D), b16("dec_h2_16", h2, D)
-        self._defer("decoder", lambda: self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2,
-                                                         "decoder/lstm_2/bias"))
+
+        def lstm2_wgrads():
+            cast16(h1b, h1, D)
+            cast16(h2b, h2, D)
+            self._lstm_wgrads(h1b, D, h2b, D, dg2b if dg2b is not None else dg2, rows, k2, "decoder/lstm_2/bias")
+        self._defer("decoder", lstm2_wgrads)
         if "decoder2" in self.queue_groups:      # LSTM 2's weight gradients under LSTM 1's recurrence (measured: worse)
             self._flush_deferred()
         dh1 = self._buf("d_h1", rows * D, torch.float32)
@@ -1102,8 +1108,11 @@ class Tacotron2(object):
         self._tick("dec_lstm_bwd:loop1")
         dg1b = self._bufs.get("d_g1b") if w16 is not None else None
         hcb = b16("dec_hc_16", hc, A + E)
-        self._defer("decoder", lambda: self._lstm_wgrads(hcb, A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1,
-                                                         "decoder/lstm_1/bias"))
+
+        def lstm1_wgrads():
+            cast16(hcb, hc, A + E)
+            self._lstm_wgrads(hcb, A + E, h1b, D, dg1b if dg1b is not None else dg1, rows, k1, "decoder/lstm_1/bias")
+        self._defer("decoder", lstm1_wgrads)
         dhc = self._buf("d_hc", rows * (A + E), torch.float32)
         if dg1b is not None:
             ops.gemm(dg1b, w16, dhc, rows, A + E, 4 * D, 4 * D, 4 * D, A + E, a_mode=0, b_mode=0, b_off=k1)
