@@ -618,6 +618,7 @@ __global__ __launch_bounds__(PST) void lstm_wide_bwd_ps_kernel(WideArgs a, ps_u6
       }
       wstamp(a, bs, 1);
       if (a.trace && blockIdx.x == 0 && tid == 0 && bs < 256) a.trace[bs * 8 + 5] = passes;
+      if (a.trace && blockIdx.x == 0 && tid == 7 * 64 && bs < 256) a.trace[bs * 8 + 7] = wall_clock64();      // wave 7's polls done
 #pragma unroll
       for (int i = 0; i < IPL; ++i) {
         red[((wave * ITEMS) + lane + 64 * i) * 2] = s0[i];
@@ -702,6 +703,7 @@ __global__ __launch_bounds__(PST) void lstm_wide_bwd_ps_kernel(WideArgs a, ps_u6
   };
   load_ops(p.T - 1);
   for (int t = p.T - 1; t >= 0; --t) {
+    if (a.trace && blockIdx.x == 0 && e == 0 && p.T - 1 - t < 256) a.trace[(p.T - 1 - t) * 8 + 6] = wall_clock64();      // a cell wave reaches A
     ps_barrier();                            // A
     if (abortf[0]) return;
     float dgv[TB][4];

@@ -41,6 +41,7 @@ def report_ps(name, work, S):
     print("  cell update (cell waves) + barrier B                 %6.2f us" % us(r[:, 3] - r[:, 2]))
     print("  MFMA + publish                                       %6.2f us" % us(r[:, 4] - r[:, 3]))
     print("  publish -> the NEXT step's granules all in           %6.2f us" % us(nx[:, 1] - r[:, 4]))
+    print("  (step start -> wave 7's polls done %.2f us, -> the cell waves reach barrier A %.2f us)" % (us(r[:, 7] - r[:, 0]), us(r[:, 6] - r[:, 0])))
 
 
 def main():
