@@ -325,7 +325,97 @@ __device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&a
   }
 }
 
-template <int AMODE, int BMODE>
+// ---- vector epilogue.  The 256-tile kernel issues its MFMAs with the operands SWAPPED (a = the B fragment, b = the A
+// fragment), so a 16 x 16 accumulator holds the TRANSPOSED tile: lane l owns output row m = l & 15 and the four
+// consecutive columns n = (l >> 4) * 4 + r.  One 16-byte (fp32) / 8-byte (bf16) store per tile and lane instead of four
+// 4-byte ones, one row-mask test per row instead of per element, and bias / addend / gate / the BatchNorm-backward
+// operand (stat_z) come in as vectors.  Round 3: the scalar form cost ~10 us of a 60 us tile, and +60 us per launch
+// with the BatchNorm-backward statistics in it.
+__device__ __forceinline__ float4 ldv4(const void* base, bool bf16, long off) {
+  if (bf16) {
+    const bf16x4 v = *(const bf16x4*)((const bf16_t*)base + off);
+    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+  }
+  return *(const float4*)((const float*)base + off);
+}
+template <int NJ>       // 16-column tiles per quadrant: 2 in the 256-tile kernel, 4 (a wave's 64 x 64) in the 128-tile kernels
+__device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&acc)[4][NJ], int mq, int nq, int lane) {
+  const Epi e = make_epi(p);
+  const int li = lane & 15, c4 = (lane >> 4) * 4;
+  const bool want_stats = p.stat_part != nullptr;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = nq + j * 16 + c4;               // this lane's four columns n .. n + 3: all inside or all outside N (N % 4 == 0)
+    if (n >= p.N) continue;                       // whole 16-lane rows take this branch together (row16_sum below)
+    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), smean = bias, sistd = bias;
+    if (e.bias) bias = *(const float4*)(e.bias + n);
+    if (e.sz) { smean = *(const float4*)(e.smean + n); sistd = *(const float4*)(e.sistd + n); }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = mq + i * 16 + li;
+      if (m >= p.M) continue;
+      const bool valid = row_valid(e, m);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
+      float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e.addend) ad = ldv4(e.addend, e.add_bf16, (long)m * e.ld_add + n);
+      const float aa[4] = {ad.x, ad.y, ad.z, ad.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = apply_act(e.alpha * v[r] + bb[r] + aa[r], e.act);
+      if (e.gate) {
+        const float4 gt = ldv4(e.gate, e.gate_dtype == NS_BF16, (long)m * e.ld_gate + n);
+        const float gg[4] = {gt.x, gt.y, gt.z, gt.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (!(gg[r] > 0.f)) v[r] = 0.f;
+      }
+      if (!valid) { v[0] = v[1] = v[2] = v[3] = 0.f; }
+      const long off = (long)m * e.ldc + n;
+      if (e.accumulate == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd((float*)e.C + off + r, v[r]);
+      } else if (e.accumulate == 1) {
+        const float4 old = *(const float4*)((float*)e.C + off);
+        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (e.c_dtype == NS_BF16) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; v[r] = (float)o[r]; }    // statistics on the stored values
+        *(bf16x4*)((bf16_t*)e.C + off) = o;
+      } else {
+        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
+      }
+      if (want_stats && valid) {
+        if (e.sz) {
+          const float4 zz = ldv4(e.sz, e.sz_bf16, (long)m * e.ld_sz + n);
+          s2[0] += v[0] * ((zz.x - smean.x) * sistd.x); s2[1] += v[1] * ((zz.y - smean.y) * sistd.y);
+          s2[2] += v[2] * ((zz.z - smean.z) * sistd.z); s2[3] += v[3] * ((zz.w - smean.w) * sistd.w);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s2[r] += v[r] * v[r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s1[r] += v[r];
+      }
+    }
+    if (want_stats) {      // this quadrant's 64 rows = one statistics slot: add the 16 row lanes of each column group
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
+      if (li == 0) {
+        const long slot = mq >> 6;
+        *(float4*)(p.stat_part + slot * p.N + n) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *(float4*)(p.stat_part + (p.stat_slots + slot) * p.N + n) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      }
+    }
+  }
+}
+
+// VEC: the products are issued with the operands swapped, so the accumulators hold the transposed tiles and the vector
+// epilogue of the 256-tile kernel applies (x256_quadrant; the host asks for it when C and the epilogue operands allow
+// 16-byte accesses and nothing is added atomically).  Round 3, switches in the kernel: of the 64 us of the encoder's
+// convolution data gradient (5244 x 512 x 2560) 25 were the element-wise epilogue - 64 four-byte stores per lane.
+template <int AMODE, int BMODE, bool VEC>
 __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][A 16K | B 16K]
@@ -407,7 +497,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = VEC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       char* nA = smem + (cur ^ 1) * 32768;
@@ -417,7 +508,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
     __syncthreads();
   }
 
-  mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+  if (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
 // ------------------------------------------------------------------ 256 x 256 tiles, 8 phases per two K-tiles
@@ -443,90 +535,6 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
 // 838 (128^2 kernel: 662 / - / 610); three-segment product 344 algorithmic = 1032 issued (in-kernel split: 239).
 constexpr int XHALF = 16384, XBUF = 65536;
 
-// ---- vector epilogue.  The 256-tile kernel issues its MFMAs with the operands SWAPPED (a = the B fragment, b = the A
-// fragment), so a 16 x 16 accumulator holds the TRANSPOSED tile: lane l owns output row m = l & 15 and the four
-// consecutive columns n = (l >> 4) * 4 + r.  One 16-byte (fp32) / 8-byte (bf16) store per tile and lane instead of four
-// 4-byte ones, one row-mask test per row instead of per element, and bias / addend / gate / the BatchNorm-backward
-// operand (stat_z) come in as vectors.  Round 3: the scalar form cost ~10 us of a 60 us tile, and +60 us per launch
-// with the BatchNorm-backward statistics in it.
-__device__ __forceinline__ float4 ldv4(const void* base, bool bf16, long off) {
-  if (bf16) {
-    const bf16x4 v = *(const bf16x4*)((const bf16_t*)base + off);
-    return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
-  }
-  return *(const float4*)((const float*)base + off);
-}
-__device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&acc)[4][2], int mq, int nq, int lane) {
-  const Epi e = make_epi(p);
-  const int li = lane & 15, c4 = (lane >> 4) * 4;
-  const bool want_stats = p.stat_part != nullptr;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = nq + j * 16 + c4;               // this lane's four columns n .. n + 3: all inside or all outside N (N % 128 == 0)
-    if (n >= p.N) continue;                       // whole 16-lane rows take this branch together (row16_sum below)
-    float4 bias = make_float4(0.f, 0.f, 0.f, 0.f), smean = bias, sistd = bias;
-    if (e.bias) bias = *(const float4*)(e.bias + n);
-    if (e.sz) { smean = *(const float4*)(e.smean + n); sistd = *(const float4*)(e.sistd + n); }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int m = mq + i * 16 + li;
-      if (m >= p.M) continue;
-      const bool valid = row_valid(e, m);
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      const float bb[4] = {bias.x, bias.y, bias.z, bias.w};
-      float4 ad = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e.addend) ad = ldv4(e.addend, e.add_bf16, (long)m * e.ld_add + n);
-      const float aa[4] = {ad.x, ad.y, ad.z, ad.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = apply_act(e.alpha * v[r] + bb[r] + aa[r], e.act);
-      if (e.gate) {
-        const float4 gt = ldv4(e.gate, e.gate_dtype == NS_BF16, (long)m * e.ld_gate + n);
-        const float gg[4] = {gt.x, gt.y, gt.z, gt.w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) if (!(gg[r] > 0.f)) v[r] = 0.f;
-      }
-      if (!valid) { v[0] = v[1] = v[2] = v[3] = 0.f; }
-      const long off = (long)m * e.ldc + n;
-      if (e.accumulate == 2) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd((float*)e.C + off + r, v[r]);
-      } else if (e.accumulate == 1) {
-        const float4 old = *(const float4*)((float*)e.C + off);
-        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
-      } else if (e.c_dtype == NS_BF16) {
-        bf16x4 o;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { o[r] = (bf16_t)v[r]; v[r] = (float)o[r]; }    // statistics on the stored values
-        *(bf16x4*)((bf16_t*)e.C + off) = o;
-      } else {
-        *(float4*)((float*)e.C + off) = make_float4(v[0], v[1], v[2], v[3]);
-      }
-      if (want_stats && valid) {
-        if (e.sz) {
-          const float4 zz = ldv4(e.sz, e.sz_bf16, (long)m * e.ld_sz + n);
-          s2[0] += v[0] * ((zz.x - smean.x) * sistd.x); s2[1] += v[1] * ((zz.y - smean.y) * sistd.y);
-          s2[2] += v[2] * ((zz.z - smean.z) * sistd.z); s2[3] += v[3] * ((zz.w - smean.w) * sistd.w);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) s2[r] += v[r] * v[r];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s1[r] += v[r];
-      }
-    }
-    if (want_stats) {      // this quadrant's 64 rows = one statistics slot: add the 16 row lanes of each column group
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { s1[r] = row16_sum(s1[r]); s2[r] = row16_sum(s2[r]); }
-      if (li == 0) {
-        const long slot = mq >> 6;
-        *(float4*)(p.stat_part + slot * p.N + n) = make_float4(s1[0], s1[1], s1[2], s1[3]);
-        *(float4*)(p.stat_part + (p.stat_slots + slot) * p.N + n) = make_float4(s2[0], s2[1], s2[2], s2[3]);
-      }
-    }
-  }
-}
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -834,7 +842,7 @@ __device__ __forceinline__ void stagef_store(const StageF& s, char* img_hi, char
   }
 }
 
-template <int AMODE, int BMODE, int PASSES>
+template <int AMODE, int BMODE, int PASSES, bool VEC>      // VEC: as in gemm_mfma_kernel
 __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][A hi 8K | A lo 8K | B hi 8K | B lo 8K]
@@ -921,11 +929,19 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if (PASSES > 1) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        if (VEC) {         // same terms in the same order, operands swapped
+          if (PASSES > 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], ah[i], acc[i][j], 0, 0, 0);
+        } else {
+          if (PASSES > 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          }
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
     if (more) {
       char* nb = smem + (cur ^ 1) * 32768;
@@ -934,7 +950,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     }
     __syncthreads();
   }
-  mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+  if (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
 // skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h).
@@ -998,6 +1015,16 @@ static thread_local const char* g_last_kernel = "";
 extern "C" const char* ns_gemm_last_kernel(void) { return g_last_kernel; }
 
 // the 256-tile kernel: large k-contiguous bf16 products whose tiles fill the chip
+// the vector epilogue (x256_quadrant): 16-byte (fp32) / 8-byte (bf16) accesses of C and of every per-element epilogue
+// operand, four consecutive columns per lane, plain stores
+static bool vec_epilogue_ok(const ns_gemm_params& p) {
+  auto al = [](const void* q, long ld, bool bf16) { return !q || ((((uintptr_t)q) & (bf16 ? 7 : 15)) == 0 && ld % 4 == 0); };
+  if (p.accumulate == 2 || p.split_k != 1 || p.N % 4 != 0) return false;
+  if (p.batch > 1 && p.batch_stride_c % 4 != 0) return false;
+  return al(p.C, p.ldc, p.c_dtype == NS_BF16) && al(p.addend, p.ld_add, p.addend_dtype == NS_BF16) &&
+         al(p.gate, p.ld_gate, p.dtype == NS_BF16) && al(p.stat_z, p.ld_stat_z, p.stat_z_dtype == NS_BF16) &&
+         al(p.bias, 4, false) && al(p.stat_mean, 4, false) && al(p.stat_istd, 4, false) && al(p.stat_part, 4, false);
+}
 static bool x256_ok(const ns_gemm_params& p) {
   if (p.dtype != NS_BF16 || p.a_mode != 0 || p.b_mode != 0 || p.split_k != 1) return false;
   if (p.b_seg_len != 0 && (p.b_seg_len % 64 != 0 || p.b_seg_stride % 8 != 0)) return false;
@@ -1110,16 +1137,20 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     dim3 grid(tiles, p.split_k, p.batch);
     const size_t lds = 65536;
     p.stat_slots = 2 * ceil_div(p.M, GBM);
+    const bool vec = vec_epilogue_ok(p);
 #define LAUNCH_MFMA(AM, BM_)                                                                      \
   do {                                                                                            \
     static bool attr_set = false;                                                                 \
     if (!attr_set) {                                                                              \
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<AM, BM_>,                               \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<AM, BM_, false>,                        \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<AM, BM_, true>,                         \
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
       attr_set = true;                                                                            \
     }                                                                                             \
     g_last_kernel = "gemm_mfma_kernel<" #AM ", " #BM_ ">";                                        \
-    hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_>), grid, dim3(256), lds, stream, p);             \
+    if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, true>), grid, dim3(256), lds, stream, p);  \
+    else hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, false>), grid, dim3(256), lds, stream, p);     \
   } while (0)
     if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
     else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_MFMA(0, 1);
@@ -1155,16 +1186,20 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
       dim3 grid(tiles, p.split_k, p.batch);
       const size_t lds = 65536;
       p.stat_slots = 2 * ceil_div(p.M, GBM);
+      const bool vec = vec_epilogue_ok(p);
 #define LAUNCH_F32(AM, BM_, PS)                                                                     \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \
     if (!attr_set) {                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_mfma_f32_kernel<AM, BM_, PS>,                     \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_f32_kernel<AM, BM_, PS, false>,              \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_f32_kernel<AM, BM_, PS, true>,               \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_set = true;                                                                              \
     }                                                                                               \
     g_last_kernel = "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ">";                             \
-    hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS>), grid, dim3(256), lds, stream, p);       \
+    if (vec) hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, true>), grid, dim3(256), lds, stream, p);   \
+    else hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, false>), grid, dim3(256), lds, stream, p);      \
   } while (0)
 #define LAUNCH_F32_MODES(PS)                                                   \
   do {                                                                         \

@@ -327,7 +327,9 @@ def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
             n = int(np.prod(shape))
             d = (gs[0][off:off + n] - g1[off:off + n]).abs().max().item()
             sc = gs[0][off:off + n].abs().max().item()
-            assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
+            # the floor: a split-K sum over 32000 rows that cancels down to ~1e-6 (the location convolution's kernel)
+            # moves by ~1e-9 with the order of its atomic adds - fp32 rounding of the partial sums, not of the result
+            assert d <= 2e-5 * sc + 5e-9, (name, d, sc)
 
 
 @pytest.mark.parametrize("mode", ["bf16", "mixed"])
