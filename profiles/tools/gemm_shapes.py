@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from nspeech_amd import ops, profiling  # noqa: E402
 
 # (label, M, N, K, a_mode, b_mode, dtype, c dtype, f32_passes, split_k)
-SHAPES_ALL = [
+SHAPES = [
     ("encoder conv data gradient", 5244, 512, 2560, 0, 0, "bf16", "f32", 0, 1),
     ("decoder input product bwd", 5248, 512, 1024, 0, 0, "bf16", "f32", 0, 1),
     ("postnet data gradient (x256 shape on 128 tiles)", 32124, 512, 2560, 0, 0, "bf16", "f32", 0, 1),
@@ -24,9 +24,6 @@ SHAPES_ALL = [
     ("fp32 weight gradient, 1 pass", 1024, 400, 6432, 1, 1, "f32", "f32", 1, 12),
     ("fp32 data gradient, 1 pass", 6432, 1024, 400, 0, 0, "f32", "f32", 1, 1),
 ]
-
-
-SHAPES = [s for s in SHAPES_ALL if not os.environ.get("NS_GEMM_DBG") or s[6] == "bf16"]
 
 
 def main():
