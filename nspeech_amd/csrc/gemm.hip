@@ -1148,7 +1148,7 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
       attr_set = true;                                                                            \
     }                                                                                             \
-    g_last_kernel = "gemm_mfma_kernel<" #AM ", " #BM_ ">";                                        \
+    g_last_kernel = vec ? "gemm_mfma_kernel<" #AM ", " #BM_ ", true>" : "gemm_mfma_kernel<" #AM ", " #BM_ ", false>";  \
     if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, true>), grid, dim3(256), lds, stream, p);  \
     else hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, false>), grid, dim3(256), lds, stream, p);     \
   } while (0)
@@ -1197,7 +1197,8 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_set = true;                                                                              \
     }                                                                                               \
-    g_last_kernel = "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ">";                             \
+    g_last_kernel = vec ? "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", true>"                  \
+                        : "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", false>";                \
     if (vec) hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, true>), grid, dim3(256), lds, stream, p);   \
     else hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, false>), grid, dim3(256), lds, stream, p);      \
   } while (0)
