@@ -247,7 +247,7 @@ struct Stage { uint4 v[4]; };
 
 // global -> registers for one 128x64 operand tile.  r0 = first row/col of the tile in the
 // non-contracted dim, extent = size of that dim, k0 = first k, K = contraction size.
-template <int MODE>
+template <int MODE, int BK = GBK>
 __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld, int r0, int extent,
                                            int k0, int K, int tid) {
   if (MODE == 0) {
@@ -262,7 +262,7 @@ __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld
   } else {
     const int c = tid & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BK / 16; ++i) {
       const int kr = (tid >> 4) + 16 * i;
       const int k = k0 + kr, r = r0 + c * 8;
       if (k < K && r < extent) s.v[i] = *(const uint4*)(base + (long)k * ld + r);
@@ -270,7 +270,7 @@ __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld
     }
   }
 }
-template <int MODE>
+template <int MODE, int BK = GBK>
 __device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) {
   if (MODE == 0) {
     const int c = tid & 7;
@@ -282,7 +282,7 @@ __device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) 
   } else {
     const int c = tid & 15;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < BK / 16; ++i) {
       const int kr = (tid >> 4) + 16 * i;
       *(uint4*)(img + col_img_off_chunk(kr, c)) = s.v[i];
     }
@@ -415,10 +415,14 @@ __device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&a
 // epilogue of the 256-tile kernel applies (x256_quadrant; the host asks for it when C and the epilogue operands allow
 // 16-byte accesses and nothing is added atomically).  Round 3, switches in the kernel: of the 64 us of the encoder's
 // convolution data gradient (5244 x 512 x 2560) 25 were the element-wise epilogue - 64 four-byte stores per lane.
-template <int AMODE, int BMODE, bool VEC>
-__global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
+// BK = 32 (both operands k-slow only: the weight-gradient products): 32 KB of LDS and half the stage registers per
+// workgroup, so three workgroups share a CU where BK = 64 allows two.
+template <int AMODE, int BMODE, bool VEC, int BK = GBK>
+__global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gemm_params p) {
+  static_assert(BK == 64 || (BK == 32 && AMODE == 1 && BMODE == 1), "BK = 32: k-slow images only (their rows are k)");
+  constexpr int IMG = BK * 256;                 // bytes per operand image (BK = 64: 16 KB for either layout)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  // [stage][A 16K | B 16K]
+  // [stage][A IMG | B IMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int tiles_n = (p.N + GBN - 1) / GBN;
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   const int tm = wgid / tiles_n, tn = wgid % tiles_n;
   const int m0 = tm * GBM, n0 = tn * GBN;
 
-  const int nk = (p.K + GBK - 1) / GBK;
+  const int nk = (p.K + BK - 1) / BK;
   const int per = (nk + p.split_k - 1) / p.split_k;
   const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
   batch_shift(p, blockIdx.z);
@@ -461,27 +465,27 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
   Stage sa, sb;
   if (kt0 < kt1) {
     int kin;
-    const bf16_t* bb = b_tile_base(kt0 * GBK, kin);
-    stage_load<AMODE>(sa, A, p.lda, m0, p.M, kt0 * GBK, p.K, tid);
-    stage_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
-    stage_store<AMODE>(sa, smem, tid);
-    stage_store<BMODE>(sb, smem + 16384, tid);
+    const bf16_t* bb = b_tile_base(kt0 * BK, kin);
+    stage_load<AMODE, BK>(sa, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
+    stage_load<BMODE, BK>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+    stage_store<AMODE, BK>(sa, smem, tid);
+    stage_store<BMODE, BK>(sb, smem + IMG, tid);
   }
   __syncthreads();
 
   for (int kt = kt0; kt < kt1; ++kt) {
     const int cur = (kt - kt0) & 1;
-    char* imgA = smem + cur * 32768;
-    char* imgB = imgA + 16384;
+    char* imgA = smem + cur * 2 * IMG;
+    char* imgB = imgA + IMG;
     const bool more = kt + 1 < kt1;
     if (more) {
       int kin;
-      const bf16_t* bb = b_tile_base((kt + 1) * GBK, kin);
-      stage_load<AMODE>(sa, A, p.lda, m0, p.M, (kt + 1) * GBK, p.K, tid);
-      stage_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
+      const bf16_t* bb = b_tile_base((kt + 1) * BK, kin);
+      stage_load<AMODE, BK>(sa, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+      stage_load<BMODE, BK>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
     }
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8 af[4], bfr[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -501,9 +505,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_kernel(ns_gemm_params p) {
                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
-      char* nA = smem + (cur ^ 1) * 32768;
-      stage_store<AMODE>(sa, nA, tid);
-      stage_store<BMODE>(sb, nA + 16384, tid);
+      char* nA = smem + (cur ^ 1) * 2 * IMG;
+      stage_store<AMODE, BK>(sa, nA, tid);
+      stage_store<BMODE, BK>(sb, nA + IMG, tid);
     }
     __syncthreads();
   }
@@ -1152,7 +1156,17 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, true>), grid, dim3(256), lds, stream, p);  \
     else hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, false>), grid, dim3(256), lds, stream, p);     \
   } while (0)
-    if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
+    // BK = 32 (four workgroups per CU instead of two) pays when a launch has more workgroups than the 512 the BK = 64
+    // form keeps resident: 1280 workgroups 202 -> 169 us, 640: 73 -> 52 us; at <= 512 (what the models' split-K rule
+    // asks for) it is slower alone (84 -> 99 us) and no faster beside another stream's kernels
+    // (profiles/r03_gemm_128_ablation.txt).  NS_GEMM_BK32 = 0 / 1 forces it off / on.
+    static const int bk32_env = [] { const char* e = getenv("NS_GEMM_BK32"); return e ? atoi(e) : -1; }();
+    const bool bk32 = bk32_env >= 0 ? bk32_env != 0 : (long)tiles * p.split_k * p.batch >= 600;
+    if (p.a_mode == 1 && p.b_mode == 1 && bk32 && (p.b_seg_len == 0 || p.b_seg_len % 32 == 0)) {
+      g_last_kernel = vec ? "gemm_mfma_kernel<1, 1, true, 32>" : "gemm_mfma_kernel<1, 1, false, 32>";
+      if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, true, 32>), grid, dim3(256), 32768, stream, p);
+      else hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, false, 32>), grid, dim3(256), 32768, stream, p);
+    } else if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
     else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_MFMA(0, 1);
     else if (p.a_mode == 1 && p.b_mode == 0) LAUNCH_MFMA(1, 0);
     else LAUNCH_MFMA(1, 1);

@@ -92,6 +92,31 @@ def test_gemm_splitk_atomic_and_segments(dev, dtype):
     assert (dX.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
 
 
+def test_gemm_splitk_many_workgroups_takes_the_32_deep_tiles(dev):
+    """A k-slow x k-slow bf16 product with more workgroups than the 64-deep form keeps resident (>= 600) runs on the
+    BK = 32 instantiation of gemm_mfma_kernel (four workgroups per CU); odd K, ragged M and N, split-K atomics."""
+    from nspeech_amd import ops, profiling
+    Kc, M, N = 4099, 520, 1288                     # 5 x 11 tiles x 12 splits = 660 workgroups
+    A = _mk((Kc, M), torch.bfloat16, dev, 16)
+    B = _mk((Kc, N), torch.bfloat16, dev, 17)
+    Cm = torch.full((M, N), 0.5, dtype=torch.float32, device=dev)
+    ops.gemm(A, B, Cm, M, N, Kc, M, N, N, a_mode=1, b_mode=1, accumulate=2, split_k=12)
+    torch.cuda.synchronize()
+    assert profiling._last_kernel().endswith("32>"), profiling._last_kernel()
+    ref = 0.5 + A.double().cpu().t() @ B.double().cpu()
+    assert (Cm.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
+    # and without split-K (plain stores through the vector epilogue), still >= 600 workgroups
+    M2, N2, K2 = 3208, 3080, 96                    # 26 x 25 tiles
+    A2 = _mk((K2, M2), torch.bfloat16, dev, 18)
+    B2 = _mk((K2, N2), torch.bfloat16, dev, 19)
+    C2 = torch.zeros((M2, N2), dtype=torch.float32, device=dev)
+    ops.gemm(A2, B2, C2, M2, N2, K2, M2, N2, N2, a_mode=1, b_mode=1)
+    torch.cuda.synchronize()
+    assert profiling._last_kernel().endswith("32>"), profiling._last_kernel()
+    ref2 = A2.double().cpu().t() @ B2.double().cpu()
+    assert (C2.double().cpu() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item() + 1e-3
+
+
 @pytest.mark.parametrize("passes,tol", [(3, 3e-5), (1, 2e-2)])
 @pytest.mark.parametrize("a_mode,b_mode", [(0, 0), (0, 1), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 136, 320), (32, 256, 512), (260, 72, 1000)])
