@@ -247,13 +247,13 @@ struct Stage { uint4 v[4]; };
 
 // global -> registers for one 128x64 operand tile.  r0 = first row/col of the tile in the
 // non-contracted dim, extent = size of that dim, k0 = first k, K = contraction size.
-template <int MODE, int BK = GBK>
+template <int MODE, int BK = GBK, int ROWS = 128>     // ROWS: rows of a k-contiguous tile (64: the half-height A tile)
 __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld, int r0, int extent,
                                            int k0, int K, int tid) {
   if (MODE == 0) {
     const int c = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
       const int row = (tid >> 3) + 32 * i;
       const int r = r0 + row, k = k0 + c * 8;
       if (r < extent && k < K) s.v[i] = *(const uint4*)(base + (long)r * ld + k);
@@ -270,12 +270,12 @@ __device__ __forceinline__ void stage_load(Stage& s, const bf16_t* base, long ld
     }
   }
 }
-template <int MODE, int BK = GBK>
+template <int MODE, int BK = GBK, int ROWS = 128>
 __device__ __forceinline__ void stage_store(const Stage& s, char* img, int tid) {
   if (MODE == 0) {
     const int c = tid & 7;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
       const int row = (tid >> 3) + 32 * i;
       *(uint4*)(img + row_img_off(row, c)) = s.v[i];
     }
@@ -417,16 +417,21 @@ __device__ __forceinline__ void x256_quadrant(const ns_gemm_params& p, f32x4 (&a
 // convolution data gradient (5244 x 512 x 2560) 25 were the element-wise epilogue - 64 four-byte stores per lane.
 // BK = 32 (both operands k-slow only: the weight-gradient products): 32 KB of LDS and half the stage registers per
 // workgroup, so three workgroups share a CU where BK = 64 allows two.
-template <int AMODE, int BMODE, bool VEC, int BK = GBK>
+// TM = 64 (k-contiguous A, vector epilogue only): 64 x 128 tiles, the four waves side by side (64 x 32 each), for
+// products whose 128-row tiles would leave a third of the CUs without a workgroup (M ~ 5 000 rows: 164 tiles).
+template <int AMODE, int BMODE, bool VEC, int BK = GBK, int TM = GBM>
 __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gemm_params p) {
+  static_assert(TM == 128 || (TM == 64 && AMODE == 0 && VEC && BK == 64), "TM = 64: k-contiguous A, vector epilogue");
+  constexpr int WN = TM == 128 ? 2 : 4;         // waves along N
+  constexpr int NJ = 8 / WN;                    // 16-column tiles per wave
   static_assert(BK == 64 || (BK == 32 && AMODE == 1 && BMODE == 1), "BK = 32: k-slow images only (their rows are k)");
   constexpr int IMG = BK * 256;                 // bytes per operand image (BK = 64: 16 KB for either layout)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][A IMG | B IMG]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + GBN - 1) / GBN;
-  const int tiles_m = (p.M + GBM - 1) / GBM;
+  const int tiles_m = (p.M + TM - 1) / TM;
   // XCD-aware bijective remap: workgroups that share an XCD (id % 8) walk neighbouring tiles
   const int nwg = tiles_m * tiles_n;
   int wgid;
@@ -435,7 +440,7 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   const int tm = wgid / tiles_n, tn = wgid % tiles_n;
-  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int m0 = tm * TM, n0 = tn * GBN;
 
   const int nk = (p.K + BK - 1) / BK;
   const int per = (nk + p.split_k - 1) / p.split_k;
@@ -445,11 +450,11 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
   const bf16_t* A = (const bf16_t*)p.A;
   const bf16_t* B = (const bf16_t*)p.B;
 
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   auto b_tile_base = [&](int k0, int& kin) -> const bf16_t* {
     if (p.b_seg_len > 0) {
@@ -466,9 +471,9 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
   if (kt0 < kt1) {
     int kin;
     const bf16_t* bb = b_tile_base(kt0 * BK, kin);
-    stage_load<AMODE, BK>(sa, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
+    stage_load<AMODE, BK, TM>(sa, A, p.lda, m0, p.M, kt0 * BK, p.K, tid);
     stage_load<BMODE, BK>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
-    stage_store<AMODE, BK>(sa, smem, tid);
+    stage_store<AMODE, BK, TM>(sa, smem, tid);
     stage_store<BMODE, BK>(sb, smem + IMG, tid);
   }
   __syncthreads();
@@ -481,38 +486,38 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
     if (more) {
       int kin;
       const bf16_t* bb = b_tile_base((kt + 1) * BK, kin);
-      stage_load<AMODE, BK>(sa, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+      stage_load<AMODE, BK, TM>(sa, A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
       stage_load<BMODE, BK>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8 af[4], bfr[4];
+      bf16x8 af[4], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (AMODE == 0) af[i] = frag_row(imgA, wm * 64 + i * 16 + (lane & 15), ks * 4 + (lane >> 4));
         else af[i] = frag_col(imgA, ks * 32, wm * 64 + i * 16, lane);
       }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (BMODE == 0) bfr[j] = frag_row(imgB, wn * 64 + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
-        else bfr[j] = frag_col(imgB, ks * 32, wn * 64 + j * 16, lane);
+      for (int j = 0; j < NJ; ++j) {
+        if (BMODE == 0) bfr[j] = frag_row(imgB, wn * (NJ * 16) + j * 16 + (lane & 15), ks * 4 + (lane >> 4));
+        else bfr[j] = frag_col(imgB, ks * 32, wn * (NJ * 16) + j * 16, lane);
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
           acc[i][j] = VEC ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0)
                           : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if (more) {
       char* nA = smem + (cur ^ 1) * 2 * IMG;
-      stage_store<AMODE, BK>(sa, nA, tid);
+      stage_store<AMODE, BK, TM>(sa, nA, tid);
       stage_store<BMODE, BK>(sb, nA + IMG, tid);
     }
     __syncthreads();
   }
 
-  if (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
   else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
@@ -795,13 +800,13 @@ __device__ __forceinline__ int row32_img_off(int row, int chunk16) {   // 64-B r
 }
 struct StageF { float4 v[4]; };
 
-template <int MODE>
+template <int MODE, int ROWS = 128>
 __device__ __forceinline__ void stagef_load(StageF& s, const float* base, long ld, int r0, int extent, int k0,
                                             int K, int tid) {
   if (MODE == 0) {
     const int c = tid & 7;            // 8 float4 per 32-float row
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ROWS / 32; ++i) {
       const int row = (tid >> 3) + 32 * i;
       const int r = r0 + row, k = k0 + c * 4;
       if (r < extent && k < K) s.v[i] = *(const float4*)(base + (long)r * ld + k);
@@ -827,10 +832,10 @@ __device__ __forceinline__ void split4(const float4& x, bf16x4& hi, bf16x4& lo) 
     lo[i] = (bf16_t)(f[i] - (float)h);
   }
 }
-template <int MODE, int PASSES>
+template <int MODE, int PASSES, int ROWS = 128>
 __device__ __forceinline__ void stagef_store(const StageF& s, char* img_hi, char* img_lo, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < (MODE == 0 ? ROWS / 32 : 4); ++i) {
     bf16x4 hi, lo;
     split4(s.v[i], hi, lo);
     int off;
@@ -846,14 +851,17 @@ __device__ __forceinline__ void stagef_store(const StageF& s, char* img_hi, char
   }
 }
 
-template <int AMODE, int BMODE, int PASSES, bool VEC>      // VEC: as in gemm_mfma_kernel
+template <int AMODE, int BMODE, int PASSES, bool VEC, int TM = GBM>      // VEC, TM: as in gemm_mfma_kernel
 __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p) {
+  static_assert(TM == 128 || (TM == 64 && AMODE == 0 && VEC), "TM = 64: k-contiguous A, vector epilogue");
+  constexpr int WN = TM == 128 ? 2 : 4;
+  constexpr int NJ = 8 / WN;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // [stage][A hi 8K | A lo 8K | B hi 8K | B lo 8K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (p.N + GBN - 1) / GBN;
-  const int tiles_m = (p.M + GBM - 1) / GBM;
+  const int tiles_m = (p.M + TM - 1) / TM;
   const int nwg = tiles_m * tiles_n;
   int wgid;
   {
@@ -861,18 +869,18 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
   const int tm = wgid / tiles_n, tn = wgid % tiles_n;
-  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int m0 = tm * TM, n0 = tn * GBN;
   const int nk = (p.K + FBK - 1) / FBK;
   const int per = (nk + p.split_k - 1) / p.split_k;
   const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
   batch_shift(p, blockIdx.z);
   const float* A = (const float*)p.A;
   const float* B = (const float*)p.B;
-  f32x4 acc[4][4];
+  f32x4 acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   auto b_tile_base = [&](int k0, int& kin) -> const float* {
     if (p.b_seg_len > 0) {
       int sg = k0 / p.b_seg_len;
@@ -887,9 +895,9 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
   if (kt0 < kt1) {
     int kin;
     const float* bb = b_tile_base(kt0 * FBK, kin);
-    stagef_load<AMODE>(sa, A, p.lda, m0, p.M, kt0 * FBK, p.K, tid);
+    stagef_load<AMODE, TM>(sa, A, p.lda, m0, p.M, kt0 * FBK, p.K, tid);
     stagef_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
-    stagef_store<AMODE, PASSES>(sa, smem, smem + 8192, tid);
+    stagef_store<AMODE, PASSES, TM>(sa, smem, smem + 8192, tid);
     stagef_store<BMODE, PASSES>(sb, smem + 16384, smem + 24576, tid);
   }
   __syncthreads();
@@ -903,10 +911,10 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     if (more) {
       int kin;
       const float* bb = b_tile_base((kt + 1) * FBK, kin);
-      stagef_load<AMODE>(sa, A, p.lda, m0, p.M, (kt + 1) * FBK, p.K, tid);
+      stagef_load<AMODE, TM>(sa, A, p.lda, m0, p.M, (kt + 1) * FBK, p.K, tid);
       stagef_load<BMODE>(sb, bb, p.ldb, n0, p.N, kin, KB, tid);
     }
-    bf16x8 ah[4], al[4], bh[4], bl[4];
+    bf16x8 ah[4], al[4], bh[NJ], bl[NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (AMODE == 0) {
@@ -919,20 +927,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
       }
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
       if (BMODE == 0) {
-        const int off = row32_img_off(wn * 64 + j * 16 + (lane & 15), lane >> 4);
+        const int off = row32_img_off(wn * (NJ * 16) + j * 16 + (lane & 15), lane >> 4);
         bh[j] = *(const bf16x8*)(iBh + off);
         if (PASSES > 1) bl[j] = *(const bf16x8*)(iBl + off);
       } else {
-        bh[j] = frag_col(iBh, 0, wn * 64 + j * 16, lane);
-        if (PASSES > 1) bl[j] = frag_col(iBl, 0, wn * 64 + j * 16, lane);
+        bh[j] = frag_col(iBh, 0, wn * (NJ * 16) + j * 16, lane);
+        if (PASSES > 1) bl[j] = frag_col(iBl, 0, wn * (NJ * 16) + j * 16, lane);
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         if (VEC) {         // same terms in the same order, operands swapped
           if (PASSES > 1) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bh[j], al[i], acc[i][j], 0, 0, 0);
@@ -949,12 +957,12 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
       }
     if (more) {
       char* nb = smem + (cur ^ 1) * 32768;
-      stagef_store<AMODE, PASSES>(sa, nb, nb + 8192, tid);
+      stagef_store<AMODE, PASSES, TM>(sa, nb, nb + 8192, tid);
       stagef_store<BMODE, PASSES>(sb, nb + 16384, nb + 24576, tid);
     }
     __syncthreads();
   }
-  if (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * 64, lane);
+  if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
   else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
 }
 
@@ -1028,6 +1036,12 @@ static bool vec_epilogue_ok(const ns_gemm_params& p) {
   return al(p.C, p.ldc, p.c_dtype == NS_BF16) && al(p.addend, p.ld_add, p.addend_dtype == NS_BF16) &&
          al(p.gate, p.ld_gate, p.dtype == NS_BF16) && al(p.stat_z, p.ld_stat_z, p.stat_z_dtype == NS_BF16) &&
          al(p.bias, 4, false) && al(p.stat_mean, 4, false) && al(p.stat_istd, 4, false) && al(p.stat_part, 4, false);
+}
+// 64 x 128 tiles instead of 128 x 128: when the 128-row tiling leaves CUs idle and halving the tile height adds workgroups
+static bool half_tiles_wanted(const ns_gemm_params& p, int tiles128) {
+  static const int env = [] { const char* e = getenv("NS_GEMM_HALF"); return e ? atoi(e) : -1; }();
+  if (env >= 0) return env != 0;
+  return tiles128 * p.batch <= 192 && p.M > 64;
 }
 static bool x256_ok(const ns_gemm_params& p) {
   if (p.dtype != NS_BF16 || p.a_mode != 0 || p.b_mode != 0 || p.split_k != 1) return false;
@@ -1142,6 +1156,12 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     const size_t lds = 65536;
     p.stat_slots = 2 * ceil_div(p.M, GBM);
     const bool vec = vec_epilogue_ok(p);
+    // 64-row tiles when the 128-row ones leave CUs without a workgroup (<= 192 tiles) and A is k-contiguous
+    const bool half = vec && p.a_mode == 0 && half_tiles_wanted(p, tiles);
+    if (half) {
+      grid.x = ceil_div(p.M, 64) * ceil_div(p.N, GBN);
+      p.stat_slots = ceil_div(p.M, 64);
+    }
 #define LAUNCH_MFMA(AM, BM_)                                                                      \
   do {                                                                                            \
     static bool attr_set = false;                                                                 \
@@ -1156,13 +1176,26 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, true>), grid, dim3(256), lds, stream, p);  \
     else hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, false>), grid, dim3(256), lds, stream, p);     \
   } while (0)
+#define LAUNCH_MFMA_HALF(BM_)                                                                     \
+  do {                                                                                            \
+    static bool attr_set = false;                                                                 \
+    if (!attr_set) {                                                                              \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_kernel<0, BM_, true, 64, 64>,                  \
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
+      attr_set = true;                                                                            \
+    }                                                                                             \
+    g_last_kernel = "gemm_mfma_kernel<0, " #BM_ ", true, 64, 64>";                                \
+    hipLaunchKernelGGL((gemm_mfma_kernel<0, BM_, true, 64, 64>), grid, dim3(256), lds, stream, p);    \
+  } while (0)
+    static const int bk32_env = [] { const char* e = getenv("NS_GEMM_BK32"); return e ? atoi(e) : -1; }();
+    const bool bk32 = bk32_env >= 0 ? bk32_env != 0 : (long)tiles * p.split_k * p.batch >= 600;
     // BK = 32 (four workgroups per CU instead of two) pays when a launch has more workgroups than the 512 the BK = 64
     // form keeps resident: 1280 workgroups 202 -> 169 us, 640: 73 -> 52 us; at <= 512 (what the models' split-K rule
     // asks for) it is slower alone (84 -> 99 us) and no faster beside another stream's kernels
     // (profiles/r03_gemm_128_ablation.txt).  NS_GEMM_BK32 = 0 / 1 forces it off / on.
-    static const int bk32_env = [] { const char* e = getenv("NS_GEMM_BK32"); return e ? atoi(e) : -1; }();
-    const bool bk32 = bk32_env >= 0 ? bk32_env != 0 : (long)tiles * p.split_k * p.batch >= 600;
-    if (p.a_mode == 1 && p.b_mode == 1 && bk32 && (p.b_seg_len == 0 || p.b_seg_len % 32 == 0)) {
+    if (half) {
+      if (p.b_mode == 0) LAUNCH_MFMA_HALF(0); else LAUNCH_MFMA_HALF(1);
+    } else if (p.a_mode == 1 && p.b_mode == 1 && bk32 && (p.b_seg_len == 0 || p.b_seg_len % 32 == 0)) {
       g_last_kernel = vec ? "gemm_mfma_kernel<1, 1, true, 32>" : "gemm_mfma_kernel<1, 1, false, 32>";
       if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, true, 32>), grid, dim3(256), 32768, stream, p);
       else hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, false, 32>), grid, dim3(256), 32768, stream, p);
@@ -1170,6 +1203,7 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_MFMA(0, 1);
     else if (p.a_mode == 1 && p.b_mode == 0) LAUNCH_MFMA(1, 0);
     else LAUNCH_MFMA(1, 1);
+#undef LAUNCH_MFMA_HALF
 #undef LAUNCH_MFMA
     NS_CHECK_LAUNCH("gemm_mfma");
     return NS_OK;
@@ -1201,6 +1235,11 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
       const size_t lds = 65536;
       p.stat_slots = 2 * ceil_div(p.M, GBM);
       const bool vec = vec_epilogue_ok(p);
+      const bool half = vec && p.a_mode == 0 && half_tiles_wanted(p, tiles);
+      if (half) {
+        grid.x = ceil_div(p.M, 64) * ceil_div(p.N, GBN);
+        p.stat_slots = ceil_div(p.M, 64);
+      }
 #define LAUNCH_F32(AM, BM_, PS)                                                                     \
   do {                                                                                              \
     static bool attr_set = false;                                                                   \
@@ -1216,14 +1255,28 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     if (vec) hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, true>), grid, dim3(256), lds, stream, p);   \
     else hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, false>), grid, dim3(256), lds, stream, p);      \
   } while (0)
+#define LAUNCH_F32_HALF(BM_, PS)                                                                    \
+  do {                                                                                              \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_mfma_f32_kernel<0, BM_, PS, true, 64>,            \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    g_last_kernel = "gemm_mfma_f32_kernel<0, " #BM_ ", " #PS ", true, 64>";                         \
+    hipLaunchKernelGGL((gemm_mfma_f32_kernel<0, BM_, PS, true, 64>), grid, dim3(256), lds, stream, p);         \
+  } while (0)
 #define LAUNCH_F32_MODES(PS)                                                   \
   do {                                                                         \
-    if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_F32(0, 0, PS);                  \
+    if (half && p.b_mode == 0) LAUNCH_F32_HALF(0, PS);                         \
+    else if (half) LAUNCH_F32_HALF(1, PS);                                     \
+    else if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_F32(0, 0, PS);             \
     else if (p.a_mode == 0 && p.b_mode == 1) LAUNCH_F32(0, 1, PS);             \
     else if (p.a_mode == 1 && p.b_mode == 0) LAUNCH_F32(1, 0, PS);             \
     else LAUNCH_F32(1, 1, PS);                                                 \
   } while (0)
       if (three) LAUNCH_F32_MODES(3); else LAUNCH_F32_MODES(1);
+#undef LAUNCH_F32_HALF
 #undef LAUNCH_F32_MODES
 #undef LAUNCH_F32
       NS_CHECK_LAUNCH("gemm_mfma_f32");
