@@ -1040,8 +1040,8 @@ static bool vec_epilogue_ok(const ns_gemm_params& p) {
 // 64 x 128 tiles instead of 128 x 128: when the 128-row tiling leaves CUs idle and halving the tile height adds workgroups
 static bool half_tiles_wanted(const ns_gemm_params& p, int tiles128) {
   static const int env = [] { const char* e = getenv("NS_GEMM_HALF"); return e ? atoi(e) : -1; }();
-  if (env >= 0) return env != 0;
-  return tiles128 * p.batch <= 192 && p.M > 64;
+  if (env == 0 || env == 1) return env != 0;
+  return tiles128 * p.batch <= (env > 1 ? env : 256) && p.M > 64;      // (NS_GEMM_HALF = n > 1: the threshold; 256: the halves still fit two per CU)
 }
 static bool x256_ok(const ns_gemm_params& p) {
   if (p.dtype != NS_BF16 || p.a_mode != 0 || p.b_mode != 0 || p.split_k != 1) return false;
