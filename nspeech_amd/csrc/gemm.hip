@@ -1172,7 +1172,7 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                  \
       attr_set = true;                                                                            \
     }                                                                                             \
-    g_last_kernel = vec ? "gemm_mfma_kernel<" #AM ", " #BM_ ", true>" : "gemm_mfma_kernel<" #AM ", " #BM_ ", false>";  \
+    g_last_kernel = vec ? "gemm_mfma_kernel<" #AM ", " #BM_ ", true, 64, 128>" : "gemm_mfma_kernel<" #AM ", " #BM_ ", false, 64, 128>";  \
     if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, true>), grid, dim3(256), lds, stream, p);  \
     else hipLaunchKernelGGL((gemm_mfma_kernel<AM, BM_, false>), grid, dim3(256), lds, stream, p);     \
   } while (0)
@@ -1196,7 +1196,7 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
     if (half) {
       if (p.b_mode == 0) LAUNCH_MFMA_HALF(0); else LAUNCH_MFMA_HALF(1);
     } else if (p.a_mode == 1 && p.b_mode == 1 && bk32 && (p.b_seg_len == 0 || p.b_seg_len % 32 == 0)) {
-      g_last_kernel = vec ? "gemm_mfma_kernel<1, 1, true, 32>" : "gemm_mfma_kernel<1, 1, false, 32>";
+      g_last_kernel = vec ? "gemm_mfma_kernel<1, 1, true, 32, 128>" : "gemm_mfma_kernel<1, 1, false, 32, 128>";
       if (vec) hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, true, 32>), grid, dim3(256), 32768, stream, p);
       else hipLaunchKernelGGL((gemm_mfma_kernel<1, 1, false, 32>), grid, dim3(256), 32768, stream, p);
     } else if (p.a_mode == 0 && p.b_mode == 0) LAUNCH_MFMA(0, 0);
@@ -1250,8 +1250,8 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);              \
       attr_set = true;                                                                              \
     }                                                                                               \
-    g_last_kernel = vec ? "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", true>"                  \
-                        : "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", false>";                \
+    g_last_kernel = vec ? "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", true, 128>"             \
+                        : "gemm_mfma_f32_kernel<" #AM ", " #BM_ ", " #PS ", false, 128>";           \
     if (vec) hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, true>), grid, dim3(256), lds, stream, p);   \
     else hipLaunchKernelGGL((gemm_mfma_f32_kernel<AM, BM_, PS, false>), grid, dim3(256), lds, stream, p);      \
   } while (0)

@@ -102,7 +102,7 @@ def test_gemm_splitk_many_workgroups_takes_the_32_deep_tiles(dev):
     Cm = torch.full((M, N), 0.5, dtype=torch.float32, device=dev)
     ops.gemm(A, B, Cm, M, N, Kc, M, N, N, a_mode=1, b_mode=1, accumulate=2, split_k=12)
     torch.cuda.synchronize()
-    assert profiling._last_kernel().endswith("32>"), profiling._last_kernel()
+    assert profiling._last_kernel().endswith("32, 128>"), profiling._last_kernel()
     ref = 0.5 + A.double().cpu().t() @ B.double().cpu()
     assert (Cm.double().cpu() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item() + 1e-3
     # and without split-K (plain stores through the vector epilogue), still >= 600 workgroups
@@ -112,7 +112,7 @@ def test_gemm_splitk_many_workgroups_takes_the_32_deep_tiles(dev):
     C2 = torch.zeros((M2, N2), dtype=torch.float32, device=dev)
     ops.gemm(A2, B2, C2, M2, N2, K2, M2, N2, N2, a_mode=1, b_mode=1)
     torch.cuda.synchronize()
-    assert profiling._last_kernel().endswith("32>"), profiling._last_kernel()
+    assert profiling._last_kernel().endswith("32, 128>"), profiling._last_kernel()
     ref2 = A2.double().cpu().t() @ B2.double().cpu()
     assert (C2.double().cpu() - ref2).abs().max().item() <= 2e-5 * ref2.abs().max().item() + 1e-3
 
