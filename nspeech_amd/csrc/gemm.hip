@@ -325,6 +325,28 @@ __device__ __forceinline__ void mfma_epilogue(const ns_gemm_params& p, f32x4 (&a
   }
 }
 
+// Which (output tile, k slice) a workgroup of the 128-tile kernels takes.  The hardware deals consecutive workgroups of the
+// dispatch order (x fastest, then y) to the 8 XCDs in turn, and each XCD has its own L2.
+//  - no split-K: the tiles one XCD gets are neighbours (column tiles fastest), so its L2 holds their shared A rows;
+//  - split-K (round 3): the XCDs take contiguous runs of the SLICE-major list of (k slice, tile) items, so the workgroups
+//    of one XCD read ONE k range of both operands and every byte of it is fetched by one L2 only.  Before, an XCD had a
+//    fixed tenth of the tiles for every k slice: the weight gradient of a 5-tap convolution (2560 x 512 x 32124, split 6)
+//    fetched 385 MB per launch for 66 MB of unique operand bytes - all of dY once per XCD, the input once per tap.
+__device__ __forceinline__ void xcd_work_item(const ns_gemm_params& p, int nwg, int& tile, int& ksl) {
+  if (p.split_k > 1 && p.batch == 1) {
+    const int W = nwg * p.split_k;
+    const int L = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xcd = L & 7, q = W >> 3, r = W & 7;
+    const int j = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+    ksl = j / nwg;
+    tile = j - ksl * nwg;
+  } else {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    ksl = blockIdx.y;
+  }
+}
+
 // ---- vector epilogue.  The 256-tile kernel issues its MFMAs with the operands SWAPPED (a = the B fragment, b = the A
 // fragment), so a 16 x 16 accumulator holds the TRANSPOSED tile: lane l owns output row m = l & 15 and the four
 // consecutive columns n = (l >> 4) * 4 + r.  One 16-byte (fp32) / 8-byte (bf16) store per tile and lane instead of four
@@ -434,17 +456,14 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
   const int tiles_m = (p.M + TM - 1) / TM;
   // XCD-aware bijective remap: workgroups that share an XCD (id % 8) walk neighbouring tiles
   const int nwg = tiles_m * tiles_n;
-  int wgid;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
+  int wgid, ksl;                                 // output tile, k slice
+  xcd_work_item(p, nwg, wgid, ksl);
   const int tm = wgid / tiles_n, tn = wgid % tiles_n;
   const int m0 = tm * TM, n0 = tn * GBN;
 
   const int nk = (p.K + BK - 1) / BK;
   const int per = (nk + p.split_k - 1) / p.split_k;
-  const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+  const int kt0 = ksl * per, kt1 = min(nk, kt0 + per);
   batch_shift(p, blockIdx.z);
 
   const bf16_t* A = (const bf16_t*)p.A;
@@ -518,7 +537,7 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
   }
 
   if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
-  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, ksl == 0);
 }
 
 // ------------------------------------------------------------------ 256 x 256 tiles, 8 phases per two K-tiles
@@ -863,16 +882,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
   const int tiles_n = (p.N + GBN - 1) / GBN;
   const int tiles_m = (p.M + TM - 1) / TM;
   const int nwg = tiles_m * tiles_n;
-  int wgid;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
+  int wgid, ksl;                                 // output tile, k slice
+  xcd_work_item(p, nwg, wgid, ksl);
   const int tm = wgid / tiles_n, tn = wgid % tiles_n;
   const int m0 = tm * TM, n0 = tn * GBN;
   const int nk = (p.K + FBK - 1) / FBK;
   const int per = (nk + p.split_k - 1) / p.split_k;
-  const int kt0 = blockIdx.y * per, kt1 = min(nk, kt0 + per);
+  const int kt0 = ksl * per, kt1 = min(nk, kt0 + per);
   batch_shift(p, blockIdx.z);
   const float* A = (const float*)p.A;
   const float* B = (const float*)p.B;
@@ -963,7 +979,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     __syncthreads();
   }
   if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
-  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, blockIdx.y == 0);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, ksl == 0);
 }
 
 // skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h).
