@@ -236,6 +236,98 @@ def wavenet_bench(seed=1234):
     return out
 
 
+def real_dynamics_bench(hp, model, args, one_step):
+    """The timed step again on targets that are not saturated: the synthetic speech of SURVEY 8d through the feature
+    kernels with min_level_db = -100 (the value the reference's comment intends, SURVEY Q1).  Same shapes, same kernels;
+    what can differ is data-dependent work - none in this path - and the loss.  10 steps after 3."""
+    old = hp.min_level_db
+    hp.min_level_db = -100
+    try:
+        inputs, lengths, mel, lin = synthetic_batch(hp, args.batch, args.t_in, args.t_out, 1234)
+    finally:
+        hp.min_level_db = old
+    sat = float((np.abs(mel - 1.0) < 1e-6).mean())
+    model.initialize(inputs, lengths, None, mel, lin)
+    for _ in range(3):
+        one_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        one_step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 10
+    return {"ms_per_step": dt * 1e3, "value": args.batch * args.t_out / dt, "loss": model.read_losses(),
+            "mel_target_mean": float(mel.mean()), "mel_target_std": float(mel.std()), "mel_targets_saturated_frac": sat,
+            "note": "targets = features of the same synthetic speech with min_level_db = -100 (not saturated)"}
+
+
+def e2e_bench(hp, model, args, device):
+    """train.py's own loop at the benchmark shape on synthetic FILES: an LJSpeech-layout corpus of 64
+    utterances of 12.45 s (-> T_out 1000) and 80-159 characters is written to a temporary directory; the feeder thread
+    reads the wavs, extracts the features on the GPU, sorts / pads / deals batches as the reference does, and
+    train.train_step() runs the step and reads the loss back EVERY step (train.py:80).  Timed after one pass over the
+    corpus (features cached as the reference caches them).  Two forms: features cached in HBM and batches assembled on
+    the device (train.py's default), and features cached in host RAM with pinned uploads on a copy stream."""
+    import copy
+    import shutil
+    import tempfile
+    import train as train_cli
+    from nspeech_amd.datasets.datafeeder import DataFeeder, DeviceStager
+    from nspeech_amd.utils import audio as A
+    rng = np.random.default_rng(4321)
+    tmp = tempfile.mkdtemp(prefix="nspeech_e2e_")
+    out = {}
+    try:
+        os.makedirs(os.path.join(tmp, "wavs"))
+        hop = int(hp.frame_shift_ms / 1000 * hp.sample_rate)
+        L = (args.t_out - 4) * hop          # T = 1 + L // hop = t_out - 3 frames -> padded to t_out (datafeeder.py:204-206)
+        letters = np.array(list("abcdefghijklmnopqrstuvwxyz    "))
+        with open(os.path.join(tmp, "metadata.csv"), "w") as f:
+            for i in range(2 * args.batch):
+                A.save_wav(synthetic_speech(rng, L / hp.sample_rate, hp.sample_rate)[:L], os.path.join(tmp, "wavs", "U%03d.wav" % i))
+                n = int(rng.integers(args.t_in // 2, args.t_in))
+                text = "a" + "".join(rng.choice(letters, n - 2)) + "z"
+                f.write("U%03d|%s|%s\n" % (i, text, text))
+        hpf = copy.deepcopy(hp)
+        hpf.batch_size, hpf.batch_group_size = args.batch, 2
+        for key, dev_cache in (("hbm_cache", True), ("host_cache", False)):
+            feeder = DataFeeder(hpf, ljspeech=tmp, seed=7, pinned=True, device_cache=dev_cache).start()
+            batches = DeviceStager(feeder, device)
+            for _ in range(4):                          # first pass over the corpus: wav reads + feature extraction
+                train_cli.train_step(model, batches)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.e2e_steps):
+                loss = train_cli.train_step(model, batches)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / args.e2e_steps
+            To = int(model.mel_targets.shape[1])
+            out[key] = {"e2e_ms_per_step": dt * 1e3, "mel_frames_per_s": args.batch * To / dt, "t_out": To,
+                        "t_in": int(model.inputs.shape[1]), "loss": loss}
+        out["note"] = ("train.py's loop (feeder thread -> batch on the GPU -> step -> loss read back every step) on %d "
+                       "synthetic wav files; hbm_cache: features stay in HBM, batches assembled on the device (train.py "
+                       "default); host_cache: features in RAM, pinned H2D on a copy stream" % (2 * args.batch))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def launch_ranks(n):
+    """Start `n` ranks of this script under torch.distributed.run on this node and relay their output.  The driver's own
+    multi-GPU runs launch torch.distributed.run themselves; this is the same command line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                 # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("[bench] starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,9 +342,19 @@ def main():
     ap.add_argument("--phases", action="store_true", help="print a per-phase time table to stderr")
     ap.add_argument("--train-only", action="store_true",
                     help="skip the Griffin-Lim / synthesis / WaveNet legs (profiling passes of the headline workload)")
+    ap.add_argument("--e2e-steps", type=int, default=12,
+                    help="steps of the end-to-end leg (feeder thread + pinned H2D + per-step loss read-back); 0 = skip")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks as a CHILD process (never re-exec a process that may
+        # have touched the GPU) and relay rank 0's JSON line.  Nothing above has made a HIP call.
+        sys.exit(launch_ranks(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or let bench.py start "
+                         "the ranks itself: run it without torch.distributed.run)\n" % (args.gpus, world, args.gpus))
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # NSPEECH_DIST_BACKEND=gloo lets the multi-rank flow be rehearsed with several ranks on ONE GPU (tests); the
@@ -306,6 +408,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss = model.read_losses()
+    # who took part: every rank reports its device, rank 0 checks the count against --gpus
+    seen, devices = world, [torch.cuda.get_device_name(local)]
+    if world > 1:
+        seen = dist.get_world_size()
+        names = [None] * world
+        dist.all_gather_object(names, "rank %d: cuda:%d %s" % (rank, local, torch.cuda.get_device_name(local)))
+        devices = names
+        if seen != args.gpus:
+            raise RuntimeError("bench.py: --gpus %d but the process group has %d ranks" % (args.gpus, seen))
     ms = dt / args.steps * 1e3
     frames = args.batch * args.t_out * world
 
@@ -384,7 +495,18 @@ def main():
             "phases_note": "one extra step with every launch on one stream (sum = single-stream step); the timed steps "
                            "run the weight-gradient products on a second stream",
         }
+        res["ranks_seen"] = seen
+        res["rank_devices"] = devices
         if world == 1 and not args.train_only:
+            # the same step on targets with real dynamics: under the shipped min_level_db = +100 the
+            # normalisation saturates and every target frame is the same vector; with -100 the features of the
+            # same synthetic speech spread over [0, 1]
+            res["real_dynamics"] = real_dynamics_bench(hp, model, args, one_step)
+            if args.e2e_steps > 0:
+                em = create_model("taco2", hp, device="cuda:%d" % local, dtype=args.dtype, seed=1234)
+                em.add_optimizer(global_step=0)
+                res["e2e"] = e2e_bench(hp, em, args, "cuda:%d" % local)
+                del em
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
             res["inference"] = inference_bench(hp, args.dtype)
             res["wavenet"] = wavenet_bench()

@@ -230,6 +230,13 @@ typedef struct {
 } ns_adam_params;
 int ns_adam(const ns_adam_params* p, ns_stream_t stream);
 
+/* Moments of `nseg` segments of a flat fp32 buffer: out[4 s + {0,1,2,3}] = sum, sum of squares, min, max over
+ * x[offsets[s] .. offsets[s+1]) (offsets: DEVICE int64[nseg + 1]).  The training summaries of tacotron2.py:163-188
+ * (tf.summary.histogram of outputs / targets, per-variable tf.norm of the gradients, max_gradient_norm), reduced on the
+ * device so that a summary costs one small read-back. */
+typedef struct { const float* x; const int64_t* offsets; int nseg; float* out; } ns_segment_stats_params;
+int ns_segment_stats(const ns_segment_stats_params* p, ns_stream_t stream);
+
 /* Zero `bytes` (a multiple of 16, p 16-byte aligned) with a kernel on the stream.  Kernel, not hipMemsetAsync: a memset
  * NODE of a captured HIP graph was seen to replay wrongly on ROCm 7.2 (see csrc/core.hip). */
 int ns_zero(void* p, size_t bytes, ns_stream_t stream);
@@ -280,6 +287,19 @@ typedef struct {
   void* dgates_bf16;                    /* optional [N*P, 4H] bf16 copy of dgates written and re-read by the
                                            backward recurrence (with wh_bf16: pure bf16 operand loads) */
   void* h_bf16; int64_t ld_h_bf16;      /* optional bf16 copy of h, written by the fp32 form of ns_lstm_cluster_fwd */
+  /* Zoneout (Krueger et al. 2017; BASELINE north_star: "2-layer Zoneout-LSTM decoder").  The reference builds plain
+   * LSTMBlockCells (tacotron2.py:69-70), so both thresholds 0 - the default - IS the reference and takes the code path
+   * it always took.  With a threshold > 0, training step t keeps the OLD value of a unit with probability rate:
+   *   c[t] = m_c ? c[t-1] : c'[t],   h[t] = m_h ? h[t-1] : h'[t],   c' = f c[t-1] + i j,  h' = o tanh(c')
+   * where m(t, n, u) = (mix(seed, t, n, u) >> 8) < thr with thr = floor(rate * 2^24) and mix = three rounds of the
+   * 32-bit murmur3 finaliser over seed ^ t * 0x9E3779B9, ^ n * 0x7FEB352D, ^ u * 0x846CA68B (csrc/common.h:
+   * ns_zone_keep; counter-based, so the backward pass regenerates the masks instead of storing them).  The saved gates
+   * are those of the plain cell; `c` holds the zoned state.  The backward calls apply the matching gradient (the carry
+   * of dh through kept units needs a second [N*H] row of `work`: ns_lstm_seq_work_bytes()).  Supported by
+   * ns_lstm_seq_fwd / _bwd, ns_lstm_wide_fwd and the partial-sum form of ns_lstm_wide_bwd; the other persistent forms
+   * report "unsupported" and the caller falls back to the step launches. */
+  uint32_t zoneout_thr_cell, zoneout_thr_output;
+  uint32_t zoneout_seed_cell, zoneout_seed_output;
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -337,6 +357,11 @@ typedef struct {
   float forget_bias;
   int f32_passes;
   const void* wT_hi; const void* wT_lo;   /* optional pre-split weights (dtype NS_F32) */
+  /* zoneout at inference = the expectation of the training masks (ns_lstm_seq_params): with a rate > 0,
+   * c = zc c_prev + (1 - zc) c', h = zh h_prev + (1 - zh) h'; h_prev = this cell's previous output rows (dtype, row
+   * stride hp_sn; NULL = zeros).  Both rates 0 (the default, = the reference's plain cells) reads nothing. */
+  float zoneout_cell, zoneout_output;
+  const void* h_prev; int64_t hp_sn;
 } ns_lstm_step_params;
 int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t stream);
 

@@ -55,6 +55,18 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.0f);
 }
 
+// Zoneout masks (include/nspeech_hip.h, ns_lstm_seq_params): true = the unit keeps its old value at this step.
+__host__ __device__ __forceinline__ uint32_t ns_fmix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+  return x;
+}
+__host__ __device__ __forceinline__ bool ns_zone_keep(uint32_t seed, uint32_t t, uint32_t n, uint32_t u, uint32_t thr) {
+  uint32_t x = ns_fmix32(seed ^ (t * 0x9E3779B9u));
+  x = ns_fmix32(x ^ (n * 0x7FEB352Du));
+  x = ns_fmix32(x ^ (u * 0x846CA68Bu));
+  return (x >> 8) < thr;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case NS_ACT_RELU: return v > 0.f ? v : 0.f;

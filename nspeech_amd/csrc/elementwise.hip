@@ -681,6 +681,36 @@ extern "C" int ns_sumsq(const ns_sumsq_params* p, ns_stream_t s) {
   return NS_OK;
 }
 
+// ------------------------------------------------------------------ per-segment moments (training summaries)
+// One workgroup per segment [offsets[s], offsets[s+1]) of a flat fp32 buffer: sum, sum of squares, min, max.  Fixed
+// summation order (lane-strided partial sums, then the block tree), no atomics.  Not on the step's path: the training
+// loop calls it every --summary-interval steps (tacotron2.py:163-188: gradient norms and value histograms).
+__global__ __launch_bounds__(1024) void segment_stats_kernel(ns_segment_stats_params p) {
+  __shared__ float red[32];
+  const int sgm = blockIdx.x;
+  const long lo = p.offsets[sgm], hi = p.offsets[sgm + 1];
+  float s = 0.f, q = 0.f, mn = INFINITY, mx = -INFINITY;
+  for (long i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+    const float v = p.x[i];
+    s += v; q += v * v; mn = fminf(mn, v); mx = fmaxf(mx, v);
+  }
+  s = block_sum(s, red);
+  q = block_sum(q, red);
+  mx = block_max(mx, red);
+  mn = -block_max(-mn, red);
+  if (threadIdx.x == 0) {
+    float* o = p.out + 4 * (long)sgm;
+    o[0] = s; o[1] = q; o[2] = mn; o[3] = mx;
+  }
+}
+extern "C" int ns_segment_stats(const ns_segment_stats_params* p, ns_stream_t s) {
+  NS_CHECK_ARG(p && p->x && p->offsets && p->out && p->nseg >= 0, "ns_segment_stats: null");
+  if (p->nseg == 0) return NS_OK;
+  hipLaunchKernelGGL(segment_stats_kernel, dim3(p->nseg), dim3(1024), 0, (hipStream_t)s, *p);
+  NS_CHECK_LAUNCH("segment_stats");
+  return NS_OK;
+}
+
 __global__ void adam_kernel(ns_adam_params p) {
   // a timed-out persistent recurrence left an invalid gradient: update nothing (uniform over the grid: every thread
   // reads the same words, which no kernel of this step writes any more)

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
   const int en = nb + er, eu = u0 + euu;
   const bool eok = tid < RPW * UPW && en < a.N && eu < H;
   float pz[4] = {0.f, 0.f, 0.f, 0.f};
-  float pcp = 0.f;
+  float pcp = 0.f, php = 0.f;
   bool pmask = false;
   if (eok) {
 #pragma unroll
@@ -43,6 +43,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     }
     if (a.c_prev) pcp = a.c_prev[(long)en * a.c_sn + eu];
     pmask = a.lengths && a.t >= a.lengths[en];
+    if (a.zmode && a.hp) php = ldf(a.hp + (long)en * a.hp_sn + eu);
   }
 
   if constexpr (sizeof(T) == 2) {
@@ -190,6 +191,13 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + a.forget_bias), go = sigmoidf_(z[3]);
     float c = gf * cp + gi * gj;
     float h = go * tanhf_(c);
+    if (a.zmode == 1) {          // zoneout, training: the unit keeps its old value where the mask says so
+      if (ns_zone_keep(a.zseed_c, (uint32_t)a.t, (uint32_t)n, (uint32_t)u, a.zthr_c)) c = cp;
+      if (ns_zone_keep(a.zseed_h, (uint32_t)a.t, (uint32_t)n, (uint32_t)u, a.zthr_h)) h = php;
+    } else if (a.zmode == 2) {   // zoneout, inference: the expectation of the above
+      c = a.zc * cp + (1.f - a.zc) * c;
+      h = a.zh * php + (1.f - a.zh) * h;
+    }
     if (masked) { c = 0.f; h = 0.f; }
     a.c_out[(long)n * a.co_sn + u] = c;
     stf(a.h_out + (long)n * a.h_sn + u, h);
@@ -243,7 +251,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
   const int er = tid / UPW, euu = tid % UPW;
   const int en = nb + er, eu = u0 + euu;
   const bool eok = tid < RPW * UPW && en < a.N && eu < H;
-  float pdh = 0.f, pgi = 0.f, pgj = 0.f, pgf = 0.f, pgo = 0.f, pc = 0.f, pcp = 0.f, pdc = 0.f;
+  float pdh = 0.f, pgi = 0.f, pgj = 0.f, pgf = 0.f, pgo = 0.f, pc = 0.f, pcp = 0.f, pdc = 0.f, pdhc = 0.f;
   bool pmask = false;
   if (eok) {
     pmask = a.lengths && a.t >= a.lengths[en];
@@ -254,6 +262,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
     pc = a.c[(long)en * a.c_sn + eu];
     if (a.c_prev) pcp = a.c_prev[(long)en * a.c_sn + eu];
     if (!a.first) pdc = a.dc_carry[(long)en * H + eu];
+    if (a.zmode && !a.first) pdhc = a.dh_carry[(long)en * H + eu];
   }
 
   if constexpr (sizeof(T) == 2) {
@@ -377,19 +386,32 @@ __global__ __launch_bounds__(LTHREADS) void lstm_bwd_step_kernel(LstmBwdStepPair
     stf(dg + u, 0.f); stf(dg + H + u, 0.f); stf(dg + 2 * H + u, 0.f); stf(dg + 3 * H + u, 0.f);
     if (dgb) { dgb[u] = (bf16_t)0.f; dgb[H + u] = (bf16_t)0.f; dgb[2 * H + u] = (bf16_t)0.f; dgb[3 * H + u] = (bf16_t)0.f; }
     a.dc_carry[ci] = 0.f;
+    if (a.zmode) a.dh_carry[ci] = 0.f;
     return;
   }
   float dh = pdh;
 #pragma unroll
   for (int w = 0; w < LW; ++w) dh += red[w][r][uu];
-  const float gi = pgi, gj = pgj, gf = pgf, go = pgo, c = pc, cp = pcp;
+  const float gi = pgi, gj = pgj, gf = pgf, go = pgo, cp = pcp;
+  float c = pc, dcin = pdc, dckeep = 0.f;
+  if (a.zmode) {
+    // h[t] = m_h ? h[t-1] : h'[t]: the gradient of a kept unit passes to step t-1 untouched; c[t] likewise, and the
+    // saved c is the ZONED state, so tanh needs the plain cell's c' = f c[t-1] + i j again
+    dh += pdhc;
+    const bool mh = ns_zone_keep(a.zseed_h, (uint32_t)a.t, (uint32_t)n, (uint32_t)u, a.zthr_h);
+    const bool mc = ns_zone_keep(a.zseed_c, (uint32_t)a.t, (uint32_t)n, (uint32_t)u, a.zthr_c);
+    a.dh_carry[ci] = mh ? dh : 0.f;
+    if (mh) dh = 0.f;
+    if (mc) { dckeep = dcin; dcin = 0.f; }
+    c = gf * cp + gi * gj;
+  }
   const float tc = tanhf_(c);
   const float d_o = dh * tc * go * (1.f - go);
-  const float dc = dh * go * (1.f - tc * tc) + pdc;
+  const float dc = dh * go * (1.f - tc * tc) + dcin;
   const float d_i = dc * gj * gi * (1.f - gi);
   const float d_j = dc * gi * (1.f - gj * gj);
   const float d_f = dc * cp * gf * (1.f - gf);
-  a.dc_carry[ci] = dc * gf;
+  a.dc_carry[ci] = dc * gf + dckeep;
   stf(dg + u, d_i); stf(dg + H + u, d_j); stf(dg + 2 * H + u, d_f); stf(dg + 3 * H + u, d_o);
   if (dgb) { dgb[u] = (bf16_t)d_i; dgb[H + u] = (bf16_t)d_j; dgb[2 * H + u] = (bf16_t)d_f; dgb[3 * H + u] = (bf16_t)d_o; }
 }
@@ -421,7 +443,8 @@ template int lstm_bwd_step_launch2<bf16_t>(const LstmBwdStepPair<bf16_t>&, hipSt
 // ------------------------------------------------------------------ host time loops
 extern "C" size_t ns_lstm_seq_work_bytes(const ns_lstm_seq_params* p) {
   if (!p) return 0;
-  return sizeof(float) * (size_t)p->N * p->H + 256;
+  const bool zone = p->zoneout_thr_cell || p->zoneout_thr_output;      // + the dh carry through kept units
+  return sizeof(float) * (size_t)p->N * p->H * (zone ? 2 : 1) + 256;
 }
 
 template <typename T>
@@ -444,6 +467,12 @@ static void fill_fwd(LstmStep<T>& a, const ns_lstm_seq_params& p, int step) {
   a.lengths = p.lengths; a.t = t;
   a.passes = p.f32_passes;
   a.wT_hi = (const bf16_t*)p.whT_hi; a.wT_lo = (const bf16_t*)p.whT_lo;
+  if (p.zoneout_thr_cell || p.zoneout_thr_output) {
+    a.zmode = 1;
+    a.zthr_c = p.zoneout_thr_cell; a.zthr_h = p.zoneout_thr_output;
+    a.zseed_c = p.zoneout_seed_cell; a.zseed_h = p.zoneout_seed_output;
+    a.hp = has_prev ? (const T*)p.h + rowp * p.ld_h : nullptr; a.hp_sn = P * p.ld_h;
+  }
 }
 
 template <typename T>
@@ -471,6 +500,12 @@ static void fill_bwd(LstmBwdStep<T>& a, const ns_lstm_seq_params& p, int step, f
   if (p.dgates_bf16 && sizeof(T) == 4) {
     a.dgates_b = (bf16_t*)p.dgates_bf16 + row * 4 * H;
     a.dg_next_b = has_next ? (const bf16_t*)p.dgates_bf16 + rown * 4 * H : nullptr;
+  }
+  if (p.zoneout_thr_cell || p.zoneout_thr_output) {
+    a.zmode = 1;
+    a.zthr_c = p.zoneout_thr_cell; a.zthr_h = p.zoneout_thr_output;
+    a.zseed_c = p.zoneout_seed_cell; a.zseed_h = p.zoneout_seed_output;
+    a.dh_carry = dc_carry + (long)p.N * H;
   }
 }
 
@@ -559,6 +594,10 @@ extern "C" int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t s) {
     a.h_out = (T*)p->h_out; a.h_sn = p->h_sn; a.h_out2 = (T*)p->h_out2; a.h2_sn = p->h2_sn;
     a.c_out = p->c_out; a.co_sn = p->co_sn;
     a.wT_hi = (const bf16_t*)p->wT_hi; a.wT_lo = (const bf16_t*)p->wT_lo;
+    if (p->zoneout_cell > 0.f || p->zoneout_output > 0.f) {
+      a.zmode = 2; a.zc = p->zoneout_cell; a.zh = p->zoneout_output;
+      a.hp = (const T*)p->h_prev; a.hp_sn = p->hp_sn;
+    }
     return lstm_step_launch<T>(a, (hipStream_t)s);
   };
   if (p->dtype == NS_BF16) return run(bf16_t{});

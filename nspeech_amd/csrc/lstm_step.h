@@ -19,6 +19,9 @@ struct LstmStep {
   float forget_bias;
   int passes;                        // fp32 operands: 0 exact FMA, 1/3 split-bf16 MFMA
   const bf16_t* wT_hi; const bf16_t* wT_lo;   // optional pre-split copies of an fp32 wT
+  // zoneout (ns_lstm_seq_params): zmode 0 = plain cell, 1 = masks (training), 2 = expectation with rates zc / zh
+  int zmode; uint32_t zthr_c, zthr_h, zseed_c, zseed_h; float zc, zh;
+  const T* hp; long hp_sn;           // h of the previous step, this cell's H columns (null = zeros); read with zmode != 0
 };
 // up to two independent cells (the two directions of a BiLSTM) in one launch: blockIdx.z
 template <typename T>
@@ -42,6 +45,9 @@ struct LstmBwdStep {
   int passes;
   const bf16_t* w_bf16;                    // optional bf16 copy of an fp32 w (passes == 1)
   const bf16_t* dg_next_b; bf16_t* dgates_b;   // optional bf16 copies of dg_next / dgates (same strides)
+  // zoneout masks of the forward pass (zmode 1): dh_carry [N,H] in/out carries dh through units that kept h
+  int zmode; uint32_t zthr_c, zthr_h, zseed_c, zseed_h;
+  float* dh_carry;
 };
 template <typename T>
 struct LstmBwdStepPair { LstmBwdStep<T> s[2]; int n; };

@@ -299,6 +299,8 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
   const auto hrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.h, 0, (int)hbytes, 0x00020000);
   const bool tr = a.trace && blockIdx.x == 0 && e == 0;
   float cst = 0.f;
+  float hprev = 0.f;          // zoneout: this thread's h of the step before (fp32, before the store's rounding)
+  const bool zone = p.zoneout_thr_cell != 0u || p.zoneout_thr_output != 0u;
   float pz[4] = {0.f, 0.f, 0.f, 0.f};
   auto load_xg = [&](int t) {
     if (eok) {
@@ -321,8 +323,17 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
       z[j] = s;
     }
     float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + p.forget_bias), go = sigmoidf_(z[3]);
-    cst = gf * cst + gi * gj;
-    float hv = go * tanhf_(cst);
+    float hv;
+    if (!zone) {
+      cst = gf * cst + gi * gj;
+      hv = go * tanhf_(cst);
+    } else {                  // ns_lstm_seq_params: a kept unit carries c / h of step t-1 on, h' comes from the plain c'
+      const float cn = gf * cst + gi * gj;
+      hv = go * tanhf_(cn);
+      if (!ns_zone_keep(p.zoneout_seed_cell, (uint32_t)t, (uint32_t)en, (uint32_t)(u0 + eu), p.zoneout_thr_cell)) cst = cn;
+      if (ns_zone_keep(p.zoneout_seed_output, (uint32_t)t, (uint32_t)en, (uint32_t)(u0 + eu), p.zoneout_thr_output)) hv = hprev;
+      hprev = hv;
+    }
     if (t >= elen) { cst = 0.f; hv = 0.f; gi = gj = gf = go = 0.f; }
     // (audit) hst: written and read by the SAME cell wave (wave w owns rows 8w .. 8w+7 on both sides), so the release
     // fence + wave barrier below is all the ordering it needs; no other role touches it
@@ -682,10 +693,11 @@ __global__ __launch_bounds__(PST) void lstm_wide_bwd_ps_kernel(WideArgs a, ps_u6
   const bool eok = en < p.N;
   const int elen = (eok && p.lengths) ? p.lengths[en] : p.T;
   const int half = er & 1;
-  float dcc[TB];
+  float dcc[TB], dhc[TB];
+  const bool zone = p.zoneout_thr_cell != 0u || p.zoneout_thr_output != 0u;
   float pg[TB][4], pdh[TB], pc[TB], pcp[TB];
 #pragma unroll
-  for (int c = 0; c < TB; ++c) { dcc[c] = 0.f; pdh[c] = 0.f; pc[c] = 0.f; pcp[c] = 0.f; pg[c][0] = pg[c][1] = pg[c][2] = pg[c][3] = 0.f; }
+  for (int c = 0; c < TB; ++c) { dcc[c] = 0.f; dhc[c] = 0.f; pdh[c] = 0.f; pc[c] = 0.f; pcp[c] = 0.f; pg[c][0] = pg[c][1] = pg[c][2] = pg[c][3] = 0.f; }
   auto load_ops = [&](int t) {
     if (eok) {
       const long rowi = (long)en * p.P + p.padl + t;
@@ -714,14 +726,25 @@ __global__ __launch_bounds__(PST) void lstm_wide_bwd_ps_kernel(WideArgs a, ps_u6
 #pragma unroll
       for (int w = 0; w < PSW; ++w) dh += red[(w * ITEMS + item) * 2 + half];
       const float gi = pg[c][0], gj = pg[c][1], gf = pg[c][2], go = pg[c][3];
-      const float tc = tanhf_(pc[c]);
-      const float dc = dh * go * (1.f - tc * tc) + dcc[c];
+      float cc = pc[c], dcin = dcc[c], dckeep = 0.f;
+      if (zone) {             // the gradient of the forward kernel's masks (include/nspeech_hip.h, ns_lstm_seq_params)
+        const uint32_t uu = (uint32_t)(u0 + eu + 16 * c);
+        dh += dhc[c];
+        const bool mh = ns_zone_keep(p.zoneout_seed_output, (uint32_t)t, (uint32_t)en, uu, p.zoneout_thr_output);
+        const bool mc = ns_zone_keep(p.zoneout_seed_cell, (uint32_t)t, (uint32_t)en, uu, p.zoneout_thr_cell);
+        dhc[c] = mh ? dh : 0.f;
+        if (mh) dh = 0.f;
+        if (mc) { dckeep = dcin; dcin = 0.f; }
+        cc = gf * pcp[c] + gi * gj;
+      }
+      const float tc = tanhf_(cc);
+      const float dc = dh * go * (1.f - tc * tc) + dcin;
       dgv[c][0] = dc * gj * gi * (1.f - gi);
       dgv[c][1] = dc * gi * (1.f - gj * gj);
       dgv[c][2] = dc * pcp[c] * gf * (1.f - gf);
       dgv[c][3] = dh * tc * go * (1.f - go);
-      dcc[c] = dc * gf;
-      if (t >= elen || !eok) { dgv[c][0] = dgv[c][1] = dgv[c][2] = dgv[c][3] = 0.f; dcc[c] = 0.f; }
+      dcc[c] = dc * gf + dckeep;
+      if (t >= elen || !eok) { dgv[c][0] = dgv[c][1] = dgv[c][2] = dgv[c][3] = 0.f; dcc[c] = 0.f; dhc[c] = 0.f; }
 #pragma unroll
       for (int j = 0; j < 4; ++j) dgi[er * LDW + j * UPB + eu + 16 * c] = (bf16_t)dgv[c][j];
     }
@@ -762,6 +785,12 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
     if (!p->xg || !p->h || !p->c || !al16(p->h) || (p->ld_h * esz) % 16 != 0) return false;
     if ((double)p->N * p->P * p->ld_h * esz >= 2.0e9) return false;
   } else {
+    if (p->zoneout_thr_cell || p->zoneout_thr_output) {       // only the partial-sum backward kernel applies the masks
+      const char* ps_env = getenv("NS_WIDE_PS");
+      const int ps_mode = ps_env ? atoi(ps_env) : 32;
+      const int upb = ps_mode == 16 ? 16 : 32;
+      if (!(H % 128 == 0 && ps_mode != 0 && ((p->N + 7) / 8) * (H / upb) <= 256)) return false;
+    }
     if (p->dtype == NS_F32 && !(p->f32_passes == 1 && p->wh_bf16 && p->dgates_bf16)) return false;
     if (p->dtype == NS_BF16 && !p->wh) return false;
     if (!p->gates || !p->c || !p->dh || !p->dgates) return false;

@@ -74,7 +74,14 @@ def load_librispeech_corpus(path):
     return items
 
 
-def prepare_batch(batch, outputs_per_step, rng, longest=0):
+def _pinned_zeros(shape):
+    """Zero-filled float32 array in page-locked host memory (torch's caching host allocator; the array keeps the tensor
+    alive), so that the upload of a prepared batch is one asynchronous DMA with no staging copy."""
+    import torch
+    return torch.zeros(shape, dtype=torch.float32, pin_memory=True).numpy()
+
+
+def prepare_batch(batch, outputs_per_step, rng, longest=0, alloc=None):
     """datafeeder.py:189-220.  batch: list of (ids, speaker_id, mel [T,M], linear [T,F]).
     `longest`: data-parallel runs pass the longest target of the GLOBAL batch (all ranks), so that every rank pads to
     the same T_out and the mean of the ranks' unmasked mean losses is the global mean."""
@@ -86,8 +93,11 @@ def prepare_batch(batch, outputs_per_step, rng, longest=0):
     inputs = np.full((N, Ti), _pad, np.int32)
     lengths = np.zeros((N,), np.int32)
     speakers = np.zeros((N,), np.int32)
-    mel = np.full((N, To, batch[0][2].shape[1]), _pad, np.float32)
-    lin = np.full((N, To, batch[0][3].shape[1]), _pad, np.float32)
+    if alloc is None:
+        mel = np.full((N, To, batch[0][2].shape[1]), _pad, np.float32)
+        lin = np.full((N, To, batch[0][3].shape[1]), _pad, np.float32)
+    else:                       # _pad is 0
+        mel, lin = alloc((N, To, batch[0][2].shape[1])), alloc((N, To, batch[0][3].shape[1]))
     for i, (ids, spk, m, l) in enumerate(batch):
         inputs[i, :len(ids)] = ids
         lengths[i] = len(ids)
@@ -97,13 +107,47 @@ def prepare_batch(batch, outputs_per_step, rng, longest=0):
     return inputs, lengths, speakers, mel, lin
 
 
+def prepare_batch_device(batch, outputs_per_step, rng, longest, device, stream):
+    """prepare_batch for examples whose features are CUDA tensors (the HBM-resident cache): the padded target arrays are
+    assembled ON the device - a zero fill and one device-to-device copy per utterance, issued on the feeder's own
+    stream - so a training batch never crosses PCIe.  Returns the batch with device targets and the event that marks
+    them complete."""
+    import torch
+    batch = list(batch)
+    rng.shuffle(batch)
+    Ti = max(len(e[0]) for e in batch)
+    To = _round_up(max(max(int(e[3].shape[0]) for e in batch), longest) + 1, outputs_per_step)
+    N = len(batch)
+    inputs = np.full((N, Ti), _pad, np.int32)
+    lengths = np.zeros((N,), np.int32)
+    speakers = np.zeros((N,), np.int32)
+    with torch.cuda.stream(stream):
+        mel = torch.zeros((N, To, batch[0][2].shape[1]), dtype=torch.float32, device=device)
+        lin = torch.zeros((N, To, batch[0][3].shape[1]), dtype=torch.float32, device=device)
+        for i, (ids, spk, m, l) in enumerate(batch):
+            inputs[i, :len(ids)] = ids
+            lengths[i] = len(ids)
+            speakers[i] = spk
+            mel[i, :m.shape[0]].copy_(m)
+            lin[i, :l.shape[0]].copy_(l)
+        ev = torch.cuda.Event()
+        ev.record(stream)
+    return inputs, lengths, speakers, mel, lin, ev
+
+
 class DataFeeder(object):
     """next_batch() -> (inputs [N,T_in] int32, input_lengths [N], mel [N,T_out,M], linear [N,T_out,F]);
     `speaker_ids` of the last batch are kept in .speaker_ids (single-speaker corpora: zeros)."""
 
     def __init__(self, hparams, ljspeech=None, seed=0, rank=0, world=1, cmudict=None, prefetch=True, features=None,
-                 loader=None, vctk=None, librispeech=None, device=None):
+                 loader=None, vctk=None, librispeech=None, device=None, pinned=False, device_cache=False):
         self.hp = hparams
+        # device_cache: the features of every utterance stay in HBM where the feature kernel wrote them (the reference
+        # keeps them in host RAM, `processed_data`, datafeeder.py:165-176) and batches are assembled on the device.
+        # All of LJSpeech is 24 h x 80 frames/s x 1105 floats = 30.5 GB of float32 - a tenth of one MI355X's 288 GB.
+        self._device_cache = bool(device_cache) and features is None
+        self._stream = None
+        self._alloc = _pinned_zeros if pinned else None      # targets prepared in page-locked memory (DeviceStager)
         # the GPU the feature kernels of the prefetch thread must run on: torch's current device is per host thread,
         # so the worker binds it itself (a rank that called set_device(local) only in its main thread would otherwise
         # extract features on GPU 0)
@@ -153,13 +197,31 @@ class DataFeeder(object):
         wav_path, text, local_speaker, dataset = self.items[self._offset]
         self._offset += 1
         if wav_path not in self.cache:
-            lin, mel = self._features(self._loader(wav_path))
-            self.cache[wav_path] = (np.ascontiguousarray(mel.T, np.float32), np.ascontiguousarray(lin.T, np.float32))
+            if self._device_cache:
+                import torch
+                with torch.cuda.stream(self._feeder_stream()):
+                    lin, mel = audio.spectrogram_and_mel_device(self._loader(wav_path))      # [T, F], [T, M] in HBM
+                self.cache[wav_path] = (mel, lin)
+            else:
+                lin, mel = self._features(self._loader(wav_path))
+                self.cache[wav_path] = (np.ascontiguousarray(mel.T, np.float32), np.ascontiguousarray(lin.T, np.float32))
         mel, lin = self.cache[wav_path]
         if self._cmudict and self._rng.random() < _p_cmudict:
             text = " ".join(self._maybe_get_arpabet(w) for w in text.split(" "))
         ids = np.asarray(text_to_sequence(text, self.cleaners), dtype=np.int32)
         return ids, self.speaker2id[dataset, str(local_speaker)], mel, lin
+
+    def _feeder_stream(self):
+        if self._stream is None:
+            import torch
+            self._stream = torch.cuda.Stream(device=self.device)
+        return self._stream
+
+    def _prepare(self, batch, r, longest=0):
+        if self._device_cache:
+            import torch
+            return prepare_batch_device(batch, r, self._rng, longest, torch.device("cuda", self.device), self._feeder_stream())
+        return prepare_batch(batch, r, self._rng, longest, alloc=self._alloc)
 
     def _next_group(self):
         n, r = self.hp.batch_size, self.hp.outputs_per_step
@@ -180,7 +242,7 @@ class DataFeeder(object):
             # group spans per_rank * world items
             order = list(range(len(batches)))
             self._order_rng.shuffle(order)
-            return [prepare_batch(batches[j], r, self._rng) for j in order]
+            return [self._prepare(batches[j], r) for j in order]
         # global batch j = group[j*n*world : (j+1)*n*world]; every rank shuffles the batch order with the SHARED
         # generator (global step k is the same batch j on all ranks) and pads to the longest target of the whole
         # global batch, so T_out is equal across ranks and averaging the rank gradients is the global mean loss
@@ -188,7 +250,7 @@ class DataFeeder(object):
                    for j in range(len(batches))]
         order = list(range(len(batches)))
         self._order_rng.shuffle(order)
-        return [prepare_batch(batches[j], r, self._rng, longest[j]) for j in order]
+        return [self._prepare(batches[j], r, longest[j]) for j in order]
 
     # ------------------------------------------------------------------ queue
     def _worker(self):
@@ -219,6 +281,63 @@ class DataFeeder(object):
             if not self._pending:
                 self._pending = self._next_group()
             b = self._pending.pop(0)
-        inputs, lengths, speakers, mel, lin = b
+        if len(b) == 6:           # assembled on the device: the caller's stream waits for the feeder's copies
+            import torch
+            inputs, lengths, speakers, mel, lin, ev = b
+            main = torch.cuda.current_stream(mel.device)
+            main.wait_event(ev)
+            mel.record_stream(main)
+            lin.record_stream(main)
+        else:
+            inputs, lengths, speakers, mel, lin = b
         self.speaker_ids = speakers
         return inputs, lengths, mel, lin
+
+
+class DeviceStager(object):
+    """Targets of batch k+1 travel to the GPU while step k computes: the feeder's NumPy batch is copied into pinned
+    host memory (by the feeder's own thread when it was built with pinned=True: prepare_batch then fills page-locked
+    arrays directly) and uploaded with asynchronous copies on a COPY stream of its own; next_batch() makes the compute
+    stream wait for that copy's event and returns device tensors for the two big arrays (mel + linear targets, 136 MB
+    per step at the LJSpeech batch shape - 2.2 ms of PCIe time that would otherwise sit in front of every step) and the
+    small ones (ids, lengths, speakers) as they came.  The reference's counterpart is the FIFOQueue + feed_dict of
+    datafeeder.py:72-88, which TensorFlow drains into device memory on its own threads."""
+
+    def __init__(self, feeder, device):
+        import torch
+        self.feeder, self.torch = feeder, torch
+        self.device = torch.device(device)
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self.speaker_ids = None
+        self._next = None
+
+    def _stage(self):
+        torch = self.torch
+        inputs, lengths, mel, lin = self.feeder.next_batch()
+        speakers = self.feeder.speaker_ids
+        if torch.is_tensor(mel):        # HBM-resident feature cache: the batch was assembled on the device
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            return inputs, lengths, speakers, mel, lin, ev, None
+        pm, pl = torch.from_numpy(mel), torch.from_numpy(lin)
+        if not pm.is_pinned():          # a feeder built without pinned=True: one staging copy here, in the caller's thread
+            pm, pl = pm.pin_memory(), pl.pin_memory()
+        with torch.cuda.stream(self.copy_stream):
+            dm = pm.to(self.device, non_blocking=True)
+            dl = pl.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return inputs, lengths, speakers, dm, dl, ev, (pm, pl)
+
+    def next_batch(self):
+        """(inputs, lengths, mel [device], linear [device]); .speaker_ids as DataFeeder.  Stages the batch after it."""
+        torch = self.torch
+        cur = self._next or self._stage()
+        inputs, lengths, speakers, dm, dl, ev, _pinned = cur
+        main = torch.cuda.current_stream(self.device)
+        main.wait_event(ev)
+        dm.record_stream(main)          # allocated on the copy stream, consumed on the compute stream
+        dl.record_stream(main)
+        self.speaker_ids = speakers
+        self._next = self._stage()
+        return inputs, lengths, dm, dl

@@ -100,6 +100,11 @@ class Tacotron2(object):
         self._side_groups = set()
         self._side_busy = False
         self.use_pv = True        # projected-memory form of the attention loop (ns_taco2_attn_params.pv)
+        # Zoneout on the two decoder LSTMs (north_star: "2-layer Zoneout-LSTM decoder"; the reference builds plain
+        # LSTMBlockCells, tacotron2.py:69-70, so the shipped rate is 0 and nothing below changes a bit of the reference
+        # path).  Training draws fresh counter-based masks per step (ns_lstm_seq_params); synthesis uses the expectation.
+        self.zoneout_rate = float(getattr(hparams, "zoneout_rate", 0.0) or 0.0)
+        self.zoneout_base_seed = (int(seed) * 2654435761 + 97) & 0xFFFFFFFF
         self._status_words = {}
         self._bwd_sums = {}       # conv tag -> (sum dy, sum dy*xhat) left by the product that formed that layer's dy
         # which kernel family ran each recurrence of the last pass: {"attn:fwd": "cluster" | "step",
@@ -443,9 +448,41 @@ class Tacotron2(object):
         return self
 
     def add_stats(self):
-        self.stats = lambda: dict(loss=self.loss, loss_mel=self.mel_loss, loss_linear=self.linear_loss,
-                                  learning_rate=self.learning_rate)
+        """tacotron2.py:163-188: `model.stats` is what train.py:91-93 evaluates every --summary-interval steps."""
+        self.stats = self.summary
         return self
+
+    def summary(self):
+        """The reference's summaries (tacotron2.py:163-188) of the LAST step as plain numbers: the four loss / learning-rate
+        scalars, max_gradient_norm and the per-variable gradient norms behind the `gradient_norm` histogram (unclipped
+        gradients, as compute_gradients returns them), and min / max / mean / std for each of the four value histograms
+        (outputs and targets).  The moments are reduced on the device (ns_segment_stats); one small read-back.  The image
+        summaries are slices `[:0]` in the reference, i.e. empty, and have no counterpart."""
+        ent = list(self.layout.entries.items())
+        # one offsets array of (start, end) pairs: even segments are the variables, odd ones the alignment gaps
+        pairs = []
+        for _, (o, sh) in ent:
+            pairs += [o, o + int(np.prod(sh))]
+        nvar = len(ent)
+        goff = torch.tensor(pairs + [pairs[-1]], dtype=torch.int64, device=self.device)
+        gout = self._buf("sum_gout", 4 * (2 * nvar), torch.float32)
+        ops.segment_stats(self.flat_g, goff, 2 * nvar, gout)
+        vals = {}
+        one = self._buf("sum_vout", 16, torch.float32)
+        for name in ("mel_outputs", "linear_outputs", "mel_targets", "linear_targets"):
+            buf = getattr(self, name).float().contiguous()          # the outputs are views of padded buffers: gather
+            n = buf.numel()
+            o2 = torch.tensor([0, n], dtype=torch.int64, device=self.device)
+            ops.segment_stats(buf, o2, 1, one)
+            sm, sq, mn, mx = [float(x) for x in one[:4].cpu().numpy()]
+            mean = sm / n
+            vals[name] = dict(min=mn, max=mx, mean=mean, std=math.sqrt(max(sq / n - mean * mean, 0.0)))
+        g = gout[:8 * nvar].cpu().numpy().reshape(2 * nvar, 4)[0::2]
+        norms = np.sqrt(np.maximum(g[:, 1], 0.0)) / self.world_size
+        out = dict(loss=self.loss, loss_mel=self.mel_loss, loss_linear=self.linear_loss, learning_rate=self.learning_rate,
+                   max_gradient_norm=float(norms.max()), gradient_norm={k: float(v) for (k, _), v in zip(ent, norms)},
+                   histograms=vals)
+        return out
 
     # ------------------------------------------------------------------ layer helpers
     def _stats_buf(self, tag, cout):
@@ -642,6 +679,19 @@ class Tacotron2(object):
         return out
 
     use_wide = True         # persistent whole-sequence kernels for the wide decoder LSTMs where the shape allows
+
+    def zoneout_args(self, layer):
+        """(thr_cell, thr_output, seed_cell, seed_output) of decoder LSTM `layer` (1 | 2) for the CURRENT global step, or
+        None at rate 0.  The backward pass of a step asks again and gets the same seeds (global_step moves in
+        apply_gradients)."""
+        if self.zoneout_rate <= 0.0:
+            return None
+        thr = ops.zoneout_threshold(self.zoneout_rate)
+        base = self.zoneout_base_seed
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            base ^= (torch.distributed.get_rank() * 0x9E3779B9) & 0xFFFFFFFF      # every rank its own masks
+        return (thr, thr, ops.zoneout_seed(base, self.global_step, 2 * layer),
+                ops.zoneout_seed(base, self.global_step, 2 * layer + 1))
 
     def _run_lstm(self, direction, tag, *a, **kw):
         """One decoder LSTM over all steps: the persistent wide-cell kernel when it applies, else one launch per step."""
@@ -890,7 +940,7 @@ class Tacotron2(object):
         g1 = self._buf("dec_g1", rows * 4 * D, T_)
         self._tick("dec_lstm:xg1")
         self._run_lstm("fwd", "dec1", N, S, D, S1, 1, xg1, 4 * D, self.tsh["l1_whT"], None, None, False, h1, D, c1, g1,
-                       whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"))
+                       whT_hi=self.tsh.get("l1_whT_hi"), whT_lo=self.tsh.get("l1_whT_lo"), zoneout=self.zoneout_args(1))
         self._tick("dec_lstm:loop1")
         xg2 = self._buf("dec_xg2", rows * 4 * D, torch.float32)
         self._xg_gemm(h1, xg2, rows, D, 4 * D, "l2_xT", k2, self._o("decoder/lstm_2/bias"))
@@ -899,7 +949,7 @@ class Tacotron2(object):
         g2 = self._buf("dec_g2", rows * 4 * D, T_)
         self._tick("dec_lstm:xg2")
         self._run_lstm("fwd", "dec2", N, S, D, S1, 1, xg2, 4 * D, self.tsh["l2_whT"], None, None, False, h2, D, c2, g2,
-                       whT_hi=self.tsh.get("l2_whT_hi"), whT_lo=self.tsh.get("l2_whT_lo"))
+                       whT_hi=self.tsh.get("l2_whT_hi"), whT_lo=self.tsh.get("l2_whT_lo"), zoneout=self.zoneout_args(2))
         self._tick("dec_lstm:loop2")
         dec = self._buf("dec_out", rows * M * r, torch.float32)
         ops.gemm(h2, self._W(self.T), dec, rows, M * r, D, D, M * r, M * r, b_mode=1,
@@ -1073,7 +1123,7 @@ class Tacotron2(object):
         self._run_lstm("bwd", "dec2", N, S, D, S1, 1, B["dec_xg2"], 4 * D, None, self._W(self.T), None, False, h2, D,
                        B["dec_c2"], B["dec_g2"], dh=dh2, ld_dh=D, dgates=dg2, work=work, wh_off=k2 + D * 4 * D,
                        wh_bf16=self._bf16_w(T_), wh_bf16_off=k2 + D * 4 * D,
-                       dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_))
+                       dgates_bf16=self._dgb("d_g2b", rows * 4 * D, T_), zoneout=self.zoneout_args(2))
         self._tick("dec_lstm_bwd:loop2")
         w16 = self._bf16_w(T_)
         dg2b = self._bufs.get("d_g2b") if w16 is not None else None
@@ -1104,7 +1154,7 @@ class Tacotron2(object):
         self._run_lstm("bwd", "dec1", N, S, D, S1, 1, B["dec_xg1"], 4 * D, None, self._W(self.T), None, False, h1, D,
                        B["dec_c1"], B["dec_g1"], dh=dh1, ld_dh=D, dgates=dg1, work=work, wh_off=k1 + (A + E) * 4 * D,
                        wh_bf16=self._bf16_w(T_), wh_bf16_off=k1 + (A + E) * 4 * D,
-                       dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_))
+                       dgates_bf16=self._dgb("d_g1b", rows * 4 * D, T_), zoneout=self.zoneout_args(1))
         self._tick("dec_lstm_bwd:loop1")
         dg1b = self._bufs.get("d_g1b") if w16 is not None else None
         hcb = b16("dec_hc_16", hc, A + E)

@@ -31,8 +31,11 @@ def _infer_shadows(m):
 
 
 def _lstm_step(m, a, a_off, a_sn, K, wT, bias_off, c_prev, c_prev_off, c_sn, h_out, h_off, h_sn, h_out2, h2_off,
-               h2_sn, c_out, c_off, N, H):
+               h2_sn, c_out, c_off, N, H, zoneout=0.0):
     p = L.struct("ns_lstm_step_params")
+    if zoneout > 0.0:          # the expectation of the training masks; h_prev = the last H columns of the [input | h] row
+        p.zoneout_cell = p.zoneout_output = float(zoneout)
+        p.h_prev, p.hp_sn = ops.ptr(a, a_off + K - H), a_sn
     p.dtype, p.N, p.H, p.K = ops.dt(a), N, H, K
     p.a, p.a_sn, p.wT = ops.ptr(a, a_off), a_sn, ops.ptr(wT)
     p.bias = ops.ptr(m.flat_p, bias_off)
@@ -165,10 +168,10 @@ def _decode_steps(m, N, Ti, Pi, Tia, S, S1, enc, keys_t):
         # decoder LSTMs on [input | h_prev]
         _lstm_step(m, x1, sl * X1, S1 * X1, X1, tsh["l1T_full"], o("decoder/lstm_1/bias"),
                    c1 if s > 0 else None, s * D, S1 * D, x2, sl * X2, S1 * X2, x1, nx * X1 + A + E, S1 * X1,
-                   c1, sl * D, N, D)
+                   c1, sl * D, N, D, zoneout=m.zoneout_rate)
         _lstm_step(m, x2, sl * X2, S1 * X2, X2, tsh["l2T_full"], o("decoder/lstm_2/bias"),
                    c2 if s > 0 else None, s * D, S1 * D, h2, sl * D, S1 * D, x2, nx * X2 + D, S1 * X2,
-                   c2, sl * D, N, D)
+                   c2, sl * D, N, D, zoneout=m.zoneout_rate)
         ops.gemm(h2, tsh["wpT"], dec, N, M * r, D, S1 * D, D, S1 * M * r, a_off=sl * D, c_off=sl * M * r,
                  bias=m.flat_p, bias_off=o("decoder/output_projection/bias"))
         # feed the last of the r frames back
@@ -248,7 +251,9 @@ def _infer_body(m):
 
     # ---- decoder loop: one persistent launch where the shape allows (one or two utterances at the shipped or the test
     # widths), else a chain of single-step launches
-    done = _decode_persistent(m, N, Ti, Pi, Tia, S, enc, keys) if getattr(m, "use_decode_kernel", True) else None
+    # (the one-launch decoder has plain cells: with a zoneout rate the step launches apply its expectation)
+    one_launch = getattr(m, "use_decode_kernel", True) and m.zoneout_rate <= 0.0
+    done = _decode_persistent(m, N, Ti, Pi, Tia, S, enc, keys) if one_launch else None
     m.last_paths["decode"] = "persistent" if done is not None else "step"
     if done is not None:
         dec, al, S1 = done

@@ -176,6 +176,13 @@ def sumsq(x, n, out, out_off=0, work=None):
     L.call("ns_sumsq", p, stream())
 
 
+def segment_stats(x, offsets, nseg, out):
+    """out[4 s + (sum, sum of squares, min, max)] over x[offsets[s] : offsets[s + 1]]; offsets = device int64 tensor."""
+    p = L.struct("ns_segment_stats_params")
+    _fill(p, x=ptr(x), offsets=ptr(offsets), nseg=nseg, out=ptr(out))
+    L.call("ns_segment_stats", p, stream())
+
+
 def adam(pw, g, m, v, n, gnorm_sq, clip, grad_scale, lr_t, beta1, beta2, eps, shadow=None, status=(), skipped=None):
     """status: work buffers of this step's persistent recurrences (their first int is the status word); if one is
     non-zero the kernel updates nothing and sets skipped[0] = 1."""
@@ -208,8 +215,11 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
 def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,
                     dh=None, ld_dh=0, dgates=None, work=None, xg_off=0, whT_off=0, wh_off=0, h_off=0, dh_off=0,
                     forget_bias=1.0, whT_hi=None, whT_lo=None, wh_bf16=None, wh_bf16_off=0, dgates_bf16=None,
-                    h_bf16=None, h_bf16_off=0, ld_h_bf16=0, dtype=None):
+                    h_bf16=None, h_bf16_off=0, ld_h_bf16=0, dtype=None, zoneout=None):
+    """zoneout = (thr_cell, thr_output, seed_cell, seed_output) or None (plain cell), see zoneout_threshold()."""
     p = L.struct("ns_lstm_seq_params")
+    if zoneout is not None:
+        p.zoneout_thr_cell, p.zoneout_thr_output, p.zoneout_seed_cell, p.zoneout_seed_output = [int(x) for x in zoneout]
     if h_bf16 is not None:
         p.h_bf16, p.ld_h_bf16 = ptr(h_bf16, h_bf16_off), ld_h_bf16
     _fill(p, dtype=dt(h) if dtype is None else dtype, N=N, T=T, H=H, P=P, padl=padl, xg=ptr(xg, xg_off), ld_xg=ld_xg,
@@ -218,6 +228,27 @@ def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, l
           dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES,
           whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off), dgates_bf16=ptr(dgates_bf16))
     return p
+
+
+def zoneout_threshold(rate):
+    """A zoneout rate as the 24-bit threshold the kernels compare the mixed counter with (ns_lstm_seq_params)."""
+    return int(float(rate) * 16777216.0)
+
+
+def _fmix32(x):
+    x &= 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x85EBCA6B) & 0xFFFFFFFF
+    x ^= x >> 13
+    x = (x * 0xC2B2AE35) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def zoneout_seed(base, step, stream_id):
+    """The 32-bit seed of one mask stream (layer, cell | output) of training step `step`: every step draws new masks,
+    every data-parallel rank draws its own (the caller folds the rank into `base`)."""
+    return _fmix32(_fmix32((base & 0xFFFFFFFF) ^ ((step * 0x9E3779B9) & 0xFFFFFFFF)) ^ ((stream_id * 0x7FEB352D) & 0xFFFFFFFF))
 
 
 def lstm_seq(direction, dtype_t, *a, **kw):

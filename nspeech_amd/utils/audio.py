@@ -256,7 +256,7 @@ def inv_preemphasis(x):
 
 
 # ---------------------------------------------------------------- spectrograms
-def _spectrograms(y, want_lin, want_mel, want_stft=False):
+def _spectrograms(y, want_lin, want_mel, want_stft=False, on_device=False):
     hp = get_hparams()
     n_fft, hop, win = _stft_parameters()
     tb = _get_tables()
@@ -279,6 +279,8 @@ def _spectrograms(y, want_lin, want_mel, want_stft=False):
     L.call("ns_spectrogram", p, ops.stream())
     if want_stft:
         return torch.view_as_complex(cx.view(T, hp.num_freq, 2)).t().cpu().numpy()
+    if on_device:
+        return lin, mel
     out_lin = lin.view(T, hp.num_freq).t().cpu().numpy() if want_lin else None
     out_mel = mel.view(T, hp.num_mels).t().cpu().numpy() if want_mel else None
     return out_lin, out_mel
@@ -296,6 +298,14 @@ def spectrogram_and_mel(y):
     """Both features from ONE STFT (the reference recomputes the STFT for each, process.py:28-33)."""
     a, b = _spectrograms(y, True, True)
     return np.ascontiguousarray(a), np.ascontiguousarray(b)
+
+
+def spectrogram_and_mel_device(y):
+    """The same two features left where the kernel wrote them: (linear [T, F], mel [T, M]) float32 CUDA tensors in the
+    time-major layout a training batch uses - for the feeder's HBM-resident feature cache (datasets/datafeeder.py)."""
+    hp = get_hparams()
+    lin, mel = _spectrograms(y, True, True, on_device=True)
+    return lin.view(-1, hp.num_freq), mel.view(-1, hp.num_mels)
 
 
 def griffin_lim_gpu(spec, iters=None, raw_magnitude=False):

@@ -290,6 +290,9 @@ def save_tf_checkpoint(prefix, tensors, entries_per_block=64):
 
 
 # ------------------------------------------------------------------ names
+OPTIMIZER_SCOPE = "model/optimizer/"      # train.py:49 variable_scope('model') + tacotron2.py:146 variable_scope('optimizer')
+
+
 def name_candidates(name):
     """Spellings under which a TF1 graph of the reference may have saved this build's variable `name` (relative to
     'model/inference/').  The first is this build's own convention; the others follow the scopes TF 1.x wrappers add
@@ -340,24 +343,47 @@ def map_checkpoint(tensors, layout, stat_layout, name_map=None):
             found[name] = a.astype(np.float32)
             used.add(hit)
             hits[name] = hit
-    extra = sorted(k for k in tensors if k not in used and "/Adam" not in k and not k.endswith("_power") and k != "global_step")
+    extra = sorted(k for k in tensors if k not in used and not k.endswith("/Adam") and not k.endswith("/Adam_1")
+                   and not k.endswith("_power") and k != "global_step")
     report = dict(missing=missing, unused=extra, global_step=int(tensors["global_step"]) if "global_step" in tensors else None)
     params = {k: found[k] for k in layout.entries if k in found}
     stats = {k: found[k] for k in stat_layout.entries if k in found}
-    # tf.train.AdamOptimizer keeps its moments as slot variables beside each trainable, `<variable>/Adam` (m) and
-    # `<variable>/Adam_1` (v) (the reference saves them with the model, train.py:60 - tf.train.Saver over all variables);
-    # the bias-correction powers beta1_power / beta2_power are functions of the update count, which global_step carries.
-    # They are taken only as a complete set: report["adam_slots"] = (m, v) dicts by this build's names, or None.
+    # tf.train.AdamOptimizer keeps its moments as slot variables named after each trainable, `<variable>/Adam` (m) and
+    # `<variable>/Adam_1` (v) (the reference saves them with the model, train.py:60 - tf.train.Saver over all variables).
+    # TF 1.x creates a slot inside `variable_scope(None, primary.op.name + "/" + slot_name)`, i.e. NESTED under whatever
+    # variable scope is open when the optimizer builds its slots: the reference opens 'model' (train.py:49) and then
+    # 'optimizer' (tacotron2.py:146), so its checkpoints should hold `model/optimizer/model/inference/<var>/Adam[_1]`
+    # and `model/optimizer/beta{1,2}_power` [3P: TensorFlow is not installed here, unverified].  Both spellings are
+    # taken: the bare `<variable>/Adam`, else any single tensor whose name ENDS with `/<variable>/Adam`.
+    # The bias-correction powers are functions of the update count, which global_step carries.
+    # The slots are taken only as a complete set: report["adam_slots"] = (m, v) dicts by this build's names, or None with
+    # report["adam_slots_reason"] saying why.
+    def slot(hit, suffix):
+        if hit + suffix in tensors:
+            return hit + suffix
+        tail = "/" + hit + suffix
+        c = [k for k in tensors if k.endswith(tail)]
+        return c[0] if len(c) == 1 else None
+
     m, v = {}, {}
+    reason = None
+    has_any = any(k.endswith("/Adam") or k.endswith("/Adam_1") for k in tensors)
     for name in layout.entries:
         hit = hits.get(name)
-        if hit is None or hit + "/Adam" not in tensors or hit + "/Adam_1" not in tensors:
+        km, kv = (slot(hit, "/Adam"), slot(hit, "/Adam_1")) if hit is not None else (None, None)
+        if km is None or kv is None:
+            reason = ("no Adam slot tensors in the checkpoint" if not has_any else
+                      "no (unique) Adam slots for %s (looked for %s/Adam[_1] bare and under any scope prefix)" % (name, hit))
             break
-        am, av = np.asarray(tensors[hit + "/Adam"]), np.asarray(tensors[hit + "/Adam_1"])
+        am, av = np.asarray(tensors[km]), np.asarray(tensors[kv])
         if tuple(am.shape) != tuple(params[name].shape) or tuple(av.shape) != tuple(params[name].shape):
             raise ValueError("%s: Adam slots of %s have shapes %s / %s, the variable %s" % (name, hit, am.shape, av.shape, params[name].shape))
         m[name], v[name] = am.astype(np.float32), av.astype(np.float32)
-    report["adam_slots"] = (m, v) if len(m) == len(layout.entries) and not missing else None
+    if reason is None and missing:
+        reason = "variables missing from the checkpoint"
+    report["adam_slots"] = (m, v) if reason is None and len(m) == len(layout.entries) else None
+    report["adam_slots_reason"] = reason
+    report["adam_slots_present"] = has_any
     return params, stats, report
 
 
@@ -372,23 +398,31 @@ def load_into_model(model, prefix, name_map=None):
         model.global_step = report["global_step"]
     if report.get("adam_slots") is not None and hasattr(model, "load_adam_slots"):
         model.load_adam_slots(*report["adam_slots"])       # resume with the reference's optimizer state (train.py:67-71)
+    elif report.get("adam_slots_present"):
+        import sys
+        sys.stderr.write("[tf_bundle] %s holds Adam slot tensors that were NOT taken (%s): the moments start from zero\n"
+                         % (prefix, report.get("adam_slots_reason")))
     return report
 
 
 def export_model(model, prefix, with_adam_slots=False):
     """Writes the model's trainables, BatchNorm moving statistics and global_step as a TF bundle under this build's
-    names ('model/inference/...'); with_adam_slots: also the Adam moments as `<variable>/Adam`, `/Adam_1` slot variables
-    and beta1_power / beta2_power, the way tf.train.Saver writes a training checkpoint."""
+    names ('model/inference/...'); with_adam_slots: also the optimizer state the way the reference's graph names it
+    (see map_checkpoint): the moments as `model/optimizer/model/inference/<variable>/Adam`, `/Adam_1` and
+    `model/optimizer/beta{1,2}_power` = beta^(updates + 1) - TF initialises the powers to beta and multiplies once per
+    update (adam.py: _create_slots / _finish) [3P, unverified here]."""
     t = {"model/inference/" + k: v for k, v in model.numpy_params().items()}
     t.update({"model/inference/" + k: v for k, v in model.numpy_stats().items()})
     t["global_step"] = np.asarray(model.global_step, np.int64)
     if with_adam_slots and hasattr(model, "numpy_adam_slots"):
         m, v = model.numpy_adam_slots()
-        t.update({"model/inference/" + k + "/Adam": a for k, a in m.items()})
-        t.update({"model/inference/" + k + "/Adam_1": a for k, a in v.items()})
-        lr_t = max(1, model.global_step)
-        t["beta1_power"] = np.asarray(getattr(model, "adam_beta1", 0.9) ** lr_t, np.float32)
-        t["beta2_power"] = np.asarray(getattr(model, "adam_beta2", 0.999) ** lr_t, np.float32)
+        t.update({OPTIMIZER_SCOPE + "model/inference/" + k + "/Adam": a for k, a in m.items()})
+        t.update({OPTIMIZER_SCOPE + "model/inference/" + k + "/Adam_1": a for k, a in v.items()})
+        hp = getattr(model, "_hparams", None)
+        adam = getattr(hp, "adam", None) or {}
+        n = int(model.global_step) + 1
+        t[OPTIMIZER_SCOPE + "beta1_power"] = np.asarray(float(adam.get("beta1", 0.9)) ** n, np.float32)
+        t[OPTIMIZER_SCOPE + "beta2_power"] = np.asarray(float(adam.get("beta2", 0.999)) ** n, np.float32)
     save_tf_checkpoint(prefix, t)
 
 

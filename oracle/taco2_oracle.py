@@ -32,15 +32,29 @@ MASK_LOG = None
 # by arithmetic, and every gradient can be compared in the max norm at sizes where some of the ~1e6 pre-activations
 # always lie within rounding of zero (the outputs move by |pre-activation| <~ 1e-5 at the flipped elements, no more).
 MASK_FORCE = None
+# Test aid, read with MASK_FORCE: when set to a list, every forced ReLU appends (number of elements whose own sign
+# differs from the forced branch, the largest |pre-activation| among them, the site's rms pre-activation, its element
+# count).  The tests bound both: a forced branch may differ from the oracle's own only where the pre-activation lies
+# within the implementation's rounding of zero - a wrong epilogue (ReLU, gate, row mask) of the implementation shows up
+# here as flips at pre-activations of ordinary size instead of being copied into the oracle.
+FLIP_LOG = None
+# Test aid: the `zoneout` argument taco2_forward() uses when its caller passes none (tests/test_zoneout_gpu.py sets it
+# around the shared oracle drivers of tests/util.py).  None = the reference's plain decoder cells.
+ZONEOUT = None
 
 
 def _relu(x):
     if MASK_LOG is not None:
         MASK_LOG.append((x.detach() > 0).numpy())
     if MASK_FORCE is not None:
-        m = torch.from_numpy(MASK_FORCE.pop(0)).to(x.dtype)
-        assert m.shape == x.shape, (m.shape, x.shape)
-        return x * m
+        mb = torch.from_numpy(MASK_FORCE.pop(0))
+        assert mb.shape == x.shape, (mb.shape, x.shape)
+        if FLIP_LOG is not None:
+            xd = x.detach()
+            fl = (xd > 0) != mb.bool()
+            FLIP_LOG.append((int(fl.sum()), float(xd[fl].abs().max()) if bool(fl.any()) else 0.0,
+                             float(xd.pow(2).mean().sqrt()), xd.numel()))
+        return x * mb.to(x.dtype)
     return torch.relu(x)
 
 
@@ -79,11 +93,64 @@ def conv1d_bn(x, p, scope, activation, training, bn_updates=None):
 
 
 def lstm_block_cell(x, c, h, kernel, bias):
-    """tf.contrib.rnn.LSTMBlockCell: [i,j,f,o] = [x,h].W + b; forget_bias = 1.0; no peepholes."""
+    """tf.contrib.rnn.LSTMBlockCell: [i,j,f,o] = [x,h].W + b; forget_bias = 1.0; no peepholes.
+
+    [3P] assumption, stated because nothing in this container can check it (TensorFlow 1.7 is absent): the cell
+    state is NOT clipped.  The reference constructs every cell as `LSTMBlockCell(n)` with no further argument
+    (modules.py:41-42,90; tacotron2.py:69-70), so TF 1.7's default applies.  The fused LSTMBlockCell op carries a
+    `cell_clip` attribute; as far as the author of this restatement recalls the 1.5+ Python wrapper
+    (contrib/rnn/python/ops/lstm_ops.py: `cell_clip=None` -> the op is handed -1, "no clipping"; the releases before
+    it had `clip_cell=True` and the op's own default of 3), 1.7 does not clip - SURVEY Appendix C says the same - but
+    that is memory, not a checked fact.  It matters: with random-initialised weights the expand BiLSTM's cell state
+    reaches |c| = 3.4 over the 1000 steps of the benchmark shape (measured, tests/test_taco2_fullwidth_gpu.py prints it),
+    so a build that clips at 3 would differ from this restatement - and from the kernels, which follow it - there."""
     z = torch.cat([x, h], dim=-1) @ kernel + bias
     i, j, f, o = z.chunk(4, dim=-1)
     c2 = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
     h2 = torch.sigmoid(o) * torch.tanh(c2)
+    return c2, h2
+
+
+def zoneout_masks(seed, thr, steps, N, H):
+    """The counter-based keep masks of the kernels under test (include/nspeech_hip.h, ns_lstm_seq_params; csrc/common.h
+    ns_zone_keep), restated in NumPy integer arithmetic: mask[t, n, u] = (mix(seed, t, n, u) >> 8) < thr, mix = three
+    rounds of the murmur3 32-bit finaliser.  True = the unit keeps its old value.  Bit-exact by construction (uint32
+    wrap-around on both sides); tests/test_zoneout_gpu.py pins it against the kernel's own output."""
+    import numpy as np
+
+    def fmix(x):
+        x = x.astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        x = (x.astype(np.uint64) * np.uint64(0x85EBCA6B)).astype(np.uint32)
+        x ^= x >> np.uint32(13)
+        x = (x.astype(np.uint64) * np.uint64(0xC2B2AE35)).astype(np.uint32)
+        x ^= x >> np.uint32(16)
+        return x
+
+    def mul(a, c):
+        return (a.astype(np.uint64) * np.uint64(c)).astype(np.uint32)
+
+    t = np.arange(steps, dtype=np.uint32)[:, None, None]
+    n = np.arange(N, dtype=np.uint32)[None, :, None]
+    u = np.arange(H, dtype=np.uint32)[None, None, :]
+    x = fmix(np.uint32(seed) ^ mul(t, 0x9E3779B9))
+    x = fmix(x ^ mul(n, 0x7FEB352D))
+    x = fmix(x ^ mul(u, 0x846CA68B))
+    return (x >> np.uint32(8)) < np.uint32(thr)
+
+
+def zoneout_cell(x, c, h, kernel, bias, keep_c=None, keep_h=None, rate=None):
+    """Zoneout LSTM (Krueger et al. 2017) around lstm_block_cell: the plain cell proposes (c', h'), each unit keeps its
+    old value where its mask is set (training: keep_c / keep_h, bool [N, H]) or, at inference, moves to the expectation
+    rate * old + (1 - rate) * new.  The zoned h is both the cell's output and its recurrent state.  Not in the
+    reference (plain cells, tacotron2.py:69-70); rate 0 / no masks = lstm_block_cell."""
+    c2, h2 = lstm_block_cell(x, c, h, kernel, bias)
+    if keep_c is not None:
+        kc = torch.from_numpy(keep_c).to(c2.dtype)
+        kh = torch.from_numpy(keep_h).to(c2.dtype)
+        return kc * c + (1 - kc) * c2, kh * h + (1 - kh) * h2
+    if rate:
+        return rate * c + (1 - rate) * c2, rate * h + (1 - rate) * h2
     return c2, h2
 
 
@@ -163,13 +230,18 @@ def speaker_projection(p, speaker_ids, scope):
 
 
 def taco2_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets=None,
-                  max_iters=None, collect=False, speaker_ids=None):
+                  max_iters=None, collect=False, speaker_ids=None, zoneout=None):
     """tacotron2.py:15-128.  Training mode iff linear_targets is given (line 34).
 
+    zoneout: None (the reference: plain decoder cells) or, for the zoneout option of the build (hparam zoneout_rate),
+    dict(rate=r, masks={1: (keep_c, keep_h), 2: (...)}) with bool arrays [steps, N, units] for a training pass (see
+    zoneout_masks) or dict(rate=r) for the inference expectation.
     p: dict name -> torch tensor (TF layouts, names below 'model/inference/').
     Returns dict with mel_outputs, linear_outputs, alignments [N,T_in,steps], decoder_outputs
     and bn_updates (the UPDATE_OPS moving-average assignments, tacotron2.py:157-161)."""
     training = linear_targets is not None
+    if zoneout is None:
+        zoneout = ZONEOUT
     N, Ti = inputs.shape
     M = hp["num_mels"]
     r = hp["outputs_per_step"]
@@ -218,8 +290,15 @@ def taco2_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets
         align = location_sensitive_alignments(h_att, align, keys, lengths, p, D + "/attention")
         ctx = (align[:, :, None] * values).sum(dim=1)
         x1 = torch.cat([h_att, ctx], dim=-1)                    # rnn_wrappers.py:58-64
-        c1, h1 = lstm_block_cell(x1, c1, h1, p[D + "/lstm_1/kernel"], p[D + "/lstm_1/bias"])
-        c2, h2 = lstm_block_cell(h1, c2, h2, p[D + "/lstm_2/kernel"], p[D + "/lstm_2/bias"])
+        if zoneout is None:
+            c1, h1 = lstm_block_cell(x1, c1, h1, p[D + "/lstm_1/kernel"], p[D + "/lstm_1/bias"])
+            c2, h2 = lstm_block_cell(h1, c2, h2, p[D + "/lstm_2/kernel"], p[D + "/lstm_2/bias"])
+        else:
+            zm = zoneout.get("masks")
+            k1 = (zm[1][0][s], zm[1][1][s]) if zm else (None, None)
+            k2 = (zm[2][0][s], zm[2][1][s]) if zm else (None, None)
+            c1, h1 = zoneout_cell(x1, c1, h1, p[D + "/lstm_1/kernel"], p[D + "/lstm_1/bias"], k1[0], k1[1], zoneout["rate"])
+            c2, h2 = zoneout_cell(h1, c2, h2, p[D + "/lstm_2/kernel"], p[D + "/lstm_2/bias"], k2[0], k2[1], zoneout["rate"])
         out = h2 @ p[D + "/output_projection/kernel"] + p[D + "/output_projection/bias"]
         outs.append(out)
         aligns.append(align)

@@ -9,7 +9,7 @@ Reference semantics: tacotron2.py:55-107 (decoder, postnet, expand), modules.py:
 import numpy as np
 import pytest
 
-from util import make_batch, oracle_report, stabilise_targets
+from util import check_flips, make_batch, oracle_report, stabilise_targets
 
 pytestmark = pytest.mark.gpu
 
@@ -53,11 +53,17 @@ def test_taco2_shipped_widths_match_oracle(dev, mode, shape):
     m.check_status()
     for k, v in PATHS[mode].items():
         assert rep["paths"].get(k) == v, (k, rep["paths"])
+    _check(rep, mode, shape)
+
+
+def _check(rep, mode, shape):
     b = BOUNDS[mode]
     worst = sorted(rep["grad"].items(), key=lambda kv: -kv[1][0])[:3]
-    print("\n%s %s: ReLU flips %d; outputs (rel L2, rel max, L1) %s; worst gradients %s" % (
-        mode, shape, rep["flips"], {k: tuple(float("%.2e" % x) for x in v) for k, v in rep["out"].items()},
+    print("\n%s %s: ReLU flips %s; outputs (rel L2, rel max, L1) %s; worst gradients %s" % (
+        mode, shape, {k: (v[0], v[1], float("%.2e" % v[2])) for k, v in rep["flip_families"].items()},
+        {k: tuple(float("%.2e" % x) for x in v) for k, v in rep["out"].items()},
         [(k, float("%.2e" % v[0])) for k, v in worst]))
+    check_flips(rep, mode)
     assert rep["out"]["mel_outputs"][2] < b["mel_l1"], rep["out"]["mel_outputs"]
     for k, (l2, mx, l1) in rep["out"].items():
         assert mx < b["out"], (k, l2, mx, l1)
@@ -67,3 +73,26 @@ def test_taco2_shipped_widths_match_oracle(dev, mode, shape):
     assert not bad, bad
     med = float(np.median([v[0] for v in rep["grad"].values()]))
     assert med < b["grad_l2_median"], med
+
+
+def test_taco2_benchmark_launch_matches_oracle_at_its_own_lengths(dev):
+    """The benchmarked launch itself (BASELINE config 2: batch 32, T_in 160, T_out 1000 -> 200 decoder steps, 1000 expand
+    BiLSTM steps; precision mode `mixed`, every persistent kernel) against the float64 oracle: forward AND backward on
+    the host, about two minutes on the GPU box's 16 cores (VERDICT r3 weak #1).  Same bounds as the short shapes above."""
+    import torch
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models import create_model
+    hp = hparams_mod.load("taco2")
+    N, Ti, To = 32, 160, 1000
+    m = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=5)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=52)
+    rep = oracle_report(m, hp, inputs, lengths, mel, lin, stabilise=2e-3)
+    m.check_status()
+    for k, v in PATHS["mixed"].items():
+        assert rep["paths"].get(k) == v, (k, rep["paths"])
+    assert rep["paths"].get("encl:fwd") == "cluster" and rep["paths"].get("encl:bwd") == "cluster", rep["paths"]
+    # the oracle's LSTM cells do not clip their state (oracle/taco2_oracle.py: lstm_block_cell, a [3P] assumption): how far
+    # the states of this pass go says how much hangs on it
+    print("largest |cell state|: %s" % {name: round(float(m._bufs[name].abs().max().item()), 3) for name in (
+        "dec_c1", "dec_c2", "dec_ca", "expl_c_fw", "expl_c_bw", "encl_c_fw", "encl_c_bw")})
+    _check(rep, "mixed", (N, Ti, To))

@@ -115,6 +115,59 @@ def test_name_mapping_onto_the_tacotron2_layout(tmp_path):
     wrong[tf_names["embedding/embedding"] + "/Adam_1"] = np.zeros((2, 2), np.float32)
     with pytest.raises(ValueError):
         B.map_checkpoint(wrong, lay, st)
+    # the spelling the REFERENCE's graph gives its slots: the optimizer is built inside
+    # variable_scope('model') / variable_scope('optimizer') (train.py:49, tacotron2.py:146) and TF 1.x nests a slot's
+    # name under the open scope: model/optimizer/<variable op name>/Adam[_1], model/optimizer/beta{1,2}_power
+    ref = dict(tensors)
+    ref.pop("model/inference/embedding/embedding/Adam")
+    ref.pop("beta2_power")
+    for name in pv:
+        ref["model/optimizer/" + tf_names[name] + "/Adam"] = full[tf_names[name] + "/Adam"]
+        ref["model/optimizer/" + tf_names[name] + "/Adam_1"] = full[tf_names[name] + "/Adam_1"]
+    ref["model/optimizer/beta1_power"] = np.asarray(0.9 ** 78, np.float32)
+    ref["model/optimizer/beta2_power"] = np.asarray(0.999 ** 78, np.float32)
+    prefix3 = str(tmp_path / "model.ckpt-79")
+    B.save_tf_checkpoint(prefix3, ref)
+    _, _, rep5 = B.map_checkpoint(B.load_tf_checkpoint(prefix3), lay, st)
+    assert rep5["adam_slots"] is not None and rep5["adam_slots_reason"] is None, rep5["adam_slots_reason"]
+    m5, v5 = rep5["adam_slots"]
+    assert all(np.array_equal(m5[k], m[k]) and np.array_equal(v5[k], v[k]) for k in pv)
+    assert rep5["unused"] == ["model/inference/something/else"]
+    # an incomplete set says why it was not taken
+    part = dict(ref)
+    part.pop("model/optimizer/" + tf_names["dense/bias"] + "/Adam_1")
+    _, _, rep6 = B.map_checkpoint(part, lay, st)
+    assert rep6["adam_slots"] is None and rep6["adam_slots_present"] and "dense/bias" in rep6["adam_slots_reason"]
+    assert rep["adam_slots_reason"] and rep["adam_slots_present"]
+
+
+def test_export_writes_the_reference_optimizer_names(tmp_path):
+    """export_model(with_adam_slots=True) -> model/optimizer/model/inference/<var>/Adam[_1] and beta powers =
+    beta^(global_step + 1), what a TF Saver of the reference's graph would look up."""
+    class _M(object):
+        global_step = 4
+
+        class _hparams(object):
+            adam = {"beta1": 0.9, "beta2": 0.999}
+
+        def numpy_params(self):
+            return {"a/kernel": np.ones((2, 3), np.float32)}
+
+        def numpy_stats(self):
+            return {"a/moving_mean": np.zeros(3, np.float32)}
+
+        def numpy_adam_slots(self):
+            return {"a/kernel": np.full((2, 3), 2.0, np.float32)}, {"a/kernel": np.full((2, 3), 3.0, np.float32)}
+
+    prefix = str(tmp_path / "model.ckpt-4")
+    B.export_model(_M(), prefix, with_adam_slots=True)
+    t = B.load_tf_checkpoint(prefix)
+    assert set(t) == {"global_step", "model/inference/a/kernel", "model/inference/a/moving_mean",
+                      "model/optimizer/model/inference/a/kernel/Adam", "model/optimizer/model/inference/a/kernel/Adam_1",
+                      "model/optimizer/beta1_power", "model/optimizer/beta2_power"}
+    assert abs(float(t["model/optimizer/beta1_power"]) - 0.9 ** 5) < 1e-7
+    assert abs(float(t["model/optimizer/beta2_power"]) - 0.999 ** 5) < 1e-7
+    assert float(t["model/optimizer/model/inference/a/kernel/Adam_1"][0, 0]) == 3.0
 
 
 def test_reader_against_hand_assembled_bundle(tmp_path):

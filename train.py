@@ -75,6 +75,28 @@ class CheckpointSaver(object):
         return path
 
 
+def train_step(model, batches, world=1):
+    """One iteration of the training loop = the reference's sess.run([global_step, loss, optimize]) (train.py:80): take
+    the next batch (targets already on their way to the GPU, see DeviceStager), run the step, read the loss back.
+    Returns the loss (the mean over the ranks when data-parallel, so that every rank takes the same abort decision)."""
+    inputs, lengths, mel, lin = batches.next_batch()
+    loss = model.step(inputs, lengths, mel, lin, speaker_ids=batches.speaker_ids)
+    if world > 1:
+        t = torch.tensor([loss], device="cuda")
+        torch.distributed.all_reduce(t)
+        loss = float(t.item()) / world
+    return loss
+
+
+def write_summary(path, step, stats):
+    """One JSON object per summary step in LOGDIR/events.jsonl: what the reference hands tf.summary.FileWriter
+    (train.py:63,91-93; tacotron2.py:163-188) as scalars - loss, loss_mel, loss_linear, learning_rate,
+    max_gradient_norm - plus the per-variable gradient norms and min / max / mean / std of the four value histograms."""
+    import json
+    with open(path, "a") as f:
+        f.write(json.dumps(dict(step=int(step), wall_time=time.time(), **stats)) + "\n")
+
+
 def train(log_dir, args):
     rank, local, world = parallel.init_distributed()
     torch.cuda.set_device(local)
@@ -82,7 +104,7 @@ def train(log_dir, args):
     logf = os.path.join(log_dir, "train.log") if rank == 0 else None
     log("Checkpoint path: %s" % os.path.join(log_dir, "model.ckpt"), logf)
     log(hparams_mod.debug_string(hp), logf)
-    from nspeech_amd.datasets.datafeeder import DataFeeder
+    from nspeech_amd.datasets.datafeeder import DataFeeder, DeviceStager
     cmu = None
     if getattr(hp, "use_cmudict", False):       # datafeeder.py:96-108 (commented out in the reference)
         from nspeech_amd.utils.text import cmudict
@@ -94,7 +116,8 @@ def train(log_dir, args):
         log("Loaded CMUDict with %d unambiguous entries" % len(cmu), logf)
     # shared seed: every rank walks the same item order and keeps its round-robin share of each sorted group
     feeder = DataFeeder(hp, ljspeech=args.ljspeech, vctk=args.vctk, librispeech=args.librispeech, seed=1234, rank=rank,
-                        world=world, cmudict=cmu).start()
+                        world=world, cmudict=cmu, pinned=True,
+                        device_cache=(args.feature_cache == "device")).start()
     hp.num_speakers = len(feeder.speaker2id)        # train.py:45
     log("Loaded %d different speaker(s)" % hp.num_speakers, logf)
     model = create_model(args.model, hp, device="cuda:%d" % local, dtype=args.precision, world_size=world)
@@ -116,15 +139,12 @@ def train(log_dir, args):
     model.add_stats()
     time_window, loss_window = ValueWindow(100), ValueWindow(100)
     saver = CheckpointSaver(log_dir)
+    batches = DeviceStager(feeder, "cuda:%d" % local)      # pinned H2D of batch k+1 on a copy stream under step k
+    events = os.path.join(log_dir, "events.jsonl") if rank == 0 else None
     paths_logged = None
     while args.max_steps is None or model.global_step < args.max_steps:
         t0 = time.time()
-        inputs, lengths, mel, lin = feeder.next_batch()
-        loss = model.step(inputs, lengths, mel, lin, speaker_ids=feeder.speaker_ids)
-        if world > 1:   # every rank must agree on the abort decision
-            t = torch.tensor([loss], device="cuda")
-            torch.distributed.all_reduce(t)
-            loss = float(t.item()) / world
+        loss = train_step(model, batches, world)
         step = model.global_step
         paths = getattr(model, "last_paths", None)
         if paths and paths != paths_logged:         # which kernel family ran each recurrence (a batch shape that falls
@@ -132,12 +152,15 @@ def train(log_dir, args):
             log("Recurrence kernels: %s" % ", ".join("%s=%s" % kv for kv in sorted(paths.items())), logf)
         time_window.append(time.time() - t0)
         loss_window.append(loss)
-        frames = mel.shape[0] * mel.shape[1] * world
+        frames = model.mel_targets.shape[0] * model.mel_targets.shape[1] * world
         log("Step %-7d [%.03f sec/step, loss=%.05f, avg_loss=%.05f, %.0f mel_frames/s]" %
             (step, time_window.average, loss, loss_window.average, frames / time_window.average), logf)
         if loss > 100 or math.isnan(loss):          # train.py:87-89
             log("Loss exploded to %.05f at step %d!" % (loss, step), logf)
             raise Exception("Loss Exploded")
+        if rank == 0 and args.summary_interval and step % args.summary_interval == 0:      # train.py:91-93
+            log("Writing summary at step: %d" % step, logf)
+            write_summary(events, step, model.stats())
         if rank == 0 and step % args.checkpoint_interval == 0:
             path = saver.save(model, step)
             log("Saved checkpoint %s" % path, logf)
@@ -166,6 +189,10 @@ def main():
     ap.add_argument("--threads", type=int, default=1)
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "bf16x3", "fp32"])
     ap.add_argument("--max-steps", "--max_steps", type=int, default=None)
+    ap.add_argument("--feature-cache", "--feature_cache", default="device", choices=["device", "host"],
+                    help="where the feeder keeps the spectrogram features of the corpus: 'device' = in HBM, batches "
+                         "assembled on the GPU (all of LJSpeech is 30.5 GB of float32); 'host' = in RAM as the reference "
+                         "does (datafeeder.py:165-176), uploaded through pinned buffers on a copy stream")
     args = ap.parse_args()
     if "WORLD_SIZE" not in os.environ:
         os.environ.setdefault("HIP_VISIBLE_DEVICES", args.gpu)

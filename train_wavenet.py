@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""simple_wavenet training CLI with the reference's flags (train_wavenet.py:19-135) on the MI355X-native model.
+
+  python3 train_wavenet.py --ljspeech DIR [--model simple_wavenet] [--hparams sample_size=8000,batch_size=8] ...
+
+LOGDIR/RUN/train.log, model.ckpt-STEP (torch.save of a name -> tensor dict under the TF variable names), a scalars line
+in events.jsonl every --summary-interval steps.  The shipped train.yaml has sample_size = 1 (one predicted sample per
+piece); pass a larger one for real training."""
+import argparse
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from nspeech_amd import hparams as hparams_mod  # noqa: E402
+from nspeech_amd.models import create_model  # noqa: E402
+from train import CheckpointSaver, ValueWindow, log, write_summary  # noqa: E402
+
+
+def train_wavenet(log_dir, args, hp):
+    from nspeech_amd.datasets.wavenet_feeder import WavenetFeeder
+    logf = os.path.join(log_dir, "train.log")
+    log("Checkpoint path: %s" % os.path.join(log_dir, "model.ckpt"), logf)
+    log("Using model: %s" % args.model, logf)
+    log(hparams_mod.debug_string(hp), logf)
+    model = create_model(args.model, hp, device="cuda:0", dtype=args.precision)
+    feeder = WavenetFeeder(hp, model.rf, ljspeech=args.ljspeech or None, vctk=args.vctk or None,
+                           librispeech=args.librispeech or None, seed=1234)
+    log("Loaded data refs for %d examples" % len(feeder.items), logf)
+    log("Loaded %d different speaker(s)" % len(feeder.speaker2id), logf)
+    hp.num_speakers = len(feeder.speaker2id)            # train_wavenet.py:40-41
+    hp.gc_category_cardinality = hp.num_speakers
+    step0 = 0
+    if args.restore_step:
+        path = "%s-%d" % (os.path.join(log_dir, "model.ckpt"), args.restore_step)
+        model.load_state_dict(torch.load(path, map_location="cpu", weights_only=True))
+        step0 = model.global_step
+        log("Resuming from checkpoint: %s" % path, logf)
+    else:
+        log("Starting new training run ", logf)
+    model.add_loss(hp.l2_regularization_strength or None)
+    model.add_optimizer(step0)
+    model.add_stats()
+    time_window, loss_window = ValueWindow(100), ValueWindow(100)
+    saver = CheckpointSaver(log_dir)
+    events = os.path.join(log_dir, "events.jsonl")
+    while args.max_steps is None or model.global_step < args.max_steps:
+        t0 = time.time()
+        loss = model.step(feeder.next_batch())           # train_wavenet.py:75
+        step = model.global_step
+        time_window.append(time.time() - t0)
+        loss_window.append(loss)
+        log("Step %-7d [%.03f sec/step, loss=%.05f, avg_loss=%.05f, queue=%.02f]" % (
+            step, time_window.average, loss, loss_window.average, feeder.size / float(feeder.capacity)), logf)
+        if loss > 100 or math.isnan(loss):
+            log("Loss exploded to %.05f at step %d!" % (loss, step), logf)
+            raise Exception("Loss Exploded")
+        if args.summary_interval and step % args.summary_interval == 0:
+            log("Writing summary at step: %d" % step, logf)
+            write_summary(events, step, model.stats())
+        if step % args.checkpoint_interval == 0:
+            log("Saving checkpoint to: %s" % saver.save(model, step), logf)
+    return model
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--log-dir", "--log_dir", default=os.path.expanduser("logs"))
+    ap.add_argument("--vctk", default="")
+    ap.add_argument("--ljspeech", default="")
+    ap.add_argument("--librispeech", default="")
+    ap.add_argument("--model", default="simple_wavenet")       # the reference's default 'wavenet' (WaveNetModel) is not built
+    ap.add_argument("--name", default=None)
+    ap.add_argument("--hparams", default="")
+    ap.add_argument("--restore-step", "--restore_step", type=int, default=None)
+    ap.add_argument("--summary-interval", "--summary_interval", type=int, default=1000)
+    ap.add_argument("--checkpoint-interval", "--checkpoint_interval", type=int, default=1000)
+    ap.add_argument("--slack-url", "--slack_url", default=None)
+    ap.add_argument("--tf-log-level", "--tf_log_level", type=int, default=1)
+    ap.add_argument("--git", action="store_true")
+    ap.add_argument("--gpu", default=0, type=int)
+    ap.add_argument("--threads", default=1, type=int)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--max-steps", "--max_steps", type=int, default=None)
+    args = ap.parse_args()
+    if args.model == "wavenet":
+        sys.exit("train_wavenet.py: only --model simple_wavenet is built (wavenet_simple.py); WaveNetModel with global / "
+                 "local conditioning is out of scope (DESIGN 9)")
+    os.environ.setdefault("HIP_VISIBLE_DEVICES", str(args.gpu))
+    run_name = args.name or args.model
+    log_dir = os.path.join(args.log_dir, run_name)
+    os.makedirs(log_dir, exist_ok=True)
+    hp = hparams_mod.load("wavenet")
+    hp.parse(args.hparams)
+    train_wavenet(log_dir, args, hp)
+
+
+if __name__ == "__main__":
+    main()
