@@ -27,7 +27,8 @@ extern "C" {
 
 typedef void* ns_stream_t; /* hipStream_t */
 
-enum { NS_OK = 0, NS_ERR_BAD_ARG = -1, NS_ERR_UNSUPPORTED_SHAPE = -2, NS_ERR_LAUNCH = -3 };
+enum { NS_OK = 0, NS_ERR_BAD_ARG = -1, NS_ERR_UNSUPPORTED_SHAPE = -2, NS_ERR_LAUNCH = -3,
+       NS_ERR_SHORT_BUFFER = -4 /* a caller-owned output buffer is too small; retry with a larger one */ };
 enum { NS_F32 = 0, NS_BF16 = 1 };
 enum { NS_ACT_NONE = 0, NS_ACT_RELU = 1, NS_ACT_TANH = 2, NS_ACT_SIGMOID = 3,
        NS_ACT_SOFTSIGN = 4 /* x / (1 + |x|): the speaker projections, rnn_wrappers.py:29, modules.py:159,167 */ };
@@ -105,9 +106,19 @@ typedef struct {
    * sums are taken on the accumulated value. */
   const void* stat_z; int64_t ld_stat_z; int stat_z_dtype;
   const float* stat_mean; const float* stat_istd;
+  /* Deterministic split-K (round 4).  With split_k > 1 the k slices of an output tile used to meet in fp32 atomic adds,
+   * in whatever order they finished: the weight gradients (tacotron2.py:153) differed in their last bits from run to
+   * run.  With splitk_work set (caller-owned scratch of ns_gemm_splitk_work_bytes(M, N, split_k) bytes, no need to clear
+   * it) and splitk_count (int[ns_gemm_splitk_counters(M, N)], ZERO before the first call; every call leaves it zero)
+   * each slice stores its partial tile in the scratch and raises the tile's counter; the slice that arrives LAST adds
+   * the partial tiles up in slice order 0, 1, ... - whichever slice it is - and runs the epilogue once: a fixed
+   * summation order, no waiting, no float atomics.  Both NULL: the atomic form.  batch must be 1. */
+  float* splitk_work; int* splitk_count;
 } ns_gemm_params;
 int ns_gemm(const ns_gemm_params* p, ns_stream_t stream);
 size_t ns_gemm_stat_part_floats(int M, int N);
+size_t ns_gemm_splitk_work_bytes(int M, int N, int split_k);
+size_t ns_gemm_splitk_counters(int M, int N);
 /* name of the kernel the calling thread's last ns_gemm call launched (e.g. "gemm_mfma_f32_kernel<0, 1, 3>"): lets a
  * caller attribute its own event timings to the names a profiler reports. */
 const char* ns_gemm_last_kernel(void);
@@ -138,7 +149,8 @@ int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t stream);
 typedef struct {
   const int* ids;
   const float* dout;       /* fp32 [N,P,D] */
-  float* dtable;           /* [V,D] += */
+  float* dtable;           /* [V,D] += : one workgroup per table row gathers the positions that hold it, in position order
+                              (a fixed summation order, no float atomics: tacotron2.py:153's gradient is bit-reproducible) */
   int N, T, P, padl, D, V;
 } ns_embedding_bwd_params;
 int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t stream);
@@ -185,13 +197,18 @@ typedef struct {
 } ns_bn_bwd_params;
 int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t stream);
 
-/* out[c] += sum over rows of x[row,c]  (bias gradients). */
+/* out[c] += sum over rows of x[row,c]  (bias gradients).  With `work` (caller-owned fp32 scratch of
+ * ns_colsum_work_floats(C) floats whose FIRST 1024 words are zero before the first call; every call leaves them zero) the
+ * row blocks park their partial sums there and the last one to arrive adds them in block order: a fixed summation
+ * order.  work NULL: the row blocks meet in float atomics (order varies from run to run). */
 typedef struct {
   const void* x; int dtype; int64_t ld;
   int rows, C;
   float* out;
+  float* work;
 } ns_colsum_params;
 int ns_colsum(const ns_colsum_params* p, ns_stream_t stream);
+size_t ns_colsum_work_floats(int C);
 
 /* L1 losses of tacotron2.py:130-139 and their gradient in one pass.
  * pred fp32 padded [N,P,ldp] (valid rows padl..padl+T), target fp32 [N,T,F].
@@ -401,6 +418,7 @@ typedef struct {
   const float* wcl; const float* v;
 } ns_attention_step_bwd_params;
 int ns_attention_step_bwd(const ns_attention_step_bwd_params* p, ns_stream_t stream);
+size_t ns_attention_post_part_floats(int N, int Tia, int A);
 /* Sums over all S decoder steps that no recurrence needs: dkeys_t (plain store), dv +=, dwcl +=. */
 typedef struct {
   int N, S, Ti, Tia, A, kw;
@@ -408,6 +426,9 @@ typedef struct {
   const float* keys_t; const float* q; const float* align; const float* de;   /* [N,S+1,...] slot layout */
   const float* wcl; const float* v;
   float* dkeys_t; float* dv; float* dwcl;
+  /* optional scratch of ns_attention_post_part_floats(N, Tia, A) floats: the (utterance, position block) partial sums of
+   * dv / dwcl are parked there and added in a fixed order by a second launch instead of meeting in float atomics */
+  float* part;
 } ns_attention_post_bwd_params;
 int ns_attention_post_bwd(const ns_attention_post_bwd_params* p, ns_stream_t stream);
 /* keys[n, padl+t, u] += keys_t[n,u,t] */
@@ -515,6 +536,9 @@ typedef struct {
    * written into columns D2..D2+Dsp of every slot by the caller, wattT / watt hold all D2+Dsp+A input rows, and the
    * caller forms the projection's gradient from dga (sum over the slots) after the backward call. */
   int Dsp;
+  /* backward, optional: scratch for the fixed-order sums of dv / dwcl (ns_attention_post_part_floats(N, Tia, A) floats,
+   * see ns_attention_post_bwd_params.part); NULL = float atomics */
+  float* post_part;
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);
@@ -692,7 +716,8 @@ int ns_preemphasis(const ns_preemphasis_params* p, ns_stream_t stream);
  * utils/audio.py:13-14).  data = the whole file in HOST memory.  ns_flac_info: stream parameters (total_samples per
  * channel, 0 when the encoder left it out; md5_16 = STREAMINFO's MD5 of the decoded PCM, may be NULL).
  * ns_flac_decode: out[sample * channels + channel] int32 in HOST memory, capacity / *decoded in samples per channel;
- * every frame is checked against its CRC-8 and CRC-16. */
+ * every frame is checked against its CRC-8 and CRC-16.  NS_ERR_SHORT_BUFFER: the stream holds more than `capacity`
+ * samples (only possible when STREAMINFO carries no total). */
 int ns_flac_info(const uint8_t* data, size_t n, int* sample_rate, int* channels, int* bits_per_sample,
                  int64_t* total_samples, uint8_t* md5_16);
 int ns_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64_t capacity, int64_t* decoded);

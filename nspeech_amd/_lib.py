@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libnspeech_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "nspeech_hip.h")
 
 NS_F32, NS_BF16 = 0, 1
+NS_ERR_SHORT_BUFFER = -4
 ACT_NONE, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_SOFTSIGN = 0, 1, 2, 3, 4
 
 _lib = None

@@ -461,6 +461,7 @@ struct AttnPost {
   const float* wcl; const float* v;
   float* dkeys_t;          // [N,A,Tia] out (plain store)
   float* dv; float* dwcl;  // +=
+  float* part;             // optional [N * position blocks][1 + MAXKW][A]: parked partial sums (fixed-order finish)
 };
 template <int KW>          // KW = the filter width when it is the usual 7 (straight-line step), 0 = a.kw at run time
 __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
@@ -601,13 +602,16 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
       const float dkj = (j & 1) ? dk[j >> 1].y : dk[j >> 1].x;
       const float dvj = (j & 1) ? dvp[j >> 1].y : dvp[j >> 1].x;
       if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = dkj;
+      // dv, dwcl: sums over every utterance and position block.  With `part` this block's share is parked and
+      // attn_post_finish_kernel adds the shares in a fixed order; without it they meet in float atomics.
+      float* pp = a.part ? a.part + ((long)n * gridDim.x + tc) * (1 + MAXKW) * A : nullptr;
       const float sv_ = wave_sum(dvj);
-      if (lane == 0) atomicAdd(a.dv + u0 + j, sv_);
+      if (lane == 0) { if (pp) pp[u0 + j] = sv_; else atomicAdd(a.dv + u0 + j, sv_); }
 #pragma unroll
       for (int k = 0; k < MAXKW; ++k)
         if (k < kw) {
           const float sw = wave_sum((j & 1) ? dwp[k][j >> 1].y : dwp[k][j >> 1].x);
-          if (lane == 0) atomicAdd(a.dwcl + k * A + u0 + j, sw);
+          if (lane == 0) { if (pp) pp[(1 + k) * A + u0 + j] = sw; else atomicAdd(a.dwcl + k * A + u0 + j, sw); }
         }
     }
   }
@@ -772,6 +776,29 @@ extern "C" int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   return attn_fwd_t<float>(*p, (hipStream_t)s);
 }
 
+// second stage of attn_post_kernel's sums with AttnPost.part: thread = (k, unit); shares added in block order
+__global__ void attn_post_finish_kernel(const float* part, int nblocks, int A, int kw, float* dv, float* dwcl) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (1 + kw) * A) return;
+  const int k = i / A, u = i - k * A;
+  float s = 0.f;
+  for (int b = 0; b < nblocks; ++b) s += part[((long)b * (1 + MAXKW) + k) * A + u];
+  if (k == 0) dv[u] += s; else dwcl[(k - 1) * A + u] += s;
+}
+static int launch_attn_post(const AttnPost& q, int N, hipStream_t s) {
+  dim3 grid(ceil_div(q.Tia, 64), ceil_div(q.A, 4 * PU), N);
+  if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
+  else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, s, q);
+  if (q.part)
+    hipLaunchKernelGGL(attn_post_finish_kernel, dim3(ceil_div((1 + q.kw) * q.A, 256)), dim3(256), 0, s, q.part, (int)(grid.x * N),
+                       q.A, q.kw, q.dv, q.dwcl);
+  return NS_OK;
+}
+extern "C" size_t ns_attention_post_part_floats(int N, int Tia, int A) {
+  if (N <= 0 || Tia <= 0 || A <= 0) return 0;
+  return (size_t)N * ceil_div(Tia, 64) * (1 + MAXKW) * (size_t)(ceil_div(A, 4 * PU) * 4 * PU);
+}
+
 // Hoisted part of the backward pass, after the time loop (also the tail of the persistent backward kernel): the sums
 // over all steps that no recurrence needs (dkeys, dv, dWcl), the total context gradients and dvalues.
 template <typename T>
@@ -785,10 +812,8 @@ int ns_attn_bwd_post(const ns_taco2_attn_params& p, hipStream_t s) {
     AttnPost q = {};
     q.S = p.S; q.Ti = p.Ti; q.A = p.A; q.kw = p.kw; q.Tia = p.Tia; q.lengths = p.lengths;
     q.keys_t = p.keys_t; q.q = p.q; q.align = p.align; q.de = p.de; q.wcl = p.wcl; q.v = p.v;
-    q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl;
-    dim3 grid(ceil_div(p.Tia, 64), ceil_div(p.A, 4 * PU), p.N);
-    if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, s, q);
+    q.dkeys_t = dkeys_t; q.dv = p.dv; q.dwcl = p.dwcl; q.part = p.post_part;
+    launch_attn_post(q, p.N, s);
     NS_CHECK_LAUNCH("attn_post");
   }
   if (pvm) {
@@ -1021,10 +1046,8 @@ extern "C" int ns_attention_post_bwd(const ns_attention_post_bwd_params* p, ns_s
   AttnPost q = {};
   q.S = p->S; q.Ti = p->Ti; q.A = p->A; q.kw = p->kw; q.Tia = p->Tia; q.lengths = p->lengths;
   q.keys_t = p->keys_t; q.q = p->q; q.align = p->align; q.de = p->de; q.wcl = p->wcl; q.v = p->v;
-  q.dkeys_t = p->dkeys_t; q.dv = p->dv; q.dwcl = p->dwcl;
-  dim3 grid(ceil_div(p->Tia, 64), ceil_div(p->A, 4 * PU), p->N);
-  if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, (hipStream_t)s, q);
-  else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, (hipStream_t)s, q);
+  q.dkeys_t = p->dkeys_t; q.dv = p->dv; q.dwcl = p->dwcl; q.part = p->part;
+  launch_attn_post(q, p->N, (hipStream_t)s);
   NS_CHECK_LAUNCH("attention_post_bwd");
   return NS_OK;
 }

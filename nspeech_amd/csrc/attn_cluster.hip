@@ -1204,6 +1204,7 @@ bool cluster_shape_ok(const ns_taco2_attn_params* p) {
   if (p->A != 256 && p->A != 64) return false;
   if (p->Ti > 256 || p->Tia > 256 || p->kw > KWMAX || p->S < 1 || p->N < 1) return false;
   if (p->Dsp < 0) return false;
+  if ((long)p->N * CG > ns_device_cus()) return false;      // a cluster of CG workgroups per utterance, all resident at once
   return true;
 }
 }  // namespace
@@ -1363,7 +1364,7 @@ static bool decode_shape_ok(const ns_taco2_decode_params* q) {
   if (!((p->A == 256 && p->E == 512 && q->D == 1024) || (p->A == 64 && p->E == 64 && q->D == 64))) return false;
   if (p->N < 1 || p->N > 2 || p->Tia > 256 || p->Ti > p->Tia) return false;
   const int NW1 = (q->D + DEC_UPW1 - 1) / DEC_UPW1, NW2 = (q->D + DEC_UPW2 - 1) / DEC_UPW2;
-  if (p->N * CG + NW1 + NW2 > 256) return false;       // every workgroup resident at once, one per CU
+  if (p->N * CG + NW1 + NW2 > ns_device_cus()) return false;       // every workgroup resident at once, one per CU
   if ((256 + NW2 - 1) / NW2 > 64) return false;        // feedback columns per LSTM-2 workgroup (red2 rows)
   return true;
 }

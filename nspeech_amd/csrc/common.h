@@ -15,6 +15,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 // ---------------------------------------------------------------- errors
 void ns_set_error(const char* fmt, ...);
 int ns_zero_async(void* p, size_t bytes, hipStream_t s);   // core.hip: kernel fill (graph-replay safe, see there)
+// core.hip: compute units of the CURRENT device (cached per device; 256 on a whole MI355X, fewer in a CPX / DPX partition).
+// The persistent kernels need every workgroup of a launch resident at once, one per CU: their *_supported() checks
+// compare the grid with this instead of a literal 256, so a smaller device takes the launch-per-step kernels.
+int ns_device_cus();
 // gemm.hip: s1[n] = sum over the slots of part[slot][n], s2[n] (nullable) = the same over part[slots + slot][n], fixed order
 int ns_stats_finalize(const float* part, int slots, int N, float* s1, float* s2, hipStream_t s);
 

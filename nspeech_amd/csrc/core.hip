@@ -11,6 +11,18 @@ void ns_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+int ns_device_cus() {
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); return 256; }
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 extern "C" int ns_version(void) { return 100; }
 extern "C" const char* ns_device_arch(void) { return "gfx950"; }
 extern "C" const char* ns_last_error(void) { return g_err; }

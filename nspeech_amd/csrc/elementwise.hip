@@ -53,19 +53,50 @@ extern "C" int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t s) {
   NS_CHECK_LAUNCH("embedding_fwd");
   return NS_OK;
 }
-__global__ void embedding_bwd_kernel(ns_embedding_bwd_params p) {
-  const int row = blockIdx.x;
-  const int n = row / p.T, t = row % p.T;
-  int id = p.ids[row];
-  id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
-  const float* src = p.dout + ((long)n * p.P + p.padl + t) * p.D;
-  float* dst = p.dtable + (long)id * p.D;
-  for (int d = threadIdx.x; d < p.D; d += blockDim.x) atomicAdd(dst + d, src[d]);
+// One workgroup per table row v: walk the N*T positions 256 at a time, list the ones that hold v (ballot + prefix: the
+// list is in position order), then every thread adds its columns of those rows in list order.  Fixed summation order,
+// no float atomics (round 4; the scatter form added rows in whatever order their workgroups ran).
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(ns_embedding_bwd_params p) {
+  __shared__ int list[256];
+  __shared__ int wcnt[4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n_pos = p.N * p.T;
+  constexpr int MAXD = 4;                       // columns per thread: D <= 1024
+  float acc[MAXD] = {0.f, 0.f, 0.f, 0.f};
+  for (int base = 0; base < n_pos; base += 256) {
+    const int pos = base + tid;
+    bool hit = false;
+    if (pos < n_pos) {
+      int id = p.ids[pos];
+      id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
+      hit = id == v;
+    }
+    const unsigned long long b = __ballot(hit);
+    if (lane == 0) wcnt[wave] = __popcll(b);
+    __syncthreads();
+    int off = __popcll(b & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) off += wcnt[w];
+    const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    if (hit) list[off] = pos;
+    __syncthreads();
+    for (int e = 0; e < total; ++e) {
+      const int q = list[e];
+      const float* src = p.dout + ((long)(q / p.T) * p.P + p.padl + q % p.T) * p.D;
+#pragma unroll
+      for (int i = 0; i < MAXD; ++i)
+        if (tid + 256 * i < p.D) acc[i] += src[tid + 256 * i];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < MAXD; ++i)
+    if (tid + 256 * i < p.D) p.dtable[(long)v * p.D + tid + 256 * i] += acc[i];
 }
 extern "C" int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->ids && p->dout && p->dtable, "ns_embedding_bwd: null");
+  NS_CHECK_ARG(p->D <= 1024 && p->V >= 1, "ns_embedding_bwd: D <= 1024");
   if (p->N * p->T == 0) return NS_OK;
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(p->N * p->T), dim3(64), 0, (hipStream_t)s, *p);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(p->V), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("embedding_bwd");
   return NS_OK;
 }
@@ -489,6 +520,8 @@ extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
 
 // ------------------------------------------------------------------ column sums
 constexpr int CS_ROWS = 32;
+constexpr int COLSUM_MAX_BLOCKS = 64;     // row blocks of a launch = partial sums per column
+constexpr int COLSUM_CNT = 1024;          // ns_colsum_params.work: [0, 1024) arrival counters (as int), then the partial sums
 __global__ void colsum_kernel(ns_colsum_params p) {
   const int r0 = blockIdx.x * CS_ROWS;
   for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
@@ -534,19 +567,75 @@ __global__ __launch_bounds__(256) void colsum4_kernel(ns_colsum_params p) {
     for (int i = 0; i < 4; ++i) {
       float a = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
-      if (4 * q + i < p.C) atomicAdd(p.out + 4 * q + i, a);
+      if (4 * q + i < p.C) {
+        if (p.work) p.work[COLSUM_CNT + (long)blockIdx.x * p.C + 4 * q + i] = a;      // parked: the last row block adds them in order
+        else atomicAdd(p.out + 4 * q + i, a);
+      }
     }
   }
+  if (!p.work) return;
+  // fixed-order finish: row blocks -> fence -> this column block's counter; the last one adds partials 0, 1, ... per column
+  __shared__ int last;
+  __threadfence();
+  __syncthreads();
+  int* counter = (int*)p.work + blockIdx.y;
+  if (tid == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int c0 = blockIdx.y * BN4_QUADS * 4;
+  if (tid < BN4_QUADS * 4 && c0 + tid < p.C) {
+    float a = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) a += __builtin_nontemporal_load(p.work + COLSUM_CNT + (long)b * p.C + c0 + tid);
+    p.out[c0 + tid] += a;
+  }
+  if (tid == 0) *counter = 0;
 }
+extern "C" size_t ns_colsum_work_floats(int C) { return (size_t)COLSUM_CNT + (size_t)COLSUM_MAX_BLOCKS * (size_t)(C > 0 ? C : 0); }
+
+// the deterministic form for rows the vector kernel cannot take (ragged C or unaligned rows): thread = column, a row
+// block per blockIdx.x, same parked partial sums and fixed-order finish
+__global__ __launch_bounds__(256) void colsum_det_kernel(ns_colsum_params p) {
+  __shared__ int last;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const int rpb = (p.rows + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rpb, r1 = min(p.rows, r0 + rpb);
+  if (c < p.C) {
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a += ld_dyn(p.x, p.dtype, (long)r * p.ld + c);
+    p.work[COLSUM_CNT + (long)blockIdx.x * p.C + c] = a;
+  }
+  __threadfence();
+  __syncthreads();
+  int* counter = (int*)p.work + blockIdx.y;
+  if (threadIdx.x == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (c < p.C) {
+    float a = 0.f;
+    for (int b = 0; b < (int)gridDim.x; ++b) a += __builtin_nontemporal_load(p.work + COLSUM_CNT + (long)b * p.C + c);
+    p.out[c] += a;
+  }
+  if (threadIdx.x == 0) *counter = 0;
+}
+
 extern "C" int ns_colsum(const ns_colsum_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_colsum: null");
   if (p->rows <= 0 || p->C <= 0) return NS_OK;
   const int esz = p->dtype == NS_BF16 ? 2 : 4;
+  NS_CHECK_ARG(!p->work || p->C <= 64 * COLSUM_CNT, "ns_colsum: the deterministic form takes C <= 65536");
   // a ragged last quad reads into the row's padding (C rounded up to 4 <= ld) and adds only its valid columns
   if ((p->C + 3) / 4 * 4 <= p->ld && p->ld % 4 == 0 && ((uintptr_t)p->x % (4 * esz)) == 0) {
     const dim3 grid(max(1, min(64, ceil_div(p->rows, 128))), ceil_div((p->C + 3) / 4, BN4_QUADS));
     if (p->dtype == NS_BF16) hipLaunchKernelGGL(colsum4_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)s, *p);
     else hipLaunchKernelGGL(colsum4_kernel<float>, grid, dim3(256), 0, (hipStream_t)s, *p);
+    NS_CHECK_LAUNCH("colsum");
+    return NS_OK;
+  }
+  if (p->work) {
+    ns_colsum_params q = *p;
+    hipLaunchKernelGGL(colsum_det_kernel, dim3(COLSUM_MAX_BLOCKS, ceil_div(p->C, 256)), dim3(256), 0, (hipStream_t)s, q);
     NS_CHECK_LAUNCH("colsum");
     return NS_OK;
   }

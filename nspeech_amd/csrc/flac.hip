@@ -270,7 +270,7 @@ extern "C" int ns_flac_decode(const uint8_t* data, size_t n, int32_t* out, int64
     const uint16_t want16 = (uint16_t)br.bits(16);
     if (br.fail) { ns_set_error("flac: truncated frame"); rc = NS_ERR_BAD_ARG; break; }
     if (crc16(data + off, body) != want16) { ns_set_error("flac: frame CRC-16 mismatch at byte %zu", off); rc = NS_ERR_BAD_ARG; break; }
-    if (done + blocksize > capacity) { ns_set_error("flac: output buffer too small"); rc = NS_ERR_BAD_ARG; break; }
+    if (done + blocksize > capacity) { ns_set_error("flac: output buffer too small"); rc = NS_ERR_SHORT_BUFFER; break; }
     for (int i = 0; i < blocksize; ++i)
       for (int c = 0; c < C; ++c) out[(done + i) * C + c] = (int32_t)ch[c][i];
     done += blocksize;

@@ -89,6 +89,55 @@ __device__ __forceinline__ void batch_shift(ns_gemm_params& p, int z) {
   p.C = (char*)p.C + (long)z * p.batch_stride_c * ec;
 }
 
+// ---- deterministic split-K (ns_gemm_params.splitk_work): every k slice of an output tile parks its partial sums in the
+// scratch - PER float4 per thread, thread-major, so the stores and the loads are whole 16-byte lines of one wave and the
+// layout never has to be interpreted - and raises the tile's counter; the LAST slice to arrive reads all of them back in
+// slice order (its own included: the order must not depend on who is last) and goes on into the epilogue.  Visibility:
+// partial stores -> agent-scope fence -> counter (the pattern of sumsq_kernel; per-XCD L2s are written back / invalidated
+// by the fences).  Returns true for the workgroup that runs the epilogue.  A (tile, slice) slot is 256 x PER float4 = the
+// tile's elements x 4 bytes.
+template <int PER>
+__device__ __forceinline__ bool splitk_gather(const ns_gemm_params& p, float4 (&v)[PER], int tile, int ksl, int tid) {
+  __shared__ int sk_last;
+  constexpr size_t SLOT = 256 * PER;
+  float4* slot0 = (float4*)p.splitk_work + (size_t)tile * p.split_k * SLOT;
+  float4* mine = slot0 + (size_t)ksl * SLOT;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) mine[i * 256 + tid] = v[i];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) sk_last = atomicAdd(p.splitk_count + tile, 1) == p.split_k - 1;
+  __syncthreads();
+  if (!sk_last) return false;
+  __threadfence();
+#pragma unroll
+  for (int i = 0; i < PER; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int s = 0; s < p.split_k; ++s) {
+    const float4* src = slot0 + (size_t)s * SLOT;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const f32x4 x = __builtin_nontemporal_load((const f32x4*)src + i * 256 + tid);
+      v[i].x += x[0]; v[i].y += x[1]; v[i].z += x[2]; v[i].w += x[3];
+    }
+  }
+  if (tid == 0) p.splitk_count[tile] = 0;         // left clean for the next call
+  return true;
+}
+template <int NJ>
+__device__ __forceinline__ bool splitk_gather_acc(const ns_gemm_params& p, f32x4 (&acc)[4][NJ], int tile, int ksl, int tid) {
+  float4 v[4 * NJ];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) v[i * NJ + j] = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+  if (!splitk_gather<4 * NJ>(p, v, tile, ksl, tid)) return false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){v[i * NJ + j].x, v[i * NJ + j].y, v[i * NJ + j].z, v[i * NJ + j].w};
+  return true;
+}
+
 // ------------------------------------------------------------------ generic kernel
 template <typename T>
 __device__ __forceinline__ float ld_a(const ns_gemm_params& p, int m, int k) {
@@ -150,8 +199,17 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(ns_gemm_params p) {
     }
     __syncthreads();
   }
+  bool add_bias = (ksl == 0);
+  if (p.splitk_work && p.split_k > 1) {           // deterministic split-K: the last slice of the tile sums and stores
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+    if (!splitk_gather<4>(p, v, blockIdx.y * gridDim.x + blockIdx.x, ksl, tid)) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i][0] = v[i].x; acc[i][1] = v[i].y; acc[i][2] = v[i].z; acc[i][3] = v[i].w; }
+    add_bias = true;
+  }
   Epi e = make_epi(p);
-  const bool add_bias = (ksl == 0);
   float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
   for (int i = 0; i < 4; ++i) {
     int m = m0 + ty * 4 + i;
@@ -536,8 +594,13 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
     __syncthreads();
   }
 
+  bool add_bias = ksl == 0;
+  if (p.splitk_work && p.split_k > 1) {           // deterministic split-K: the last slice of the tile sums and stores
+    if (!splitk_gather_acc<NJ>(p, acc, wgid, ksl, tid)) return;
+    add_bias = true;
+  }
   if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
-  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, ksl == 0);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, add_bias);
 }
 
 // ------------------------------------------------------------------ 256 x 256 tiles, 8 phases per two K-tiles
@@ -978,8 +1041,13 @@ __global__ __launch_bounds__(256, 2) void gemm_mfma_f32_kernel(ns_gemm_params p)
     }
     __syncthreads();
   }
+  bool add_bias = ksl == 0;
+  if (p.splitk_work && p.split_k > 1) {           // deterministic split-K: the last slice of the tile sums and stores
+    if (!splitk_gather_acc<NJ>(p, acc, wgid, ksl, tid)) return;
+    add_bias = true;
+  }
   if constexpr (VEC) x256_quadrant(p, acc, m0 + wm * 64, n0 + wn * (NJ * 16), lane);
-  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, ksl == 0);
+  else mfma_epilogue(p, acc, m0, n0, wm, wn, lane, add_bias);
 }
 
 // skinny (M <= 32) variant: fp32 fragments straight from memory, split in registers (common.h).
@@ -1091,6 +1159,13 @@ int ns_stats_finalize(const float* part, int slots, int N, float* s1, float* s2,
   return NS_OK;
 }
 
+extern "C" size_t ns_gemm_splitk_work_bytes(int M, int N, int split_k) {
+  if (split_k <= 1) return 0;
+  // a (tile, slice) slot holds the tile's elements as fp32; the largest tiles of a split-K kernel are 128 x 128
+  return (size_t)split_k * ((size_t)ceil_div(M, 128) * 128) * ((size_t)ceil_div(N, 128) * 128) * sizeof(float);
+}
+extern "C" size_t ns_gemm_splitk_counters(int M, int N) { return (size_t)ceil_div(M, 64) * ceil_div(N, 64); }
+
 extern "C" int ns_gemm(const ns_gemm_params* pp, ns_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   NS_CHECK_ARG(pp != nullptr, "ns_gemm: null params");
@@ -1116,6 +1191,8 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
   NS_CHECK_ARG(p.dtype == NS_F32 || p.dtype == NS_BF16, "ns_gemm: bad dtype %d", p.dtype);
   NS_CHECK_ARG(p.c_dtype == NS_F32 || p.c_dtype == NS_BF16, "ns_gemm: bad c_dtype %d", p.c_dtype);
   if (p.split_k < 1) p.split_k = 1;
+  NS_CHECK_ARG((p.splitk_work != nullptr) == (p.splitk_count != nullptr), "ns_gemm: splitk_work and splitk_count come together");
+  NS_CHECK_ARG(!p.splitk_work || p.split_k == 1 || p.batch <= 1, "ns_gemm: deterministic split-K takes no batch");
   NS_CHECK_ARG(p.accumulate >= 0 && p.accumulate <= 2, "ns_gemm: bad accumulate");
   NS_CHECK_ARG(p.accumulate == 0 || p.c_dtype == NS_F32, "ns_gemm: accumulate needs fp32 C");
   NS_CHECK_ARG(p.split_k == 1 || (p.accumulate == 2 && p.act == NS_ACT_NONE && !p.col_sum),

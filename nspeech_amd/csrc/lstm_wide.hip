@@ -775,7 +775,7 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
   if (H != 256 && H != 512 && H != 1024) return false;
   const int nrg = (p->N + 15) / 16;
   const int nub = backward ? H / 16 : H / 8;
-  if (nub % 8 != 0 || nrg * nub > 256) return false;
+  if (nub % 8 != 0 || nrg * nub > ns_device_cus()) return false;
   if (nub_out) *nub_out = nub;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   const long esz = p->dtype == NS_BF16 ? 2 : 4;
@@ -789,7 +789,7 @@ bool wide_shape_ok(const ns_lstm_seq_params* p, int backward, int* nub_out) {
       const char* ps_env = getenv("NS_WIDE_PS");
       const int ps_mode = ps_env ? atoi(ps_env) : 32;
       const int upb = ps_mode == 16 ? 16 : 32;
-      if (!(H % 128 == 0 && ps_mode != 0 && ((p->N + 7) / 8) * (H / upb) <= 256)) return false;
+      if (!(H % 128 == 0 && ps_mode != 0 && ((p->N + 7) / 8) * (H / upb) <= ns_device_cus())) return false;
     }
     if (p->dtype == NS_F32 && !(p->f32_passes == 1 && p->wh_bf16 && p->dgates_bf16)) return false;
     if (p->dtype == NS_BF16 && !p->wh) return false;
@@ -869,7 +869,7 @@ extern "C" int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stre
   a.trace = getenv("NS_WIDE_TRACE") ? (long long*)((char*)work + 256) : nullptr;
   int rc = ns_zero_async(work, 256, s);
   if (rc) return rc;
-  const bool r8 = ((p->N + 7) / 8) * nub <= 256;
+  const bool r8 = ((p->N + 7) / 8) * nub <= ns_device_cus();
   // the partial-sum exchange (lstm_wide_bwd_ps_kernel): 8-row groups, H a multiple of 128; NS_WIDE_PS=0 keeps the sweep
   // form, 16 the 16-unit blocks
   {
@@ -877,7 +877,7 @@ extern "C" int ns_lstm_wide_bwd(const ns_lstm_seq_params* p, void* work, ns_stre
     const int ps_mode = ps_env ? atoi(ps_env) : 32;
     const int nrg = (p->N + 7) / 8;
     const int upb = ps_mode == 16 ? 16 : 32, nb = p->H / upb, items = upb * 4;
-    if (p->H % 128 == 0 && ps_mode != 0 && nrg * nb <= 256) {      // 8-row groups x unit blocks, one workgroup per CU
+    if (p->H % 128 == 0 && ps_mode != 0 && nrg * nb <= ns_device_cus()) {      // 8-row groups x unit blocks, one workgroup per CU
       ps_u64* xbuf = (ps_u64*)(((uintptr_t)work + 256 + WIDE_TRACE_BYTES + 15) & ~(uintptr_t)15);
       const size_t xbytes = (size_t)nrg * 2 * nb * nb * items * sizeof(ps_u64);
       rc = ns_zero_async(xbuf, xbytes, s);

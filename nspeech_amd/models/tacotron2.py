@@ -1205,7 +1205,8 @@ class Tacotron2(object):
                     watt_bf16=(self._bf16_w(T_), wa) if self._bf16_w(T_) is not None else None,
                     dga_bf16=self._dgb("d_gab", rows * 4 * A, T_),
                     de=self._buf("d_energy", rows * Tia, torch.float32),
-                    dctx_t=self._buf("d_ctx_t", rows * E, T_))
+                    dctx_t=self._buf("d_ctx_t", rows * E, T_),
+                    post_part=ops.attention_post_part(self.device, N, Tia, A))
         if self._attn_cluster_fwd:
             cw = self._buf("attn_cluster_work_b", ops.taco2_attn_cluster_work_floats(**args), torch.float32)
             ops.taco2_attn_cluster("bwd", cw, **args)
@@ -1299,10 +1300,21 @@ class Tacotron2(object):
         ops.sumsq(self.flat_g, n, self.scal, out_off=8, work=self._buf("sumsq_work", 1032, torch.float32))
         # a persistent recurrence that timed out leaves an invalid gradient: the kernel then updates nothing and raises
         # scal[9]; read_losses() reports it.  No host round trip in front of the optimiser.
+        status = list(self._status_words.values())
+        if len(status) > 12:
+            raise RuntimeError("more persistent recurrences (%d) than ns_adam_params.status holds (12)" % len(status))
+        if self.reducer is not None and getattr(self.reducer, "active", False) and status:
+            # data parallel: the skip must be COLLECTIVE - a rank whose recurrence timed out has already put
+            # its invalid gradient into the sum, so every rank has to drop the update, not just that one.  The largest
+            # status word of this rank, maximised over the ranks, is the one word the optimiser kernel then looks at.
+            flag = torch.stack([w[:1].view(torch.int32)[0] for w in status]).abs().max().reshape(1)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX, group=self.reducer.group)
+            self._dp_status = flag
+            status = [flag]
         ops.adam(self.flat_p, self.flat_g, self.flat_m, self.flat_v, n, self.scal[8:], self.gradient_clip,
                  1.0 / self.world_size, lr_t, b1, b2, 1e-8,
                  shadow=self.flat_s if self.flat_s is not self.flat_p else None,
-                 status=list(self._status_words.values()), skipped=self.scal[9:])
+                 status=status, skipped=self.scal[9:])
         self.refresh_shadows()
         self.learning_rate = lr
         self.global_step += 1
@@ -1315,6 +1327,7 @@ class Tacotron2(object):
         s = self.scal.cpu().numpy()
         self.check_status()
         if s[9] != 0:
+            self.global_step -= 1         # nothing was applied (on any rank: the skip is collective)
             raise RuntimeError("the optimiser step was skipped: a persistent recurrence reported a timeout")
         N, To = d["N"], d["To"]
         self.mel_loss = float(s[0]) / (N * To * hp.num_mels)

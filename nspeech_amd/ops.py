@@ -4,6 +4,7 @@ Every function takes torch CUDA tensors purely as (device pointer, dtype) carrie
 enqueues HIP kernels on torch's current stream.  No torch math happens here.
 """
 import ctypes as C
+import ctypes as C_          # (the name C is also a parameter of colsum)
 
 import torch
 
@@ -77,7 +78,32 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
         p.batch_stride_a, p.batch_stride_b, p.batch_stride_c = batch_strides
     if a_lo is not None:        # pre-split fp32 values: A / B hold the high parts (same offsets and strides)
         p.A_lo, p.B_lo = ptr(a_lo, a_off), ptr(b_lo, b_off)
+    if split_k > 1 and batch == 1 and DETERMINISTIC_SPLITK:
+        work, count = _splitk_scratch(Cm.device, M, N, split_k)
+        p.splitk_work, p.splitk_count = ptr(work), ptr(count)
     L.call("ns_gemm", p, stream())
+
+
+# Split-K products add their k slices in a FIXED order (ns_gemm_params.splitk_work): two runs of a training step give the
+# same gradient bits.  NS_SPLITK_ATOMIC=1 restores the fp32-atomic form (A/B timing).
+DETERMINISTIC_SPLITK = __import__("os").environ.get("NS_SPLITK_ATOMIC", "0") != "1"
+_SPLITK = {}
+
+
+def _splitk_scratch(device, M, N, split_k):
+    """(partial-tile scratch, zeroed tile counters) of the deterministic split-K, one pair per (device, stream): a
+    product and the next one on the same stream run back to back, products on different streams must not share."""
+    lib = L.lib()
+    fb, fc = lib.ns_gemm_splitk_work_bytes, lib.ns_gemm_splitk_counters
+    fb.restype = fc.restype = L.C.c_size_t
+    need, cnt = int(fb(int(M), int(N), int(split_k))), int(fc(int(M), int(N)))
+    key = (device, stream())
+    cur = _SPLITK.get(key)
+    if cur is None or cur[0].numel() * 4 < need or cur[1].numel() < cnt:
+        w = torch.empty(max(need // 4, cur[0].numel() if cur else 0), dtype=torch.float32, device=device)
+        c = torch.zeros(max(cnt, cur[1].numel() if cur else 0, 4096), dtype=torch.int32, device=device)
+        cur = _SPLITK[key] = (w, c)
+    return cur
 
 
 _STAT_PART = {}
@@ -156,9 +182,26 @@ def bn_bwd(dy, z, dpre, rows, C, mean, istd, gamma, dgamma, dbeta, dbias, work, 
     L.call("ns_bn_bwd", p, stream())
 
 
+_COLSUM_WORK = {}
+
+
+def _scratch(store, key_extra, floats, zero_head=0):
+    """Grow-only fp32 scratch per (device, stream); the first `zero_head` words are zero when it is handed out first (the
+    kernels that count arrivals there leave them zero)."""
+    key = (key_extra, stream())
+    buf = store.get(key)
+    if buf is None or buf.numel() < floats:
+        buf = store[key] = torch.zeros(int(floats), dtype=torch.float32, device=key_extra)
+    return buf
+
+
 def colsum(x, ld, rows, C, out, x_off=0, out_off=0):
+    """out[c] += column sums of x, added in a fixed order (ns_colsum_params.work): bias gradients are bit-reproducible."""
     p = L.struct("ns_colsum_params")
-    _fill(p, x=ptr(x, x_off), dtype=dt(x), ld=ld, rows=rows, C=C, out=ptr(out, out_off))
+    fn = L.lib().ns_colsum_work_floats
+    fn.restype = C_.c_size_t
+    work = _scratch(_COLSUM_WORK, x.device, int(fn(int(C))))
+    _fill(p, x=ptr(x, x_off), dtype=dt(x), ld=ld, rows=rows, C=C, out=ptr(out, out_off), work=ptr(work))
     L.call("ns_colsum", p, stream())
 
 
@@ -414,8 +457,19 @@ def attention_step_bwd(like, N, Ti, Pi, padl, Tia, A, E, kw, lengths, keys, keys
     L.call("ns_attention_step_bwd", p, stream())
 
 
+_POST_PART = {}
+
+
+def attention_post_part(device, N, Tia, A):
+    """Scratch of the fixed-order dv / dwcl sums (ns_attention_post_bwd_params.part, ns_taco2_attn_params.post_part)."""
+    fn = L.lib().ns_attention_post_part_floats
+    fn.restype = C.c_size_t
+    return _scratch(_POST_PART, device, int(fn(int(N), int(Tia), int(A))))
+
+
 def attention_post_bwd(N, S, Ti, Tia, A, kw, lengths, keys_t, q, align, de, wcl, v, dkeys_t, dv, dwcl):
     p = L.struct("ns_attention_post_bwd_params")
+    p.part = ptr(attention_post_part(keys_t.device, N, Tia, A))
     _fill(p, N=N, S=S, Ti=Ti, Tia=Tia, A=A, kw=kw, lengths=ptr(lengths), keys_t=ptr(keys_t), q=ptr(q), align=ptr(align),
           de=ptr(de), wcl=_pp(wcl), v=_pp(v), dkeys_t=ptr(dkeys_t), dv=_pp(dv), dwcl=ptr(dwcl))
     L.call("ns_attention_post_bwd", p, stream())

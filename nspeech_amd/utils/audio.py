@@ -147,6 +147,9 @@ def _strip_id3(data):
     return data
 
 
+MAX_FLAC_SECONDS = 3600      # longest stream _load_flac decodes (an unbounded retry loop could be OOM-killed)
+
+
 def _load_flac(path):
     """FLAC file -> (float32 [samples, channels] in [-1, 1), sample rate): ns_flac_decode (csrc/flac.hip, host code),
     checked against the MD5 of the decoded PCM that the encoder stored in STREAMINFO (all-zero = not stored)."""
@@ -158,15 +161,21 @@ def _load_flac(path):
     sr, ch, bps, total = C.c_int(), C.c_int(), C.c_int(), C.c_int64()
     md5 = (C.c_uint8 * 16)()
     L.check(lib.ns_flac_info(buf, C.c_size_t(len(data)), C.byref(sr), C.byref(ch), C.byref(bps), C.byref(total), md5), "ns_flac_info")
-    # no total in STREAMINFO: start from a modest guess and double on "output buffer too small" (no bound follows from
-    # the file size: a CONSTANT subframe codes a whole block in a few bytes)
-    cap = total.value if total.value > 0 else max(1 << 16, len(data))
+    # no total in STREAMINFO: start from a modest guess and double on NS_ERR_SHORT_BUFFER.  No bound follows from the
+    # file size (a CONSTANT subframe codes a whole block in a few bytes), so a damaged or crafted stream could ask for
+    # gigabytes: the decoded length is capped at MAX_FLAC_SECONDS of audio (an utterance corpus has nothing near it).
+    limit = int(MAX_FLAC_SECONDS * max(sr.value, 1))
+    if total.value > limit:
+        raise ValueError("%s: STREAMINFO announces %d samples, more than the %d s this loader accepts" % (path, total.value, MAX_FLAC_SECONDS))
+    cap = total.value if total.value > 0 else min(max(1 << 16, len(data)), limit)
     got = C.c_int64()
     while True:
         out = np.empty((cap, ch.value), dtype=np.int32)
         rc = lib.ns_flac_decode(buf, C.c_size_t(len(data)), out.ctypes.data_as(C.POINTER(C.c_int32)), C.c_int64(cap), C.byref(got))
-        if rc != 0 and total.value == 0 and b"output buffer too small" in lib.ns_last_error() and cap < (1 << 31):
-            cap *= 2
+        if rc == L.NS_ERR_SHORT_BUFFER and total.value == 0:
+            if cap >= limit:
+                raise ValueError("%s: more than %d s of audio in a stream without a sample count" % (path, MAX_FLAC_SECONDS))
+            cap = min(2 * cap, limit)
             continue
         L.check(rc, "ns_flac_decode")
         break

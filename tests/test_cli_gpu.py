@@ -36,12 +36,23 @@ def test_train_checkpoint_resume_eval(tmp_path):
     _corpus(data)
     logs = str(tmp_path / "logs")
     base = [sys.executable, os.path.join(ROOT, "train.py"), "--ljspeech", data, "--model", "taco2", "--log_dir", logs,
-            "--hparams", SMALL, "--checkpoint_interval", "2", "--precision", "bf16"]
+            "--hparams", SMALL, "--checkpoint_interval", "2", "--precision", "bf16", "--summary-interval", "1"]
     r = subprocess.run(base + ["--max_steps", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     run = os.path.join(logs, "logs-taco2")
     assert os.path.exists(os.path.join(run, "model.ckpt-2")) and os.path.exists(os.path.join(run, "train.log"))
     assert os.path.exists(os.path.join(run, "step-000002-audio.wav"))
+    # --summary-interval (train.py:91-93 / tacotron2.py:163-188): one scalars line per summary step
+    import json
+    ev = [json.loads(l) for l in open(os.path.join(run, "events.jsonl"))]
+    assert [e["step"] for e in ev] == [1, 2]
+    for e in ev:
+        assert set(("loss", "loss_mel", "loss_linear", "learning_rate", "max_gradient_norm")) <= set(e)
+        assert abs(e["loss"] - (e["loss_mel"] + e["loss_linear"])) < 1e-5 * e["loss"]
+        assert e["max_gradient_norm"] == max(e["gradient_norm"].values()) > 0
+        h = e["histograms"]
+        assert set(h) == {"mel_outputs", "linear_outputs", "mel_targets", "linear_targets"}
+        assert 0.0 <= h["mel_targets"]["min"] <= h["mel_targets"]["mean"] <= h["mel_targets"]["max"] <= 1.0
     r = subprocess.run(base + ["--max-steps", "3", "--restore-step", "2"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "Resuming from checkpoint" in r.stdout and "Step 3 " in r.stdout
@@ -117,3 +128,29 @@ def test_multi_speaker_train_and_eval(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "--checkpoint", ck, "--model", "taco2",
                         "--hparams", SMALL, "--precision", "bf16"], capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
+
+
+def test_wavenet_train_then_generate(tmp_path):
+    """train_wavenet.py (train_wavenet.py:19-135) on the same tiny corpus with a narrow network, then
+    generate_wavenet.py (generate_wavenet.py:48-171) from its checkpoint: the persistent incremental generator and the
+    full-window path, which carries the reference's own temperature-1.0 consistency check (:133-138)."""
+    data = str(tmp_path / "lj")
+    os.makedirs(data)
+    _corpus(data)
+    logs = str(tmp_path / "logs")
+    small = "dilations_length=4,dilations_depth=2,skip_channels=64,sample_size=400,batch_size=4,queue_size=16"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_wavenet.py"), "--ljspeech", data, "--log-dir", logs,
+                        "--hparams", small, "--max-steps", "3", "--checkpoint-interval", "3", "--summary-interval", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    run = os.path.join(logs, "simple_wavenet")
+    ckpt = os.path.join(run, "model.ckpt-3")
+    assert os.path.exists(ckpt) and "Step 3 " in r.stdout and os.path.exists(os.path.join(run, "events.jsonl"))
+    for fast, n in (("true", "300"), ("false", "12")):
+        out = str(tmp_path / ("gen_%s.wav" % fast))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "generate_wavenet.py"), ckpt, "--samples", n, "--hparams", small,
+                            "--fast_generation", fast, "--wav_out_path", out, "--wav_seed", os.path.join(data, "wavs", "utt0.wav")],
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        with wave.open(out, "rb") as f:
+            assert f.getframerate() == 16000 and f.getnframes() >= int(n)

@@ -276,8 +276,9 @@ def test_taco2_full_size_mixed_gradients_follow_split_bf16(dev):
 @pytest.mark.parametrize("mode", ["fp32", "mixed"])
 def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
     """BatchNorm batch statistics and the BatchNorm-backward sums are added up in a fixed order (no float atomics), so
-    two passes over the same inputs give the same bits for every output and for the gradient that flows through the
-    network; only the final weight-gradient sums (split-K atomics, bias / table scatter sums) may differ, by rounding."""
+    two passes over the same inputs give the same bits for every output, for the gradient that flows through the
+    network and - since the split-K products, bias sums and table rows add in a fixed order too - for every weight
+    gradient."""
     N, Ti, To = 6, 30, 60
     hp = small_hparams()
     m = _model(hp, mode)
@@ -292,21 +293,19 @@ def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
     a, b = runs
     for k in ("mel", "lin", "al", "dmel", "dvalues"):
         assert torch.equal(a[k], b[k]), k
-    g0, g1 = a["g"].double(), b["g"].double()
+    # and for the whole gradient (round 4): split-K products, bias sums, the embedding table's rows and the attention
+    # post-pass add in a fixed order - no float atomic is left between the loss and flat_g
+    g0, g1 = a["g"], b["g"]
     for name, (off, shape) in m.layout.entries.items():
-        if name.endswith("conv1d/bias"):          # in front of BatchNorm: the true gradient is zero, the rest is noise
-            continue
         n = int(np.prod(shape))
-        d = (g0[off:off + n] - g1[off:off + n]).abs().max().item()
-        sc = g0[off:off + n].abs().max().item()
-        assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
+        assert torch.equal(g0[off:off + n], g1[off:off + n]), (name, (g0[off:off + n] - g1[off:off + n]).abs().max().item())
 
 
 @pytest.mark.parametrize("size", ["small", "full"])
 def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
     """The decoder / attention / postnet weight gradients that run on a second stream beside the encoder BiLSTM
-    (Tacotron2.overlap_wgrads) equal the ones launched in line, up to the rounding of the split-K atomic sums - at the
-    benchmark shape too, where a buffer reused too early would show."""
+    (Tacotron2.overlap_wgrads) equal the ones launched in line BIT FOR BIT (the split-K sums have a fixed order since
+    round 4) - at the benchmark shape too, where a buffer reused too early would show."""
     from nspeech_amd import hparams as hparams_mod
     if size == "small":
         hp, (N, Ti, To) = small_hparams(), (6, 30, 60)
@@ -321,26 +320,19 @@ def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
         m.backward()
         torch.cuda.synchronize()
         assert not m._deferred
-        gs.append(m.flat_g.double().clone())
+        gs.append(m.flat_g.clone())
     assert m._side is not None           # the second stream was really used
     for g1 in gs[1:]:
         for name, (off, shape) in m.layout.entries.items():
-            if name.endswith("conv1d/bias"):
-                continue
             n = int(np.prod(shape))
-            d = (gs[0][off:off + n] - g1[off:off + n]).abs().max().item()
-            sc = gs[0][off:off + n].abs().max().item()
-            # the floor: a split-K sum over 32000 rows that cancels down to ~1e-6 (the location convolution's kernel)
-            # moves by ~1e-9 with the order of its atomic adds - fp32 rounding of the partial sums, not of the result
-            assert d <= 2e-5 * sc + 5e-9, (name, d, sc)
+            assert torch.equal(gs[0][off:off + n], g1[off:off + n]), (name, (gs[0][off:off + n] - g1[off:off + n]).abs().max().item())
 
 
 @pytest.mark.parametrize("mode", ["bf16", "mixed"])
 def test_taco2_full_width_backward_repeats_over_many_launches(dev, mode):
     """The persistent kernels start their workgroups at slightly different times from launch to launch; nothing in the
     results may depend on that.  Thirty forward + backward passes at the shipped widths (the cluster kernels need
-    them) must agree bit for bit in every buffer of the backward chain that no float atomic feeds, and in the
-    gradient up to the rounding of the split-K sums.  (Found this way: a missing barrier in front of the attention
+    them) must agree bit for bit in every buffer of the backward chain and in the whole gradient.  (Found this way: a missing barrier in front of the attention
     backward's first history fill gave one workgroup a zero alignment once in 20 - 50 launches.)"""
     from nspeech_amd import hparams as hparams_mod
     hp = hparams_mod.load("taco2")
@@ -364,7 +356,7 @@ def test_taco2_full_width_backward_repeats_over_many_launches(dev, mode):
             continue
         for k, v in snap.items():
             assert torch.equal(v, ref[k]), (mode, run, k, (v.float() - ref[k].float()).abs().max().item())
-        assert (g - gref).abs().max().item() <= 2e-5 * gref.abs().max().item(), (mode, run)
+        assert torch.equal(g, gref), (mode, run, (g - gref).abs().max().item())
 
 
 def test_model_audio_is_griffin_lim_of_the_linear_outputs(dev):

@@ -40,7 +40,7 @@ def test_export_import_round_trip_and_synthesis(dev, tmp_path):
 def test_training_checkpoint_with_adam_slots_resumes_the_same_trajectory(dev, tmp_path):
     """train.py:60,67-71: the reference saves and restores its optimizer slots with the model.  A bundle written with the
     Adam moments (`<variable>/Adam`, `/Adam_1`, beta powers) restores them: the next training step from the restored
-    model equals the next step of the original (to the float atomics' last bits); without the slots the moments start afresh
+    model equals the next step of the original bit for bit; without the slots the moments start afresh
     and it does not."""
     from nspeech_amd.models import create_model
     from nspeech_amd.utils import tf_bundle as B
@@ -62,10 +62,9 @@ def test_training_checkpoint_with_adam_slots_resumes_the_same_trajectory(dev, tm
         b.add_optimizer(b.global_step)
         b.step(inputs, lengths, mel, lin)
         outs.append(b.flat_p.clone())
-    # the step adds with float atomics in a few places (embedding rows, bias / loss sums), so two runs of it agree to the
-    # last bits only: the restored trajectory within 1e-6 of the original's parameters (an Adam update is ~1e-3), the one
-    # without the moments off by the size of an update
+    # no float atomic is left between the loss and the update (round 4), so the restored model's next step IS the
+    # original's, bit for bit; the one without the moments is off by the size of an update (~1e-3)
     d_full = (outs[0] - a.flat_p).abs().max().item()
     d_bare = (outs[1] - a.flat_p).abs().max().item()
-    assert d_full < 1e-6, d_full
+    assert torch.equal(outs[0], a.flat_p), d_full
     assert d_bare > 1e-4, d_bare

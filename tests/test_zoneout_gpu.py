@@ -112,4 +112,5 @@ def test_zoneout_inference_is_the_expectation(dev):
         got = getattr(m, name).float().cpu().numpy()
         ref = out[name].numpy()
         assert np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), name
-    assert np.abs(out["decoder_outputs"].numpy() - plain["decoder_outputs"].numpy()).max() > 1e-4
+    ref, pl = out["decoder_outputs"].numpy(), plain["decoder_outputs"].numpy()
+    assert np.abs(ref - pl).max() > 0.05 * np.abs(pl).max()        # and it is not the plain cell (measured: 0.2)
