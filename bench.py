@@ -290,23 +290,33 @@ def e2e_bench(hp, model, args, device):
                 f.write("U%03d|%s|%s\n" % (i, text, text))
         hpf = copy.deepcopy(hp)
         hpf.batch_size, hpf.batch_group_size = args.batch, 2
-        for key, dev_cache in (("hbm_cache", True), ("host_cache", False)):
+        for key, dev_cache, sync in (("hbm_cache", True, False), ("hbm_cache_sync_loss", True, True), ("host_cache", False, False)):
             feeder = DataFeeder(hpf, ljspeech=tmp, seed=7, pinned=True, device_cache=dev_cache).start()
             batches = DeviceStager(feeder, device)
+            pipe = None if sync else train_cli.LossPipeline(model, batches)
+            run = (lambda: train_cli.train_step(model, batches)) if sync else pipe.step
             for _ in range(4):                          # first pass over the corpus: wav reads + feature extraction
-                train_cli.train_step(model, batches)
+                run()
+            if pipe is not None:
+                pipe.drain()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
+            last = None
             for _ in range(args.e2e_steps):
-                loss = train_cli.train_step(model, batches)
+                last = run()
+            if pipe is not None:
+                last = pipe.drain()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / args.e2e_steps
+            loss = last if sync else last[1]
             To = int(model.mel_targets.shape[1])
             out[key] = {"e2e_ms_per_step": dt * 1e3, "mel_frames_per_s": args.batch * To / dt, "t_out": To,
                         "t_in": int(model.inputs.shape[1]), "loss": loss}
-        out["note"] = ("train.py's loop (feeder thread -> batch on the GPU -> step -> loss read back every step) on %d "
-                       "synthetic wav files; hbm_cache: features stay in HBM, batches assembled on the device (train.py "
-                       "default); host_cache: features in RAM, pinned H2D on a copy stream" % (2 * args.batch))
+        out["note"] = ("train.py's loop (feeder thread -> batch on the GPU -> step -> EVERY step's loss read back) on %d "
+                       "synthetic wav files; hbm_cache: features stay in HBM, batches assembled on the device, the loss "
+                       "read-back one step behind the launches (train.py's defaults); hbm_cache_sync_loss: the same with "
+                       "the host waiting for each step's loss before it issues the next (--sync-loss); host_cache: "
+                       "features in RAM, pinned H2D on a copy stream (--feature-cache host)" % (2 * args.batch))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return out
@@ -502,6 +512,20 @@ def main():
             # normalisation saturates and every target frame is the same vector; with -100 the features of the
             # same synthetic speech spread over [0, 1]
             res["real_dynamics"] = real_dynamics_bench(hp, model, args, one_step)
+            # the same step with hparams.deterministic_gradients (every sum of the backward pass in a fixed order)
+            model.deterministic = True
+            for _ in range(3):
+                one_step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                one_step()
+            torch.cuda.synchronize()
+            dtd = (time.perf_counter() - t0) / 10
+            model.deterministic = False
+            res["deterministic_gradients"] = {"ms_per_step": dtd * 1e3, "value": args.batch * args.t_out / dtd,
+                                              "note": "bit-reproducible gradients (split-K partial tiles parked and added in "
+                                                      "slice order); the headline runs the default, fp32-atomic split-K"}
             if args.e2e_steps > 0:
                 em = create_model("taco2", hp, device="cuda:%d" % local, dtype=args.dtype, seed=1234)
                 em.add_optimizer(global_step=0)

@@ -149,11 +149,15 @@ int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t stream);
 typedef struct {
   const int* ids;
   const float* dout;       /* fp32 [N,P,D] */
-  float* dtable;           /* [V,D] += : one workgroup per table row gathers the positions that hold it, in position order
-                              (a fixed summation order, no float atomics: tacotron2.py:153's gradient is bit-reproducible) */
+  float* dtable;           /* [V,D] += : workgroup (row, utterance) gathers that utterance's positions holding the row, in
+                              position order; the utterances' shares are added in utterance order (a fixed summation
+                              order, no float atomics: tacotron2.py:153's gradient is bit-reproducible) */
   int N, T, P, padl, D, V;
+  float* work;             /* fp32 scratch of ns_embedding_bwd_work_floats(N, D, V) floats whose FIRST 1024 words are zero
+                              before the first call; every call leaves them zero */
 } ns_embedding_bwd_params;
 int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t stream);
+size_t ns_embedding_bwd_work_floats(int N, int D, int V);
 
 /* tf.layers.batch_normalization (modules.py:198), axis -1, eps 1e-3, momentum 0.99.
  * Training: statistics come from col_sum / col_sumsq (accumulated by the producing GEMM)

@@ -462,6 +462,7 @@ struct AttnPost {
   float* dkeys_t;          // [N,A,Tia] out (plain store)
   float* dv; float* dwcl;  // +=
   float* part;             // optional [N * position blocks][1 + MAXKW][A]: parked partial sums (fixed-order finish)
+  int dbg;                 // NS_POST_DBG (diagnostics): 1 = a barrier in front of the stage store, 2 = the run-time-kw kernel
 };
 template <int KW>          // KW = the filter width when it is the usual 7 (straight-line step), 0 = a.kw at run time
 __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
         }
       }
     }
+    if (a.dbg & 1) __syncthreads();
     if (s0 + POST_SB <= a.S) sstore(buf ^ 1);
     __syncthreads();
   }
@@ -785,9 +787,12 @@ __global__ void attn_post_finish_kernel(const float* part, int nblocks, int A, i
   for (int b = 0; b < nblocks; ++b) s += part[((long)b * (1 + MAXKW) + k) * A + u];
   if (k == 0) dv[u] += s; else dwcl[(k - 1) * A + u] += s;
 }
-static int launch_attn_post(const AttnPost& q, int N, hipStream_t s) {
+static int launch_attn_post(const AttnPost& q0, int N, hipStream_t s) {
+  AttnPost q = q0;
+  static const int dbg_env = [] { const char* e = getenv("NS_POST_DBG"); return e ? atoi(e) : 0; }();
+  q.dbg = dbg_env;
   dim3 grid(ceil_div(q.Tia, 64), ceil_div(q.A, 4 * PU), N);
-  if (q.kw == 7) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
+  if (q.kw == 7 && !(q.dbg & 2)) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, s, q);
   if (q.part)
     hipLaunchKernelGGL(attn_post_finish_kernel, dim3(ceil_div((1 + q.kw) * q.A, 256)), dim3(256), 0, s, q.part, (int)(grid.x * N),

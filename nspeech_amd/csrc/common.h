@@ -59,6 +59,26 @@ __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(2.8853900817779268f * x) + 1.0f);
 }
 
+// Hand-off of data between workgroups WITHOUT an agent-scope fence (a fence writes back / invalidates the whole per-XCD
+// L2 - measured: the fixed-order split-K with __threadfence() doubled the weight-gradient products' time): every
+// handed-off store is write-through (sc1) and drained (`ns_drain_stores`) in front of the arrival counter, every load of
+// handed-off bytes bypasses the L2s (sc1).  MI355X_MICROARCH.md, "Correctness boundaries", second valid form.
+__device__ __forceinline__ void ns_st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ns_ld_sc1(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ns_st_sc1(float4* p, const float4& v) {
+  unsigned long long* q = (unsigned long long*)p;
+  __hip_atomic_store(q, ((unsigned long long)__float_as_uint(v.y) << 32) | __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, ((unsigned long long)__float_as_uint(v.w) << 32) | __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 ns_ld_sc1(const float4* p) {
+  const unsigned long long* q = (const unsigned long long*)p;
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
+}
+__device__ __forceinline__ void ns_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 // Zoneout masks (include/nspeech_hip.h, ns_lstm_seq_params): true = the unit keeps its old value at this step.
 __host__ __device__ __forceinline__ uint32_t ns_fmix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;

@@ -53,21 +53,26 @@ extern "C" int ns_embedding_fwd(const ns_embedding_params* p, ns_stream_t s) {
   NS_CHECK_LAUNCH("embedding_fwd");
   return NS_OK;
 }
-// One workgroup per table row v: walk the N*T positions 256 at a time, list the ones that hold v (ballot + prefix: the
-// list is in position order), then every thread adds its columns of those rows in list order.  Fixed summation order,
-// no float atomics (round 4; the scatter form added rows in whatever order their workgroups ran).
+// Fixed summation order, no float atomics (round 4; the scatter form added rows in whatever order their workgroups ran).
+// Workgroup (v, n) gathers utterance n's positions that hold table row v - 256 positions at a time, listed in position
+// order by ballot + prefix - and adds its columns of those rows in list order (four row loads in flight).  Its share is
+// parked in `work`; the last of the N workgroups of row v to arrive adds the shares in utterance order into dtable.
+// (One workgroup per row alone was 0.4 ms at the benchmark shape: the padding id holds a quarter of all positions and
+// its workgroup walked them as one dependent chain.)
+constexpr int EMB_CNT = 1024;                    // ns_embedding_bwd_params.work: [0, 1024) arrival counters, then [V][N][D]
 __global__ __launch_bounds__(256) void embedding_bwd_kernel(ns_embedding_bwd_params p) {
   __shared__ int list[256];
   __shared__ int wcnt[4];
-  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n_pos = p.N * p.T;
+  __shared__ int last;
+  const int v = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int MAXD = 4;                       // columns per thread: D <= 1024
   float acc[MAXD] = {0.f, 0.f, 0.f, 0.f};
-  for (int base = 0; base < n_pos; base += 256) {
-    const int pos = base + tid;
+  const float* rows = p.dout + ((long)n * p.P + p.padl) * p.D;
+  for (int base = 0; base < p.T; base += 256) {
+    const int t = base + tid;
     bool hit = false;
-    if (pos < n_pos) {
-      int id = p.ids[pos];
+    if (t < p.T) {
+      int id = p.ids[n * p.T + t];
       id = id < 0 ? 0 : (id >= p.V ? p.V - 1 : id);
       hit = id == v;
     }
@@ -77,26 +82,51 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(ns_embedding_bwd_par
     int off = __popcll(b & ((1ull << lane) - 1ull));
     for (int w = 0; w < wave; ++w) off += wcnt[w];
     const int total = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    if (hit) list[off] = pos;
+    if (hit) list[off] = t;
     __syncthreads();
-    for (int e = 0; e < total; ++e) {
-      const int q = list[e];
-      const float* src = p.dout + ((long)(q / p.T) * p.P + p.padl + q % p.T) * p.D;
+    for (int e = 0; e < total; e += 4) {
+      float x[4][MAXD];
 #pragma unroll
-      for (int i = 0; i < MAXD; ++i)
-        if (tid + 256 * i < p.D) acc[i] += src[tid + 256 * i];
+      for (int q = 0; q < 4; ++q) {
+        const float* src = rows + (long)list[min(e + q, total - 1)] * p.D;
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) x[q][i] = (e + q < total && tid + 256 * i < p.D) ? src[tid + 256 * i] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < MAXD; ++i) acc[i] += x[q][i];
     }
     __syncthreads();
   }
+  float* share = p.work + EMB_CNT + ((long)v * p.N + n) * p.D;
 #pragma unroll
   for (int i = 0; i < MAXD; ++i)
-    if (tid + 256 * i < p.D) p.dtable[(long)v * p.D + tid + 256 * i] += acc[i];
+    if (tid + 256 * i < p.D) ns_st_sc1(share + tid + 256 * i, acc[i]);
+  ns_drain_stores();
+  __syncthreads();
+  int* counter = (int*)p.work + v;
+  if (tid == 0) last = atomicAdd(counter, 1) == p.N - 1;
+  __syncthreads();
+  if (!last) return;
+#pragma unroll
+  for (int i = 0; i < MAXD; ++i) {
+    if (tid + 256 * i < p.D) {
+      float a = 0.f;
+      for (int m = 0; m < p.N; ++m) a += ns_ld_sc1(p.work + EMB_CNT + ((long)v * p.N + m) * p.D + tid + 256 * i);
+      p.dtable[(long)v * p.D + tid + 256 * i] += a;
+    }
+  }
+  if (tid == 0) *counter = 0;
+}
+extern "C" size_t ns_embedding_bwd_work_floats(int N, int D, int V) {
+  return (size_t)EMB_CNT + (size_t)(V > 0 ? V : 0) * (size_t)(N > 0 ? N : 0) * (size_t)(D > 0 ? D : 0);
 }
 extern "C" int ns_embedding_bwd(const ns_embedding_bwd_params* p, ns_stream_t s) {
-  NS_CHECK_ARG(p && p->ids && p->dout && p->dtable, "ns_embedding_bwd: null");
-  NS_CHECK_ARG(p->D <= 1024 && p->V >= 1, "ns_embedding_bwd: D <= 1024");
+  NS_CHECK_ARG(p && p->ids && p->dout && p->dtable && p->work, "ns_embedding_bwd: null (work: ns_embedding_bwd_work_floats)");
+  NS_CHECK_ARG(p->D <= 1024 && p->V >= 1 && p->V <= EMB_CNT, "ns_embedding_bwd: D <= 1024, V <= 1024");
   if (p->N * p->T == 0) return NS_OK;
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(p->V), dim3(256), 0, (hipStream_t)s, *p);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(p->V, p->N), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("embedding_bwd");
   return NS_OK;
 }
@@ -568,27 +598,37 @@ __global__ __launch_bounds__(256) void colsum4_kernel(ns_colsum_params p) {
       float a = 0.f;
       for (int r = 0; r < BN4_LANES; ++r) a += red[r * BN4_QUADS + ql][i];
       if (4 * q + i < p.C) {
-        if (p.work) p.work[COLSUM_CNT + (long)blockIdx.x * p.C + 4 * q + i] = a;      // parked: the last row block adds them in order
+        if (p.work) ns_st_sc1(p.work + COLSUM_CNT + (long)blockIdx.x * p.C + 4 * q + i, a);      // parked: the last row block adds them in order
         else atomicAdd(p.out + 4 * q + i, a);
       }
     }
   }
   if (!p.work) return;
-  // fixed-order finish: row blocks -> fence -> this column block's counter; the last one adds partials 0, 1, ... per column
+  // fixed-order finish: write-through partials, drained -> this column block's counter; the last one adds partials 0, 1, ...
   __shared__ int last;
-  __threadfence();
+  ns_drain_stores();
   __syncthreads();
   int* counter = (int*)p.work + blockIdx.y;
   if (tid == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
+  // 64 columns x 4 groups of 16 row blocks: every thread has its 16 loads in flight at once and adds them in block order,
+  // the four group sums are added in group order (the serial 64-load chain of one thread per column cost 20 us a call)
   const int c0 = blockIdx.y * BN4_QUADS * 4;
-  if (tid < BN4_QUADS * 4 && c0 + tid < p.C) {
-    float a = 0.f;
-    for (int b = 0; b < (int)gridDim.x; ++b) a += __builtin_nontemporal_load(p.work + COLSUM_CNT + (long)b * p.C + c0 + tid);
-    p.out[c0 + tid] += a;
+  constexpr int GB = COLSUM_MAX_BLOCKS / 4;
+  const int cc = tid & 63, grp = tid >> 6;
+  float pv[GB];
+#pragma unroll
+  for (int i = 0; i < GB; ++i) {
+    const int b = grp * GB + i;
+    pv[i] = (b < (int)gridDim.x && c0 + cc < p.C) ? ns_ld_sc1(p.work + COLSUM_CNT + (long)b * p.C + c0 + cc) : 0.f;
   }
+  float a = 0.f;
+#pragma unroll
+  for (int i = 0; i < GB; ++i) a += pv[i];
+  red[tid][0] = a;
+  __syncthreads();
+  if (tid < 64 && c0 + tid < p.C) p.out[c0 + tid] += ((red[tid][0] + red[64 + tid][0]) + red[128 + tid][0]) + red[192 + tid][0];
   if (tid == 0) *counter = 0;
 }
 extern "C" size_t ns_colsum_work_floats(int C) { return (size_t)COLSUM_CNT + (size_t)COLSUM_MAX_BLOCKS * (size_t)(C > 0 ? C : 0); }
@@ -603,18 +643,17 @@ __global__ __launch_bounds__(256) void colsum_det_kernel(ns_colsum_params p) {
   if (c < p.C) {
     float a = 0.f;
     for (int r = r0; r < r1; ++r) a += ld_dyn(p.x, p.dtype, (long)r * p.ld + c);
-    p.work[COLSUM_CNT + (long)blockIdx.x * p.C + c] = a;
+    ns_st_sc1(p.work + COLSUM_CNT + (long)blockIdx.x * p.C + c, a);
   }
-  __threadfence();
+  ns_drain_stores();
   __syncthreads();
   int* counter = (int*)p.work + blockIdx.y;
   if (threadIdx.x == 0) last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
   __syncthreads();
   if (!last) return;
-  __threadfence();
   if (c < p.C) {
     float a = 0.f;
-    for (int b = 0; b < (int)gridDim.x; ++b) a += __builtin_nontemporal_load(p.work + COLSUM_CNT + (long)b * p.C + c);
+    for (int b = 0; b < (int)gridDim.x; ++b) a += ns_ld_sc1(p.work + COLSUM_CNT + (long)b * p.C + c);
     p.out[c] += a;
   }
   if (threadIdx.x == 0) *counter = 0;

@@ -93,32 +93,46 @@ __device__ __forceinline__ void batch_shift(ns_gemm_params& p, int z) {
 // scratch - PER float4 per thread, thread-major, so the stores and the loads are whole 16-byte lines of one wave and the
 // layout never has to be interpreted - and raises the tile's counter; the LAST slice to arrive reads all of them back in
 // slice order (its own included: the order must not depend on who is last) and goes on into the epilogue.  Visibility:
-// partial stores -> agent-scope fence -> counter (the pattern of sumsq_kernel; per-XCD L2s are written back / invalidated
-// by the fences).  Returns true for the workgroup that runs the epilogue.  A (tile, slice) slot is 256 x PER float4 = the
+// write-through partial stores, drained -> counter; L2-bypassing loads (common.h: ns_st_sc1 / ns_ld_sc1 - no fence).  Returns true for the workgroup that runs the epilogue.  A (tile, slice) slot is 256 x PER float4 = the
 // tile's elements x 4 bytes.
 template <int PER>
 __device__ __forceinline__ bool splitk_gather(const ns_gemm_params& p, float4 (&v)[PER], int tile, int ksl, int tid) {
   __shared__ int sk_last;
-  constexpr size_t SLOT = 256 * PER;
-  float4* slot0 = (float4*)p.splitk_work + (size_t)tile * p.split_k * SLOT;
-  float4* mine = slot0 + (size_t)ksl * SLOT;
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned SLOT_BYTES = 256u * PER * 16u;
+  // 16-byte write-through stores / L2-bypassing loads through a buffer descriptor over the scratch (aux 16 = sc1)
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.splitk_work, 0, 0x7ffffff0, 0x00020000);
+  const unsigned tile0 = (unsigned)tile * (unsigned)p.split_k * SLOT_BYTES + (unsigned)tid * 16u;
+  const unsigned mine = tile0 + (unsigned)ksl * SLOT_BYTES;
 #pragma unroll
-  for (int i = 0; i < PER; ++i) mine[i * 256 + tid] = v[i];
-  __threadfence();
+  for (int i = 0; i < PER; ++i) {
+    const u32x4 x = {__float_as_uint(v[i].x), __float_as_uint(v[i].y), __float_as_uint(v[i].z), __float_as_uint(v[i].w)};
+    __builtin_amdgcn_raw_buffer_store_b128(x, rs, mine + (unsigned)i * 4096u, 0, 16);
+  }
+  ns_drain_stores();
   __syncthreads();
   if (tid == 0) sk_last = atomicAdd(p.splitk_count + tile, 1) == p.split_k - 1;
   __syncthreads();
   if (!sk_last) return false;
-  __threadfence();
+  // the tail of the launch: one workgroup reads split_k slots - the next slot's loads are in flight while this one is added
 #pragma unroll
   for (int i = 0; i < PER; ++i) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  u32x4 cur[PER], nxt[PER];
+#pragma unroll
+  for (int i = 0; i < PER; ++i) cur[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, tile0 + (unsigned)i * 4096u, 0, 16);
   for (int s = 0; s < p.split_k; ++s) {
-    const float4* src = slot0 + (size_t)s * SLOT;
+    if (s + 1 < p.split_k) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i)
+        nxt[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, tile0 + (unsigned)(s + 1) * SLOT_BYTES + (unsigned)i * 4096u, 0, 16);
+    }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
-      const f32x4 x = __builtin_nontemporal_load((const f32x4*)src + i * 256 + tid);
-      v[i].x += x[0]; v[i].y += x[1]; v[i].z += x[2]; v[i].w += x[3];
+      v[i].x += __uint_as_float(cur[i][0]); v[i].y += __uint_as_float(cur[i][1]);
+      v[i].z += __uint_as_float(cur[i][2]); v[i].w += __uint_as_float(cur[i][3]);
     }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) cur[i] = nxt[i];
   }
   if (tid == 0) p.splitk_count[tile] = 0;         // left clean for the next call
   return true;
@@ -1193,6 +1207,8 @@ static int gemm_dispatch(ns_gemm_params& p, hipStream_t stream) {
   if (p.split_k < 1) p.split_k = 1;
   NS_CHECK_ARG((p.splitk_work != nullptr) == (p.splitk_count != nullptr), "ns_gemm: splitk_work and splitk_count come together");
   NS_CHECK_ARG(!p.splitk_work || p.split_k == 1 || p.batch <= 1, "ns_gemm: deterministic split-K takes no batch");
+  NS_CHECK_ARG(!p.splitk_work || ns_gemm_splitk_work_bytes(p.M, p.N, p.split_k) < 0x7ffffff0ull,
+               "ns_gemm: deterministic split-K scratch beyond 2 GB (32-bit buffer offsets): lower split_k");
   NS_CHECK_ARG(p.accumulate >= 0 && p.accumulate <= 2, "ns_gemm: bad accumulate");
   NS_CHECK_ARG(p.accumulate == 0 || p.c_dtype == NS_F32, "ns_gemm: accumulate needs fp32 C");
   NS_CHECK_ARG(p.split_k == 1 || (p.accumulate == 2 && p.act == NS_ACT_NONE && !p.col_sum),

@@ -618,6 +618,7 @@ class Tacotron(Tacotron2):
     def backward(self):
         hp = self._hparams
         T_ = self.T
+        ops.DETERMINISTIC_SPLITK = self.deterministic
         d, st = self.dims, self._state
         N, Ti, To, S, Pi, Po, Fp = d["N"], d["Ti"], d["To"], d["S"], d["Pi"], d["Po"], d["Fp"]
         r, M, F = hp.outputs_per_step, hp.num_mels, hp.num_freq

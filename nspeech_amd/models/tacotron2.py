@@ -103,6 +103,10 @@ class Tacotron2(object):
         # Zoneout on the two decoder LSTMs (north_star: "2-layer Zoneout-LSTM decoder"; the reference builds plain
         # LSTMBlockCells, tacotron2.py:69-70, so the shipped rate is 0 and nothing below changes a bit of the reference
         # path).  Training draws fresh counter-based masks per step (ns_lstm_seq_params); synthesis uses the expectation.
+        # bit-reproducible gradients: every sum between the loss and flat_g has a fixed order; the split-K products' part of
+        # it (ops.DETERMINISTIC_SPLITK) costs 2 % of the step and is a switch (hparam deterministic_gradients / NS_DETERMINISTIC)
+        env = os.environ.get("NS_DETERMINISTIC")
+        self.deterministic = (env == "1") if env is not None else bool(getattr(hparams, "deterministic_gradients", False))
         self.zoneout_rate = float(getattr(hparams, "zoneout_rate", 0.0) or 0.0)
         self.zoneout_base_seed = (int(seed) * 2654435761 + 97) & 0xFFFFFFFF
         self._status_words = {}
@@ -370,6 +374,13 @@ class Tacotron2(object):
         with torch.cuda.stream(self._side_stream()):
             for _, fn in calls:
                 fn()
+
+    def _wait_side(self):
+        """The main stream waits (on the device) for what the second stream has been given so far."""
+        if self._side_busy and self._side is not None and os.environ.get("NS_NO_WAIT_SIDE") != "1":
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     def _join_deferred(self):
         self._flush_deferred()
@@ -1024,6 +1035,7 @@ class Tacotron2(object):
         E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
         S1 = S + 1
         g = self.flat_g
+        ops.DETERMINISTIC_SPLITK = self.deterministic
         ops.zero(g)
         ops.zero(self.scal)
         self._deferred = []
@@ -1207,6 +1219,14 @@ class Tacotron2(object):
                     de=self._buf("d_energy", rows * Tia, torch.float32),
                     dctx_t=self._buf("d_ctx_t", rows * E, T_),
                     post_part=ops.attention_post_part(self.device, N, Tia, A))
+        # The queued convolution weight gradients were released for the window of the two decoder-LSTM recurrences (half the
+        # chip idle).  What is left of them now cannot run beside the attention recurrence anyway - its workgroups hold
+        # every CU's register file - it would only straddle it (one launch "lasted" 2.05 ms): the
+        # main stream waits for the second stream here, on the device.  It also keeps the attention post-pass alone on
+        # the chip: with the library's weight-gradient workgroups resident beside it, its dWcl sums came out different in
+        # the last bits from run to run (identical inputs, bit-stable alone or beside foreign kernels; round 4,
+        # profiles/r04_determinism.txt) - the one place where bit-reproducibility depended on what else ran.
+        self._wait_side()
         if self._attn_cluster_fwd:
             cw = self._buf("attn_cluster_work_b", ops.taco2_attn_cluster_work_floats(**args), torch.float32)
             ops.taco2_attn_cluster("bwd", cw, **args)
@@ -1336,9 +1356,40 @@ class Tacotron2(object):
         self.grad_norm = math.sqrt(max(float(s[8]), 0.0)) / self.world_size
         return self.loss
 
+    def losses_async(self):
+        """Enqueue the read-back of this step's loss scalars into pinned host memory and return a handle for
+        losses_finish() - no host synchronisation here, so the caller can issue the next step's launches while this one
+        still runs (train.py's loop: every step's loss is read, one step behind the launches)."""
+        ring = getattr(self, "_scal_host", None)
+        if ring is None:
+            ring = self._scal_host = [torch.zeros(16, dtype=torch.float32).pin_memory() for _ in range(4)]
+            self._scal_turn = 0
+        host = ring[self._scal_turn % len(ring)]
+        self._scal_turn += 1
+        host.copy_(self.scal, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
+        d = self.dims
+        return dict(host=host, event=ev, N=d["N"], To=d["To"], n_prio=self._n_prio, step=self.global_step,
+                    lr=self.learning_rate)
+
+    def losses_finish(self, handle):
+        """Wait for a losses_async() read-back and turn it into (loss, mel_loss, linear_loss).  A skipped optimiser step
+        (a persistent recurrence timed out: ns_adam_params.status) raises here, as read_losses() does."""
+        hp = self._hparams
+        handle["event"].synchronize()
+        s = handle["host"].numpy()
+        if s[9] != 0:
+            raise RuntimeError("the optimiser step %d was skipped: a persistent recurrence reported a timeout" % handle["step"])
+        N, To = handle["N"], handle["To"]
+        mel_loss = float(s[0]) / (N * To * hp.num_mels)
+        lin_loss = 0.5 * float(s[2]) / (N * To * hp.num_freq) + 0.5 * float(s[3]) / (N * To * handle["n_prio"])
+        return mel_loss + lin_loss, mel_loss, lin_loss
+
     def step(self, inputs=None, input_lengths=None, mel_targets=None, linear_targets=None, grad_hook=None,
              read_loss=True, speaker_ids=None):
-        """One training step = the reference's sess.run([global_step, loss, optimize]) (train.py:80)."""
+        """One training step = the reference's sess.run([global_step, loss, optimize]) (train.py:80).
+        read_loss: True = wait and return the loss; "async" = return a losses_async() handle; False = nothing."""
         if inputs is not None:
             self.initialize(inputs, input_lengths, speaker_ids, mel_targets, linear_targets)
         else:
@@ -1347,4 +1398,6 @@ class Tacotron2(object):
         if grad_hook is not None:
             grad_hook(self.flat_g)
         self.apply_gradients()
+        if read_loss == "async":
+            return self.losses_async()
         return self.read_losses() if read_loss else None

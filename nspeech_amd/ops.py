@@ -84,9 +84,11 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, a_mode=0, b_mode=0, a_off=0, b_off=0,
     L.call("ns_gemm", p, stream())
 
 
-# Split-K products add their k slices in a FIXED order (ns_gemm_params.splitk_work): two runs of a training step give the
-# same gradient bits.  NS_SPLITK_ATOMIC=1 restores the fp32-atomic form (A/B timing).
-DETERMINISTIC_SPLITK = __import__("os").environ.get("NS_SPLITK_ATOMIC", "0") != "1"
+# Split-K products can add their k slices in a FIXED order (ns_gemm_params.splitk_work): with every other sum of the
+# backward pass already ordered, two runs of a training step then give the same gradient bits.  It costs the partial tiles'
+# trip through memory (measured at the benchmark shape: +14 us per weight-gradient product, +0.4 ms = 2 % of the step), so
+# it is a switch: models set it from hparams.deterministic_gradients (default off), NS_DETERMINISTIC=1 / 0 forces it.
+DETERMINISTIC_SPLITK = __import__("os").environ.get("NS_DETERMINISTIC", "0") == "1"
 _SPLITK = {}
 
 
@@ -144,9 +146,15 @@ def embedding_fwd(ids, table, out, N, T, P, padl, D, V, table_off=0):
     L.call("ns_embedding_fwd", p, stream())
 
 
+_EMB_WORK = {}
+
+
 def embedding_bwd(ids, dout, dtable, N, T, P, padl, D, V, dtable_off=0):
     p = L.struct("ns_embedding_bwd_params")
-    _fill(p, ids=ptr(ids), dout=ptr(dout), dtable=ptr(dtable, dtable_off), N=N, T=T, P=P, padl=padl, D=D, V=V)
+    fn = L.lib().ns_embedding_bwd_work_floats
+    fn.restype = C.c_size_t
+    work = _scratch(_EMB_WORK, dout.device, int(fn(int(N), int(D), int(V))))
+    _fill(p, ids=ptr(ids), dout=ptr(dout), dtable=ptr(dtable, dtable_off), N=N, T=T, P=P, padl=padl, D=D, V=V, work=ptr(work))
     L.call("ns_embedding_bwd", p, stream())
 
 

@@ -282,6 +282,7 @@ def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
     N, Ti, To = 6, 30, 60
     hp = small_hparams()
     m = _model(hp, mode)
+    m.deterministic = True          # hparams.deterministic_gradients: the split-K products park their partial tiles
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=21)
     runs = []
     for _ in range(2):
@@ -301,6 +302,31 @@ def test_taco2_two_passes_are_bitwise_repeatable(dev, mode):
         assert torch.equal(g0[off:off + n], g1[off:off + n]), (name, (g0[off:off + n] - g1[off:off + n]).abs().max().item())
 
 
+def test_taco2_default_atomic_split_k_agrees_to_rounding(dev):
+    """The default (hparams.deterministic_gradients false): split-K products meet in fp32 atomics, so two passes agree in
+    everything but the last bits of those sums; the deterministic pass lies within the same rounding of both."""
+    N, Ti, To = 6, 30, 60
+    hp = small_hparams()
+    m = _model(hp, "mixed")
+    assert m.deterministic is False
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=21)
+    gs = []
+    for det in (False, False, True):
+        m.deterministic = det
+        m.initialize(inputs, lengths, None, mel, lin)
+        m.backward()
+        torch.cuda.synchronize()
+        gs.append(m.flat_g.double().clone())
+    for g1 in gs[1:]:
+        for name, (off, shape) in m.layout.entries.items():
+            if name.endswith("conv1d/bias"):
+                continue
+            n = int(np.prod(shape))
+            d = (gs[0][off:off + n] - g1[off:off + n]).abs().max().item()
+            sc = gs[0][off:off + n].abs().max().item()
+            assert d <= 2e-5 * sc + 1e-9, (name, d, sc)
+
+
 @pytest.mark.parametrize("size", ["small", "full"])
 def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
     """The decoder / attention / postnet weight gradients that run on a second stream beside the encoder BiLSTM
@@ -313,6 +339,7 @@ def test_taco2_weight_gradients_on_the_second_stream_change_nothing(dev, size):
         hp, (N, Ti, To) = hparams_mod.load("taco2"), (32, 160, 1000)
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=17)
     m = _model(hp, "mixed", seed=7)
+    m.deterministic = True
     gs = []
     for overlap in (False, True, True):
         m.overlap_wgrads = overlap
@@ -339,6 +366,7 @@ def test_taco2_full_width_backward_repeats_over_many_launches(dev, mode):
     N, Ti, To = 8, 48, 100
     inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=3)
     m = _model(hp, mode, seed=5)
+    m.deterministic = True
     m.overlap_wgrads = False            # one stream: every buffer has its final contents when the pass returns
     exact = ("d_energy", "d_q", "d_ga", "d_p2", "d_f1", "d_ctx_t", "d_hc", "d_h1", "d_h2", "d_keys_t", "d_enc_a",
              "d_enc_b", "d_act_a", "d_act_b", "d_mel")

@@ -47,6 +47,7 @@ def test_training_checkpoint_with_adam_slots_resumes_the_same_trajectory(dev, tm
     hp = small_hparams(max_iters=5)
     inputs, lengths, mel, lin = make_batch(hp, 2, 7, 10, seed=4)
     a = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=21)
+    a.deterministic = True           # hparams.deterministic_gradients: "the same trajectory" is then meant bit for bit
     a.add_optimizer(0)
     for _ in range(3):
         a.step(inputs, lengths, mel, lin)
@@ -57,6 +58,7 @@ def test_training_checkpoint_with_adam_slots_resumes_the_same_trajectory(dev, tm
     outs = []
     for prefix in (full, bare):
         b = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=99)
+        b.deterministic = True
         rep = B.load_into_model(b, prefix)
         assert (rep["adam_slots"] is not None) == (prefix == full) and b.global_step == 3
         b.add_optimizer(b.global_step)

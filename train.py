@@ -88,6 +88,39 @@ def train_step(model, batches, world=1):
     return loss
 
 
+class LossPipeline(object):
+    """The training loop with the loss read-back one step behind the launches (default; --sync-loss turns it off): step
+    k's launches are issued, then step k-1's loss - already on its way into pinned memory - is waited for, logged and
+    checked.  Every step's loss is read and the explosion check of train.py:87-89 sees every value, one step later; the
+    GPU never waits for the host between two steps (measured at the benchmark shape: 22.2 ms per step with a
+    synchronous read-back against 19.9 ms of device time, bench.py `e2e`)."""
+
+    def __init__(self, model, batches, world=1):
+        self.model, self.batches, self.world = model, batches, world
+        self.pending = None
+
+    def _finish(self, handle):
+        loss = self.model.losses_finish(handle)[0]
+        if self.world > 1:      # every rank must agree on the abort decision
+            t = torch.tensor([loss], device="cuda")
+            torch.distributed.all_reduce(t)
+            loss = float(t.item()) / self.world
+        return handle["step"], loss, handle["lr"]
+
+    def step(self):
+        """Issue one step; returns (step, loss, learning rate) of the step BEFORE it, or None on the first call."""
+        inputs, lengths, mel, lin = self.batches.next_batch()
+        handle = self.model.step(inputs, lengths, mel, lin, speaker_ids=self.batches.speaker_ids, read_loss="async")
+        done = self._finish(self.pending) if self.pending is not None else None
+        self.pending = handle
+        return done
+
+    def drain(self):
+        done = self._finish(self.pending) if self.pending is not None else None
+        self.pending = None
+        return done
+
+
 def write_summary(path, step, stats):
     """One JSON object per summary step in LOGDIR/events.jsonl: what the reference hands tf.summary.FileWriter
     (train.py:63,91-93; tacotron2.py:163-188) as scalars - loss, loss_mel, loss_linear, learning_rate,
@@ -141,16 +174,17 @@ def train(log_dir, args):
     saver = CheckpointSaver(log_dir)
     batches = DeviceStager(feeder, "cuda:%d" % local)      # pinned H2D of batch k+1 on a copy stream under step k
     events = os.path.join(log_dir, "events.jsonl") if rank == 0 else None
-    paths_logged = None
-    while args.max_steps is None or model.global_step < args.max_steps:
-        t0 = time.time()
-        loss = train_step(model, batches, world)
-        step = model.global_step
+    state = dict(paths=None, t_prev=time.time())
+
+    def report(step, loss):
+        """Log line + explosion check of one finished step (train.py:82-89)."""
         paths = getattr(model, "last_paths", None)
-        if paths and paths != paths_logged:         # which kernel family ran each recurrence (a batch shape that falls
-            paths_logged = dict(paths)              # off the persistent kernels runs ~2x slower: say so, once per change)
+        if paths and paths != state["paths"]:       # which kernel family ran each recurrence (a batch shape that falls
+            state["paths"] = dict(paths)            # off the persistent kernels runs ~2x slower: say so, once per change)
             log("Recurrence kernels: %s" % ", ".join("%s=%s" % kv for kv in sorted(paths.items())), logf)
-        time_window.append(time.time() - t0)
+        now = time.time()
+        time_window.append(now - state["t_prev"])
+        state["t_prev"] = now
         loss_window.append(loss)
         frames = model.mel_targets.shape[0] * model.mel_targets.shape[1] * world
         log("Step %-7d [%.03f sec/step, loss=%.05f, avg_loss=%.05f, %.0f mel_frames/s]" %
@@ -158,14 +192,38 @@ def train(log_dir, args):
         if loss > 100 or math.isnan(loss):          # train.py:87-89
             log("Loss exploded to %.05f at step %d!" % (loss, step), logf)
             raise Exception("Loss Exploded")
-        if rank == 0 and args.summary_interval and step % args.summary_interval == 0:      # train.py:91-93
+
+    pipe = None if args.sync_loss else LossPipeline(model, batches, world)
+    while args.max_steps is None or model.global_step < args.max_steps:
+        nxt = model.global_step + 1
+        due_summary = bool(args.summary_interval) and nxt % args.summary_interval == 0
+        due_ckpt = nxt % args.checkpoint_interval == 0
+        if pipe is not None and not (due_summary or due_ckpt):
+            done = pipe.step()                      # issue step `nxt`, collect the loss of the step before it
+            if done is not None:
+                report(done[0], done[1])
+            continue
+        # a step whose summary / checkpoint is due runs synchronously: the files describe the model after exactly `nxt`
+        # updates (every rank takes this branch at the same step - the loss all-reduces stay in the same order)
+        if pipe is not None:
+            done = pipe.drain()
+            if done is not None:
+                report(done[0], done[1])
+        loss = train_step(model, batches, world)
+        step = model.global_step
+        report(step, loss)
+        if rank == 0 and due_summary:                                                   # train.py:91-93
             log("Writing summary at step: %d" % step, logf)
             write_summary(events, step, model.stats())
-        if rank == 0 and step % args.checkpoint_interval == 0:
+        if rank == 0 and due_ckpt:
             path = saver.save(model, step)
             log("Saved checkpoint %s" % path, logf)
             wav = audio.inv_preemphasis(model.audio[0].cpu().numpy())      # train.py:100-107 fetches model.audio[0]
             audio.save_wav(wav[:audio.find_endpoint(wav)], os.path.join(log_dir, "step-%06d-audio.wav" % step))
+    if pipe is not None:
+        done = pipe.drain()
+        if done is not None:
+            report(done[0], done[1])
     return model
 
 
@@ -189,6 +247,9 @@ def main():
     ap.add_argument("--threads", type=int, default=1)
     ap.add_argument("--precision", default="mixed", choices=["mixed", "bf16", "bf16x3", "fp32"])
     ap.add_argument("--max-steps", "--max_steps", type=int, default=None)
+    ap.add_argument("--sync-loss", "--sync_loss", action="store_true",
+                    help="wait for every step's loss before issuing the next step (default: the read-back runs one step "
+                         "behind the launches, see LossPipeline)")
     ap.add_argument("--feature-cache", "--feature_cache", default="device", choices=["device", "host"],
                     help="where the feeder keeps the spectrogram features of the corpus: 'device' = in HBM, batches "
                          "assembled on the GPU (all of LJSpeech is 30.5 GB of float32); 'host' = in RAM as the reference "
