@@ -275,6 +275,12 @@ typedef struct {
   void* dst_hi; void* dst_lo;
 } ns_cast2d_params;
 int ns_cast2d(const ns_cast2d_params* p, ns_stream_t stream);
+/* Many ns_cast2d calls as ONE launch (the per-step refresh of the weight shadows after tf.train.AdamOptimizer's update,
+ * tacotron2.py:159-161).  table_dev: `n` parameter blocks in DEVICE memory, each of which ns_cast2d_batchable() accepted
+ * (it returns the block's number of 64 x 64 tiles, 0 = not eligible: ragged or unaligned); tile_end_dev: DEVICE int[n],
+ * the running sums of those tile counts; total_tiles = the last of them. */
+int ns_cast2d_batchable(const ns_cast2d_params* p);
+int ns_cast2d_batch(const ns_cast2d_params* table_dev, const int* tile_end_dev, int n, int total_tiles, ns_stream_t stream);
 
 /* ------------------------------------------------------------------ LSTM over time
  * tf.contrib.rnn.LSTMBlockCell inside dynamic_rnn / bidirectional_dynamic_rnn / dynamic_decode

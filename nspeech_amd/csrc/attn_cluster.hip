@@ -1204,7 +1204,8 @@ bool cluster_shape_ok(const ns_taco2_attn_params* p) {
   if (p->A != 256 && p->A != 64) return false;
   if (p->Ti > 256 || p->Tia > 256 || p->kw > KWMAX || p->S < 1 || p->N < 1) return false;
   if (p->Dsp < 0) return false;
-  if ((long)p->N * CG > ns_device_cus()) return false;      // a cluster of CG workgroups per utterance, all resident at once
+  if (CG > ns_device_cus()) return false;      // ONE utterance's cluster of CG workgroups must be resident at once; the clusters
+                                               // are independent chains (more of them than CUs / CG just take turns)
   return true;
 }
 }  // namespace

@@ -959,6 +959,67 @@ __global__ __launch_bounds__(256) void cast2d_vec_kernel(ns_cast2d_params p) {
     if (bx + c < p.cols && by + r4 < p.rows) cast2d_put4(p, (long)(bx + c) * p.ld_dst + by + r4, f);
   }
 }
+// Many casts in ONE launch (the per-step refresh of the operand-dtype weight shadows: ~25 small transposes that cost a
+// launch each): block b of the grid looks its descriptor up in a DEVICE table by the prefix sums of the tile counts and
+// runs the body of cast2d_vec_kernel on it.  Every descriptor must qualify for the vector kernel (ns_cast2d_batch checks
+// what it can on the host: the table itself lives on the device, so the caller vouches for it via ns_cast2d_batchable).
+__global__ __launch_bounds__(256) void cast2d_batch_kernel(const ns_cast2d_params* tab, const int* tile_end, int n) {
+  __shared__ float tile[64][65];
+  __shared__ int which, first;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n - 1;                     // smallest d with tile_end[d] > blockIdx.x
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (tile_end[mid] > (int)blockIdx.x) hi = mid; else lo = mid + 1; }
+    which = lo;
+    first = lo ? tile_end[lo - 1] : 0;
+  }
+  __syncthreads();
+  const ns_cast2d_params p = tab[which];
+  const int t = (int)blockIdx.x - first, tx = (p.cols + 63) / 64;
+  const int bx = (t % tx) * 64, by = (t / tx) * 64;
+  const int q = threadIdx.x & 15, l = threadIdx.x >> 4;
+  float4 v[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = by + l + 16 * i, c = bx + q * 4;
+    v[i] = (r < p.rows && c < p.cols) ? *(const float4*)(p.src + (long)r * p.ld_src + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (!p.transpose) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = by + l + 16 * i, c = bx + q * 4;
+      const float f[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+      if (r < p.rows && c < p.cols) cast2d_put4(p, (long)r * p.ld_dst + c, f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float* tt = &tile[l + 16 * i][q * 4];
+    tt[0] = v[i].x; tt[1] = v[i].y; tt[2] = v[i].z; tt[3] = v[i].w;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = l + 16 * i, r4 = q * 4;
+    const float f[4] = {tile[r4][c], tile[r4 + 1][c], tile[r4 + 2][c], tile[r4 + 3][c]};
+    if (bx + c < p.cols && by + r4 < p.rows) cast2d_put4(p, (long)(bx + c) * p.ld_dst + by + r4, f);
+  }
+}
+static bool cast2d_vec_ok(const ns_cast2d_params* p) {
+  auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
+  const int dsz = p->dst_dtype == NS_BF16 ? 8 : 16;
+  return p->src && (p->dst || p->dst_hi) && !p->dst_hi == !p->dst_lo && p->rows > 0 && p->cols > 0 && p->cols % 4 == 0 &&
+         p->ld_src % 4 == 0 && p->ld_dst % 4 == 0 && (!p->transpose || p->rows % 4 == 0) && al(p->src, 16) && al(p->dst, dsz) &&
+         al(p->dst_hi, 8) && al(p->dst_lo, 8);
+}
+extern "C" int ns_cast2d_batchable(const ns_cast2d_params* p) { return p && cast2d_vec_ok(p) ? (p->cols + 63) / 64 * ((p->rows + 63) / 64) : 0; }
+extern "C" int ns_cast2d_batch(const ns_cast2d_params* table_dev, const int* tile_end_dev, int n, int total_tiles, ns_stream_t s) {
+  NS_CHECK_ARG(table_dev && tile_end_dev && n >= 1 && total_tiles >= 1, "ns_cast2d_batch: null / empty");
+  hipLaunchKernelGGL(cast2d_batch_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)s, table_dev, tile_end_dev, n);
+  NS_CHECK_LAUNCH("cast2d_batch");
+  return NS_OK;
+}
+
 extern "C" int ns_cast2d(const ns_cast2d_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->src && (p->dst || p->dst_hi), "ns_cast2d: null");
   NS_CHECK_ARG(!p->dst_hi == !p->dst_lo, "ns_cast2d: dst_hi and dst_lo come as a pair");

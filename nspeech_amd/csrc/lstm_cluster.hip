@@ -1512,8 +1512,9 @@ static int cluster3_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_pa
 extern "C" int ns_lstm_cluster_supported(const ns_lstm_seq_params* p0, const ns_lstm_seq_params* p1, int backward) {
   if (!p0 || !p1) return 0;
   if (!(p0->reverse == 0 && p1->reverse == 1 && p0->N == p1->N && p0->T == p1->T && p0->H == p1->H)) return 0;
-  // two directions x 16-row groups x (H / 32 workgroups at most, the fp32 form), every one resident at once
-  if (2L * ((p0->N + 15) / 16) * ((p0->H + 31) / 32) > ns_device_cus()) return 0;
+  // a chain (direction, 16-row group) = H / 64 workgroups (H / 32 in the fp32 form) that must be resident together; the
+  // chains are independent of one another
+  if ((p0->H + 31) / 32 > ns_device_cus()) return 0;
   if (cluster_supported(p0, p1)) return 1;
   return !backward && cluster3_supported(p0, p1);
 }

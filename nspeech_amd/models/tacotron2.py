@@ -203,7 +203,28 @@ class Tacotron2(object):
         """Flat weight buffer to use as a GEMM operand of dtype D."""
         return self.flat_p if D == torch.float32 else self.flat_s
 
+    use_cast_batch = os.environ.get("NS_CAST_BATCH", "1") != "0"
+
     def refresh_shadows(self, full=False):
+        """Operand-dtype copies of the weights (after every optimiser step).  The ~25 transposing casts of a refresh are
+        recorded once and replayed as ONE launch (ops.CastBatch / ns_cast2d_batch: their pointers never change); what does
+        not fit the batch (ragged casts, the folded location filter's product) runs as before."""
+        if full or not self.use_cast_batch or self.device.type != "cuda":
+            return self._refresh_shadows(full)
+        batch = getattr(self, "_cast_batch", None)
+        if batch is None:
+            batch = self._cast_batch = ops.CastBatch(self.device).record(lambda: self._refresh_shadows(False))
+        else:
+            ops.CAST_RECORD = dropped = []      # the batch below does the eligible casts: here they only fall into this list
+            try:
+                self._refresh_shadows(False)
+            finally:
+                ops.CAST_RECORD = None
+            if len(dropped) != batch.n:         # the set of shadows changed (it does not, today): record again
+                batch = self._cast_batch = ops.CastBatch(self.device).record(lambda: self._refresh_shadows(False))
+        batch.run()
+
+    def _refresh_shadows(self, full=False):
         """Operand-dtype copies of the weights: k-contiguous (transposed) ones for the in-loop
         products, the folded location filter, and the 16-byte padded linear head."""
         hp = self._hparams
@@ -1220,13 +1241,15 @@ class Tacotron2(object):
                     dctx_t=self._buf("d_ctx_t", rows * E, T_),
                     post_part=ops.attention_post_part(self.device, N, Tia, A))
         # The queued convolution weight gradients were released for the window of the two decoder-LSTM recurrences (half the
-        # chip idle).  What is left of them now cannot run beside the attention recurrence anyway - its workgroups hold
-        # every CU's register file - it would only straddle it (one launch "lasted" 2.05 ms): the
-        # main stream waits for the second stream here, on the device.  It also keeps the attention post-pass alone on
-        # the chip: with the library's weight-gradient workgroups resident beside it, its dWcl sums came out different in
-        # the last bits from run to run (identical inputs, bit-stable alone or beside foreign kernels; round 4,
-        # profiles/r04_determinism.txt) - the one place where bit-reproducibility depended on what else ran.
-        self._wait_side()
+        # chip idle); what is left of them now straddles the attention recurrence - its workgroups hold every CU's register
+        # file, so the rest of a product's workgroups are placed when it ends (one launch "lasted"
+        # 2.05 ms; it delays nothing on the main stream).  With deterministic gradients the main stream waits for the
+        # second stream here (on the device; measured +0.15 ms): with this library's weight-gradient workgroups resident
+        # beside the attention post-pass its dWcl sums came out different in the last bits from run to run (identical
+        # inputs, bit-stable alone or beside foreign kernels; profiles/r04_determinism.txt) - the one place where
+        # bit-reproducibility depended on what else ran.
+        if self.deterministic:
+            self._wait_side()
         if self._attn_cluster_fwd:
             cw = self._buf("attn_cluster_work_b", ops.taco2_attn_cluster_work_floats(**args), torch.float32)
             ops.taco2_attn_cluster("bwd", cw, **args)

@@ -253,6 +253,9 @@ def zero(t):
     L.check(L.lib().ns_zero(C.c_void_p(ptr(t)), C.c_size_t(nbytes), C.c_void_p(stream())), "ns_zero")
 
 
+CAST_RECORD = None        # a list: cast2d() appends its parameter block instead of launching (CastBatch)
+
+
 def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0, dst_hi=None, dst_lo=None):
     """dst may be None when the pre-split pair (dst_hi, dst_lo) is all that is wanted."""
     p = L.struct("ns_cast2d_params")
@@ -260,7 +263,46 @@ def cast2d(src, rows, cols, ld_src, dst, ld_dst, transpose, src_off=0, dst_off=0
           dst_dtype=dt(dst) if dst is not None else NS_F32, ld_dst=ld_dst, transpose=int(transpose))
     if dst_hi is not None:
         p.dst_hi, p.dst_lo = ptr(dst_hi, dst_off), ptr(dst_lo, dst_off)
+    if CAST_RECORD is not None and L.lib().ns_cast2d_batchable(C.byref(p)) > 0:
+        CAST_RECORD.append(p)
+        return
     L.call("ns_cast2d", p, stream())
+
+
+class CastBatch(object):
+    """A fixed set of cast2d calls replayed as ONE launch (ns_cast2d_batch).  record(fn): run fn() with cast2d()
+    collecting its eligible parameter blocks (the others launch as usual); the table goes to the device once - every
+    pointer in it must stay valid, which holds for a model's flat parameter buffer and its shadow copies."""
+
+    def __init__(self, device):
+        self.device = device
+        self.table = self.ends = None
+        self.n = self.total = 0
+
+    def record(self, fn):
+        global CAST_RECORD
+        CAST_RECORD = rec = []
+        try:
+            fn()
+        finally:
+            CAST_RECORD = None
+        if not rec:
+            return self
+        lib = L.lib()
+        ends, tot = [], 0
+        for p in rec:
+            tot += int(lib.ns_cast2d_batchable(C.byref(p)))
+            ends.append(tot)
+        raw = b"".join(bytes(p) for p in rec)
+        self.table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(self.device)
+        self.ends = torch.tensor(ends, dtype=torch.int32, device=self.device)
+        self.n, self.total = len(rec), tot
+        return self
+
+    def run(self):
+        if self.n:
+            L.check(L.lib().ns_cast2d_batch(C.c_void_p(self.table.data_ptr()), C.c_void_p(self.ends.data_ptr()), self.n,
+                                            self.total, C.c_void_p(stream())), "ns_cast2d_batch")
 
 
 def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, ld_h, c, gates,

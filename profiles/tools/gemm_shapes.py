@@ -23,6 +23,10 @@ SHAPES = [
     ("expand dense, 3 passes", 32124, 512, 400, 0, 1, "f32", "f32", 3, 1),
     ("fp32 weight gradient, 1 pass", 1024, 400, 6432, 1, 1, "f32", "f32", 1, 12),
     ("fp32 data gradient, 1 pass", 6432, 1024, 400, 0, 0, "f32", "f32", 1, 1),
+    # (the same shape again: round 3's log showed 2 356 us for the LAST row - VERDICT r3 weak #15; if that was the row
+    # and not its position, both rows show it)
+    ("fp32 data gradient, 1 pass (again)", 6432, 1024, 400, 0, 0, "f32", "f32", 1, 1),
+    ("fp32 weight gradient, 1 pass (again)", 1024, 400, 6432, 1, 1, "f32", "f32", 1, 12),
 ]
 
 

@@ -10,6 +10,18 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The float64 oracle runs on torch-CPU.  A GPU box shows every core of its host but grants a 16-core share per GPU:
+    # with one thread per visible core the oracle's many small ops crawl (the full-length parity test at N = 8 took 249 s
+    # that way, 4x what 8 cores need) - keep to the share, as bench.py's cpu_baseline does.
+    try:
+        import torch
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cores = os.cpu_count() or 1
+        torch.set_num_threads(max(1, min(cores, 16)))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")

@@ -71,7 +71,7 @@ def test_zoneout_wide_kernels_match_oracle_at_shipped_widths(dev, mode):
     from test_taco2_fullwidth_gpu import BOUNDS
     hp = hparams_mod.load("taco2")
     hp.zoneout_rate = 0.1
-    N, Ti, To = 4, 32, 50
+    N, Ti, To = 3, 24, 40
     m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=5)
     O.ZONEOUT = _with_zoneout(m, To // hp.outputs_per_step, N, hp.decoder_lstm_units)
     try:
