@@ -778,14 +778,29 @@ extern "C" int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t s) {
   return attn_fwd_t<float>(*p, (hipStream_t)s);
 }
 
-// second stage of attn_post_kernel's sums with AttnPost.part: thread = (k, unit); shares added in block order
-__global__ void attn_post_finish_kernel(const float* part, int nblocks, int A, int kw, float* dv, float* dwcl) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (1 + kw) * A) return;
-  const int k = i / A, u = i - k * A;
+// second stage of attn_post_kernel's sums with AttnPost.part: 64 (k, unit) columns per workgroup x 4 groups of shares; a
+// thread adds its group's shares in block order (eight loads in flight), the four group sums are added in group order
+__global__ __launch_bounds__(256) void attn_post_finish_kernel(const float* part, int nblocks, int A, int kw, float* dv, float* dwcl) {
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + c;
+  const bool ok = i < (1 + kw) * A;
+  const int k = ok ? i / A : 0, u = ok ? i - k * A : 0;
+  const int per = (nblocks + 3) / 4, b0 = grp * per, b1 = min(nblocks, b0 + per);
   float s = 0.f;
-  for (int b = 0; b < nblocks; ++b) s += part[((long)b * (1 + MAXKW) + k) * A + u];
-  if (k == 0) dv[u] += s; else dwcl[(k - 1) * A + u] += s;
+  for (int b = b0; b < b1; b += 8) {
+    float x[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) x[j] = (ok && b + j < b1) ? part[((long)(b + j) * (1 + MAXKW) + k) * A + u] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[j];
+  }
+  red[grp][c] = s;
+  __syncthreads();
+  if (grp == 0 && ok) {
+    const float t = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+    if (k == 0) dv[u] += t; else dwcl[(k - 1) * A + u] += t;
+  }
 }
 static int launch_attn_post(const AttnPost& q0, int N, hipStream_t s) {
   AttnPost q = q0;
@@ -795,7 +810,7 @@ static int launch_attn_post(const AttnPost& q0, int N, hipStream_t s) {
   if (q.kw == 7 && !(q.dbg & 2)) hipLaunchKernelGGL(attn_post_kernel<7>, grid, dim3(256), 0, s, q);
   else hipLaunchKernelGGL(attn_post_kernel<0>, grid, dim3(256), 0, s, q);
   if (q.part)
-    hipLaunchKernelGGL(attn_post_finish_kernel, dim3(ceil_div((1 + q.kw) * q.A, 256)), dim3(256), 0, s, q.part, (int)(grid.x * N),
+    hipLaunchKernelGGL(attn_post_finish_kernel, dim3(ceil_div((1 + q.kw) * q.A, 64)), dim3(256), 0, s, q.part, (int)(grid.x * N),
                        q.A, q.kw, q.dv, q.dwcl);
   return NS_OK;
 }
