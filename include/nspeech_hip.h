@@ -225,6 +225,7 @@ typedef struct {
   int N, T, P, padl, F;
   int n_prio; float w_all, w_prio;
   float* loss_acc;
+  int vec4;                /* set by the library (four columns per thread where the layout allows) */
 } ns_l1_loss_params;
 int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t stream);
 

@@ -703,7 +703,57 @@ template <bool WIDE>
 __global__ __launch_bounds__(256) void l1_loss_kernel(ns_l1_loss_params p) {
   __shared__ float red[32];
   float s_all = 0.f, s_pr = 0.f;
-  if (WIDE) {
+  if (WIDE && p.vec4) {
+    // wide rows, four columns per lane: prediction rows are 16-byte aligned (padded leading dimension), target rows are
+    // not (F = 1025 floats) - their quads come through 4-byte-aligned 16-byte loads, which global memory takes
+    struct __attribute__((packed, aligned(4))) f4u { float v[4]; };
+    const int lane = threadIdx.x & 63;
+    const long rows = (long)p.N * p.T;
+    const int nq = p.F >> 2;                       // whole quads; the F % 4 tail columns go to the first lanes
+    for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
+      const int t = (int)(row % p.T);
+      const long n = row / p.T;
+      const long prow = n * p.P + p.padl + t;
+      const float* pr_ = p.pred + prow * p.ldp;
+      const float* tg_ = p.target + row * p.F;
+      for (int q0 = lane; q0 < nq; q0 += 64 * 4) {
+        float4 a[4];
+        f4u b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = q0 + 64 * j;
+          if (q < nq) { a[j] = *(const float4*)(pr_ + 4 * q); b[j] = *(const f4u*)(tg_ + 4 * q); }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = q0 + 64 * j;
+          if (q >= nq) continue;
+          const float av[4] = {a[j].x, a[j].y, a[j].z, a[j].w};
+          float g[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const float d = av[i] - b[j].v[i], ab = fabsf(d);
+            s_all += ab;
+            const bool pr = 4 * q + i < p.n_prio;
+            if (pr) s_pr += ab;
+            g[i] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (p.w_all + (pr ? p.w_prio : 0.f));
+          }
+          if (p.dpred) {
+            if (p.dpred_dtype == NS_BF16) {
+              bf16x4 o;
+#pragma unroll
+              for (int i = 0; i < 4; ++i) o[i] = (bf16_t)g[i];
+              *(bf16x4*)((bf16_t*)p.dpred + prow * p.ldd + 4 * q) = o;
+            } else {
+              *(float4*)((float*)p.dpred + prow * p.ldd + 4 * q) = make_float4(g[0], g[1], g[2], g[3]);
+            }
+          }
+        }
+      }
+      const int f = 4 * nq + lane;
+      if (f < p.F) l1_point(p, pr_[f], tg_[f], prow, f, s_all, s_pr);
+    }
+  } else if (WIDE) {
     const int lane = threadIdx.x & 63;
     const long rows = (long)p.N * p.T;
     for (long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6); row < rows; row += (long)gridDim.x * 4) {
@@ -726,6 +776,29 @@ __global__ __launch_bounds__(256) void l1_loss_kernel(ns_l1_loss_params p) {
           if (f < p.F) l1_point(p, a[j], b[j], prow, f, s_all, s_pr);
         }
       }
+    }
+  } else if (p.vec4) {
+    // narrow rows, four columns per thread (F % 4 == 0, 16-byte aligned rows, fp32 gradient): 32-bit index arithmetic and
+    // 16-byte accesses (the flat loop below divided a 64-bit index twice per ELEMENT: 59 us for the 10 MB mel spectrogram)
+    const int q4 = p.F >> 2;
+    const unsigned total4 = (unsigned)p.N * (unsigned)p.T * (unsigned)q4;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += gridDim.x * blockDim.x) {
+      const unsigned nt = i / (unsigned)q4, f = (i - nt * (unsigned)q4) * 4u;
+      const unsigned n = nt / (unsigned)p.T, t = nt - n * (unsigned)p.T;
+      const long prow = (long)n * p.P + p.padl + t;
+      const float4 a = *(const float4*)(p.pred + prow * p.ldp + f);
+      const float4 b = *(const float4*)(p.target + (long)nt * p.F + f);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+      float g[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = av[j] - bv[j], ab = fabsf(d);
+        s_all += ab;
+        const bool pr = (int)f + j < p.n_prio;
+        if (pr) s_pr += ab;
+        g[j] = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * (p.w_all + (pr ? p.w_prio : 0.f));
+      }
+      if (p.dpred) *(float4*)((float*)p.dpred + prow * p.ldd + f) = make_float4(g[0], g[1], g[2], g[3]);
     }
   } else {
     const long total = (long)p.N * p.T * p.F;
@@ -750,9 +823,20 @@ extern "C" int ns_l1_loss(const ns_l1_loss_params* p, ns_stream_t s) {
   const long rows = (long)p->N * p->T, total = rows * p->F;
   if (total <= 0) return NS_OK;
   if (p->F >= 256) {
-    hipLaunchKernelGGL(l1_loss_kernel<true>, dim3((int)min((long)2048, (rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, *p);
+    ns_l1_loss_params q = *p;
+    auto al = [](const void* x, int b) { return (((uintptr_t)x) % b) == 0; };
+    q.vec4 = p->ldp % 4 == 0 && al(p->pred, 16) && al(p->target, 4) &&
+             (!p->dpred || (p->ldd % 4 == 0 && al(p->dpred, p->dpred_dtype == NS_BF16 ? 8 : 16)));
+    // every block ends in two float atomics on the SAME two words: 2048 blocks spent ~60 us queueing there (the L2 takes
+    // same-address atomics one at a time) - 512 blocks keep the loads in flight that the memory system needs
+    hipLaunchKernelGGL(l1_loss_kernel<true>, dim3((int)min((long)512, (rows + 3) / 4)), dim3(256), 0, (hipStream_t)s, q);
   } else {
-    hipLaunchKernelGGL(l1_loss_kernel<false>, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)s, *p);
+    ns_l1_loss_params q = *p;
+    auto al16 = [](const void* x) { return (((uintptr_t)x) & 15) == 0; };
+    q.vec4 = p->F % 4 == 0 && p->ldp % 4 == 0 && al16(p->pred) && al16(p->target) && total / 4 < 0x7fffffffL &&
+             (!p->dpred || (p->dpred_dtype == NS_F32 && p->ldd % 4 == 0 && al16(p->dpred)));
+    const long items = q.vec4 ? total / 4 : total;
+    hipLaunchKernelGGL(l1_loss_kernel<false>, dim3((int)min((long)256, (items + 255) / 256)), dim3(256), 0, (hipStream_t)s, q);
   }
   NS_CHECK_LAUNCH("l1_loss");
   return NS_OK;
@@ -766,12 +850,12 @@ __global__ void sumsq_kernel(ns_sumsq_params p) {
   const long n4 = p.n / 4;
   const float4* x4 = (const float4*)p.x;
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 4 * stride) {      // four 16-byte loads in flight
-    float4 v[4];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += 8 * stride) {      // eight 16-byte loads in flight
+    float4 v[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = i + u * stride < n4 ? x4[i + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int u = 0; u < 8; ++u) v[u] = i + u * stride < n4 ? x4[i + u * stride] : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
+    for (int u = 0; u < 8; ++u) s += v[u].x * v[u].x + v[u].y * v[u].y + v[u].z * v[u].z + v[u].w * v[u].w;
   }
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.n; i += (long)gridDim.x * blockDim.x)
     s += p.x[i] * p.x[i];
@@ -803,7 +887,8 @@ extern "C" int ns_sumsq(const ns_sumsq_params* p, ns_stream_t s) {
   NS_CHECK_ARG(p && p->x && p->out, "ns_sumsq: null");
   NS_CHECK_ARG((((uintptr_t)p->x) & 15) == 0, "ns_sumsq: x must be 16-byte aligned");
   if (p->n <= 0) return NS_OK;
-  int grid = (int)min((long)1024, (p->n / 4 + 255) / 256 + 1);
+  // (512 blocks: every block ends in an atomic on one counter, and the L2 takes same-address atomics one at a time)
+  int grid = (int)min((long)512, (p->n / 4 + 255) / 256 + 1);
   hipLaunchKernelGGL(sumsq_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, *p);
   NS_CHECK_LAUNCH("sumsq");
   return NS_OK;
