@@ -462,7 +462,7 @@ struct AttnPost {
   float* dkeys_t;          // [N,A,Tia] out (plain store)
   float* dv; float* dwcl;  // +=
   float* part;             // optional [N * position blocks][1 + MAXKW][A]: parked partial sums (fixed-order finish)
-  int dbg;                 // NS_POST_DBG (diagnostics): 1 = a barrier in front of the stage store, 2 = the run-time-kw kernel
+  int dbg;                 // NS_POST_DBG (diagnostics): 1 = a barrier in front of the stage store, 2 = the run-time-kw kernel, 4 = no early exit
 };
 template <int KW>          // KW = the filter width when it is the usual 7 (straight-line step), 0 = a.kw at run time
 __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
@@ -478,6 +478,21 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
   const int kw = KW ? KW : a.kw;
   const int half = (kw - 1) / 2;
   const bool wave_on = u0 < A;                       // idle waves still stage and meet the barriers
+  if (tc * 64 >= L && !(a.dbg & 4)) {
+    // every position of this block lies past the utterance's length: all its terms are zero (d energy is masked there).
+    // Store the zeros and leave - with lengths ~U(T/2, T) a fifth of the blocks of a batch end here (block-uniform: no
+    // barrier has been reached yet)
+    if (wave_on) {
+#pragma unroll
+      for (int j = 0; j < PU; ++j) {
+        if (u0 + j < A) {
+          if (t < Tia) a.dkeys_t[((long)n * A + u0 + j) * Tia + t] = 0.f;
+          if (a.part && lane <= kw) a.part[(((long)n * gridDim.x + tc) * (1 + MAXKW) + lane) * A + u0 + j] = 0.f;
+        }
+      }
+    }
+    return;
+  }
   if (wave_on) {
     for (int i = lane; i < (1 + MAXKW) * PU; i += 64) {
       const int j = i % PU, k = i / PU;   // k = 0: v, k >= 1: wcl[k-1]
