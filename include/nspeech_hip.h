@@ -393,6 +393,50 @@ typedef struct {
 } ns_lstm_step_params;
 int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t stream);
 
+/* rows32: at most 32 activation rows against a weight matrix that stays FIXED over many calls - the step products
+ * of batched free-running synthesis (tacotron2.py:55-83 under TacoTestHelper, helpers.py:7-38: a dense layer or an
+ * LSTMBlockCell on [input | h_prev] rows per decoder step, nothing hoistable), which are bound by streaming the weights
+ * (62 MB per step for the two decoder LSTMs).  Both operands can live in memory as the split-bf16 (hi, lo) MFMA
+ * fragments the kernel consumes, so that every wave instruction loads consecutive bytes and nothing is converted:
+ *   weights: ns_rows32_pack writes them ONCE per synthesis call.  w: [K, C] row-major (the TF kernel as stored), row
+ *     stride ldw.  cell_units = 0: dense, column tile t = columns 16 t .. 16 t + 15; cell_units = H > 0 (C = 4 H): tile
+ *     t = units 4 t .. 4 t + 3 x the gates i, j, f, o.  K % 8 == 0.  packed: ns_rows32_packed_bytes(K, C) bytes.
+ *   activations ("packed rows"): a buffer of ns_rows32_rows_bytes(K) bytes holds 32 rows x K columns (K rounded up to
+ *     32); the caller ZEROES it once (rows past N and columns past K must stay finite), ns_rows32 / ns_attention_step
+ *     write into column ranges of it (rows_out, ctx_rows) and ns_rows32 reads its operand out of it (a_rows; the operand
+ *     may be a column range [a_rows_col, a_rows_col + K) of a wider buffer, a_rows_col % 32 == 0).  ns_rows32_pack_rows
+ *     converts fp32 rows into columns [col0, col0 + K) of such a buffer (rows_K = its width).
+ *   fp32 activation rows (a, a_sn) are accepted too and split in registers. */
+size_t ns_rows32_packed_bytes(int K, int C);
+int ns_rows32_pack(const float* w, int64_t ldw, int K, int C, int cell_units, void* packed, ns_stream_t stream);
+size_t ns_rows32_rows_bytes(int K);
+int ns_rows32_pack_rows(const float* a, int64_t a_sn, int N, int K, void* rows, int rows_K, int col0, ns_stream_t stream);
+typedef struct {
+  int N, K, C;                     /* rows (<= 32), contraction, output columns (4 H in the cell form) */
+  const float* a; int64_t a_sn;    /* fp32 activation rows, K floats each (16-byte aligned rows), or NULL with a_rows */
+  const void* a_rows; int a_rows_K, a_rows_col;   /* packed rows of width a_rows_K; the operand starts at column a_rows_col */
+  const void* packed;              /* ns_rows32_pack of the [K, C] weights with the same cell_units */
+  int f32_passes;                  /* 1 (bf16 operands) or 3 (split-bf16: hi.hi + hi.lo + lo.hi) */
+  const float* bias;               /* [C], nullable */
+  /* dense form (cell_units = 0): y[n, c] = act(a[n] . w[:, c] + bias[c] + add[n, c]) */
+  const float* add; int64_t add_sn;
+  int act;
+  /* destinations of y (dense) / h (cell), each optional, at least one: two fp32 row sets and two column ranges of
+   * packed rows (width rows_out_K, first column rows_out_col) */
+  float* out; int64_t out_sn;
+  float* out2; int64_t out2_sn;
+  void* rows_out; int rows_out_K, rows_out_col;
+  void* rows_out2; int rows_out2_K, rows_out2_col;
+  /* cell form (cell_units = H): the arguments of ns_lstm_step_params with the same meaning */
+  int cell_units;
+  const float* c_prev; int64_t c_sn;   /* NULL = zeros */
+  float* c_out; int64_t co_sn;
+  float forget_bias;
+  float zoneout_cell, zoneout_output;
+  const float* h_prev; int64_t hp_sn;
+} ns_rows32_params;
+int ns_rows32(const ns_rows32_params* p, ns_stream_t stream);
+
 /* One location-sensitive attention step (attention.py:30-60): energies, masked softmax, context. */
 typedef struct {
   int dtype, N, Ti, Pi, padl_i, Tia, A, E, kw;
@@ -405,6 +449,13 @@ typedef struct {
   void* ctx_out2; int64_t ctx2_sn;  /* optional */
   const float* wcl; const float* v;
   float* e_raw;                     /* fp32 [N,Tia] scratch */
+  /* optional, same launch: a second value matrix pv (dtype) [N*Pi, E2] - free-running synthesis hands in the projected
+   * memory values . W_prenet1[context rows], whose weighted sum pv_out[n, 0:E2] is the context term of the NEXT step's
+   * first prenet layer (no context -> prenet product inside the loop) */
+  const void* pv; int E2;
+  void* pv_out; int64_t pv_out_sn;
+  /* optional: the context also as columns [ctx_rows_col, ctx_rows_col + E) of ns_rows32's packed rows (width ctx_rows_K) */
+  void* ctx_rows; int ctx_rows_K, ctx_rows_col;
 } ns_attention_step_params;
 int ns_attention_step(const ns_attention_step_params* p, ns_stream_t stream);
 /* keys_t[n,u,t] = keys[n, padl+t, u] */

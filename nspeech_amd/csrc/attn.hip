@@ -76,6 +76,10 @@ struct AttnStep {
   T* ctx_out2; long ctx2_sn;           // optional second destination
   const float* wcl; const float* v;
   const float* add; long add_sn; int relu;   // optional: ctx_out = relu?(weighted sum + add[n*add_sn + c])
+  // optional second value matrix in the same launch (free-running synthesis: the projected memory, whose weighted sum
+  // is the context term of the NEXT step's prenet layer): column chunks past nch take pv / E2 / pv_out
+  const T* pv; long pv_sn; int E2, nch; T* pv_out; long pvo_sn;
+  bf16_t* ctx_rows; int cr_nkc, cr_col;      // optional: the context into ns_rows32's packed rows (row n = the utterance)
 };
 
 // x[t,u] = keys[t,u] + q[u] + sum_k align_prev[t+k-half] Wcl[k,u];  lane = t, wave = unit chunk.
@@ -111,16 +115,27 @@ __global__ __launch_bounds__(ATHREADS) void attn_energy_kernel(AttnStep<T> a) {
     float kv[UB];
 #pragma unroll
     for (int j = 0; j < UB; ++j) kv[j] = (act && ub + j < ue) ? kt[(long)(ub + j) * Tia + t] : 0.f;
-    // stage this block's constants (wave-private LDS region, no block barrier needed)
-    for (int i = lane; i < UB * CPU; i += 64) {
-      const int j = i / CPU, f = i % CPU, u = ub + j;
-      float val = 0.f;
+    // stage this block's constants (wave-private LDS region, no block barrier needed): lane -> (unit j, half); half 0
+    // fetches q, v, w0..w2, half 1 w3..w7 - ten independent loads per lane in flight at once (the former loop over
+    // (unit, field) pairs issued its loads one dependent iteration after the other: 6 round trips per step)
+    {
+      static_assert(UB == 32, "one unit per half-wave lane");
+      const int j = lane & (UB - 1), hf = lane >> 5, u = ub + j;
+      float c[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
       if (u < ue) {
-        if (f == 0) val = qn[u];
-        else if (f == 1) val = a.v[u];
-        else if (f - 2 < a.kw) val = a.wcl[(f - 2) * A + u];
+        if (hf == 0) {
+          c[0] = qn[u]; c[1] = a.v[u];
+#pragma unroll
+          for (int k = 0; k < 3; ++k) c[2 + k] = k < a.kw ? a.wcl[k * A + u] : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 3; k < MAXKW; ++k) c[k - 3] = k < a.kw ? a.wcl[k * A + u] : 0.f;
+        }
       }
-      cst[wv][i] = val;
+      float* d = &cst[wv][j * CPU + (hf ? 5 : 0)];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) d[i] = c[i];
+      if (hf) { d[5] = 0.f; d[6] = 0.f; }
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -154,11 +169,14 @@ constexpr int CCH = 128;   // context columns per workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void attn_context_kernel(AttnStep<T> a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int Ti = a.Ti, E = a.E, Tia = a.Tia;
+  const int Ti = a.Ti, Tia = a.Tia;
   float* al = sm;
   float* red = al + Tia;
   float* cpart = red + 32;
-  const int n = blockIdx.y, ch = blockIdx.x;
+  const int n = blockIdx.y;
+  const bool second = a.pv && (int)blockIdx.x >= a.nch;
+  const int ch = second ? blockIdx.x - a.nch : blockIdx.x;
+  const int E = second ? a.E2 : a.E;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int L = min(a.lengths ? a.lengths[n] : Ti, Ti);
   const float* er = a.e_raw + (long)n * Tia;
@@ -172,13 +190,13 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnStep<T> a) {
   for (int t = tid; t < Tia; t += 256) {
     const float v = t < L ? __expf(er[t] - mx) * inv : 0.f;
     al[t] = v;
-    if (ch == 0) {
+    if (blockIdx.x == 0) {
       a.aout[(long)n * a.al_sn + t] = v;
       if (a.aout_t) stf(a.aout_t + (long)n * a.al_sn + t, v);
     }
   }
   __syncthreads();
-  const T* values = a.values + (long)n * a.values_sn;
+  const T* values = second ? a.pv + (long)n * a.pv_sn : a.values + (long)n * a.values_sn;
   const int c = ch * CCH + (lane & 15) * 8;
   const int rg = lane >> 4;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -206,10 +224,15 @@ __global__ __launch_bounds__(256) void attn_context_kernel(AttnStep<T> a) {
     const int cc = ch * CCH + i;
     if (cc < E) {
       float v = cpart[i] + cpart[CCH + i] + cpart[2 * CCH + i] + cpart[3 * CCH + i];
+      if (second) {
+        stf(a.pv_out + (long)n * a.pvo_sn + cc, v);
+        continue;
+      }
       if (a.add) v += a.add[(long)n * a.add_sn + cc];
       if (a.relu) v = fmaxf(v, 0.f);
       stf(a.ctx_out + (long)n * a.ctx_sn + cc, v);
       if (a.ctx_out2) stf(a.ctx_out2 + (long)n * a.ctx2_sn + cc, v);
+      if (a.ctx_rows) ns_rows32_store(a.ctx_rows, a.cr_nkc, n, a.cr_col + cc, v);
     }
   }
 }
@@ -1015,6 +1038,9 @@ extern "C" int ns_attention_step(const ns_attention_step_params* p, ns_stream_t 
                "ns_attention_step: unsupported shape");
   const size_t lds = sizeof(float) * ((size_t)p->Tia + 32 + 4 * CCH);
   NS_CHECK_ARG(lds <= 64 * 1024, "ns_attention_step: T_in too long for LDS");
+  NS_CHECK_ARG(!p->pv || (p->pv_out && p->E2 > 0 && p->E2 % 8 == 0), "ns_attention_step: pv needs pv_out and E2 %% 8 == 0");
+  NS_CHECK_ARG(!p->ctx_rows || (p->N <= 32 && p->ctx_rows_col >= 0 && p->ctx_rows_col + p->E <= ((p->ctx_rows_K + 31) / 32) * 32),
+               "ns_attention_step: ctx_rows needs N <= 32 and the context columns inside the packed rows");
   auto run = [&](auto tag) -> int {
     using T = decltype(tag);
     AttnStep<T> a = {};
@@ -1025,8 +1051,18 @@ extern "C" int ns_attention_step(const ns_attention_step_params* p, ns_stream_t 
     a.aprev = p->aprev; a.aout = p->aout; a.al_sn = p->al_sn; a.aout_t = nullptr;
     a.ctx_out = (T*)p->ctx_out; a.ctx_sn = p->ctx_sn; a.ctx_out2 = (T*)p->ctx_out2; a.ctx2_sn = p->ctx2_sn;
     a.wcl = p->wcl; a.v = p->v; a.e_raw = p->e_raw;
+    a.nch = ceil_div(p->E, CCH);
+    int chunks = a.nch;
+    if (p->pv) {
+      a.pv = (const T*)p->pv + (long)p->padl_i * p->E2; a.pv_sn = (long)p->Pi * p->E2; a.E2 = p->E2;
+      a.pv_out = (T*)p->pv_out; a.pvo_sn = p->pv_out_sn;
+      chunks += ceil_div(p->E2, CCH);
+    }
+    if (p->ctx_rows) {
+      a.ctx_rows = (bf16_t*)p->ctx_rows; a.cr_nkc = (p->ctx_rows_K + 31) / 32; a.cr_col = p->ctx_rows_col;
+    }
     hipLaunchKernelGGL(attn_energy_kernel<T>, dim3(ceil_div(p->Ti, 64), p->N), dim3(ATHREADS), 0, s, a);
-    hipLaunchKernelGGL(attn_context_kernel<T>, dim3(ceil_div(p->E, CCH), p->N), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(attn_context_kernel<T>, dim3(chunks, p->N), dim3(256), lds, s, a);
     NS_CHECK_LAUNCH("attention_step");
     return NS_OK;
   };

@@ -176,6 +176,15 @@ __device__ __forceinline__ f32x4 mfma_split(const bf16x8& ah, const bf16x8& al, 
 }
 
 
+// ns_rows32's packed activation rows (rows32.hip): value v of row n, column k as its (hi, lo) pair at its MFMA fragment
+// position - [row tile n / 16][chunk k / 32][lane (k / 8 % 4) * 16 + n % 16][plane][k % 8]
+__device__ __forceinline__ void ns_rows32_store(bf16_t* base, int nkc, int n, int k, float v) {
+  const long i16 = (((long)(n >> 4) * nkc + (k >> 5)) * 64 + ((k >> 3) & 3) * 16 + (n & 15)) * 2;
+  const bf16_t h = (bf16_t)v;
+  base[i16 * 8 + (k & 7)] = h;
+  base[(i16 + 1) * 8 + (k & 7)] = (bf16_t)(v - (float)h);
+}
+
 // ---------------------------------------------------------------- bounded spins of the persistent kernels
 // Every wait of a persistent kernel is bounded in WALL-CLOCK time, not in iterations: a workgroup that cannot be placed
 // because a foreign kernel (a collective's channel kernel, a weight-gradient product on the second stream) holds its CU

@@ -179,6 +179,103 @@ def _decode_steps(m, N, Ti, Pi, Tia, S, S1, enc, keys_t):
 
     return dec, al
 
+def _rows32_ok(m, N):
+    """The packed step products (ns_rows32) cover fp32 decoder activations on the matrix core (`mixed`, `bf16x3`)."""
+    hp = m._hparams
+    return (getattr(m, "use_rows32", True) and m.T == torch.float32 and ops.F32_PASSES in (1, 3) and N <= 32
+            and (128 + m.Dsp + hp.attention_dim) % 8 == 0)
+
+
+def _decode_rows32(m, N, Ti, Pi, Tia, S, S1, enc, keys_t):
+    """Batched free-running decoder, one step = 8 dependent launches over weights packed once per call and activations
+    kept as MFMA fragments (csrc/rows32.hip: the step is bound by streaming the two decoder LSTMs' 62 MB).  As in the
+    one-launch decoder the frame feedback is folded into the first prenet layer (p1 = relu(h2 . (W_proj[last frame] .
+    W1[frame rows]) + ...), exact fp32 fold) and its context term comes from the projected memory (align . (memory .
+    W1[context rows])) inside the attention step, so neither the output projection nor a context product sits in the
+    loop; the frames themselves are one product over the h2 history afterwards (tacotron2.py:73).  The [input | h_prev]
+    operand rows alternate between two packed buffers (step parity): a step's cells write the next step's h_prev columns
+    while their own operand is still being read."""
+    hp = m._hparams
+    f32 = torch.float32
+    r, M = hp.outputs_per_step, hp.num_mels
+    E, A, D = 2 * hp.encoder_lstm_units, hp.attention_dim, hp.decoder_lstm_units
+    buf, o, fp = m._buf, m._o, m.flat_p
+    Dsp = m.Dsp
+    XA, X1, X2 = 128 + Dsp + A, A + E + D, 2 * D
+    rf = ops.rows32_rows_floats
+    xa = [buf("r32_xa%d" % i, rf(XA), f32) for i in (0, 1)]      # [p2 | speaker projection | h_att_prev]
+    x1 = [buf("r32_x1%d" % i, rf(X1), f32) for i in (0, 1)]      # [h_att | ctx | h1_prev]
+    x2 = [buf("r32_x2%d" % i, rf(X2), f32) for i in (0, 1)]      # [h1 | h2_prev]
+    p1 = buf("r32_p1", rf(256), f32)
+    h1 = [buf("r32_h1%d" % i, N * D, f32) for i in (0, 1)]       # fp32 h of the step before (zoneout expectation)
+    h2 = buf("r32_h2", N * S1 * D, f32)                          # h2 history: the frames come from it after the loop
+    pvc = buf("r32_pvc", N * 256, f32)                           # align . projected memory of the step before
+    ca = [buf("r32_ca%d" % i, N * A, f32) for i in (0, 1)]
+    c1 = [buf("r32_c1%d" % i, N * D, f32) for i in (0, 1)]
+    c2 = [buf("r32_c2%d" % i, N * D, f32) for i in (0, 1)]
+    q = buf("r32_q", N * A, f32)
+    ctx = buf("r32_ctx", N * E, f32)
+    al = buf("r32_al", N * S1 * Tia, f32)
+    er = buf("r32_eraw", N * Tia, f32)
+    dec = buf("r32_dec", N * S1 * M * r, f32)
+    for b in xa + x1 + x2 + h1 + [p1, h2, al, pvc]:
+        b.zero_()
+    if Dsp:
+        for i in (0, 1):
+            ops.rows32_pack_rows(m._speaker_fwd(N), Dsp, N, Dsp, xa[i], XA, 128)
+    # folded feedback (exact fp32): wpf = W_proj[:, last frame] . W1[frame rows], bpf = b_proj[last frame] . same + b1
+    w1 = o("decoder/decoder_prenet/dense_1/kernel")
+    b1 = o("decoder/decoder_prenet/dense_1/bias")
+    kp, bp = o("decoder/output_projection/kernel"), o("decoder/output_projection/bias")
+    wpf = buf("r32_wpf", D * 256, f32)
+    bpf = buf("r32_bpf", 256, f32)
+    ops.gemm(fp, fp, wpf, D, 256, M, M * r, 256, 256, b_mode=1, a_off=kp + (r - 1) * M, b_off=w1, f32_passes=0)
+    ops.gemm(fp, fp, bpf, 1, 256, M, M * r, 256, 256, b_mode=1, a_off=bp + (r - 1) * M, b_off=w1, bias=fp, bias_off=b1,
+             f32_passes=0)
+    pv = buf("r32_pv", N * Pi * 256, f32)
+    ops.gemm(enc, fp, pv, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
+
+    def pack(key, w, K, Cc, cell=0):
+        return ops.rows32_pack(w, K, Cc, cell_units=cell, out=buf(key, ops.rows32_packed_floats(K, Cc), f32))
+    k_wpf = pack("r32_k_wpf", wpf, D, 256)
+    k_w2 = pack("r32_k_w2", (fp, o("decoder/decoder_prenet/dense_2/kernel")), 256, 128)
+    k_att = pack("r32_k_att", (fp, o("decoder/attention_lstm/kernel")), XA, 4 * A, A)
+    k_wq = pack("r32_k_wq", (fp, o("decoder/attention/query_layer/kernel")), A, A)
+    k_l1 = pack("r32_k_l1", (fp, o("decoder/lstm_1/kernel")), X1, 4 * D, D)
+    k_l2 = pack("r32_k_l2", (fp, o("decoder/lstm_2/kernel")), X2, 4 * D, D)
+    b2, batt = o("decoder/decoder_prenet/dense_2/bias"), o("decoder/attention_lstm/bias")
+    bl1, bl2 = o("decoder/lstm_1/bias"), o("decoder/lstm_2/bias")
+    vatt = (fp, o("decoder/attention/attention_v"))
+    zr, ps = m.zoneout_rate, ops.F32_PASSES
+    for s in range(S):
+        sl = s + 1
+        c, n = s & 1, (s & 1) ^ 1          # this step's operand rows, the next step's
+        first = s == 0
+        # prenet: p1 = relu(frame term + context term + b1) - the <GO> frame and the initial context are zeros
+        ops.rows32(None, 0, k_wpf, N, D, 256, bias=(fp, b1) if first else bpf, add=None if first else pvc, add_sn=256,
+                   act=ACT_RELU, f32_passes=ps, a_rows=(x2[c], X2, D), rows_out=(p1, 256, 0))
+        ops.rows32(None, 0, k_w2, N, 256, 128, bias=(fp, b2), act=ACT_RELU, f32_passes=ps, a_rows=(p1, 256, 0),
+                   rows_out=(xa[c], XA, 0))
+        # attention LSTM on [p2 | speaker | h_att_prev]; h_att -> this step's x1 head and the next step's xa tail
+        ops.rows32(None, 0, k_att, N, XA, 4 * A, bias=(fp, batt), cell_units=A, c_prev=None if first else ca[n], c_sn=A,
+                   c_out=ca[c], co_sn=A, f32_passes=ps, a_rows=(xa[c], XA, 0), rows_out=(x1[c], X1, 0),
+                   rows_out2=(xa[n], XA, 128 + Dsp))
+        ops.rows32(None, 0, k_wq, N, A, A, q, A, f32_passes=ps, a_rows=(x1[c], X1, 0))
+        # energies, softmax, context (into x1) and the next prenet layer's context term
+        ops.attention_step(q, N, Ti, Pi, PADL, Tia, A, E, 7, m.input_lengths, keys_t, enc, q, A, (al, s * Tia),
+                           (al, sl * Tia), S1 * Tia, ctx, E, None, 0, m.tsh["wcl"], vatt, er, pv=pv, E2=256, pv_out=pvc,
+                           pv_out_sn=256, ctx_rows=(x1[c], X1, A))
+        # decoder LSTMs on [input | h_prev]
+        ops.rows32(None, 0, k_l1, N, X1, 4 * D, h1[c], D, bias=(fp, bl1), cell_units=D, c_prev=None if first else c1[n],
+                   c_sn=D, c_out=c1[c], co_sn=D, zoneout=zr, h_prev=h1[n], hp_sn=D, f32_passes=ps, a_rows=(x1[c], X1, 0),
+                   rows_out=(x2[c], X2, 0), rows_out2=(x1[n], X1, A + E))
+        ops.rows32(None, 0, k_l2, N, X2, 4 * D, (h2, sl * D), S1 * D, bias=(fp, bl2), cell_units=D,
+                   c_prev=None if first else c2[n], c_sn=D, c_out=c2[c], co_sn=D, zoneout=zr, h_prev=(h2, s * D),
+                   hp_sn=S1 * D, f32_passes=ps, a_rows=(x2[c], X2, 0), rows_out=(x2[n], X2, D))
+    # the output projection over the whole history, off the loop's critical path
+    ops.gemm(h2, fp, dec, N * S1, M * r, D, D, M * r, M * r, b_mode=1, b_off=kp, bias=fp, bias_off=bp)
+    return dec, al
+
 
 def forward_infer(m):
     """Runs the synthesis graph.  The first call with a given (N, T_in, max_iters) signature runs eagerly (it also
@@ -254,10 +351,14 @@ def _infer_body(m):
     # (the one-launch decoder has plain cells: with a zoneout rate the step launches apply its expectation)
     one_launch = getattr(m, "use_decode_kernel", True) and m.zoneout_rate <= 0.0
     done = _decode_persistent(m, N, Ti, Pi, Tia, S, enc, keys) if one_launch else None
-    m.last_paths["decode"] = "persistent" if done is not None else "step"
     if done is not None:
+        m.last_paths["decode"] = "persistent"
         dec, al, S1 = done
+    elif _rows32_ok(m, N):
+        m.last_paths["decode"] = "rows32"
+        dec, al = _decode_rows32(m, N, Ti, Pi, Tia, S, S1, enc, keys_t)
     else:
+        m.last_paths["decode"] = "step"
         dec, al = _decode_steps(m, N, Ti, Pi, Tia, S, S1, enc, keys_t)
 
     # ---- postnet, residual, expand, linear head (inference BatchNorm)

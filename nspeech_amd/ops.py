@@ -487,13 +487,72 @@ def keys_transpose_add(keys, keys_t, N, Ti, Tia, Pi, padl, A):
 
 
 def attention_step(like, N, Ti, Pi, padl, Tia, A, E, kw, lengths, keys_t, values, q, q_sn, aprev, aout, al_sn, ctx_out,
-                   ctx_sn, ctx_out2, ctx2_sn, wcl, v, e_raw):
+                   ctx_sn, ctx_out2, ctx2_sn, wcl, v, e_raw, pv=None, E2=0, pv_out=None, pv_out_sn=0, ctx_rows=None):
     p = L.struct("ns_attention_step_params")
+    if pv is not None:
+        _fill(p, pv=ptr(pv), E2=E2, pv_out=_pp(pv_out), pv_out_sn=pv_out_sn)
+    if ctx_rows is not None:
+        _fill(p, ctx_rows=ptr(ctx_rows[0]), ctx_rows_K=ctx_rows[1], ctx_rows_col=ctx_rows[2])
     _fill(p, dtype=dt(like), N=N, Ti=Ti, Pi=Pi, padl_i=padl, Tia=Tia, A=A, E=E, kw=kw, lengths=ptr(lengths),
           keys_t=ptr(keys_t), values=ptr(values), q=_pp(q), q_sn=q_sn, aprev=_pp(aprev), aout=_pp(aout), al_sn=al_sn,
           ctx_out=_pp(ctx_out), ctx_sn=ctx_sn, ctx_out2=_pp(ctx_out2), ctx2_sn=ctx2_sn, wcl=_pp(wcl), v=_pp(v),
           e_raw=ptr(e_raw))
     L.call("ns_attention_step", p, stream())
+
+
+def rows32_packed_floats(K, Cc):
+    fn = L.lib().ns_rows32_packed_bytes
+    fn.restype = C.c_size_t
+    return int(fn(K, Cc)) // 4
+
+
+def rows32_pack(w, K, Cc, ldw=None, cell_units=0, out=None):
+    """The [K, Cc] fp32 matrix at `w` (tensor or (tensor, offset)) as ns_rows32's packed split-bf16 fragments."""
+    t = w[0] if isinstance(w, tuple) else w
+    packed = out if out is not None else torch.empty(rows32_packed_floats(K, Cc), dtype=torch.float32, device=t.device)
+    L.check(L.lib().ns_rows32_pack(C.c_void_p(_pp(w)), C.c_int64(ldw if ldw is not None else Cc), K, Cc, cell_units,
+                                   C.c_void_p(ptr(packed)), C.c_void_p(stream())), "ns_rows32_pack")
+    return packed
+
+
+def rows32_rows(K, device):
+    """Zeroed packed activation rows (32 rows x K columns) for ns_rows32 / ns_attention_step."""
+    fn = L.lib().ns_rows32_rows_bytes
+    fn.restype = C.c_size_t
+    return torch.zeros(int(fn(K)) // 4, dtype=torch.float32, device=device)
+
+
+def rows32_rows_floats(K):
+    fn = L.lib().ns_rows32_rows_bytes
+    fn.restype = C.c_size_t
+    return int(fn(K)) // 4
+
+
+def rows32_pack_rows(a, a_sn, N, K, rows, rows_K, col0=0):
+    """fp32 rows `a` (tensor or (tensor, offset)) into columns [col0, col0 + K) of packed rows of width rows_K."""
+    L.check(L.lib().ns_rows32_pack_rows(C.c_void_p(_pp(a)), C.c_int64(a_sn), N, K, C.c_void_p(ptr(rows)), rows_K, col0,
+                                        C.c_void_p(stream())), "ns_rows32_pack_rows")
+
+
+def rows32(a, a_sn, packed, N, K, Cc, out=None, out_sn=0, bias=None, add=None, add_sn=0, act=0, out2=None, out2_sn=0,
+           cell_units=0, c_prev=None, c_sn=0, c_out=None, co_sn=0, forget_bias=1.0, zoneout=0.0, h_prev=None, hp_sn=0,
+           f32_passes=3, a_rows=None, rows_out=None, rows_out2=None):
+    """ns_rows32: <= 32 rows against packed weights; dense (+bias, +add, act) or, with cell_units = H, an LSTMBlockCell on
+    [input | h_prev] rows (destinations receive h).  The operand is fp32 rows (a, a_sn) or a_rows = (packed rows, their
+    width, first column); rows_out / rows_out2 = (packed rows, width, first column) destinations.  Tensor arguments may
+    be (tensor, element offset) pairs."""
+    p = L.struct("ns_rows32_params")
+    _fill(p, N=N, K=K, C=Cc, a=_pp(a), a_sn=a_sn, packed=ptr(packed), f32_passes=f32_passes, bias=_pp(bias), add=_pp(add),
+          add_sn=add_sn, act=act, out=_pp(out), out_sn=out_sn, out2=_pp(out2), out2_sn=out2_sn, cell_units=cell_units,
+          c_prev=_pp(c_prev), c_sn=c_sn, c_out=_pp(c_out), co_sn=co_sn, forget_bias=forget_bias,
+          zoneout_cell=float(zoneout), zoneout_output=float(zoneout), h_prev=_pp(h_prev), hp_sn=hp_sn)
+    if a_rows is not None:
+        _fill(p, a_rows=ptr(a_rows[0]), a_rows_K=a_rows[1], a_rows_col=a_rows[2])
+    if rows_out is not None:
+        _fill(p, rows_out=ptr(rows_out[0]), rows_out_K=rows_out[1], rows_out_col=rows_out[2])
+    if rows_out2 is not None:
+        _fill(p, rows_out2=ptr(rows_out2[0]), rows_out2_K=rows_out2[1], rows_out2_col=rows_out2[2])
+    L.call("ns_rows32", p, stream())
 
 
 def attention_step_bwd(like, N, Ti, Pi, padl, Tia, A, E, kw, lengths, keys, keys_t, values, q, q_sn, acur, aprev, al_sn,

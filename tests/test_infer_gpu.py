@@ -56,7 +56,7 @@ def test_inference_graph_replay_matches_eager(dev, N):
         for name in ("mel_outputs", "linear_outputs", "alignments"):
             got, ref = getattr(m, name).float(), getattr(e, name).float()
             assert torch.equal(got, ref), (seed, name, (got - ref).abs().max().item())
-    assert m.last_paths["decode"] == ("persistent" if N <= 2 else "step")
+    assert m.last_paths["decode"] == ("persistent" if N <= 2 else "rows32")
 
 
 @pytest.mark.parametrize("N,mode", [(1, "mixed"), (2, "mixed"), (1, "fp32"), (1, "bf16")])
@@ -74,6 +74,7 @@ def test_persistent_decoder_loop_matches_the_step_launches_at_shipped_widths(dev
     for use in (True, False):
         m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=4)
         m.use_decode_kernel = use
+        m.use_rows32 = False
         m.use_graph = False
         m.initialize(inputs, lengths)
         torch.cuda.synchronize()
@@ -91,7 +92,36 @@ def test_persistent_decoder_loop_matches_the_step_launches_at_shipped_widths(dev
     assert (al.sum(1) - 1.0).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("N", [1, 2, 3])          # 1, 2: taco2_decode_kernel (one launch); 3: the launch-per-step loop
+@pytest.mark.parametrize("N", [5, 32])
+def test_packed_step_products_match_the_step_launches_at_shipped_widths(dev, N):
+    """The batched free-running loop on packed weights (ns_rows32: folded frame feedback, context term of the prenet from
+    the projected memory, seven launches a step) against the launch-per-step loop of round 2 on the same weights, `mixed`,
+    shipped widths, 40 free-running steps, a full batch of 32 and a ragged one."""
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models import create_model
+    hp = hparams_mod.load("taco2")
+    hp.max_iters = 40
+    inputs, lengths, _, _ = make_batch(hp, N, 37, 10, seed=5)
+    outs = []
+    for use in (True, False):
+        m = create_model("taco2", hp, device="cuda:0", dtype="mixed", seed=4)
+        m.use_rows32 = use
+        m.use_graph = False
+        m.initialize(inputs, lengths)
+        torch.cuda.synchronize()
+        assert m.last_paths["decode"] == ("rows32" if use else "step")
+        outs.append({k: getattr(m, k).float().clone() for k in ("decoder_outputs", "mel_outputs", "alignments")})
+        del m
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        err = (a - b).abs().max().item() / max(1.0, b.abs().max().item())
+        print("N %d %s: packed step products vs step launches max %.3e" % (N, k, err))
+        assert err < 2e-5, (k, err)
+    assert (outs[0]["alignments"].sum(1) - 1.0).abs().max().item() < 1e-4
+
+
+# 1, 2: taco2_decode_kernel (one launch); 3, 32: the launch-per-step loop (fp32) / the packed step products (mixed)
+@pytest.mark.parametrize("N", [1, 2, 3, 32])
 @pytest.mark.parametrize("mode", ["fp32", "mixed"])
 def test_free_running_decode_matches_oracle_at_shipped_widths(dev, N, mode):
     """free-running synthesis at the SHIPPED widths (attention 256, LSTM(1024), 512-wide memory, 1025
@@ -111,7 +141,7 @@ def test_free_running_decode_matches_oracle_at_shipped_widths(dev, N, mode):
     m.use_graph = False
     m.initialize(inputs, lengths)
     m.check_status()
-    assert m.last_paths["decode"] == ("persistent" if N <= 2 else "step")
+    assert m.last_paths["decode"] == ("persistent" if N <= 2 else "rows32" if mode == "mixed" else "step")
     # measured (profiles/r04_parity_fullwidth.txt, "free-running") -> bound; a free-running loop feeds its rounding back
     # fp32: 7.5e-7 rel max (mel); mixed: 9.6e-7 (mel), linear_outputs 6.4e-5 (the bf16 expand net)
     tol = {"fp32": dict(rel=2e-5, mel_l1=5e-6), "mixed": dict(rel=2e-5, mel_l1=5e-6)}[mode]
