@@ -94,12 +94,14 @@ def test_zoneout_wide_kernels_match_oracle_at_shipped_widths(dev, mode):
     print("zoneout %s: worst gradient rel L2 %.2e" % (mode, max(v[0] for v in rep["grad"].values())))
 
 
-def test_zoneout_inference_is_the_expectation(dev):
-    """Synthesis with a zoneout rate: c = z c_prev + (1 - z) c', h likewise, through the step launches."""
+@pytest.mark.parametrize("mode,path", [("fp32", "step"), ("mixed", "rows32")])
+def test_zoneout_inference_is_the_expectation(dev, mode, path):
+    """Synthesis with a zoneout rate: c = z c_prev + (1 - z) c', h likewise, through the step launches (exact fp32: ns_lstm_step;
+    `mixed`: the packed step products, ns_rows32)."""
     from oracle import taco2_oracle as O
     from nspeech_amd.models import create_model
     hp = small_hparams(max_iters=6, zoneout_rate=0.1)
-    m = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=2)
+    m = create_model("taco2", hp, device="cuda:0", dtype=mode, seed=2)
     inputs, lengths, _, _ = make_batch(hp, 2, 12, 10, seed=4)
     p = {k: torch.tensor(v, dtype=torch.float64) for k, v in m.numpy_params().items()}
     p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in m.numpy_stats().items()})
@@ -107,7 +109,7 @@ def test_zoneout_inference_is_the_expectation(dev):
         out = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths), zoneout=dict(rate=0.1))
         plain = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths))
     m.initialize(inputs, lengths)
-    assert m.last_paths["decode"] == "step"
+    assert m.last_paths["decode"] == path
     for name in ("decoder_outputs", "mel_outputs", "alignments"):
         got = getattr(m, name).float().cpu().numpy()
         ref = out[name].numpy()
