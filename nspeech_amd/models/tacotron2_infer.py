@@ -369,8 +369,11 @@ def _infer_body(m):
     x, cin, Cp = pin, M, hp.postnet_conv_channels
     for i in range(hp.postnet_conv_layers):
         act = ACT_TANH if i < hp.postnet_conv_layers - 1 else ACT_NONE
-        x = m._conv_fwd("decoder_postnet/postnet_conv_%d" % i, x, cin, Cp, hp.postnet_conv_width, act, N, To, Po,
-                        "post%d" % i, training=False)
+        # as in the training pass: a layer whose consumer runs on the 256-tile kernel hands its output over pre-split
+        nxt = i + 1 < hp.postnet_conv_layers and m._x256_split_ok("post%d" % (i + 1), N * Po, Cp, Cp, hp.postnet_conv_width)
+        split_in = isinstance(x, tuple)
+        x = m._conv_fwd("decoder_postnet/postnet_conv_%d" % i, None if split_in else x, cin, Cp, hp.postnet_conv_width, act,
+                        N, To, Po, "post%d" % i, training=False, xsplit=x if split_in else None, emit_split=nxt)
         cin = Cp
     mel = buf("mel_out", N * Po * M, torch.float32)
     ops.gemm(x, W, mel, N * Po, M, Cp, Cp, M, M, b_mode=1, b_off=o("decoder_postnet/dense/kernel"), bias=m.flat_p,
