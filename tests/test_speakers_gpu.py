@@ -130,12 +130,15 @@ def test_multi_speaker_other_precisions_and_adam(dev):
         assert big.any() and np.abs(got[k] - new_p[k].numpy())[big].max() < 2e-4, k
 
 
-def test_multi_speaker_synthesis_matches_oracle_and_graph_replay(dev):
+@pytest.mark.parametrize("mode,N,path", [("fp32", 2, "persistent"), ("mixed", 3, "rows32")])
+def test_multi_speaker_synthesis_matches_oracle_and_graph_replay(dev, mode, N, path):
+    """fp32, two utterances: the one-launch decoder; `mixed`, three: the packed step products, whose attention-LSTM operand
+    carries the speaker projection as a column range of packed rows (ns_rows32_pack_rows)."""
     hp = small_hparams(num_speakers=3, max_iters=6)
-    m = _model(hp, "fp32")
-    N, Ti = 2, 8
+    m = _model(hp, mode)
+    Ti = 8
     inputs, lengths, _, _ = make_batch(hp, N, Ti, 10, seed=9)
-    spk = np.array([1, 2], np.int32)
+    spk = np.array([1, 2, 0][:N], np.int32)
     from oracle import taco2_oracle as O
     p = {k: torch.tensor(v, dtype=torch.float64) for k, v in m.numpy_params().items()}
     p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in m.numpy_stats().items()})
@@ -143,16 +146,17 @@ def test_multi_speaker_synthesis_matches_oracle_and_graph_replay(dev):
         out = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths), max_iters=6,
                               speaker_ids=torch.tensor(spk))
     m.initialize(inputs, lengths, spk)                    # eager
+    assert m.last_paths["decode"] == path
     eager = m.mel_outputs.clone()
     assert _rel(eager.cpu().numpy(), out["mel_outputs"].numpy()) < 1e-3
     assert _rel(m.alignments.cpu().numpy(), out["alignments"].numpy()) < 1e-3
     m.initialize(inputs, lengths, spk)                    # captured
     m.initialize(inputs, lengths, spk)                    # replayed
     assert torch.equal(m.mel_outputs, eager)
-    m.initialize(inputs, lengths, np.array([0, 0], np.int32))      # replay with other speakers: static id buffer
+    m.initialize(inputs, lengths, np.zeros(N, np.int32))      # replay with other speakers: static id buffer
     other = m.mel_outputs.clone()
     assert (other - eager).abs().max() > 1e-5
     with torch.no_grad():
         out0 = O.taco2_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths), max_iters=6,
-                               speaker_ids=torch.tensor([0, 0]))
+                               speaker_ids=torch.tensor([0] * N))
     assert _rel(other.cpu().numpy(), out0["mel_outputs"].numpy()) < 1e-3
