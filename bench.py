@@ -189,7 +189,9 @@ def inference_bench(hp, dtype, seed=1234):
         dt = (time.perf_counter() - t0) / reps
         frames = N * 300 * hpi.outputs_per_step
         out["batch_%d" % N] = {"mel_frames_per_s": frames / dt, "ms": dt * 1e3, "decoder_steps": 300,
-                               "rtf": dt / (300 * hpi.outputs_per_step * hpi.frame_shift_ms * 1e-3)}
+                               "rtf": dt / (300 * hpi.outputs_per_step * hpi.frame_shift_ms * 1e-3),
+                               # persistent: ns_taco2_decode (one launch); rows32: packed step products, 8 launches a step
+                               "decode_path": m.last_paths.get("decode")}
         del m
     return out
 
