@@ -624,9 +624,21 @@ __global__ __launch_bounds__(256) void attn_post_kernel(AttnPost a) {
             const f2 dpre = de2 * wl2[j] * ((f2){1.f, 1.f} - th * th);
             dk[j] += dpre;
             dvp[j] = de2 * th + dvp[j];
+            // dwp[k] += align[t + k - half] * dpre, two units per instruction.  The instruction form is pinned: the tap
+            // pair (apv[k], apv[k + 1]) is src0 and op_sel broadcasts its low (even k) or high (odd k) half.  Left to the
+            // compiler the broadcast operand became src1 with op_sel:[0,1,0] for the odd taps, and with that form the
+            // odd taps' sums came out wrong by ~0.15 % whenever this library's weight-gradient workgroups (MFMA waves of
+            // another kernel) shared the CU - never alone, never for the even taps (op_sel_hi:[1,0,1]), never for x above
+            // (src0 forms): profiles/r04_determinism.txt item 4 has the float64 comparison that pins it down.
 #pragma unroll
-            for (int k = 0; k < MAXKW; ++k)
-              if (KW ? k < KW : k < kw) dwp[k][j] = (f2){apv[k], apv[k]} * dpre + dwp[k][j];
+            for (int k = 0; k < MAXKW; k += 2) {
+              if (KW ? k < KW : k < kw) {
+                const f2 ap2 = (f2){apv[k], k + 1 < MAXKW ? apv[k + 1] : 0.f};
+                asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(dwp[k][j]) : "v"(ap2), "v"(dpre));
+                if (k + 1 < MAXKW && (KW ? k + 1 < KW : k + 1 < kw))
+                  asm volatile("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0]" : "+v"(dwp[k + 1][j]) : "v"(ap2), "v"(dpre));
+              }
+            }
           }
         }
       }
