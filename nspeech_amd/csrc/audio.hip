@@ -293,24 +293,35 @@ constexpr int GW_PAD = 1280;                 // float2 per wave: 16 rows of 68 (
 
 // complex values as packed pairs (re, im): an add is one v_pk_add_f32, a product two packed operations
 typedef float v2f __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ v2f mul_neg_i(v2f v) { return (v2f){v.y, -v.x}; }
+// -i v = (v.y, -v.x) as ONE instruction of its own with the swap on src0 (left as a vector expression, the compiler folds
+// the swap into whichever operand of the consuming instruction it likes - src1 included, see cmulw below)
+__device__ __forceinline__ v2f mul_neg_i(v2f v) {
+  v2f r;
+  const v2f z = {0.f, 0.f};
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(v), "v"(z));
+  return r;
+}
 // Complex arithmetic on packed (re, im) pairs with the swaps, conjugations and sign flips carried by the packed
 // instructions' own operand selects (op_sel / op_sel_hi / neg_lo / neg_hi): written from the vector types the compiler
 // spends a v_xor (sign), a v_mov (swap) and a wait state per product - 5 issue slots where 2 - 3 do (round 3: 2 426 ->
 // ~2 000 instructions per frame and iteration; the results are the same IEEE operations, bit for bit).
-//   x * (w.x + i w.y):  t = (-x.y w.y, x.x w.y);  r = (x.x w.x, x.y w.x) + t
+// Operand forms: NO instruction here selects the high half of src1 for the low lane (op_sel bit 1).  On MI355X a packed
+// fp32 instruction with that bit set misreads the operand about once per million executions while MFMA waves of another
+// kernel share the CU (profiles/tools/pk_opsel_probe.hip, profiles/r04_determinism.txt item 4); src0 / src2 selects and
+// every op_sel_hi form are not affected, so the swapped operand is always src0 (or src2).
+//   x * (w.x + i w.y):  t = (w.y x.x, -w.y x.y);  r = (x.x w.x, x.y w.x) + (t.y, t.x)
 __device__ __forceinline__ v2f cmulw(v2f x, v2f w) {
   v2f t, r;
-  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\ts_nop 0\n\t"
-      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+  asm("v_pk_mul_f32 %0, %3, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\ts_nop 0\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,1] op_sel_hi:[1,0,0]"
       : "=&v"(t), "=&v"(r) : "v"(x), "v"(w));
   return r;
 }
-//   x * conj(w) = x * (w.x - i w.y):  t = (x.y w.y, -x.x w.y)
+//   x * conj(w) = x * (w.x - i w.y):  t = (-w.y x.x, w.y x.y)
 __device__ __forceinline__ v2f cmulw_conj(v2f x, v2f w) {
   v2f t, r;
-  asm("v_pk_mul_f32 %0, %2, %3 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\ts_nop 0\n\t"
-      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+  asm("v_pk_mul_f32 %0, %3, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1]\n\ts_nop 0\n\t"
+      "v_pk_fma_f32 %1, %2, %3, %0 op_sel:[0,0,1] op_sel_hi:[1,0,0]"
       : "=&v"(t), "=&v"(r) : "v"(x), "v"(w));
   return r;
 }
@@ -319,22 +330,28 @@ __device__ __forceinline__ v2f cmulv(v2f x, float a, float b) { return cmulw(x, 
 // read, and the other product's instruction fills it
 __device__ __forceinline__ void cmulw2(v2f& x0, v2f w0, v2f& x1, v2f w1) {
   v2f t0, t1, r0, r1;
-  asm("v_pk_mul_f32 %0, %4, %5 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\t"
-      "v_pk_mul_f32 %1, %6, %7 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\t"
-      "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-      "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]"
+  asm("v_pk_mul_f32 %0, %5, %4 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %1, %7, %6 op_sel:[1,0] op_sel_hi:[1,1] neg_hi:[0,1]\n\t"
+      "v_pk_fma_f32 %2, %4, %5, %0 op_sel:[0,0,1] op_sel_hi:[1,0,0]\n\t"
+      "v_pk_fma_f32 %3, %6, %7, %1 op_sel:[0,0,1] op_sel_hi:[1,0,0]"
       : "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1) : "v"(x0), "v"(w0), "v"(x1), "v"(w1));
   x0 = r0; x1 = r1;
 }
-//   a + (u.y, -u.x) = a - i u   and   a - (u.y, -u.x) = a + i u
+//   a + (u.y, -u.x) = a - i u   and   a - (u.y, -u.x) = a + i u   (u is src0: its halves are the swapped ones)
 __device__ __forceinline__ v2f add_mi(v2f a, v2f u) {
   v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(u));
+  asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(u));
   return r;
 }
 __device__ __forceinline__ v2f add_pi(v2f a, v2f u) {
   v2f r;
-  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(u));
+  asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(r) : "v"(a), "v"(u));
+  return r;
+}
+//   conj(a + i u) = (a.x - u.y, -a.y - u.x)
+__device__ __forceinline__ v2f add_pi_conj(v2f a, v2f u) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %2, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(u));
   return r;
 }
 //   a + conj(b)   and   a - conj(b)
@@ -433,8 +450,8 @@ __device__ __forceinline__ void gl_pairs(v2f* buf, int lane, const float (&mkv)[
       //   2 X[k] = s1 - i wd = (s1.x + wd.y, s1.y - wd.x);   2 X[M-k] = (s1.x - wd.y, -s1.y - wd.x)
       const v2f s1 = add_conj(A, B), d1 = sub_conj(A, B);
       const v2f wd = cmulw(d1, w);
-      const v2f ea = {s1.x + wd.y, s1.y - wd.x};
-      const v2f eb = {s1.x - wd.y, -s1.y - wd.x};
+      const v2f ea = add_mi(s1, wd);
+      const v2f eb = add_pi_conj(s1, wd);
       // m e / max(1e-8, |e|) with e = ea / 2
       const v2f na = ea * ea, nb = eb * eb;
       const float sa = mk * __builtin_amdgcn_rsqf(fmaxf(4e-16f, na.x + na.y));
@@ -445,8 +462,8 @@ __device__ __forceinline__ void gl_pairs(v2f* buf, int lane, const float (&mkv)[
     const v2f t1 = add_conj(xa, xb), u1 = sub_conj(xa, xb);
     const v2f c1 = cmulw_conj(u1, w);                           // conj(w) u1
     if (n1 < 8 || lane == 0) {
-      if (!(n1 == 0 && lane == 0)) buf[ip] = (v2f){t1.x + c1.y, t1.y - c1.x};     // bin M - k (bin M itself does not exist)
-      buf[ik] = (v2f){t1.x - c1.y, -(t1.y + c1.x)};
+      if (!(n1 == 0 && lane == 0)) buf[ip] = add_mi(t1, c1);      // (t1.x + c1.y, t1.y - c1.x): bin M - k (bin M itself does not exist)
+      buf[ik] = add_pi_conj(t1, c1);                              // (t1.x - c1.y, -(t1.y + c1.x))
     }
   }
 }
