@@ -27,8 +27,11 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
   X(8, "v_pk_mul_f32 %0, %1, %2 op_sel:[0,1]", 1 * 5, 2 * 5)                                        \
   X(9, "v_pk_mul_f32 %0, %1, %2 op_sel:[1,0]", 2 * 3, 2 * 5)                                        \
   X(10, "v_pk_add_f32 %0, %1, %2 op_sel:[0,1]", 1 + 5, 2 + 5)                                       \
-  X(11, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0]", 2 + 3, 2 + 5)
-constexpr int NFORMS = 14;
+  X(11, "v_pk_add_f32 %0, %1, %2 op_sel:[1,0]", 2 + 3, 2 + 5)                                       \
+  X(14, "v_pk_mov_b32 %0, %1, %2 op_sel:[0,1]", 1, 5)                                               \
+  X(15, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,0]", 2, 3)                                               \
+  X(16, "v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]", 2, 5)
+constexpr int NFORMS = 17;
 
 __global__ __launch_bounds__(256) void victim(unsigned* bad, int iters) {
   f2 a = (f2){1.f, 2.f}, b = (f2){3.f, 5.f}, c = (f2){7.f, 11.f};
