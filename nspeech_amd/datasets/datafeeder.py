@@ -27,6 +27,7 @@ import numpy as np
 
 from ..utils import audio
 from ..utils.text import text_to_sequence
+from .process import trim_wav
 
 _p_cmudict = 0.5      # datafeeder.py:16
 _pad = 0              # datafeeder.py:17
@@ -140,7 +141,7 @@ class DataFeeder(object):
     `speaker_ids` of the last batch are kept in .speaker_ids (single-speaker corpora: zeros)."""
 
     def __init__(self, hparams, ljspeech=None, seed=0, rank=0, world=1, cmudict=None, prefetch=True, features=None,
-                 loader=None, vctk=None, librispeech=None, device=None, pinned=False, device_cache=False):
+                 loader=None, vctk=None, librispeech=None, device=None, pinned=False, device_cache=False, trim=True):
         self.hp = hparams
         # device_cache: the features of every utterance stay in HBM where the feature kernel wrote them (the reference
         # keeps them in host RAM, `processed_data`, datafeeder.py:165-176) and batches are assembled on the device.
@@ -179,6 +180,7 @@ class DataFeeder(object):
         self._cmudict = cmudict
         self._features = features or audio.spectrogram_and_mel
         self._loader = loader or audio.load_wav
+        self._trim = trim         # False: the corpus is already trimmed (the reference always trims, process.py:27)
         self.speaker_ids = None
         self._queue = queue.Queue(maxsize=8) if prefetch else None
         self._thread = None
@@ -200,16 +202,21 @@ class DataFeeder(object):
             if self._device_cache:
                 import torch
                 with torch.cuda.stream(self._feeder_stream()):
-                    lin, mel = audio.spectrogram_and_mel_device(self._loader(wav_path))      # [T, F], [T, M] in HBM
+                    lin, mel = audio.spectrogram_and_mel_device(self._wav(wav_path))      # [T, F], [T, M] in HBM
                 self.cache[wav_path] = (mel, lin)
             else:
-                lin, mel = self._features(self._loader(wav_path))
+                lin, mel = self._features(self._wav(wav_path))
                 self.cache[wav_path] = (np.ascontiguousarray(mel.T, np.float32), np.ascontiguousarray(lin.T, np.float32))
         mel, lin = self.cache[wav_path]
         if self._cmudict and self._rng.random() < _p_cmudict:
             text = " ".join(self._maybe_get_arpabet(w) for w in text.split(" "))
         ids = np.asarray(text_to_sequence(text, self.cleaners), dtype=np.int32)
         return ids, self.speaker2id[dataset, str(local_speaker)], mel, lin
+
+    def _wav(self, wav_path):
+        """process.py:27: the silent ends are cut before the features are taken."""
+        wav = self._loader(wav_path)
+        return trim_wav(wav) if self._trim else wav
 
     def _feeder_stream(self):
         if self._stream is None:

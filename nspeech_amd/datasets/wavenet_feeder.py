@@ -13,22 +13,7 @@ import numpy as np
 
 from ..utils import audio
 from .datafeeder import load_librispeech_corpus, load_ljspeech_metadata, load_vctk_file_names
-
-
-def trim_silence(wav, threshold, frame_length=2048, hop_length=512):
-    """process.py:45-54 over librosa.feature.rmse [3P, librosa 0.6: centred frames of 2048 every 512 samples, reflect
-    padded] -> wav[first loud frame * 512 : last loud frame * 512]; all silence -> empty."""
-    if wav.size < frame_length:
-        frame_length = wav.size
-    if wav.size == 0:
-        return wav
-    y = np.pad(wav.astype(np.float64), frame_length // 2, mode="reflect")
-    n_frames = 1 + (len(y) - frame_length) // hop_length
-    sq = np.concatenate([[0.0], np.cumsum(y * y)])
-    starts = np.arange(n_frames) * hop_length
-    energy = np.sqrt((sq[starts + frame_length] - sq[starts]) / frame_length)
-    loud = np.nonzero(energy > threshold)[0] * hop_length
-    return wav[loud[0]:loud[-1]] if loud.size else wav[:0]
+from .process import trim_silence  # noqa: F401  (process.py:45-54)
 
 
 class WavenetFeeder(object):

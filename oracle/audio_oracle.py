@@ -190,3 +190,56 @@ def find_endpoint(wav, hp, threshold_db=-40, min_silence_sec=0.8):
         if np.max(wav[x:x + window_length]) < threshold:
             return x + hop_length
     return len(wav)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# utterance processing: silence trimming in front of the feature extraction (datasets/process.py:27,39-42,56-68)
+
+def effects_split(y, top_db, frame_length, hop_length):
+    """[3P] librosa 0.6.0 `effects.split(y, top_db, frame_length=, hop_length=)` as process.py:41 calls it (ref = np.max):
+    feature.rmse on centred, reflect-padded frames -> mean square per frame -> power_to_db relative to the loudest frame
+    (amin 1e-10 on both sides, no top_db clamp) -> frames louder than -top_db -> runs of such frames as sample intervals
+    [first frame * hop, (last frame + 1) * hop) clipped to the signal.  Plain per-frame loops: this is the checker."""
+    y = np.asarray(y, np.float64)
+    n = len(y)
+    yp = np.pad(y, frame_length // 2, mode="reflect")
+    n_frames = 1 + (len(yp) - frame_length) // hop_length
+    mse = np.empty(n_frames)
+    for i in range(n_frames):
+        fr = yp[i * hop_length:i * hop_length + frame_length]
+        mse[i] = np.mean(fr * fr)
+    amin = 1e-10
+    db = 10.0 * np.log10(np.maximum(amin, mse)) - 10.0 * np.log10(max(amin, float(mse.max())))
+    loud = db > -top_db
+    out, start = [], None
+    for i in range(n_frames):
+        if loud[i] and start is None:
+            start = i
+        if not loud[i] and start is not None:
+            out.append((start, i))
+            start = None
+    if start is not None:
+        out.append((start, n_frames))
+    return [(min(a * hop_length, n), min(b * hop_length, n)) for a, b in out]
+
+
+def find_start(splits, min_samples=2000):
+    """process.py:56-60: the first interval longer than min_samples, moved min_samples to the left."""
+    for a, b in splits:
+        if b - a > min_samples:
+            return max(0, a - min_samples)
+    return 0
+
+
+def find_end(splits, num_samples, min_samples=2000):
+    """process.py:63-67: the last interval longer than min_samples, moved min_samples to the right."""
+    for a, b in reversed(splits):
+        if b - a > min_samples:
+            return min(num_samples, b + min_samples)
+    return num_samples
+
+
+def trim_wav(wav, threshold_db=25):
+    """process.py:39-42."""
+    splits = effects_split(wav, threshold_db, 1024, 512)
+    return wav[find_start(splits):find_end(splits, len(wav))]

@@ -210,3 +210,23 @@ def test_load_wav_reads_librispeech_flac_like_the_same_pcm_in_a_wav(audio, tmp_p
         f.writeframes(pcm[:, 0].astype("<i2").tobytes())
     a, b = A.load_wav(pf), A.load_wav(pw)
     assert a.shape == b.shape == (int(np.ceil(16000 * hp.sample_rate / 16000)),) and np.array_equal(a, b)
+
+
+def test_process_utterance_trims_before_the_features(audio, tmp_path):
+    """process.py:23-36: features of trim_wav(load_wav(path)) - against the oracle's trim and the oracle's spectrograms;
+    the device-cache path of the feeder sees the same frames."""
+    from nspeech_amd.datasets import process as P
+    A, hp = audio
+    rng = np.random.default_rng(3)
+    body = _speechlike(30000, 9)
+    y = np.concatenate([rng.normal(0, 1e-4, 7000), body / np.abs(body).max() * 0.6, rng.normal(0, 1e-4, 9000)]).astype(np.float32)
+    path = str(tmp_path / "utt000.wav")
+    A.save_wav(y, path)
+    wav = A.load_wav(path)
+    ref_wav = AO.trim_wav(wav)
+    assert 30000 < len(ref_wav) < len(wav) - 8000
+    idx, got_wav, lin, mel, n_frames = P.process_utterance(path)
+    assert idx == "utt000" and np.array_equal(got_wav, ref_wav)
+    rl, rm = AO.spectrogram(ref_wav, HP), AO.melspectrogram(ref_wav, HP)
+    assert lin.shape == rl.T.shape and mel.shape == rm.T.shape and n_frames == rl.shape[1] == 1 + len(ref_wav) // 250
+    assert np.abs(lin - rl.T).max() < 2e-4 and np.abs(mel - rm.T).max() < 2e-4

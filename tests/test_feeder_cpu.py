@@ -182,13 +182,13 @@ def test_multi_corpus_speaker_numbering(tmp_path):
         seen[path] = T
         return np.full((hp.num_freq, T), 0.5, np.float32), np.full((hp.num_mels, T), 0.25, np.float32)
     fd = DataFeeder(hp, ljspeech=str(lj), vctk=str(vctk), librispeech=str(libre), seed=2, prefetch=False,
-                    features=features, loader=loader)
+                    features=features, loader=loader, trim=False)
     assert len(fd.items) == 6 + 5 + 2
     assert fd.id2speaker == {0: ("libre", "1272"), 1: ("libre", "84"), 2: ("ljspeech", "0"), 3: ("vctk", "225"),
                              4: ("vctk", "301")}
     # the same numbering on another rank (sorted pairs, no dependence on set order)
     fd1 = DataFeeder(hp, ljspeech=str(lj), vctk=str(vctk), librispeech=str(libre), seed=2, rank=1, world=2,
-                     prefetch=False, features=features, loader=loader)
+                     prefetch=False, features=features, loader=loader, trim=False)
     assert fd1.speaker2id == fd.speaker2id
     # ids follow their utterances: VCTK texts name their speaker, LJSpeech rows are speaker 2
     count = {}
@@ -210,3 +210,79 @@ def test_multi_corpus_speaker_numbering(tmp_path):
             else:
                 assert sid == 2
     assert set(count) == {0, 1, 2, 3, 4}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# silence trimming in front of the features (process.py:27,39-42,56-68)
+
+def _utterance(lead, body, tail, seed, noise=1e-4, amp=0.5):
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, noise, lead + body + tail)
+    t = np.arange(body) / 20000.0
+    w[lead:lead + body] += amp * np.sin(2 * np.pi * 180 * t) * (1 + 0.3 * np.sin(2 * np.pi * 3 * t))
+    return w.astype(np.float32)
+
+
+def test_trim_wav_matches_the_oracle_frame_loops():
+    """The product's running-sum frame energies against the oracle's per-frame loops (librosa 0.6.0 effects.split restated,
+    [3P]): both margins, no silence at all, all silence, a burst too short to count, two bursts with a pause, a quiet
+    stretch just above / below the 25 dB line, and lengths around the frame grid."""
+    from oracle import audio_oracle as AO
+    from nspeech_amd.datasets import process as P
+    cases = [_utterance(6000, 40000, 9000, 0), _utterance(0, 30000, 0, 1), _utterance(500, 30000, 700, 2),
+             _utterance(3000, 1500, 3000, 3), _utterance(8000, 300, 8000, 4), np.zeros(5000, np.float32),
+             _utterance(1024, 5000, 511, 5), _utterance(1023, 5001, 513, 6), _utterance(2500, 2049, 2500, 7)]
+    two = _utterance(4000, 12000, 3000, 8)
+    cases.append(np.concatenate([two, _utterance(5000, 9000, 6000, 9)]))
+    for db in (-24.0, -26.0):          # a tail 24 / 26 dB below the loudest frame: kept / cut
+        w = _utterance(3000, 20000, 0, 10)
+        tail = _utterance(0, 6000, 4000, 11, amp=0.5 * 10 ** (db / 20))
+        cases.append(np.concatenate([w, tail]))
+    lens = []
+    for w in cases:
+        got_s = P.split(w, 25, frame_length=1024, hop_length=512)
+        ref_s = AO.effects_split(w, 25, 1024, 512)
+        assert [tuple(int(v) for v in r) for r in got_s] == ref_s
+        got, ref = P.trim_wav(w), AO.trim_wav(w)
+        assert got.dtype == w.dtype and np.array_equal(got, ref)
+        lens.append((len(w), len(got)))
+    assert lens[0] == (55000, 44960)                       # [5632, 46592) widened by 2000 on both sides
+    assert lens[1][0] == lens[1][1] and lens[2][0] == lens[2][1]
+    assert lens[3] == (7500, 6560)                         # a 1500-sample burst covers 5 frames = 2560 > 2000 samples
+    assert lens[4][0] == lens[4][1]                        # a 300-sample burst covers <= 2000 samples: nothing is cut
+    assert lens[5] == (5000, 5000)                         # all silence: every frame sits at the 1e-10 floor = "loud"
+    assert lens[-2][1] > lens[-1][1]                       # the -24 dB tail stays, the -26 dB tail goes
+
+
+def test_find_start_and_end_follow_the_reference_rules():
+    from nspeech_amd.datasets.process import _find_end, _find_start
+    splits = np.array([[100, 900], [5000, 9000], [12000, 12500], [20000, 30000]])
+    assert _find_start(splits) == 3000 and _find_end(splits, 31000) == 31000 and _find_end(splits, 40000) == 32000
+    assert _find_start(np.array([[500, 4000]])) == 0                       # clipped at the first sample
+    assert _find_start(np.zeros((0, 2), np.int64)) == 0 and _find_end(np.zeros((0, 2), np.int64), 77) == 77
+    assert _find_start(np.array([[0, 2000]])) == 0 and _find_end(np.array([[0, 2000]]), 5000) == 5000   # needs > 2000
+
+
+def test_feeder_takes_its_features_from_the_trimmed_wav(tmp_path):
+    """process.py:27: the feeder's features are those of trim_wav(load_wav(path)), not of the file."""
+    from oracle import audio_oracle as AO
+    hp = _hp(batch_size=2, batch_group_size=1)
+    root = _corpus(tmp_path, 2)
+    wavs = {0: _utterance(7000, 30000, 6000, 20), 1: _utterance(0, 26000, 9000, 21)}
+    seen = []
+
+    def loader(path):
+        return wavs[int(os.path.basename(path)[3:6])]
+
+    def features(wav):
+        seen.append(np.array(wav))
+        T = 1 + len(wav) // 250
+        return np.full((hp.num_freq, T), 0.5, np.float32), np.full((hp.num_mels, T), 0.25, np.float32)
+    f = DataFeeder(hp, ljspeech=root, seed=1, prefetch=False, features=features, loader=loader)
+    _, _, mel, _ = f.next_batch()
+    want = [AO.trim_wav(wavs[i]) for i in (0, 1)]
+    assert sorted(len(s) for s in seen) == sorted(len(w) for w in want)
+    for s in seen:
+        assert any(np.array_equal(s, w) for w in want)
+    assert all(len(w) < len(wavs[i]) for i, w in enumerate(want))
+    assert sorted(int(v) for v in mel[:, :, 0].sum(axis=1) * 4) == sorted(1 + len(w) // 250 for w in want)
