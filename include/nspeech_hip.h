@@ -526,6 +526,47 @@ typedef struct {
 } ns_gru_pointwise_params;
 int ns_gru_pointwise(const ns_gru_pointwise_params* p, ns_stream_t stream);
 
+/* Persistent whole-sequence GRU recurrence: ONE launch instead of four per time step (two gate products + two
+ * element-wise kernels) - the BiGRU(128) of both CBHGs (modules.py:172-181 under bidirectional_dynamic_rnn) and the
+ * residual GRU(256) decoder cells (tacotron.py:69-76).  tf.contrib.rnn.GRUCell with the input halves hoisted:
+ *   [r | u] = sigmoid(xg[t] + h . Wg_h),  c = tanh(xc[t] + (r * h) . Wc_h),  h' = u * h + (1 - u) * c.
+ * A chain = (direction, 16 batch rows).  H = 128: one workgroup per chain, nothing leaves the CU - the recurrent
+ * matrices (128 x 384) live in registers as MFMA fragments (hi and lo planes for three passes), the state in LDS.
+ * H = 256: a chain is a cluster of 4 workgroups with 64 units each that exchange r * h and h through `work` as
+ * {step tag, fp32} granules (two hops per step).  dtype NS_BF16: single-pass bf16 products; NS_F32: f32_passes 1
+ * (operands rounded to bf16 when loaded) or 3 (split-bf16, ~fp32).  Rows with t >= lengths[n] output zeros and carry
+ * the state unchanged; h_init (optional) is the initial state (modules.py:165-181).
+ * Forward writes the history h (dtype), ru = [r | u] and c (fp32) and rh = r * h_prev (dtype) for the backward pass and
+ * the hoisted weight gradients.  Backward reads them plus dh (gradient wrt the outputs) and writes the gate gradients
+ * dzg = [dzr | dzu], dzc (dtype) and, optionally, the gradient wrt the initial state.
+ * fw / bw: one or two directions with equal N, T, H, P, dtype (bw may be NULL).  work: ns_gru_seq_work_bytes();
+ * work[0] (int) is a status word, non-zero after the call completes = an exchange timed out, outputs invalid. */
+typedef struct {
+  int dtype, N, T, H, P, padl;      /* rows of every [N*P, .] array: n * P + padl + t */
+  int reverse;                      /* 1: walk t = T-1 .. 0 */
+  int f32_passes;                   /* dtype NS_F32: 1 or 3 */
+  const int* lengths;               /* nullable [N] */
+  const float* xg; int ld_xg;       /* [N*P, 2H]: x . Wg_x + bg */
+  const float* xc; int ld_xc;       /* [N*P, H]:  x . Wc_x + bc */
+  const void* wgT;                  /* (dtype) [2H][H]: recurrent rows of gates/kernel, transposed (k contiguous)    fwd */
+  const void* wcT;                  /* (dtype) [H][H]:  recurrent rows of candidate/kernel, transposed               fwd */
+  const void* wg; int ld_wg;        /* (dtype) [H][2H] row-major recurrent rows of gates/kernel                      bwd */
+  const void* wc; int ld_wc;        /* (dtype) [H][H]                                                                bwd */
+  void* h; int ld_h;                /* (dtype) history, this cell's H columns of row n * P + padl + t */
+  float* ru;                        /* [N*P, 2H] */
+  float* c;                         /* [N*P, H] */
+  void* rh;                         /* (dtype) [N*P, H] */
+  const float* h_init; int ld_hi;   /* nullable [N, H] */
+  const float* dh; int ld_dh;       /* bwd: gradient wrt h, addressed as h */
+  void* dzg;                        /* bwd out: (dtype) [N*P, 2H] */
+  void* dzc;                        /* bwd out: (dtype) [N*P, H] */
+  float* dh_init; int ld_dhi;       /* bwd out, nullable: [N, H] gradient wrt the initial state (overwritten) */
+} ns_gru_seq_params;
+int ns_gru_seq_supported(const ns_gru_seq_params* fw, const ns_gru_seq_params* bw, int backward);
+size_t ns_gru_seq_work_bytes(const ns_gru_seq_params* p);
+int ns_gru_seq_fwd(const ns_gru_seq_params* fw, const ns_gru_seq_params* bw, void* work, ns_stream_t stream);
+int ns_gru_seq_bwd(const ns_gru_seq_params* fw, const ns_gru_seq_params* bw, void* work, ns_stream_t stream);
+
 /* dpre = dy * act'(y) for a dense layer whose output y = act(pre) was stored (ReLU / tanh /
  * sigmoid / none); rows failing the (period, lo, hi) test give 0. */
 typedef struct {

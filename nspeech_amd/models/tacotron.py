@@ -12,6 +12,7 @@ configuration (BASELINE configs[0]), so the time loops are plain Python, not fus
 Forward ops record their backward on a tape; gradients wrt activations are fp32 and accumulate.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -212,41 +213,139 @@ class Tacotron(Tacotron2):
         return y
 
     # ---- GRU over time (tf GRUCell); h history lives in out.buf columns [col, col+H)
+    use_gru_seq = os.environ.get("NS_GRU_SEQ", "1") != "0"      # persistent whole-sequence kernels where the shape allows
+
     def _gru_seq(self, tag, x, scope, key, H, lengths, reverse, out, col, h0=None):
-        """h0: optional Act [N, 1, H], the initial state (modules.py:165-181).  The recurrent products read the state
-        history, where the slot in front of a sequence's first step holds zeros, so the initial state enters three
-        ways: h0 . Wg_h is added to the input-side gate pre-activations of the first step (t = 0; reversed: t =
-        len(n) - 1), the element-wise kernels substitute h0 for h_prev there (h_init), and the weight gradient of the
-        recurrent gate kernel gets the first steps' h0^T . dzg on top of the shifted-history product."""
+        """One GRU direction over the whole sequence (see _gru_group)."""
+        self._gru_group(tag, [dict(tag=tag, scope=scope, key=key, reverse=reverse, col=col)], x, H, lengths, out, h0)
+
+    def _gru_group(self, label, dirs, x, H, lengths, out, h0=None):
+        """One or two GRU directions (a BiGRU's fw / bw cells, modules.py:172-181) over the same input x, outputs in
+        out.buf columns [col, col + H) of each direction.  The input halves of both gate products are hoisted GEMMs; the
+        recurrence is ONE persistent launch (ns_gru_seq_*, csrc/gru.hip) where the shape allows - H in {128, 256}, a
+        split-bf16 or bf16 mode - and otherwise four launches per step from here.  last_paths["<label>:fwd|bwd"] says which.
+
+        h0: optional Act [N, 1, H], the initial state (modules.py:165-181).  The persistent kernels take it as their
+        initial state.  The per-step path's recurrent products read the state history, where the slot in front of a
+        sequence's first step holds zeros, so there the initial state enters three ways: h0 . Wg_h is added to the
+        input-side gate pre-activations of the first step (t = 0; reversed: t = len(n) - 1), the element-wise kernels
+        substitute h0 for h_prev there (h_init), and the weight gradient of the recurrent gate kernel gets the first
+        steps' h0^T . dzg on top of the shifted-history product (both paths)."""
         N, P, padl, T = x.N, x.P, x.padl, x.T
         rows, cin, ldh = x.rows, x.C, out.C
         W, g = self._W(self.T), self.flat_g
-        og, oc = self._o(scope + "/gates/kernel"), self._o(scope + "/candidate/kernel")
-        bg, bc = self._o(scope + "/gates/bias"), self._o(scope + "/candidate/bias")
-        xg = self._buf("gru:%s_xg" % tag, rows * 2 * H, torch.float32)
-        xc = self._buf("gru:%s_xc" % tag, rows * H, torch.float32)
-        ops.gemm(x.buf, W, xg, rows, 2 * H, cin, cin, 2 * H, 2 * H, b_mode=1, b_off=og, bias=self.flat_p, bias_off=bg)
-        ops.gemm(x.buf, W, xc, rows, H, cin, cin, H, H, b_mode=1, b_off=oc, bias=self.flat_p, bias_off=bc)
-        ru = self._buf("gru:%s_ru" % tag, rows * 2 * H, torch.float32)
-        cc = self._buf("gru:%s_c" % tag, rows * H, torch.float32)
-        rh = self._buf("gru:%s_rh" % tag, rows * H, self.T)
-        gT, cT = self.tsh[key + "_gT"], self.tsh[key + "_cT"]
         hb = out.buf
+        h0f = None
+        if h0 is not None:
+            h0f = self._buf("gru:%s_h0f" % label, N * H, torch.float32)
+            ops.copy3d(h0.buf, h0f, 1, N, H, (0, H), (0, H))
+        lens = self._host_lengths if lengths is not None else [T] * N
+        for dd in dirs:
+            tag, scope = dd["tag"], dd["scope"]
+            dd["og"], dd["oc"] = self._o(scope + "/gates/kernel"), self._o(scope + "/candidate/kernel")
+            dd["bg"], dd["bc"] = self._o(scope + "/gates/bias"), self._o(scope + "/candidate/bias")
+            dd["xg"] = self._buf("gru:%s_xg" % tag, rows * 2 * H, torch.float32)
+            dd["xc"] = self._buf("gru:%s_xc" % tag, rows * H, torch.float32)
+            ops.gemm(x.buf, W, dd["xg"], rows, 2 * H, cin, cin, 2 * H, 2 * H, b_mode=1, b_off=dd["og"], bias=self.flat_p,
+                     bias_off=dd["bg"])
+            ops.gemm(x.buf, W, dd["xc"], rows, H, cin, cin, H, H, b_mode=1, b_off=dd["oc"], bias=self.flat_p, bias_off=dd["bc"])
+            dd["ru"] = self._buf("gru:%s_ru" % tag, rows * 2 * H, torch.float32)
+            dd["cc"] = self._buf("gru:%s_c" % tag, rows * H, torch.float32)
+            dd["rh"] = self._buf("gru:%s_rh" % tag, rows * H, self.T)
+            dd["gT"], dd["cT"] = self.tsh[dd["key"] + "_gT"], self.tsh[dd["key"] + "_cT"]
+            dd["first"] = [int(lens[n]) - 1 if dd["reverse"] else 0 for n in range(N)]
+
+        def params(dd, bwd):
+            kw = {}
+            if bwd:
+                kw = dict(dh=(out.grad, dd["col"]), ld_dh=ldh, dzg=dd["dzg"], dzc=dd["dzc"])
+                if h0 is not None:
+                    kw.update(dh_init=dd["dh0"], ld_dhi=H)
+            # every [N*P, .] array is addressed as row n * P + padl + t: the arrays start at row 0
+            return ops.gru_seq_params(hb, N, T, H, P, padl, dd["reverse"], lengths, dd["xg"], dd["xc"], dd["gT"], dd["cT"],
+                                      (W, dd["og"] + cin * 2 * H), 2 * H, (W, dd["oc"] + cin * H), H, (hb, dd["col"]), ldh,
+                                      dd["ru"], dd["cc"], dd["rh"], h_init=h0f, ld_hi=H, **kw)
+
+        def persistent(bwd):
+            if not self.use_gru_seq or len(dirs) > 2:
+                return None
+            pp = [params(dd, bwd) for dd in dirs]
+            p1 = pp[1] if len(pp) > 1 else None
+            return (pp[0], p1) if ops.gru_seq_supported(pp[0], p1, backward=bwd) else None
+
+        pp = persistent(False)
+        if pp is not None:
+            work = self._buf("gru:%s_work" % label, ops.gru_seq_work_floats(pp[0]), torch.float32)
+            ops.gru_seq("fwd", pp[0], pp[1], work)
+            self._status_words[(label, "fwd")] = work
+            self.last_paths["%s:fwd" % label] = "seq"
+        else:
+            self.last_paths["%s:fwd" % label] = "step"
+            for dd in dirs:
+                self._gru_steps_fwd(dd, N, P, padl, T, H, ldh, lengths, hb, h0, h0f)
+
+        def bwd():
+            for dd in dirs:
+                dd["dzg"] = self._buf("gru:%s_dzg" % dd["tag"], rows * 2 * H, self.T)
+                dd["dzc"] = self._buf("gru:%s_dzc" % dd["tag"], rows * H, self.T)
+                dd["dzg"].zero_()          # the hoisted products below run over every row: pad rows must hold zeros
+                dd["dzc"].zero_()
+                if h0 is not None:
+                    dd["dh0"] = self._buf("gru:%s_dh0" % dd["tag"], N * H, torch.float32)
+            pb = persistent(True)
+            if pb is not None:
+                work = self._buf("gru:%s_work" % label, ops.gru_seq_work_floats(pb[0]), torch.float32)
+                ops.gru_seq("bwd", pb[0], pb[1], work)
+                self._status_words[(label, "bwd")] = work
+                self.last_paths["%s:bwd" % label] = "seq"
+            else:
+                self.last_paths["%s:bwd" % label] = "step"
+                for dd in dirs:
+                    self._gru_steps_bwd(dd, N, P, padl, T, H, ldh, lengths, hb, out.grad, cin, h0f)
+            sk = self._splitk
+            for dd in reversed(dirs):
+                og, oc, dzg, dzc, rh = dd["og"], dd["oc"], dd["dzg"], dd["dzc"], dd["rh"]
+                # hoisted weight gradients: x parts, h parts (h_prev = history shifted by one row), biases
+                ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
+                         split_k=sk(rows, cin, 2 * H))
+                ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
+                         split_k=sk(rows, cin, H))
+                if dd["reverse"]:
+                    ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + dd["col"],
+                             c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+                else:
+                    ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=dd["col"], b_off=2 * H,
+                             c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+                ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
+                         split_k=sk(rows, H, H))
+                if h0 is not None:
+                    # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
+                    ops.copy3d(dd["dh0"], h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
+                    dz0 = self._buf("gru:%s_dz0" % dd["tag"], N * 2 * H, self.T)
+                    for n in range(N):
+                        ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + dd["first"][n]) * 2 * H,
+                                   dst_off=n * 2 * H)
+                    ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
+                             accumulate=2)
+                ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=dd["bg"])
+                ops.colsum(dzc, H, rows, H, g, out_off=dd["bc"])
+                ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
+                ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
+        self._tape.append(bwd)
+
+    def _gru_steps_fwd(self, dd, N, P, padl, T, H, ldh, lengths, hb, h0, h0f):
+        """The launch-per-step form of one direction: two gate products + two element-wise kernels per step."""
+        xg, xc, ru, cc, rh, gT, cT, col, reverse = (dd[k] for k in ("xg", "xc", "ru", "cc", "rh", "gT", "cT", "col", "reverse"))
         hi = {}
         if h0 is not None:
-            h0f = self._buf("gru:%s_h0f" % tag, N * H, torch.float32)
-            ops.copy3d(h0.buf, h0f, 1, N, H, (0, H), (0, H))
             hi = dict(h_init=(h0f, 0), hi_sn=H, reverse=reverse, T=T)
-            # first step of utterance n: row `first[n]` of the time axis
-            lens = self._host_lengths if lengths is not None else [T] * N
-            first = [int(lens[n]) - 1 if reverse else 0 for n in range(N)]
-            sg = self._buf("gru:%s_h0g" % tag, N * 2 * H, torch.float32)
+            sg = self._buf("gru:%s_h0g" % dd["tag"], N * 2 * H, torch.float32)
             ops.gemm(h0.buf, gT, sg, N, 2 * H, H, H, H, 2 * H)
             for n in range(N):
-                ops.copy3d(sg, xg, 1, 1, 2 * H, (0, 0), (0, 0), src_off=n * 2 * H, dst_off=(n * P + padl + first[n]) * 2 * H,
-                           accumulate=1)
-        order = range(T - 1, -1, -1) if reverse else range(T)
-        for t in order:
+                ops.copy3d(sg, xg, 1, 1, 2 * H, (0, 0), (0, 0), src_off=n * 2 * H,
+                           dst_off=(n * P + padl + dd["first"][n]) * 2 * H, accumulate=1)
+        dd["hi"] = hi
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
             row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
             ops.gemm(hb, gT, ru, N, 2 * H, H, P * ldh, H, P * 2 * H, a_off=prow * ldh + col, c_off=row * 2 * H,
                      act=ACT_SIGMOID, addend=xg, addend_off=row * 2 * H, ld_add=P * 2 * H)
@@ -258,57 +357,31 @@ class Tacotron(Tacotron2):
                               c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(hb, row * ldh + col),
                               out_sn=P * ldh, **hi)
 
-        def bwd():
-            dzg = self._buf("gru:%s_dzg" % tag, rows * 2 * H, self.T)
-            dzc = self._buf("gru:%s_dzc" % tag, rows * H, self.T)
-            carry = self._buf("gru:carry", N * H, torch.float32)
-            drh = self._buf("gru:drh", N * H, torch.float32)
-            carry.zero_()
-            dzg.zero_()
-            dzc.zero_()
-            dh = out.grad
-            for t in (range(T) if reverse else range(T - 1, -1, -1)):
-                row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
-                # dh = the recurrent part (carry) + the gradient wrt this step's output where the step is valid; past the
-                # length the carry passes unchanged
-                ops.gru_pointwise(2, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
-                                  c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(dzc, row * H),
-                                  out_sn=P * H, dzg=(dzg, row * 2 * H), dzg_sn=P * 2 * H, dh=(carry, 0), dh_sn=H,
-                                  carry=(carry, 0), carry_sn=H, dh_add=(dh, row * ldh + col), dha_sn=P * ldh, **hi)
-                ops.gemm(dzc, W, drh, N, H, H, P * H, H, H, a_off=row * H, b_off=oc + cin * H)
-                ops.gru_pointwise(3, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
-                                  h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, dzg=(dzg, row * 2 * H),
-                                  dzg_sn=P * 2 * H, dh=(drh, 0), dh_sn=H, carry=(carry, 0), carry_sn=H, **hi)
-                ops.gemm(dzg, W, carry, N, H, 2 * H, P * 2 * H, 2 * H, H, a_off=row * 2 * H, b_off=og + cin * 2 * H,
-                         accumulate=1)
-            sk = self._splitk
-            # hoisted weight gradients: x parts, h parts (h_prev = history shifted by one row), biases
-            ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
-                     split_k=sk(rows, cin, 2 * H))
-            ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
-                     split_k=sk(rows, cin, H))
-            if reverse:
-                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + col,
-                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-            else:
-                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=col, b_off=2 * H,
-                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-            ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
-                     split_k=sk(rows, H, H))
-            if h0 is not None:
-                # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
-                ops.copy3d(carry, h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
-                dz0 = self._buf("gru:%s_dz0" % tag, N * 2 * H, self.T)
-                for n in range(N):
-                    ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + first[n]) * 2 * H,
-                               dst_off=n * 2 * H)
-                ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
-                         accumulate=2)
-            ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=bg)
-            ops.colsum(dzc, H, rows, H, g, out_off=bc)
-            ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
-            ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
-        self._tape.append(bwd)
+    def _gru_steps_bwd(self, dd, N, P, padl, T, H, ldh, lengths, hb, dh, cin, h0f):
+        ru, cc, col, reverse, dzg, dzc, og, oc = (dd[k] for k in ("ru", "cc", "col", "reverse", "dzg", "dzc", "og", "oc"))
+        W = self._W(self.T)
+        hi = dd.get("hi")
+        if hi is None:
+            hi = dict(h_init=(h0f, 0), hi_sn=H, reverse=reverse, T=T) if h0f is not None else {}
+        carry = self._buf("gru:carry", N * H, torch.float32)
+        drh = self._buf("gru:drh", N * H, torch.float32)
+        carry.zero_()
+        for t in (range(T) if reverse else range(T - 1, -1, -1)):
+            row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
+            # dh = the recurrent part (carry) + the gradient wrt this step's output where the step is valid; past the
+            # length the carry passes unchanged
+            ops.gru_pointwise(2, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H, c=(cc, row * H),
+                              c_sn=P * H, h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, out=(dzc, row * H),
+                              out_sn=P * H, dzg=(dzg, row * 2 * H), dzg_sn=P * 2 * H, dh=(carry, 0), dh_sn=H,
+                              carry=(carry, 0), carry_sn=H, dh_add=(dh, row * ldh + col), dha_sn=P * ldh, **hi)
+            ops.gemm(dzc, W, drh, N, H, H, P * H, H, H, a_off=row * H, b_off=oc + cin * H)
+            ops.gru_pointwise(3, hb, N, H, t, lengths, ru=(ru, row * 2 * H), ru_sn=P * 2 * H,
+                              h_prev=(hb, prow * ldh + col), hp_sn=P * ldh, dzg=(dzg, row * 2 * H),
+                              dzg_sn=P * 2 * H, dh=(drh, 0), dh_sn=H, carry=(carry, 0), carry_sn=H, **hi)
+            ops.gemm(dzg, W, carry, N, H, 2 * H, P * 2 * H, 2 * H, H, a_off=row * 2 * H, b_off=og + cin * 2 * H,
+                     accumulate=1)
+        if "dh0" in dd:
+            ops.copy3d(carry, dd["dh0"], 1, N, H, (0, H), (0, H))
 
     def _cbhg(self, name, x, lengths, scope, K, proj, training, spk=None):
         """spk: the speaker embedding rows (Act [N, 1, speaker_embed_dim]) for the encoder CBHG, modules.py:157-169."""
@@ -331,9 +404,9 @@ class Tacotron(Tacotron2):
         h0 = self._dense(name + "_h0", spk, scope + "/dense", 128, ACT_SOFTSIGN, mask=False) if spk is not None else None
         out = self._new(name + "_out", hw, 256)
         out.buf.zero_()
-        for di, d in enumerate(("fw", "bw")):
-            self._gru_seq("%s_%s" % (name, d), hw, "%s/bidirectional_rnn/%s/gru_cell" % (scope, d), "%s_%s" % (scope, d),
-                          128, lengths, d == "bw", out, di * 128, h0=h0)
+        dirs = [dict(tag="%s_%s" % (name, d), scope="%s/bidirectional_rnn/%s/gru_cell" % (scope, d), key="%s_%s" % (scope, d),
+                     reverse=d == "bw", col=di * 128) for di, d in enumerate(("fw", "bw"))]
+        self._gru_group(name + "_gru", dirs, hw, 128, lengths, out, h0)
         return out
 
     def _speaker_rows(self, N):

@@ -467,6 +467,34 @@ def gru_pointwise(mode, like, N, H, t, lengths, ru=None, ru_sn=0, c=None, c_sn=0
     L.call("ns_gru_pointwise", p, stream())
 
 
+def gru_seq_params(like, N, T, H, P, padl, reverse, lengths, xg, xc, wgT, wcT, wg, ld_wg, wc, ld_wc, h, ld_h, ru, c, rh,
+                   h_init=None, ld_hi=0, dh=None, ld_dh=0, dzg=None, dzc=None, dh_init=None, ld_dhi=0):
+    """One direction of ns_gru_seq_*; pointer arguments are tensors, (tensor, element offset) pairs or None."""
+    p = L.struct("ns_gru_seq_params")
+    _fill(p, dtype=dt(like), N=N, T=T, H=H, P=P, padl=padl, reverse=int(bool(reverse)), f32_passes=F32_PASSES or 0,
+          lengths=ptr(lengths), xg=_pp(xg), ld_xg=2 * H, xc=_pp(xc), ld_xc=H, wgT=_pp(wgT), wcT=_pp(wcT), wg=_pp(wg),
+          ld_wg=ld_wg, wc=_pp(wc), ld_wc=ld_wc, h=_pp(h), ld_h=ld_h, ru=_pp(ru), c=_pp(c), rh=_pp(rh), h_init=_pp(h_init),
+          ld_hi=ld_hi, dh=_pp(dh), ld_dh=ld_dh, dzg=_pp(dzg), dzc=_pp(dzc), dh_init=_pp(dh_init), ld_dhi=ld_dhi)
+    return p
+
+
+def gru_seq_supported(p0, p1=None, backward=False):
+    return bool(L.lib().ns_gru_seq_supported(C.byref(p0), C.byref(p1) if p1 is not None else None, int(backward)))
+
+
+def gru_seq_work_floats(p0):
+    fn = L.lib().ns_gru_seq_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(p0)) + 3) // 4
+
+
+def gru_seq(direction, p0, p1, work):
+    """Persistent whole-sequence GRU recurrence, one or two directions in one launch; work[0] is the status word."""
+    fn = getattr(L.lib(), "ns_gru_seq_fwd" if direction == "fwd" else "ns_gru_seq_bwd")
+    L.check(fn(C.byref(p0), C.byref(p1) if p1 is not None else None, C.c_void_p(ptr(work)), C.c_void_p(stream())),
+            "ns_gru_seq_" + direction)
+
+
 def _pp(x):
     """(tensor, offset) pair, tensor or None -> device address."""
     if x is None:
