@@ -59,6 +59,7 @@ struct GruArgs {
   float* dh_init[2]; int ld_dhi;
   u64* xbuf;                          // [chains][granules per chain]
   int* status;
+  long long* trace;                   // NS_GRU_TRACE=1 (diagnostic instantiation): [wave][8] segment sums of workgroup 0, 10 ns ticks
 };
 
 template <int H_> struct GCfg {
@@ -195,7 +196,7 @@ __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* im
 }
 
 // ===================================================================================================== forward
-template <int H, int P, typename T>
+template <int H, int P, typename T, bool TRACE = false>
 __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs a) {
   using C = GCfg<H>;
   constexpr int G = C::G, U = C::U, NB = C::NB, KSPLIT = C::KSPLIT, KSW = C::KSW, NR = C::NR, XS_LD = C::XS_LD;
@@ -250,11 +251,14 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     for (int i = 0; i < NR; ++i) hst[i] = (a.h_init[d] && nvalid) ? a.h_init[d][(long)n * a.ld_hi + un + i] : 0.f;
     T* hout = (T*)a.h[d];
     T* rhout = (T*)a.rh[d];
+    long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = TRACE ? wall_clock64() : 0;
+#define GRU_STAMP(k) do { if (TRACE) { __builtin_amdgcn_sched_barrier(0); const long long tn = wall_clock64(); tsum[k] += tn - tprev; tprev = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     for (int s = 0; s < T_; ++s) {
       const int t = rev ? T_ - 1 - s : s, buf = s & 1;
       const unsigned rowi = (unsigned)(n * a.P + a.padl + t);
       wg_barrier();                                        // B0: state image and stage of this slot are complete
       if (abortf[0]) return;
+      GRU_STAMP(0);
       const float* xrow = xs + (buf * 16 + col) * XS_LD + ul0 + 4 * q4;
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar;
       if (kh == 0) { ar = *(const f32x4*)xrow; au = *(const f32x4*)(xrow + U); }
@@ -266,6 +270,8 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         ar = mm<P>(wr[0][ks], wr[NPL - 1][ks], xh_, xl_, ar);
         au = mm<P>(wu[0][ks], wu[NPL - 1][ks], xh_, xl_, au);
       }
+      if (TRACE) { asm volatile("" : "+v"(ar), "+v"(au)); }
+      GRU_STAMP(1);
       float pr[NR], pu[NR];
       if constexpr (KSPLIT == 2) {
         // the partner wave (the other half of K) gets the sums of ITS registers, this wave takes the partner's for its own
@@ -289,8 +295,10 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + H + un, u);
         store_vals<T, NR>(rhout + rowi * (unsigned)H + un, rhv);
       }
+      GRU_STAMP(2);
       wg_barrier();                                        // B1: r * h image complete
       if (abortf[0]) return;
+      GRU_STAMP(3);
       f32x4 ac = {0.f, 0.f, 0.f, 0.f};
       if (kh == 0) ac = *(const f32x4*)(xrow + 2 * U);
 #pragma unroll
@@ -300,6 +308,8 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         const bf16x8 xl_ = NPL == 2 ? *(const bf16x8*)(rhimg + PS + so) : xh_;
         ac = mm<P>(wc[0][ks], wc[NPL - 1][ks], xh_, xl_, ac);
       }
+      if (TRACE) { asm volatile("" : "+v"(ac)); }
+      GRU_STAMP(4);
       float pc[NR];
       if constexpr (KSPLIT == 2) {
         const float2 give = kh ? make_float2(ac[0], ac[1]) : make_float2(ac[2], ac[3]);
@@ -328,7 +338,11 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         store_vals<float, NR>(a.c[d] + rowi * (unsigned)H + un, cv);
         store_vals<T, NR>(hout + rowi * (unsigned)a.ld_h + un, ho);
       }
+      GRU_STAMP(5);
     }
+#undef GRU_STAMP
+    if (TRACE && a.trace && blockIdx.x == 0 && lane == 0)
+      for (int k = 0; k < 8; ++k) a.trace[wave * 8 + k] = tsum[k];
   } else if (wave == GW) {
     // ================================================================ prefetcher role: 16 rows x 3U floats per slot
     // a row's section is U / 4 float4: LPR lanes per row, RPI rows per wave instruction, NJ instructions per section.
@@ -655,6 +669,10 @@ bool one_ok(const ns_gru_seq_params* p, int backward) {
   return true;
 }
 
+size_t xbytes(const ns_gru_seq_params* p, int ndir) {
+  const size_t chains = (size_t)ndir * ((p->N + 15) / 16);
+  return p->H == 256 ? chains * 3 * 16 * (size_t)p->H * sizeof(u64) : 0;
+}
 void fill(GruArgs& a, const ns_gru_seq_params* p0, const ns_gru_seq_params* p1, void* work) {
   const ns_gru_seq_params* pp[2] = {p0, p1 ? p1 : p0};
   a.N = p0->N; a.T = p0->T; a.P = p0->P; a.padl = p0->padl; a.ndir = p1 ? 2 : 1; a.nrg = (p0->N + 15) / 16;
@@ -670,12 +688,10 @@ void fill(GruArgs& a, const ns_gru_seq_params* p0, const ns_gru_seq_params* p1, 
   }
   a.status = (int*)work;
   a.xbuf = (u64*)((char*)work + 256);
+  const char* tr = getenv("NS_GRU_TRACE");
+  a.trace = (tr && atoi(tr)) ? (long long*)((char*)work + 256 + xbytes(p0, 2)) : nullptr;
 }
 
-size_t xbytes(const ns_gru_seq_params* p, int ndir) {
-  const size_t chains = (size_t)ndir * ((p->N + 15) / 16);
-  return p->H == 256 ? chains * 3 * 16 * (size_t)p->H * sizeof(u64) : 0;
-}
 }  // namespace
 
 extern "C" int ns_gru_seq_supported(const ns_gru_seq_params* p0, const ns_gru_seq_params* p1, int backward) {
@@ -686,7 +702,7 @@ extern "C" int ns_gru_seq_supported(const ns_gru_seq_params* p0, const ns_gru_se
 
 extern "C" size_t ns_gru_seq_work_bytes(const ns_gru_seq_params* p) {
   if (!p) return 0;
-  return 256 + xbytes(p, 2);
+  return 256 + xbytes(p, 2) + 16 * 8 * sizeof(long long);      // status, exchange buffers, NS_GRU_TRACE sums
 }
 
 template <int H, int P, typename T>
@@ -696,6 +712,13 @@ static void launch_fwd(const GruArgs& a, hipStream_t s) {
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)gru_fwd_kernel<H, P, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
+  }
+  if (a.trace) {       // diagnostic instantiation with in-kernel stamps (never the production path)
+    if constexpr (P == 3) {
+      (void)hipFuncSetAttribute((const void*)gru_fwd_kernel<H, P, T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL((gru_fwd_kernel<H, P, T, true>), dim3((unsigned)(a.ndir * a.nrg * C::G)), dim3(C::FW_WAVES * 64), fwd_lds<H>(P), s, a);
+      return;
+    }
   }
   hipLaunchKernelGGL((gru_fwd_kernel<H, P, T>), dim3((unsigned)(a.ndir * a.nrg * C::G)), dim3(C::FW_WAVES * 64), fwd_lds<H>(P), s, a);
 }

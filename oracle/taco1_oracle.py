@@ -7,6 +7,7 @@ h' = u*h + (1-u)*c (gate bias initialised to 1.0 - an initial VALUE, not a compu
 """
 import torch
 
+from . import taco2_oracle as _t2
 from .taco2_oracle import conv1d_bn, prenet
 
 
@@ -48,7 +49,8 @@ def bigru(x, lengths, p, scope, units, h0=None):
 
 def highwaynet(x, p, scope):
     """modules.py:185-191: H = relu(dense), T = sigmoid(dense, bias init -1): H*T + x*(1-T)."""
-    h = torch.relu(x @ p[scope + "/H/kernel"] + p[scope + "/H/bias"])
+    # _t2._relu = torch.relu unless a test records / forces the branch masks (taco2_oracle.MASK_LOG / MASK_FORCE)
+    h = _t2._relu(x @ p[scope + "/H/kernel"] + p[scope + "/H/bias"])
     t = torch.sigmoid(x @ p[scope + "/T/kernel"] + p[scope + "/T/bias"])
     return h * t + x * (1.0 - t)
 

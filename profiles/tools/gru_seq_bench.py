@@ -46,6 +46,13 @@ def run(N, T, H, ndir, dtype, passes, reps=5):
         ms = e0.elapsed_time(e1) / reps
         res.append("%s %.3f ms = %.2f us/step" % (name, ms, ms * 1e3 / T))
     print("N %d T %4d H %d dirs %d %s passes %d: %s" % (N, T, H, ndir, dtype, passes, "; ".join(res)), flush=True)
+    if os.environ.get("NS_GRU_TRACE") and passes == 3:
+        ops.gru_seq("fwd", pf[0], p1f, work)
+        torch.cuda.synchronize()
+        tr = work.view(torch.int64)[-16 * 8:].view(16, 8).cpu().numpy()
+        names = ["B0 wait", "phase-1 reads + MFMA", "gates, r*h, stores", "B1 wait", "phase-2 reads + MFMA", "tail"]
+        for w in (0, 3, 7):
+            print("   wave %d, us per step: %s" % (w, ", ".join("%s %.2f" % (nm, tr[w, k] * 0.01 / T) for k, nm in enumerate(names))))
 
 
 for dtype, passes in (("fp32", 3), ("fp32", 1), ("bf16", 0)):
