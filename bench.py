@@ -196,6 +196,69 @@ def inference_bench(hp, dtype, seed=1234):
     return out
 
 
+def taco1_bench(args, features, seed=1234):
+    """BASELINE config 1's model (Tacotron-1: CBHG encoder, Bahdanau attention with a GRU cell, residual GRU decoder, post
+    CBHG; hparams/taco1.yaml widths) at the benchmark's shape: one training step = forward + losses + backward + clip + Adam
+    on a device-resident synthetic batch of 32 x T_in 160 x T_out 1000 (r = 5), the same precision mode as the headline.
+    `gru`: the four persistent GRU recurrences (ns_gru_seq_*, csrc/gru.hip) timed alone with HIP events on the launch
+    stream; `roofline` = their gate products (recurrent halves in the loop + hoisted input halves are NOT in these
+    launches: recurrent flop only) against the bf16 MFMA peak - like the LSTM recurrences of the headline they sit at
+    their step latency, not at any throughput bound."""
+    from nspeech_amd import hparams as hparams_mod, ops
+    hp1 = hparams_mod.load("taco1")
+    N, Ti, To = args.batch, args.t_in, args.t_out
+    m = create_model("taco1", hp1, device="cuda:%d" % torch.cuda.current_device(), dtype=args.dtype, seed=seed)
+    m.add_optimizer(global_step=0)
+    inputs, lengths, mel, lin = synthetic_batch(hp1, N, Ti, To, seed, features=features)
+    m.initialize(inputs, lengths, None, mel, lin)              # uploads the batch once; the timed steps re-run it from HBM
+    step = lambda: m.step(read_loss=False)
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    m.check_status()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    m.check_status()
+    # the GRU launches alone: events around every ns_gru_seq call of one more step
+    ev, orig = [], ops.gru_seq
+
+    def timed(direction, p0, p1, work):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        orig(direction, p0, p1, work)
+        e1.record()
+        ev.append((direction, p0.H, p0.T, 2 if p1 is not None else 1, e0, e1))
+    ops.gru_seq = timed
+    try:
+        step()
+        torch.cuda.synchronize()
+    finally:
+        ops.gru_seq = orig
+    gru, flop, ms_sum = [], 0.0, 0.0
+    for direction, H, T, nd, e0, e1 in ev:
+        ms = e0.elapsed_time(e1)
+        f = nd * T * 2.0 * N * H * 3 * H                        # recurrent gate products of the launch
+        gru.append({"pass": direction, "H": H, "steps": T, "directions": nd, "ms": ms, "us_per_step": ms * 1e3 / T,
+                    "TFLOPs": f / (ms * 1e-3) / 1e12})
+        flop += f
+        ms_sum += ms
+    out = {"ms_per_step": dt * 1e3, "mel_frames_per_s": N * To / dt, "precision_mode": args.dtype,
+           "config": {"workload": "Tacotron-1 train step (fwd+bwd+clip+Adam), batch %d, T_in %d, T_out %d, r=%d, taco1.yaml widths"
+                                  % (N, Ti, To, hp1.outputs_per_step)},
+           "paths": dict(m.last_paths), "gru": gru,
+           "roofline": {"bound": "mfma", "kernel": "gru_fwd_kernel / gru_bwd_kernel (persistent GRU recurrences, %d launches)" % len(ev),
+                        "achieved": flop / (ms_sum * 1e-3) / 1e12 if ms_sum else None, "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": flop / (ms_sum * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS if ms_sum else None,
+                        "ms": ms_sum, "binding_bound": "step latency of a two-product recurrence (LDS barriers at H = 128, two "
+                                                       "CU-to-CU hops at H = 256), not MFMA throughput"}}
+    del m
+    return out
+
+
 def wavenet_bench(seed=1234):
     """BASELINE config 4 (simple_wavenet, shipped wavenet.yaml: 50 layers, receptive field 5117): one training step on
     8 clips of receptive field + 8000 samples, and incremental generation of 2000 samples behind a receptive-field
@@ -536,6 +599,7 @@ def main():
             res["griffin_lim"] = griffin_lim_bench(hp, not args.no_cpu_baseline)
             res["inference"] = inference_bench(hp, args.dtype)
             res["wavenet"] = wavenet_bench()
+            res["taco1"] = taco1_bench(args, None)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(hp, 1234)
         print(json.dumps(res))

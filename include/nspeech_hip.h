@@ -662,6 +662,46 @@ int ns_taco2_attn_cluster_fwd(const ns_taco2_attn_params* p, void* work, ns_stre
  * hoisted post-pass (dkeys, dv, dWcl, dctx_t, dvalues) as ns_taco2_attn_bwd. */
 int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stream_t stream);
 
+/* ------------------------------------------------------------------ Tacotron-1 attention RNN, persistent
+ * The recurrent part of Tacotron-1's teacher-forced decoder (tacotron.py:64-76 with AttentionWrapper(PrenetWrapper(
+ * GRUCell(256)), BahdanauAttention(256)), modules.py:76-102, rnn_wrappers.py:25-31) as ONE launch per direction:
+ *   p1 = relu(F1[s] + ctx[s-1].W1c)   p2 = relu(p1.W2 + b2)
+ *   [r | u] = sigmoid([p2, h[s-1]].Wg + bg)   c = tanh([p2, r * h[s-1]].Wc + bc)   h = u * h[s-1] + (1 - u) * c
+ *   e[t] = sum_u v[u] tanh(keys[t,u] + (h.Wq)[u])   align[s] = softmax over t < length   ctx[s] = sum_t align[s][t] values[t]
+ * in the projected-memory form of ns_taco2_attn_params (pv = values . W1c: the loop forms p1[s+1] = relu(align . pv +
+ * F1[s+1]) directly; the caller forms the contexts hc[:, :, A:] = align . values after the loop, and for the backward
+ * pass da0 = dhc[:, :, A:] . values^T before it).  An utterance runs on a cluster of 8 workgroups that keep the prenet-2 /
+ * GRU / query weights in registers as fp32 (matrix-vector products: exact FMAs), the utterance's keys and pv rows in LDS,
+ * and exchange three (backward: four) small vectors per step through `work` as tagged 8-byte granules.
+ * Shipped widths only: A = E-independent 256 units, D1 = 256, D2 = 128, T_in <= 256, no speaker rows.
+ * Per-step buffers are [N, S+1, X]: step s in slot s+1, slot 0 = the zero initial state (zero on entry).
+ * work: ns_taco1_attn_cluster_work_bytes(); work[0] (int) is a status word (non-zero after the call completes = an
+ * exchange timed out, outputs invalid). */
+typedef struct {
+  int dtype;
+  int N, S, Ti, Pi, padl_i, Tia;     /* memory row(n,t) = n*Pi + padl_i + t; Tia = ld of align */
+  int A, E, D1, D2;
+  const int* lengths;
+  const float* keys;                 /* fp32 [N*Pi, A] */
+  const void* pv;                    /* (dtype) [N*Pi, D1] */
+  const float* f1;                   /* fp32 [N,S+1,D1] */
+  const void* w2; const void* wg; const void* wc; const void* wq;   /* (dtype) [D1][D2], [D2+A][2A], [D2+A][A], [A][A] */
+  const float* b2; const float* bg; const float* bc; const float* v;
+  void* p1; void* xa; void* xc; void* hc;   /* (dtype) [N,S+1,D1], [N,S+1,D2+A] = [p2 | h_prev], same = [p2 | r*h_prev], [N,S+1,A+E] (h columns) */
+  float* ru; float* cc;              /* fp32 [N,S+1,2A], [N,S+1,A] */
+  float* q; float* align;            /* fp32 [N,S+1,A], [N,S+1,Tia] */
+  void* align_t;                     /* (dtype) [N,S+1,Tia] copy of align */
+  /* backward */
+  const float* dhc;                  /* fp32 [N,S+1,A+E]: the h columns are read */
+  const float* da0;                  /* fp32 [N,S+1,Tia] */
+  void* df1; void* dp2; void* dzg; void* dzc; void* dq;   /* (dtype) [N,S+1,D1 | D2 | 2A | A | A] out */
+  float* de;                         /* fp32 [N,S+1,Tia] out: energy gradients */
+} ns_taco1_attn_params;
+int ns_taco1_attn_cluster_supported(const ns_taco1_attn_params* p);
+size_t ns_taco1_attn_cluster_work_bytes(const ns_taco1_attn_params* p);
+int ns_taco1_attn_cluster_fwd(const ns_taco1_attn_params* p, void* work, ns_stream_t stream);
+int ns_taco1_attn_cluster_bwd(const ns_taco1_attn_params* p, void* work, ns_stream_t stream);
+
 /* Free-running synthesis loop (tacotron2.py:78-83 with TacoTestHelper, helpers.py:7-38: the last predicted frame is
  * the next step's input) as ONE persistent launch: the attention-RNN clusters of ns_taco2_attn_cluster_fwd plus
  * workgroups that keep the two decoder LSTMs (tacotron2.py:67-70) register-resident as fp32, 12 units each, exchanging

@@ -6,12 +6,12 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -std=c++17 -Wno-unused-result -Wno-unused-value"
-# per-file flags.  audio.hip, attn_cluster.hip: no SLP vectorisation - the packed-fp32 instructions it forms out of scalar
+# per-file flags.  audio.hip, attn_cluster.hip, attn_gru.hip: no SLP vectorisation - the packed-fp32 instructions it forms out of scalar
 # code pick their operand selects freely, including the src1 high-half select that MI355X misreads beside the MFMA waves of
 # another kernel (profiles/tools/pk_opsel_probe.hip; tests/test_isa_guard_cpu.py keeps every kernel of the library free of
 # that form)
 extra_flags() {
-  case "$1" in audio.hip|attn_cluster.hip) echo "-fno-slp-vectorize" ;; *) echo "" ;; esac
+  case "$1" in audio.hip|attn_cluster.hip|attn_gru.hip) echo "-fno-slp-vectorize" ;; *) echo "" ;; esac
 }
 if [ -n "$NS_ASM_DIR" ]; then
   mkdir -p "$NS_ASM_DIR"

@@ -49,6 +49,7 @@ class Tacotron(Tacotron2):
     _BUCKET_AFTER = {"backward": "all"}
 
     padl, padr = 8, 8     # bank widths up to 16: 'same' needs 7 left / 8 right; the data gradient the mirror
+    use_attn_cluster = os.environ.get("NS_TACO1_ATTN_CLUSTER", "1") != "0"     # persistent attention loop (csrc/attn_gru.hip)
     LAYOUT = staticmethod(P_.taco1_layout)
     KW = 1    # Bahdanau = location-sensitive kernel with a 1-tap zero filter
 
@@ -623,27 +624,52 @@ class Tacotron(Tacotron2):
         ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
         abg, abc = o("decoder/attention_gru/gates/bias"), o("decoder/attention_gru/candidate/bias")
         ov = o("decoder/attention/attention_v")
-        for s in range(S):
-            sl, pv = s + 1, s
-            ops.gemm(hc, tsh["w1cT"], p1, N, 256, E, S1 * HC, E, S1 * 256, a_off=pv * HC + A, c_off=sl * 256, act=ACT_RELU,
-                     addend=f1, addend_off=sl * 256, ld_add=S1 * 256)
-            ops.gemm(p1, tsh["w2T"], xa, N, 128, 256, S1 * 256, 256, S1 * XA, a_off=sl * 256, c_off=sl * XA,
-                     bias=self.flat_p, bias_off=b2, act=ACT_RELU)
-            ops.copy3d(xa, xc, N, 1, XI, (S1 * XA, 0), (S1 * XA, 0), src_off=sl * XA, dst_off=sl * XA)
-            ops.gemm(xa, tsh["att_gT"], ru, N, 2 * A, XA, S1 * XA, XA, S1 * 2 * A, a_off=sl * XA, c_off=sl * 2 * A,
-                     bias=self.flat_p, bias_off=abg, act=ACT_SIGMOID)
-            ops.gru_pointwise(0, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
-                              hp_sn=S1 * XA, out=(xc, sl * XA + XI), out_sn=S1 * XA)
-            ops.gemm(xc, tsh["att_cT"], cc, N, A, XA, S1 * XA, XA, S1 * A, a_off=sl * XA, c_off=sl * A, bias=self.flat_p,
-                     bias_off=abc, act=ACT_TANH)
-            ops.gru_pointwise(1, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
-                              h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(hc, sl * HC), out_sn=S1 * HC,
-                              out2=(xa, (sl + 1) * XA + XI) if s + 1 < S else None, out2_sn=S1 * XA)
-            ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, S1 * A, a_off=sl * HC, c_off=sl * A)
-            ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, sl * A), S1 * A,
-                               (al, pv * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, None, 0,
-                               tsh["wcl"], (self.flat_p, ov), er)
-        ops.copy3d(al, al_t, 1, N * S1, Tia, (0, Tia), (0, Tia))
+        # The whole loop as ONE persistent launch (csrc/attn_gru.hip) where the shape allows: the shipped widths, no speaker
+        # rows, T_in <= 256, 8 N workgroups resident.  Projected-memory form: pv = values . W1c, so the loop yields the
+        # next step's prenet layer directly and the 256-wide contexts are formed after it by one product per utterance.
+        self._attn_args = None
+        if self.use_attn_cluster and not Dsp:
+            wg_, wc_ = (W, ag), (W, ac_)
+            pvb = self._buf("dec_pv", N * Pi * 256, T_)
+            args = dict(dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=self.padl, Tia=Tia, A=A, E=E, D1=256, D2=128,
+                        lengths=lengths, keys=keys, pv=pvb, f1=f1, w2=(W, w2), wg=wg_, wc=wc_,
+                        wq=(W, o("decoder/attention/query_layer/kernel")), b2=(self.flat_p, b2), bg=(self.flat_p, abg),
+                        bc=(self.flat_p, abc), v=(self.flat_p, ov), p1=p1, xa=xa, xc=xc, hc=hc, ru=ru, cc=cc, q=q, align=al,
+                        align_t=al_t)
+            if ops.taco1_attn_cluster_supported(**args):
+                self._attn_args = args
+        if self._attn_args is not None:
+            ops.gemm(enc.buf, W, pvb, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
+            cw = self._buf("attn_cluster_work", ops.taco1_attn_cluster_work_floats(**self._attn_args), torch.float32)
+            ops.taco1_attn_cluster("fwd", cw, **self._attn_args)
+            self._status_words[("attn", "fwd")] = cw
+            # contexts of all steps: hc[n, :, A:] = align[n] . values[n] (slot 0: a zero alignment row)
+            ops.gemm(al_t, enc.buf, hc, S1, E, Ti, Tia, E, HC, b_mode=1, b_off=self.padl * E, c_off=A, batch=N,
+                     batch_strides=(S1 * Tia, Pi * E, S1 * HC))
+            self.last_paths["attn:fwd"] = "cluster"
+        else:
+            self.last_paths["attn:fwd"] = "step"
+            for s in range(S):
+                sl, pv = s + 1, s
+                ops.gemm(hc, tsh["w1cT"], p1, N, 256, E, S1 * HC, E, S1 * 256, a_off=pv * HC + A, c_off=sl * 256, act=ACT_RELU,
+                         addend=f1, addend_off=sl * 256, ld_add=S1 * 256)
+                ops.gemm(p1, tsh["w2T"], xa, N, 128, 256, S1 * 256, 256, S1 * XA, a_off=sl * 256, c_off=sl * XA,
+                         bias=self.flat_p, bias_off=b2, act=ACT_RELU)
+                ops.copy3d(xa, xc, N, 1, XI, (S1 * XA, 0), (S1 * XA, 0), src_off=sl * XA, dst_off=sl * XA)
+                ops.gemm(xa, tsh["att_gT"], ru, N, 2 * A, XA, S1 * XA, XA, S1 * 2 * A, a_off=sl * XA, c_off=sl * 2 * A,
+                         bias=self.flat_p, bias_off=abg, act=ACT_SIGMOID)
+                ops.gru_pointwise(0, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
+                                  hp_sn=S1 * XA, out=(xc, sl * XA + XI), out_sn=S1 * XA)
+                ops.gemm(xc, tsh["att_cT"], cc, N, A, XA, S1 * XA, XA, S1 * A, a_off=sl * XA, c_off=sl * A, bias=self.flat_p,
+                         bias_off=abc, act=ACT_TANH)
+                ops.gru_pointwise(1, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
+                                  h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(hc, sl * HC), out_sn=S1 * HC,
+                                  out2=(xa, (sl + 1) * XA + XI) if s + 1 < S else None, out2_sn=S1 * XA)
+                ops.gemm(hc, tsh["wqT"], q, N, A, A, S1 * HC, A, S1 * A, a_off=sl * HC, c_off=sl * A)
+                ops.attention_step(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys_t, enc.buf, (q, sl * A), S1 * A,
+                                   (al, pv * Tia), (al, sl * Tia), S1 * Tia, (hc, sl * HC + A), S1 * HC, None, 0,
+                                   tsh["wcl"], (self.flat_p, ov), er)
+            ops.copy3d(al, al_t, 1, N * S1, Tia, (0, Tia), (0, Tia))
         hcA = Act(self, "hc", N, S1, 1, S, HC, buf=hc)
         self._tape.append(self._attention_backward)
 
@@ -752,7 +778,8 @@ class Tacotron(Tacotron2):
         rows = N * S1
         buf = self._buf
         dzg = buf("att_dzg", rows * 2 * A, T_); dzc = buf("att_dzc", rows * A, T_)
-        dp2 = buf("att_dp2", rows * 128, T_); df1 = buf("att_df1", rows * 256, T_)
+        dp2 = buf("att_dp2", rows * 128, T_)
+        df1 = buf("att_df1", (rows + 1) * 256, T_)          # (+ one zero row read by the shifted context-gradient product)
         dq = buf("att_dq", rows * A, T_); de = buf("att_de", rows * Tia, torch.float32)
         dctx_t = buf("att_dctx_t", rows * E, T_)
         for b in (dzg, dzc, dp2, df1, dq, de, dctx_t):
@@ -766,34 +793,60 @@ class Tacotron(Tacotron2):
         ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
         w1, w2 = o("decoder/decoder_prenet/dense_1/kernel"), o("decoder/decoder_prenet/dense_2/kernel")
         wq, ov = o("decoder/attention/query_layer/kernel"), o("decoder/attention/attention_v")
-        for s in range(S - 1, -1, -1):
-            sl, pv = s + 1, s
-            last = s == S - 1
-            ops.attention_step_bwd(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys, keys_t, enc.buf,
-                                   (q, sl * A), S1 * A, (al, sl * Tia), (al, pv * Tia), S1 * Tia, (dhc, sl * HC + A), S1 * HC,
-                                   None if last else dctx_carry, gk, da, 0 if last else 1, (dq, sl * A), S1 * A,
-                                   (de, sl * Tia), (dctx_t, sl * E), S1 * E, tsh["wcl"], (self.flat_p, ov))
-            # dh_total = dhc[:, :A] + carry + dq . Wq^T
-            ops.copy3d(dhc, carry_h, N, 1, A, (S1 * HC, 0), (A, 0), src_off=sl * HC, accumulate=1)
-            ops.gemm(dq, W, carry_h, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=wq, accumulate=1)
-            ops.gru_pointwise(2, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
-                              h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(dzc, sl * A), out_sn=S1 * A,
-                              dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(carry_h, 0), dh_sn=A, carry=(carry_h, 0), carry_sn=A)
-            ops.gemm(dzc, W, drh, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=ac_ + XI * A)
-            ops.gru_pointwise(3, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
-                              hp_sn=S1 * XA, dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(drh, 0), dh_sn=A,
-                              carry=(carry_h, 0), carry_sn=A)
-            ops.gemm(dzg, W, carry_h, N, A, 2 * A, S1 * 2 * A, 2 * A, A, a_off=sl * 2 * A, b_off=ag + XI * 2 * A, accumulate=1)
-            # dp2pre = (dzg . Wg[:128]^T + dzc . Wc[:128]^T) * (p2 > 0)
-            ops.gemm(dzg, W, tmp128, N, 128, 2 * A, S1 * 2 * A, 2 * A, 128, a_off=sl * 2 * A, b_off=ag,
-                     gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
-            ops.gemm(dzc, W, tmp128, N, 128, A, S1 * A, A, 128, a_off=sl * A, b_off=ac_, accumulate=1,
-                     gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
-            ops.copy3d(tmp128, dp2, N, 1, 128, (128, 0), (S1 * 128, 0), dst_off=sl * 128)
-            ops.gemm(dp2, W, df1, N, 256, 128, S1 * 128, 128, S1 * 256, a_off=sl * 128, b_off=w2, c_off=sl * 256,
-                     gate=p1, gate_off=sl * 256, ld_gate=S1 * 256)
-            if s > 0:
-                ops.gemm(df1, W, dctx_carry, N, E, 256, S1 * 256, 256, E, a_off=sl * 256, b_off=w1 + M * 256)
+        if self._attn_args is not None:
+            # persistent form: da0 = dhc[:, :, A:] . values^T for all steps at once (the part of d(align) that needs no
+            # recurrence), the launch, then the context gradients of all steps: dctx[s] = dhc[s, A:] + df1[s+1] . W1c^T
+            da0 = buf("att_da0", rows * Tia, torch.float32)
+            if T_ == torch.float32:
+                src, lda, a0 = dhc, HC, A
+            else:
+                src, lda, a0 = buf("att_dhc_ctx", rows * E, T_), E, 0
+                ops.copy3d(dhc, src, 1, rows, E, (0, HC), (0, E), src_off=A)
+            ops.gemm(src, enc.buf, da0, S1, Ti, E, lda, E, Tia, b_mode=0, a_off=a0, b_off=self.padl * E, batch=N,
+                     batch_strides=(S1 * lda, Pi * E, S1 * Tia))
+            args = dict(self._attn_args)
+            args.update(dhc=dhc, da0=da0, df1=df1, dp2=dp2, dzg=dzg, dzc=dzc, dq=dq, de=de)
+            cw = buf("attn_cluster_work_b", ops.taco1_attn_cluster_work_floats(**args), torch.float32)
+            ops.taco1_attn_cluster("bwd", cw, **args)
+            self._status_words[("attn", "bwd")] = cw
+            dctx32 = buf("att_dctx32", rows * E, torch.float32)
+            ops.copy3d(dhc, dctx32, 1, rows, E, (0, HC), (0, E), src_off=A)
+            ops.gemm(df1, W, dctx32, rows, E, 256, 256, 256, E, a_mode=0, b_mode=0, a_off=256, b_off=w1 + M * 256, accumulate=1)
+            if T_ == torch.float32:
+                dctx_t = dctx32
+            else:
+                ops.copy3d(dctx32, dctx_t, 1, rows, E, (0, E), (0, E))
+            self.last_paths["attn:bwd"] = "cluster"
+        else:
+            self.last_paths["attn:bwd"] = "step"
+            for s in range(S - 1, -1, -1):
+                sl, pv = s + 1, s
+                last = s == S - 1
+                ops.attention_step_bwd(hc, N, Ti, Pi, self.padl, Tia, A, E, self.KW, lengths, keys, keys_t, enc.buf,
+                                       (q, sl * A), S1 * A, (al, sl * Tia), (al, pv * Tia), S1 * Tia, (dhc, sl * HC + A), S1 * HC,
+                                       None if last else dctx_carry, gk, da, 0 if last else 1, (dq, sl * A), S1 * A,
+                                       (de, sl * Tia), (dctx_t, sl * E), S1 * E, tsh["wcl"], (self.flat_p, ov))
+                # dh_total = dhc[:, :A] + carry + dq . Wq^T
+                ops.copy3d(dhc, carry_h, N, 1, A, (S1 * HC, 0), (A, 0), src_off=sl * HC, accumulate=1)
+                ops.gemm(dq, W, carry_h, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=wq, accumulate=1)
+                ops.gru_pointwise(2, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, c=(cc, sl * A), c_sn=S1 * A,
+                                  h_prev=(xa, sl * XA + XI), hp_sn=S1 * XA, out=(dzc, sl * A), out_sn=S1 * A,
+                                  dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(carry_h, 0), dh_sn=A, carry=(carry_h, 0), carry_sn=A)
+                ops.gemm(dzc, W, drh, N, A, A, S1 * A, A, A, a_off=sl * A, b_off=ac_ + XI * A)
+                ops.gru_pointwise(3, xa, N, A, s, None, ru=(ru, sl * 2 * A), ru_sn=S1 * 2 * A, h_prev=(xa, sl * XA + XI),
+                                  hp_sn=S1 * XA, dzg=(dzg, sl * 2 * A), dzg_sn=S1 * 2 * A, dh=(drh, 0), dh_sn=A,
+                                  carry=(carry_h, 0), carry_sn=A)
+                ops.gemm(dzg, W, carry_h, N, A, 2 * A, S1 * 2 * A, 2 * A, A, a_off=sl * 2 * A, b_off=ag + XI * 2 * A, accumulate=1)
+                # dp2pre = (dzg . Wg[:128]^T + dzc . Wc[:128]^T) * (p2 > 0)
+                ops.gemm(dzg, W, tmp128, N, 128, 2 * A, S1 * 2 * A, 2 * A, 128, a_off=sl * 2 * A, b_off=ag,
+                         gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
+                ops.gemm(dzc, W, tmp128, N, 128, A, S1 * A, A, 128, a_off=sl * A, b_off=ac_, accumulate=1,
+                         gate=xa, gate_off=sl * XA, ld_gate=S1 * XA)
+                ops.copy3d(tmp128, dp2, N, 1, 128, (128, 0), (S1 * 128, 0), dst_off=sl * 128)
+                ops.gemm(dp2, W, df1, N, 256, 128, S1 * 128, 128, S1 * 256, a_off=sl * 128, b_off=w2, c_off=sl * 256,
+                         gate=p1, gate_off=sl * 256, ld_gate=S1 * 256)
+                if s > 0:
+                    ops.gemm(df1, W, dctx_carry, N, E, 256, S1 * 256, 256, E, a_off=sl * 256, b_off=w1 + M * 256)
         if Dsp:
             # the speaker projection sits in rows 128 .. 128 + Dsp of both GRU kernels in every slot: its gradient is the
             # sum over an utterance's slots of dzg . Wg[128:XI]^T + dzc . Wc[128:XI]^T

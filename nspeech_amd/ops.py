@@ -467,6 +467,36 @@ def gru_pointwise(mode, like, N, H, t, lengths, ru=None, ru_sn=0, c=None, c_sn=0
     L.call("ns_gru_pointwise", p, stream())
 
 
+def _taco1_attn_params(kw):
+    p = L.struct("ns_taco1_attn_params")
+    for k, v in kw.items():
+        if v is None:
+            continue
+        if isinstance(v, tuple):        # (tensor, offset)
+            v = ptr(v[0], v[1])
+        elif hasattr(v, "data_ptr"):
+            v = ptr(v)
+        setattr(p, k, v)
+    return p
+
+
+def taco1_attn_cluster_supported(**kw):
+    return bool(L.lib().ns_taco1_attn_cluster_supported(C.byref(_taco1_attn_params(kw))))
+
+
+def taco1_attn_cluster_work_floats(**kw):
+    fn = L.lib().ns_taco1_attn_cluster_work_bytes
+    fn.restype = C.c_size_t
+    return (fn(C.byref(_taco1_attn_params(kw))) + 3) // 4
+
+
+def taco1_attn_cluster(direction, work, **kw):
+    """Tacotron-1's attention RNN (prenet -> GRU -> Bahdanau) over all decoder steps, one persistent launch; work[0] is the
+    status word."""
+    fn = getattr(L.lib(), "ns_taco1_attn_cluster_fwd" if direction == "fwd" else "ns_taco1_attn_cluster_bwd")
+    L.check(fn(C.byref(_taco1_attn_params(kw)), C.c_void_p(ptr(work)), C.c_void_p(stream())), "ns_taco1_attn_cluster_" + direction)
+
+
 def gru_seq_params(like, N, T, H, P, padl, reverse, lengths, xg, xc, wgT, wcT, wg, ld_wg, wc, ld_wc, h, ld_h, ru, c, rh,
                    h_init=None, ld_hi=0, dh=None, ld_dh=0, dzg=None, dzc=None, dh_init=None, ld_dhi=0):
     """One direction of ns_gru_seq_*; pointer arguments are tensors, (tensor, element offset) pairs or None."""

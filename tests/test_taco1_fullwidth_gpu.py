@@ -33,7 +33,9 @@ FLIPS = {       # family: (largest |x| / rms at a differing branch, largest frac
 }
 SEQ = {"enc_gru:fwd": "seq", "enc_gru:bwd": "seq", "post_gru:fwd": "seq", "post_gru:bwd": "seq", "gru_1:fwd": "seq",
        "gru_1:bwd": "seq", "gru_2:fwd": "seq", "gru_2:bwd": "seq"}
-PATHS = {"fp32": {k: "step" for k in SEQ}, "bf16x3": SEQ, "mixed": SEQ, "bf16": SEQ}
+ATT = {"attn:fwd": "cluster", "attn:bwd": "cluster"}          # csrc/attn_gru.hip: exact fp32 products, every mode
+PATHS = {"fp32": dict({k: "step" for k in SEQ}, **ATT), "bf16x3": dict(SEQ, **ATT), "mixed": dict(SEQ, **ATT),
+         "bf16": dict(SEQ, **ATT)}
 
 
 def _families(hp, S):
@@ -167,8 +169,8 @@ def test_taco1_shipped_widths_match_oracle(dev, mode, shape):
     assert rep["bn"] < (1e-4 if mode != "bf16" else 2e-2)
 
 
-def test_persistent_gru_path_equals_the_step_launches_in_the_model(dev, monkeypatch):
-    """The same model pass with the persistent GRU kernels and with four launches per step (NS_GRU_SEQ switch): both
+def test_persistent_paths_equal_the_step_launches_in_the_model(dev, monkeypatch):
+    """The same model pass with the persistent kernels (GRU recurrences, attention loop) and with the launch-per-step forms: both
     compute the same products from the same operands in split-bf16 arithmetic - outputs and gradients agree to rounding."""
     from nspeech_amd import hparams as hparams_mod
     from nspeech_amd.models import create_model
@@ -179,11 +181,13 @@ def test_persistent_gru_path_equals_the_step_launches_in_the_model(dev, monkeypa
     res = {}
     for seq in (True, False):
         monkeypatch.setattr(Tacotron, "use_gru_seq", seq)
+        monkeypatch.setattr(Tacotron, "use_attn_cluster", seq)
         m = create_model("taco1", hp, device="cuda:0", dtype="bf16x3", seed=5)
         m.initialize(inputs, lengths, None, mel, lin)
         m.backward()
         m.read_losses()
         assert m.last_paths["post_gru:fwd"] == ("seq" if seq else "step") and m.last_paths["gru_1:bwd"] == ("seq" if seq else "step")
+        assert m.last_paths["attn:fwd"] == m.last_paths["attn:bwd"] == ("cluster" if seq else "step")
         res[seq] = (m.mel_outputs.float().cpu().numpy(), m.linear_outputs.float().cpu().numpy(), m.numpy_grads(), m.loss)
     assert rel_max(res[True][0], res[False][0]) < 2e-5 and rel_max(res[True][1], res[False][1]) < 2e-5
     assert abs(res[True][3] - res[False][3]) < 1e-6 * abs(res[False][3])
