@@ -59,6 +59,7 @@ struct GruArgs {
   float* dh_init[2]; int ld_dhi;
   u64* xbuf;                          // [chains][granules per chain]
   int* status;
+  int dbg;                            // NS_GRU_DBG (timing experiments only, 0 in production): 1 no prefetch, 2 no result stores
   long long* trace;                   // NS_GRU_TRACE=1 (diagnostic instantiation): [wave][8] segment sums of workgroup 0, 10 ns ticks
 };
 
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
       for (int i = 0; i < NR; ++i) { r[i] = sigmoidf_(pr[i]); u[i] = sigmoidf_(pu[i]); rhv[i] = r[i] * hst[i]; }
       if constexpr (G == 1) put_image<NR, NPL>(rhimg, PS, swz(col, un, H), rhv);
       else publish<NR>(xr + col * H + un, (unsigned)(s + 1), rhv);
-      if (nvalid) {
+      if (nvalid && !(a.dbg & 2)) {
         store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + un, r);
         store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + H + un, u);
         store_vals<T, NR>(rhout + rowi * (unsigned)H + un, rhv);
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         if constexpr (G == 1) put_image<NR, NPL>(himg, PS, swz(col, un, H), hst);
         else publish<NR>(xh + col * H + un, (unsigned)(s + 1), hst);
       }
-      if (nvalid) {
+      if (nvalid && !(a.dbg & 2)) {
         store_vals<float, NR>(a.c[d] + rowi * (unsigned)H + un, cv);
         store_vals<T, NR>(hout + rowi * (unsigned)a.ld_h + un, ho);
       }
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     for (int s = 0; s < T_; ++s) {
       wg_barrier();                                        // B0
       if (abortf[0]) return;
-      if (s + 1 < T_) {
+      if (s + 1 < T_ && !(a.dbg & 1)) {
         pf_store((s + 1) & 1);
         if (s + 2 < T_) pf_load(s + 2);
       }
@@ -690,6 +691,8 @@ void fill(GruArgs& a, const ns_gru_seq_params* p0, const ns_gru_seq_params* p1, 
   a.xbuf = (u64*)((char*)work + 256);
   const char* tr = getenv("NS_GRU_TRACE");
   a.trace = (tr && atoi(tr)) ? (long long*)((char*)work + 256 + xbytes(p0, 2)) : nullptr;
+  const char* dbg = getenv("NS_GRU_DBG");
+  a.dbg = dbg ? atoi(dbg) : 0;
 }
 
 }  // namespace
