@@ -262,6 +262,9 @@ int ns_segment_stats(const ns_segment_stats_params* p, ns_stream_t stream);
 /* Zero `bytes` (a multiple of 16, p 16-byte aligned) with a kernel on the stream.  Kernel, not hipMemsetAsync: a memset
  * NODE of a captured HIP graph was seen to replay wrongly on ROCm 7.2 (see csrc/core.hip). */
 int ns_zero(void* p, size_t bytes, ns_stream_t stream);
+/* The same for n buffers in one launch per NS_ZERO_MANY_MAX of them (ptrs / bytes: host arrays, read before the call returns). */
+#define NS_ZERO_MANY_MAX 24
+int ns_zero_many(void* const* ptrs, const size_t* bytes, int n, ns_stream_t stream);
 
 /* hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - hi[i]): pre-split operands for f32_passes = 3. */
 typedef struct { const float* src; void* hi; void* lo; int64_t n; } ns_split_params;

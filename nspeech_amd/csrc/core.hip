@@ -46,6 +46,36 @@ int ns_zero_async(void* p, size_t bytes, hipStream_t s) {
 }
 extern "C" int ns_zero(void* p, size_t bytes, ns_stream_t stream) { return ns_zero_async(p, bytes, (hipStream_t)stream); }
 
+// Several buffers in ONE launch (a backward pass clears dozens of small gradient accumulators: one 5 us launch each
+// otherwise).  blockIdx.y = buffer, blockIdx.x strides over it.
+struct ZeroMany { uint4* p[NS_ZERO_MANY_MAX]; size_t n16[NS_ZERO_MANY_MAX]; };
+__global__ void ns_zero_many_kernel(ZeroMany z) {
+  uint4* p = z.p[blockIdx.y];
+  const size_t n16 = z.n16[blockIdx.y];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+extern "C" int ns_zero_many(void* const* ptrs, const size_t* bytes, int n, ns_stream_t stream) {
+  NS_CHECK_ARG(n >= 0 && (n == 0 || (ptrs && bytes)), "ns_zero_many: null");
+  for (int i0 = 0; i0 < n; i0 += NS_ZERO_MANY_MAX) {
+    ZeroMany z = {};
+    const int m = n - i0 < NS_ZERO_MANY_MAX ? n - i0 : NS_ZERO_MANY_MAX;
+    size_t most = 0;
+    for (int i = 0; i < m; ++i) {
+      NS_CHECK_ARG((bytes[i0 + i] & 15) == 0 && (((uintptr_t)ptrs[i0 + i]) & 15) == 0 && (ptrs[i0 + i] || !bytes[i0 + i]),
+                   "ns_zero_many: 16-byte granularity");
+      z.p[i] = (uint4*)ptrs[i0 + i];
+      z.n16[i] = bytes[i0 + i] / 16;
+      most = z.n16[i] > most ? z.n16[i] : most;
+    }
+    if (most == 0) continue;
+    const int gx = (int)((most + 255) / 256 < 256 ? (most + 255) / 256 : 256);
+    hipLaunchKernelGGL(ns_zero_many_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, z);
+    NS_CHECK_LAUNCH("ns_zero_many");
+  }
+  return NS_OK;
+}
+
 // ns_occupy / ns_wait_counter: hold CUs the way a collective's channel kernel does (see the header).  wall_clock64
 // ticks at 100 MHz.
 __global__ void ns_occupy_kernel(unsigned long long ticks, int* started) {

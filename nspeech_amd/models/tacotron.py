@@ -39,8 +39,9 @@ class Act(object):
     @property
     def grad(self):
         if self._grad is None:
+            # zero here already: _buf clears a buffer when it creates it, backward() clears every existing "g:" buffer in
+            # one launch before the tape runs
             self._grad = self.m._buf("g:" + self.name, self.rows * self.C, torch.float32)
-            self._grad.zero_()
         return self._grad
 
 
@@ -289,8 +290,8 @@ class Tacotron(Tacotron2):
             for dd in dirs:
                 dd["dzg"] = self._buf("gru:%s_dzg" % dd["tag"], rows * 2 * H, self.T)
                 dd["dzc"] = self._buf("gru:%s_dzc" % dd["tag"], rows * H, self.T)
-                dd["dzg"].zero_()          # the hoisted products below run over every row: pad rows must hold zeros
-                dd["dzc"].zero_()
+                ops.zero(dd["dzg"])          # the hoisted products below run over every row: pad rows must hold zeros
+                ops.zero(dd["dzc"])
                 if h0 is not None:
                     dd["dh0"] = self._buf("gru:%s_dh0" % dd["tag"], N * H, torch.float32)
             pb = persistent(True)
@@ -366,7 +367,7 @@ class Tacotron(Tacotron2):
             hi = dict(h_init=(h0f, 0), hi_sn=H, reverse=reverse, T=T) if h0f is not None else {}
         carry = self._buf("gru:carry", N * H, torch.float32)
         drh = self._buf("gru:drh", N * H, torch.float32)
-        carry.zero_()
+        ops.zero(carry)
         for t in (range(T) if reverse else range(T - 1, -1, -1)):
             row, prow = padl + t, padl + (t + 1 if reverse else t - 1)
             # dh = the recurrent part (carry) + the gradient wrt this step's output where the step is valid; past the
@@ -404,7 +405,7 @@ class Tacotron(Tacotron2):
             hw = self._highway("%s_hw%d" % (name, i), hw, "%s/highway_%d/highway" % (scope, i))
         h0 = self._dense(name + "_h0", spk, scope + "/dense", 128, ACT_SOFTSIGN, mask=False) if spk is not None else None
         out = self._new(name + "_out", hw, 256)
-        out.buf.zero_()
+        ops.zero(out.buf)
         dirs = [dict(tag="%s_%s" % (name, d), scope="%s/bidirectional_rnn/%s/gru_cell" % (scope, d), key="%s_%s" % (scope, d),
                      reverse=d == "bw", col=di * 128) for di, d in enumerate(("fw", "bw"))]
         self._gru_group(name + "_gru", dirs, hw, 128, lengths, out, h0)
@@ -503,7 +504,7 @@ class Tacotron(Tacotron2):
         q = buf("i_q", N * A, torch.float32); al = buf("i_al", N * S1 * Tia, torch.float32)
         er = buf("i_er", N * Tia, torch.float32); dec = buf("i_dec", N * S1 * M * r, torch.float32)
         for b in (xp, xa, hc, g1, g2, al):
-            b.zero_()
+            ops.zero(b)
         if Dsp:
             ops.copy3d(spk_dec.buf, xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
         ov = o("decoder/attention/attention_v")
@@ -616,8 +617,7 @@ class Tacotron(Tacotron2):
         al = self._buf("dec_al", N * S1 * Tia, torch.float32)
         al_t = self._buf("dec_al_t", N * S1 * Tia, T_)
         er = self._buf("dec_eraw", N * Tia, torch.float32)
-        for b in (xa, xc, hc, al):
-            b.zero_()
+        ops.zero_many((xa, xc, hc, al))
         if Dsp:                                   # rnn_wrappers.py:28-30: the same projection in every step's input
             ops.copy3d(self._spk_dec.buf, xa, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
         tsh = self.tsh
@@ -675,10 +675,10 @@ class Tacotron(Tacotron2):
 
         # ---- projection, residual GRUs, output projection (tacotron.py:69-76)
         x1 = self._dense("attproj", hcA, "decoder/attention_projection", D, ACT_NONE, mask=True)
-        h1 = self._new("dec_h1", x1, D); h1.buf.zero_()
+        h1 = self._new("dec_h1", x1, D); ops.zero(h1.buf)
         self._gru_seq("gru_1", x1, "decoder/gru_1", "gru_1", D, None, False, h1, 0)
         y1 = self._add("dec_y1", x1, h1)
-        h2 = self._new("dec_h2", y1, D); h2.buf.zero_()
+        h2 = self._new("dec_h2", y1, D); ops.zero(h2.buf)
         self._gru_seq("gru_2", y1, "decoder/gru_2", "gru_2", D, None, False, h2, 0)
         y2 = self._add("dec_y2", y1, h2)
         decA = Act(self, "dec_out", N, S1, 1, S, M * r, dtype=torch.float32)
@@ -725,11 +725,8 @@ class Tacotron(Tacotron2):
         S1, Tia = S + 1, st["Tia"]
         XA, HC = 128 + A, A + E
         g = self.flat_g
-        g.zero_()
-        self.scal.zero_()
-        for k, b in self._bufs.items():     # activation gradients accumulate: start from zero
-            if k.startswith("g:"):
-                b.zero_()
+        # activation gradients accumulate: start from zero (one launch per 24 buffers)
+        ops.zero_many([g, self.scal] + [b for k, b in self._bufs.items() if k.startswith("g:")])
         ops.F32_PASSES = self.passes_bwd
         W, o, tsh = self._W(T_), self._o, self.tsh
         sk = self._splitk
@@ -746,7 +743,7 @@ class Tacotron(Tacotron2):
                     self.scal, acc_off=0)
         # linear head
         dwl = self._buf("d_wl_pad", 256 * Fp, torch.float32)
-        dwl.zero_()
+        ops.zero(dwl)
         rows_o = N * Po
         ops.gemm(post.buf, dlin, dwl, 256, Fp, rows_o, 256, Fp, Fp, a_mode=1, b_mode=1, accumulate=2,
                  split_k=sk(rows_o, 256, Fp))
@@ -782,13 +779,12 @@ class Tacotron(Tacotron2):
         df1 = buf("att_df1", (rows + 1) * 256, T_)          # (+ one zero row read by the shifted context-gradient product)
         dq = buf("att_dq", rows * A, T_); de = buf("att_de", rows * Tia, torch.float32)
         dctx_t = buf("att_dctx_t", rows * E, T_)
-        for b in (dzg, dzc, dp2, df1, dq, de, dctx_t):
-            b.zero_()
-        carry_h = buf("att_carry_h", N * A, torch.float32); carry_h.zero_()
+        carry_h = buf("att_carry_h", N * A, torch.float32)
         dctx_carry = buf("att_dctx_carry", N * E, torch.float32)
         drh = buf("att_drh", N * A, torch.float32)
         tmp128 = buf("att_tmp128", N * 128, torch.float32)
-        gk = buf("att_gk", N * Tia * 8, torch.float32); gk.zero_()
+        gk = buf("att_gk", N * Tia * 8, torch.float32)
+        ops.zero_many((dzg, dzc, dp2, df1, dq, de, dctx_t, carry_h, gk))
         da = buf("att_da", N * Tia, torch.float32)
         ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
         w1, w2 = o("decoder/decoder_prenet/dense_1/kernel"), o("decoder/decoder_prenet/dense_2/kernel")
@@ -869,10 +865,10 @@ class Tacotron(Tacotron2):
         ops.gemm(hc, dq, g, A, A, rows, HC, A, A, a_mode=1, b_mode=1, c_off=wq, accumulate=2, split_k=sk(rows, A, A))
         # attention: sums over all steps
         dkeys_t = buf("att_dkeys_t", N * A * Tia, torch.float32)
-        dwcl = buf("att_dwcl", 8 * A, torch.float32); dwcl.zero_()
+        dwcl = buf("att_dwcl", 8 * A, torch.float32); ops.zero(dwcl)
         ops.attention_post_bwd(N, S, Ti, Tia, A, self.KW, lengths, keys_t, q, al, de, tsh["wcl"], (self.flat_p, ov), dkeys_t,
                                (g, ov), dwcl)
-        dkeys = buf("att_dkeys", N * Pi * A, torch.float32); dkeys.zero_()
+        dkeys = buf("att_dkeys", N * Pi * A, torch.float32); ops.zero(dkeys)
         ops.keys_transpose_add(dkeys, dkeys_t, N, Ti, Tia, Pi, self.padl, A)
         dkeys_T = buf("att_dkeys_T", N * Pi * A, T_)
         ops.copy3d(dkeys, dkeys_T, 1, N * Pi, A, (0, A), (0, A))

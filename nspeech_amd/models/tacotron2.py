@@ -320,7 +320,10 @@ class Tacotron2(object):
             key = "%s_%s" % (name, str(dtype))
         b = self._bufs.get(key)
         if b is None or b.numel() < numel or b.dtype != dtype:
-            b = torch.zeros(_round_up(numel, 8), dtype=dtype, device=self.device)      # whole 16-byte units (ops.zero)
+            # whole 16-byte units, cleared by the library's own fill kernel: no torch kernel runs on the hot path, not even
+            # at a buffer's first touch (the rocprof table of a training run lists ns_* kernels only)
+            b = torch.empty(_round_up(numel, 8), dtype=dtype, device=self.device)
+            ops.zero(b)
             self._bufs[key] = b
         return b
 
@@ -1050,8 +1053,7 @@ class Tacotron2(object):
         S1 = S + 1
         g = self.flat_g
         ops.DETERMINISTIC_SPLITK = self.deterministic
-        ops.zero(g)
-        ops.zero(self.scal)
+        ops.zero_many((g, self.scal))
         self._deferred = []
         self._bwd_sums = {}
         B = self._bufs
@@ -1202,8 +1204,7 @@ class Tacotron2(object):
         dq = self._buf("d_q", rows * A, T_)
         dkeys = self._buf("d_keys", N * Pi * A, torch.float32)
         dvalues = self._buf("d_values", N * Pi * E, torch.float32)
-        ops.zero(dkeys)
-        ops.zero(dvalues)
+        ops.zero_many((dkeys, dvalues))
         dwcl = self._buf("d_wcl", _round_up(7 * A, 4), torch.float32)
         ops.zero(dwcl)
         Tia = _round_up(Ti, 8)

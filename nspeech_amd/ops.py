@@ -253,6 +253,19 @@ def zero(t):
     L.check(L.lib().ns_zero(C.c_void_p(ptr(t)), C.c_size_t(nbytes), C.c_void_p(stream())), "ns_zero")
 
 
+def zero_many(tensors):
+    """Clear several tensors with one launch per 24 of them (ns_zero_many)."""
+    ts = [t for t in tensors if t is not None and t.numel()]
+    if not ts:
+        return
+    for t in ts:
+        assert (t.numel() * t.element_size()) % 16 == 0 and t.data_ptr() % 16 == 0, "ops.zero_many: 16-byte granularity"
+    n = len(ts)
+    ptrs = (C.c_void_p * n)(*[ptr(t) for t in ts])
+    nbytes = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in ts])
+    L.check(L.lib().ns_zero_many(ptrs, nbytes, n, C.c_void_p(stream())), "ns_zero_many")
+
+
 CAST_RECORD = None        # a list: cast2d() appends its parameter block instead of launching (CastBatch)
 
 
