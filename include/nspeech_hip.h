@@ -331,6 +331,11 @@ typedef struct {
    * report "unsupported" and the caller falls back to the step launches. */
   uint32_t zoneout_thr_cell, zoneout_thr_output;
   uint32_t zoneout_seed_cell, zoneout_seed_output;
+  /* LSTMBlockCell's cell_clip attribute: > 0 clips the new cell state to [-cell_clip, cell_clip] in every forward form
+   * (the clipped state is what c holds); TF's gradient kernel applies no mask for clipped values, so the backward forms
+   * are unchanged.  0 (the default) = no clipping = the reference's cells as this build reads them (modules.py:41-42,
+   * tacotron2.py:69-70 pass no cell_clip; hparam lstm_cell_clip). */
+  float cell_clip;
 } ns_lstm_seq_params;
 int ns_lstm_seq_fwd(const ns_lstm_seq_params* p, ns_stream_t stream);
 int ns_lstm_seq_bwd(const ns_lstm_seq_params* p, ns_stream_t stream);
@@ -393,6 +398,7 @@ typedef struct {
    * stride hp_sn; NULL = zeros).  Both rates 0 (the default, = the reference's plain cells) reads nothing. */
   float zoneout_cell, zoneout_output;
   const void* h_prev; int64_t hp_sn;
+  float cell_clip;                        /* as in ns_lstm_seq_params */
 } ns_lstm_step_params;
 int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t stream);
 
@@ -437,6 +443,7 @@ typedef struct {
   float forget_bias;
   float zoneout_cell, zoneout_output;
   const float* h_prev; int64_t hp_sn;
+  float cell_clip;                     /* as in ns_lstm_seq_params */
 } ns_rows32_params;
 int ns_rows32(const ns_rows32_params* p, ns_stream_t stream);
 
@@ -645,6 +652,7 @@ typedef struct {
   /* backward, optional: scratch for the fixed-order sums of dv / dwcl (ns_attention_post_part_floats(N, Tia, A) floats,
    * see ns_attention_post_bwd_params.part); NULL = float atomics */
   float* post_part;
+  float cell_clip;                 /* the attention LSTM's (and, in ns_taco2_decode, the decoder LSTMs') cell_clip, as in ns_lstm_seq_params */
 } ns_taco2_attn_params;
 int ns_taco2_attn_fwd(const ns_taco2_attn_params* p, ns_stream_t stream);
 int ns_taco2_attn_bwd(const ns_taco2_attn_params* p, ns_stream_t stream);

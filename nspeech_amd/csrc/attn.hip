@@ -767,7 +767,7 @@ static int attn_fwd_t(const ns_taco2_attn_params& p, hipStream_t s) {
     }
     // attention LSTM on [p2 | h_prev]
     LstmStep<T> l = {};
-    l.N = p.N; l.H = p.A; l.K = (int)XA; l.forget_bias = 1.0f;
+    l.N = p.N; l.H = p.A; l.K = (int)XA; l.forget_bias = 1.0f; l.cell_clip = p.cell_clip;
     l.a = xa + slot * XA; l.a_sn = S1 * XA; l.wT = (const T*)p.wattT; l.bias = p.batt;
     l.c_prev = st > 0 ? p.ca + prev * A : nullptr; l.c_sn = S1 * A;
     l.h_out = hc + slot * HC; l.h_sn = S1 * HC;

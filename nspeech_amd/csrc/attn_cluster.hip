@@ -304,7 +304,7 @@ __device__ __forceinline__ void attn_fwd_body(const ACArgs& a, float* sm, const 
         z[j] = s;
       }
       const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + 1.0f), go = sigmoidf_(z[3]);
-      cstate = gf * cstate + gi * gj;
+      cstate = ns_cell_clip(gf * cstate + gi * gj, p.cell_clip);
       const float h = go * tanhf_(cstate);
       hloc[tid] = h;
       put_granule(x2 + (size_t)g * X2N + A + tid, tag, h);                 // the peers wait for this
@@ -1114,7 +1114,7 @@ __device__ __forceinline__ void dec_lstm_role(const DecArgs& d, float* sm, const
         float c = cst[0];
 #pragma unroll
         for (int q = 1; q < NR; ++q) c = n == q ? cst[q] : c;
-        c = gf * c + gi * gj;
+        c = ns_cell_clip(gf * c + gi * gj, p.cell_clip);      // the decoder cells take the attention block's cell_clip
         const float h = go * tanhf_(c);
 #pragma unroll
         for (int q = 0; q < NR; ++q) cst[q] = n == q ? c : cst[q];

@@ -91,6 +91,12 @@ __host__ __device__ __forceinline__ bool ns_zone_keep(uint32_t seed, uint32_t t,
   return (x >> 8) < thr;
 }
 
+// tf.contrib.rnn.LSTMBlockCell's cell_clip (lstm_ops: cs = clip(ci .* i + cs_prev .* f, -cell_clip, cell_clip) when the
+// attribute is > 0; its gradient kernel applies no mask for clipped values, so the backward kernels stay as they are and
+// read the clipped states the forward kernels saved).  clip <= 0: off - the reference's cells (modules.py:41-42,
+// tacotron2.py:69-70 pass no cell_clip; whether TF 1.7's default clips is the [3P] question the switch exists for).
+__device__ __forceinline__ float ns_cell_clip(float c, float clip) { return clip > 0.f ? fminf(fmaxf(c, -clip), clip) : c; }
+
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case NS_ACT_RELU: return v > 0.f ? v : 0.f;

@@ -40,6 +40,8 @@
 #include <stdlib.h>
 
 typedef unsigned long long u64;
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
 constexpr int GW = 8;                 // compute waves per workgroup
@@ -75,8 +77,14 @@ template <int H_> struct GCfg {
   static constexpr int NPOLL = G > 1 ? 2 : 0;
   static constexpr int FW_WAVES = GW + 1 + NPOLL;   // compute, prefetcher, pollers
   static constexpr int BW_WAVES = GW + 2 + NPOLL;   // compute, two prefetchers, pollers
-  static constexpr int XS_LD = 3 * U + 4;           // forward stage row: r | u | c parts of the own units (+4: rows 4 banks apart)
-  static constexpr int ST_LD = 5 * U + 4;           // backward stage row: r | u | c | h_prev | dh
+  // The per-step operands come in by LDS-DMA (global_load_lds_dwordx4: no register staging, loads two slots ahead).  An
+  // instruction lands 64 x 16 bytes lane-linear in LDS, so the stage is laid out [16-byte chunk][16 batch rows]: lane l of
+  // instruction j fetches chunk 4 j + (l >> 4) of row l & 15 - and the compute lanes' float4 reads (row = l & 15) walk 16
+  // consecutive 16-byte units: conflict free.
+  static constexpr int NBUF = 3;                    // stage buffers: slot s + 2 is fetched while slot s is computed
+  static constexpr int SECF = (U / 4) * 64;         // floats of one fp32 section (U / 4 chunks x 16 rows x 4)
+  static constexpr int XS_F = 3 * SECF;             // forward slot: r | u | c parts of the own units
+  static constexpr int FW_NI = XS_F / 256;          // DMA instructions per forward slot (one prefetcher wave)
   static_assert(H == 128 || H == 256, "H");
   static_assert(NB * KSPLIT == GW && KS % KSPLIT == 0, "shape");
 };
@@ -200,13 +208,13 @@ __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* im
 template <int H, int P, typename T, bool TRACE = false>
 __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs a) {
   using C = GCfg<H>;
-  constexpr int G = C::G, U = C::U, NB = C::NB, KSPLIT = C::KSPLIT, KSW = C::KSW, NR = C::NR, XS_LD = C::XS_LD;
+  constexpr int G = C::G, U = C::U, NB = C::NB, KSPLIT = C::KSPLIT, KSW = C::KSW, NR = C::NR, XS_F = C::XS_F, SECF = C::SECF;
   constexpr int NPL = P == 3 ? 2 : 1, PS = 16 * (H + 8);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* himg = (bf16_t*)smem;                       // [NPL][16][H] the state, swizzled
   bf16_t* rhimg = himg + NPL * PS;                    // [NPL][16][H] r * h
-  float* xs = (float*)(rhimg + NPL * PS);             // [2][16][XS_LD]
-  float* pbuf = xs + 2 * 16 * XS_LD;                  // [GW][64][4] (K split)
+  float* xs = (float*)(rhimg + NPL * PS);             // [NBUF][XS_F] stage, filled by LDS-DMA
+  float* pbuf = xs + C::NBUF * XS_F;                  // [GW][64][4] (K split)
   int* abortf = (int*)(pbuf + (KSPLIT == 2 ? GW * 64 * 4 : 0));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -231,6 +239,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     const int b = wave % NB, kh = wave / NB;
     const int ul0 = b * 16, ug0 = g * U + ul0;
     const int mo = KSPLIT == 2 ? 2 * kh : 0;               // first of the wave's own registers (units) per lane
+    const int xoff = ((b * 4 + q4) * 16 + col) * 4;        // this lane's float4 inside a stage section
     bf16x8 wr[NPL][KSW], wu[NPL][KSW], wc[NPL][KSW];
     {
       const T* gT = (const T*)a.wgT[d];
@@ -255,14 +264,14 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = TRACE ? wall_clock64() : 0;
 #define GRU_STAMP(k) do { if (TRACE) { __builtin_amdgcn_sched_barrier(0); const long long tn = wall_clock64(); tsum[k] += tn - tprev; tprev = tn; __builtin_amdgcn_sched_barrier(0); } } while (0)
     for (int s = 0; s < T_; ++s) {
-      const int t = rev ? T_ - 1 - s : s, buf = s & 1;
+      const int t = rev ? T_ - 1 - s : s, buf = s % C::NBUF;
       const unsigned rowi = (unsigned)(n * a.P + a.padl + t);
       wg_barrier();                                        // B0: state image and stage of this slot are complete
       if (abortf[0]) return;
       GRU_STAMP(0);
-      const float* xrow = xs + (buf * 16 + col) * XS_LD + ul0 + 4 * q4;
+      const float* xrow = xs + buf * XS_F + xoff;
       f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar;
-      if (kh == 0) { ar = *(const f32x4*)xrow; au = *(const f32x4*)(xrow + U); }
+      if (kh == 0) { ar = *(const f32x4*)xrow; au = *(const f32x4*)(xrow + SECF); }
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) {
         const int so = swz(col, (kh * KSW + ks) * 32 + q4 * 8, H);
@@ -301,7 +310,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
       if (abortf[0]) return;
       GRU_STAMP(3);
       f32x4 ac = {0.f, 0.f, 0.f, 0.f};
-      if (kh == 0) ac = *(const f32x4*)(xrow + 2 * U);
+      if (kh == 0) ac = *(const f32x4*)(xrow + 2 * SECF);
 #pragma unroll
       for (int ks = 0; ks < KSW; ++ks) {
         const int so = swz(col, (kh * KSW + ks) * 32 + q4 * 8, H);
@@ -345,48 +354,40 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     if (TRACE && a.trace && blockIdx.x == 0 && lane == 0)
       for (int k = 0; k < 8; ++k) a.trace[wave * 8 + k] = tsum[k];
   } else if (wave == GW) {
-    // ================================================================ prefetcher role: 16 rows x 3U floats per slot
-    // a row's section is U / 4 float4: LPR lanes per row, RPI rows per wave instruction, NJ instructions per section.
-    // Uniform parts of every address stay in scalar registers; a lane keeps two 32-bit offsets (xg and xc rows).
-    constexpr int LPR = U / 4, RPI = 64 / LPR, NJ = 16 / RPI;
-    f32x4 pf[3][NJ];
-    const int lr = lane / LPR, lc = (lane % LPR) * 4;
-    const unsigned vo_g = (unsigned)(lr * a.P) * (unsigned)a.ld_xg + lc, vo_c = (unsigned)(lr * a.P) * (unsigned)a.ld_xc + lc;
-    auto pf_load = [&](int s) {
+    // ================================================================ prefetcher role: LDS-DMA, two slots ahead
+    // Uniform parts of every address stay in scalar registers; a lane keeps two 32-bit offsets (xg and xc rows).  Rows past
+    // N fetch row N - 1 again (their results are never stored): every slot issues exactly FW_NI instructions, which is
+    // what the counted vmcnt waits below rely on.
+    constexpr int NI = C::FW_NI, IPS = (U / 4) / 4;        // instructions per slot / per section
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nrow = min(rg * 16 + lrow, a.N - 1);
+    const unsigned vo_g = (unsigned)(nrow * a.P) * (unsigned)a.ld_xg + lq * 4, vo_c = (unsigned)(nrow * a.P) * (unsigned)a.ld_xc + lq * 4;
+    auto issue = [&](int s) {
       const int t = rev ? T_ - 1 - s : s;
+      const float* bg = a.xg[d] + (size_t)(a.padl + t) * a.ld_xg + g * U;
+      const float* bc = a.xc[d] + (size_t)(a.padl + t) * a.ld_xc + g * U;
+      float* dst = xs + (s % C::NBUF) * XS_F;
 #pragma unroll
-      for (int jj = 0; jj < NJ; ++jj) {
-        const int n0 = rg * 16 + RPI * jj;                   // uniform
-        const bool ok = n0 + lr < a.N;
-        const float* bg = a.xg[d] + (size_t)(n0 * a.P + a.padl + t) * a.ld_xg + g * U;
-        const float* bc = a.xc[d] + (size_t)(n0 * a.P + a.padl + t) * a.ld_xc + g * U;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        pf[0][jj] = ok ? *(const f32x4*)(bg + vo_g) : z;
-        pf[1][jj] = ok ? *(const f32x4*)(bg + H + vo_g) : z;
-        pf[2][jj] = ok ? *(const f32x4*)(bc + vo_c) : z;
+      for (int j = 0; j < NI; ++j) {
+        const int sec = j / IPS, jc = (j % IPS) * 16;      // section, first float of the instruction's 4 chunks
+        const float* src = sec < 2 ? bg + sec * H + jc + vo_g : bc + jc + vo_c;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);
       }
     };
-    auto pf_store = [&](int buf) {
-#pragma unroll
-      for (int sec = 0; sec < 3; ++sec)
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-          *(f32x4*)(xs + (buf * 16 + RPI * jj + lr) * XS_LD + sec * U + lc) = pf[sec][jj];
-    };
-    pf_load(0);
-    pf_store(0);
-    if (T_ > 1) pf_load(1);
+    issue(0);
+    if (T_ > 1) { issue(1); asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int s = 0; s < T_; ++s) {
-      wg_barrier();                                        // B0
+      wg_barrier();                                        // B0: slot s handed over
       if (abortf[0]) return;
-      if (s + 1 < T_ && !(a.dbg & 1)) {
-        pf_store((s + 1) & 1);
-        if (s + 2 < T_) pf_load(s + 2);
-      }
+      const bool more = s + 2 < T_ && !(a.dbg & 1);
+      if (more) issue(s + 2);                              // its buffer was last read in slot s - 1
       if (KSPLIT == 2) wg_barrier();                       // Bp1
       wg_barrier();                                        // B1
       if (abortf[0]) return;
       if (KSPLIT == 2) wg_barrier();                       // Bp2
+      if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI) : "memory");     // slot s + 1 has landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
   } else {
     // ================================================================ poller role (H = 256)
@@ -416,13 +417,15 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
 template <int H, int P, typename T>
 __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs a) {
   using C = GCfg<H>;
-  constexpr int G = C::G, U = C::U, NB = C::NB, KSPLIT = C::KSPLIT, KSW = C::KSW, NR = C::NR, ST_LD = C::ST_LD;
+  constexpr int G = C::G, U = C::U, NB = C::NB, KSPLIT = C::KSPLIT, KSW = C::KSW, NR = C::NR, SECF = C::SECF;
+  // backward slot: r | u | c | dh sections (fp32) + h_prev in the history's own type (bf16: half a section)
+  constexpr int HPF = sizeof(T) == 4 ? SECF : SECF / 2, ST_F = 4 * SECF + HPF, NI = ST_F / 256, NIW = NI / 2;
   constexpr int NPL = P == 3 ? 2 : 1, PSC = 16 * (H + 8), PSG = 16 * (2 * H + 8);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   bf16_t* dzcimg = (bf16_t*)smem;                     // [NPL][16][H]
   bf16_t* dzgimg = dzcimg + NPL * PSC;                // [NPL][16][2H]
-  float* st = (float*)(dzgimg + NPL * PSG);           // [2][16][ST_LD]
-  float* pbuf = st + 2 * 16 * ST_LD;                  // [GW][64][2] (K split)
+  float* st = (float*)(dzgimg + NPL * PSG);           // [NBUF][ST_F] stage, filled by LDS-DMA
+  float* pbuf = st + C::NBUF * ST_F;                  // [GW][64][2] (K split)
   int* abortf = (int*)(pbuf + (KSPLIT == 2 ? GW * 64 * 2 : 0));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -455,24 +458,33 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
     const bool nvalid = n < a.N;
     const int len = (a.lengths && nvalid) ? a.lengths[n] : T_;
     const int un = ug0 + 4 * q4 + mo;
-    float carry[NR];
+    float carry[NR], hini[NR];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) carry[i] = 0.f;
+    for (int i = 0; i < NR; ++i) {
+      carry[i] = 0.f;
+      hini[i] = (a.h_init[d] && nvalid) ? a.h_init[d][(long)n * a.ld_hi + un + i] : 0.f;
+    }
+    const int xoff = ((b * 4 + q4) * 16 + col) * 4 + mo;   // this lane's values inside an fp32 stage section
+    const int hoff = sizeof(T) == 4 ? xoff : ((b * 2 + (q4 >> 1)) * 16 + col) * 8 + (q4 & 1) * 4 + mo;     // ... the h_prev section
     T* dzg = (T*)a.dzg[d];
     T* dzc = (T*)a.dzc[d];
     wg_barrier();                                          // stage of the first slot
     for (int s = 0; s < T_; ++s) {
-      const int t = rev ? s : T_ - 1 - s, buf = s & 1;      // the forward pass' steps, last first
+      const int t = rev ? s : T_ - 1 - s, buf = s % C::NBUF;      // the forward pass' steps, last first
+      const int tp = rev ? t + 1 : t - 1;                  // the step whose output is this step's h_prev
       const unsigned rowi = (unsigned)(n * a.P + a.padl + t);
-      const float* srow = st + (buf * 16 + col) * ST_LD + ul0 + 4 * q4 + mo;
+      const float* srow = st + buf * ST_F + xoff;
+      const T* hrow = (const T*)(st + buf * ST_F + 4 * SECF) + hoff;
       const bool masked = t >= len;
+      // h_prev: the initial state at a sequence's first step (t = 0; reversed: t = len - 1), zero outside the sequence
+      const bool first = rev ? t == len - 1 : t == 0, tp_ok = tp >= 0 && tp < T_;
       float r[NR], hp[NR], dzcv[NR], dzuv[NR], cn[NR];
 #pragma unroll
       for (int i = 0; i < NR; ++i) {
         r[i] = srow[i];
-        const float u = srow[U + i], c = srow[2 * U + i];
-        hp[i] = srow[3 * U + i];
-        const float dh = masked ? 0.f : carry[i] + srow[4 * U + i];
+        const float u = srow[SECF + i], c = srow[2 * SECF + i];
+        hp[i] = first ? hini[i] : (tp_ok ? ldf(hrow + i) : 0.f);
+        const float dh = masked ? 0.f : carry[i] + srow[3 * SECF + i];
         dzcv[i] = dh * (1.f - u) * (1.f - c * c);
         dzuv[i] = dh * (hp[i] - c) * u * (1.f - u);
         cn[i] = masked ? carry[i] : dh * u;
@@ -542,69 +554,58 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
     }
     if (a.dh_init[d] && nvalid) store_vals<float, NR>(a.dh_init[d] + (long)n * a.ld_dhi + un, carry);
   } else if (wave < GW + 2) {
-    // ================================================================ prefetcher role (two waves): 16 rows x 5U values
-    // wave pw takes the row groups jj = pw * NJ / 2 ... of every section (r, u, c, h_prev, dh)
-    constexpr int LPR = U / 4, RPI = 64 / LPR, NJ = 16 / RPI, NJW = NJ / 2;
+    // ================================================================ prefetcher role (two waves): LDS-DMA, two slots ahead
+    // Instruction j of a slot: j < 4 * IPS -> section j / IPS (r, u from ru; c; dh), else the h_prev rows of the history
+    // (type T: 8 bf16 or 4 fp32 per 16-byte chunk).  Wave pw issues the instructions j = pw, pw + 2, ...; rows past N and a
+    // h_prev step outside the sequence fetch a valid row instead (never used): the count per slot is constant.
+    constexpr int IPS = (U / 4) / 4, EPC = 16 / (int)sizeof(T);
     const int pw = wave - GW;
-    f32x4 pf[5][NJW];
     const T* hist = (const T*)a.h[d];
-    const int lr = lane / LPR, lc = (lane % LPR) * 4;
-    const unsigned vo_ru = (unsigned)(lr * a.P) * (unsigned)(2 * H) + lc, vo_c = (unsigned)(lr * a.P) * (unsigned)H + lc;
-    const unsigned vo_dh = (unsigned)(lr * a.P) * (unsigned)a.ld_dh + lc, vo_h = (unsigned)(lr * a.P) * (unsigned)a.ld_h + lc;
-    int lenj[NJW];
-#pragma unroll
-    for (int jj = 0; jj < NJW; ++jj) {
-      const int n = rg * 16 + RPI * (pw * NJW + jj) + lr;
-      lenj[jj] = (a.lengths && n < a.N) ? a.lengths[n] : T_;
-    }
-    auto pf_load = [&](int s) {
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int nrow = min(rg * 16 + lrow, a.N - 1);
+    const unsigned vo_ru = (unsigned)(nrow * a.P) * (unsigned)(2 * H) + lq * 4, vo_c = (unsigned)(nrow * a.P) * (unsigned)H + lq * 4;
+    const unsigned vo_dh = (unsigned)(nrow * a.P) * (unsigned)a.ld_dh + lq * 4, vo_h = (unsigned)(nrow * a.P) * (unsigned)a.ld_h + lq * EPC;
+    auto issue = [&](int s) {
       const int t = rev ? s : T_ - 1 - s;
-      const int tp = rev ? t + 1 : t - 1;                  // the step whose output is this step's h_prev
-      const bool tp_ok = tp >= 0 && tp < T_;
+      const int tp = min(max(rev ? t + 1 : t - 1, 0), T_ - 1);
+      const size_t r0 = (size_t)(a.padl + t);
+      const float* bru = a.ru[d] + r0 * (2 * H) + g * U;
+      const float* bc = a.c[d] + r0 * H + g * U;
+      const float* bdh = a.dh[d] + r0 * a.ld_dh + g * U;
+      const T* bh = hist + (size_t)(a.padl + tp) * a.ld_h + g * U;
+      float* dst = st + (s % C::NBUF) * ST_F;
 #pragma unroll
-      for (int jj = 0; jj < NJW; ++jj) {
-        const int n0 = rg * 16 + RPI * (pw * NJW + jj);      // uniform
-        const int n = n0 + lr;
-        const bool ok = n < a.N;
-        const size_t r0 = (size_t)(n0 * a.P + a.padl + t);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const float* bru = a.ru[d] + r0 * (2 * H) + g * U;
-        pf[0][jj] = ok ? *(const f32x4*)(bru + vo_ru) : z;
-        pf[1][jj] = ok ? *(const f32x4*)(bru + H + vo_ru) : z;
-        pf[2][jj] = ok ? *(const f32x4*)(a.c[d] + r0 * H + g * U + vo_c) : z;
-        pf[4][jj] = ok ? *(const f32x4*)(a.dh[d] + r0 * a.ld_dh + g * U + vo_dh) : z;
-        const bool first = rev ? t == lenj[jj] - 1 : t == 0;
-        f32x4 v = z;
-        if (ok && first) {
-          if (a.h_init[d]) v = *(const f32x4*)(a.h_init[d] + (long)n * a.ld_hi + g * U + lc);
-        } else if (ok && tp_ok) {
-          const T* hp = hist + (size_t)(n0 * a.P + a.padl + tp) * a.ld_h + g * U + vo_h;
-          if constexpr (sizeof(T) == 4) v = *(const f32x4*)hp;
-          else { const bf16x4 hb = *(const bf16x4*)hp; v = (f32x4){(float)hb[0], (float)hb[1], (float)hb[2], (float)hb[3]}; }
-        }
-        pf[3][jj] = v;
+      for (int jj = 0; jj < (NI + 1) / 2; ++jj) {
+        const int j = 2 * jj + pw;                         // pw is wave-uniform: both arms below are scalar branches
+        if (j >= NI) break;
+        const int sec = j / IPS, jc = (j % IPS) * 16;
+        const void* src;
+        if (sec < 2) src = bru + sec * H + jc + vo_ru;
+        else if (sec == 2) src = bc + jc + vo_c;
+        else if (sec == 3) src = bdh + jc + vo_dh;
+        else src = bh + (j - 4 * IPS) * 4 * EPC + vo_h;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);
       }
     };
-    auto pf_store = [&](int buf) {
-#pragma unroll
-      for (int sec = 0; sec < 5; ++sec)
-#pragma unroll
-        for (int jj = 0; jj < NJW; ++jj)
-          *(f32x4*)(st + (buf * 16 + RPI * (pw * NJW + jj) + lr) * ST_LD + sec * U + lc) = pf[sec][jj];
+    // instructions this wave issues per slot (NI may be odd for bf16 histories)
+    const int mine = (NI - pw + 1) / 2;
+    auto wait_one_slot_left = [&]() {
+      // all but the newest slot's loads: the count differs between the two waves only when NI is odd
+      if (mine == (NI + 1) / 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NI + 1) / 2) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NI / 2) : "memory");
     };
-    pf_load(0);
-    pf_store(0);
-    if (T_ > 1) pf_load(1);
+    issue(0);
+    if (T_ > 1) { issue(1); wait_one_slot_left(); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     wg_barrier();
     for (int s = 0; s < T_; ++s) {
+      const bool more = s + 2 < T_;
+      if (more) issue(s + 2);                              // its buffer was last read in phase 1 of slot s - 1
       wg_barrier();                                        // B1
       if (abortf[0]) return;
-      if (s + 1 < T_) {
-        pf_store((s + 1) & 1);
-        if (s + 2 < T_) pf_load(s + 2);
-      }
       if (KSPLIT == 2) wg_barrier();                       // Bpa
-      wg_barrier();                                        // B2
+      if (more) wait_one_slot_left(); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // slot s + 1 has landed
+      wg_barrier();                                        // B2: hands slot s + 1 over
       if (abortf[0]) return;
       if (KSPLIT == 2) wg_barrier();                       // Bpb
     }
@@ -631,12 +632,13 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
 template <int H> size_t fwd_lds(int P) {
   using C = GCfg<H>;
   const int npl = P == 3 ? 2 : 1;
-  return (size_t)2 * npl * 16 * (H + 8) * 2 + sizeof(float) * 2 * 16 * C::XS_LD + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 4 : 0) + 16;
+  return (size_t)2 * npl * 16 * (H + 8) * 2 + sizeof(float) * C::NBUF * C::XS_F + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 4 : 0) + 16;
 }
-template <int H> size_t bwd_lds(int P) {
+template <int H> size_t bwd_lds(int P, bool bf16_hist) {
   using C = GCfg<H>;
   const int npl = P == 3 ? 2 : 1;
-  return (size_t)npl * 16 * (3 * H + 16) * 2 + sizeof(float) * 2 * 16 * C::ST_LD + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 2 : 0) + 16;
+  const size_t st_f = 4 * C::SECF + (bf16_hist ? C::SECF / 2 : C::SECF);
+  return (size_t)npl * 16 * (3 * H + 16) * 2 + sizeof(float) * C::NBUF * st_f + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 2 : 0) + 16;
 }
 
 int passes_of(const ns_gru_seq_params* p) { return p->dtype == NS_BF16 ? 1 : p->f32_passes; }
@@ -733,7 +735,7 @@ static void launch_bwd(const GruArgs& a, hipStream_t s) {
     (void)hipFuncSetAttribute((const void*)gru_bwd_kernel<H, P, T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr = true;
   }
-  hipLaunchKernelGGL((gru_bwd_kernel<H, P, T>), dim3((unsigned)(a.ndir * a.nrg * C::G)), dim3(C::BW_WAVES * 64), bwd_lds<H>(P), s, a);
+  hipLaunchKernelGGL((gru_bwd_kernel<H, P, T>), dim3((unsigned)(a.ndir * a.nrg * C::G)), dim3(C::BW_WAVES * 64), bwd_lds<H>(P, sizeof(T) == 2), s, a);
 }
 
 static int gru_seq_run(const ns_gru_seq_params* p0, const ns_gru_seq_params* p1, void* work, hipStream_t s, int backward) {

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(LTHREADS) void lstm_step_kernel(LstmStepPair<T> pp)
     const bool masked = pmask;
     const float cp = pcp;
     const float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + a.forget_bias), go = sigmoidf_(z[3]);
-    float c = gf * cp + gi * gj;
+    float c = ns_cell_clip(gf * cp + gi * gj, a.cell_clip);
     float h = go * tanhf_(c);
     if (a.zmode == 1) {          // zoneout, training: the unit keeps its old value where the mask says so
       if (ns_zone_keep(a.zseed_c, (uint32_t)a.t, (uint32_t)n, (uint32_t)u, a.zthr_c)) c = cp;
@@ -455,7 +455,7 @@ static void fill_fwd(LstmStep<T>& a, const ns_lstm_seq_params& p, int step) {
   const long row = p.padl + t, rowp = p.padl + tp;
   const bool has_prev = rowp >= 0 && rowp < P && step > 0;
   a = LstmStep<T>{};
-  a.N = p.N; a.H = p.H; a.K = p.H; a.forget_bias = p.forget_bias;
+  a.N = p.N; a.H = p.H; a.K = p.H; a.forget_bias = p.forget_bias; a.cell_clip = p.cell_clip;
   a.a = has_prev ? (const T*)p.h + rowp * p.ld_h : nullptr;
   a.a_sn = P * p.ld_h;
   a.wT = (const T*)p.whT;
@@ -587,7 +587,7 @@ extern "C" int ns_lstm_step(const ns_lstm_step_params* p, ns_stream_t s) {
   auto run = [&](auto tag) -> int {
     using T = decltype(tag);
     LstmStep<T> a = {};
-    a.N = p->N; a.H = p->H; a.K = p->K; a.forget_bias = p->forget_bias; a.passes = p->f32_passes;
+    a.N = p->N; a.H = p->H; a.K = p->K; a.forget_bias = p->forget_bias; a.cell_clip = p->cell_clip; a.passes = p->f32_passes;
     a.a = (const T*)p->a; a.a_sn = p->a_sn; a.wT = (const T*)p->wT;
     a.xg = p->xg; a.xg_sn = p->xg_sn; a.bias = p->bias;
     a.c_prev = p->c_prev; a.c_sn = p->c_sn;

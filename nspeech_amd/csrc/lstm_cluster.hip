@@ -35,7 +35,7 @@ struct LstmClusterArgs {
   const float* dh[2]; long ld_dh; // backward: grad wrt h outputs (offset to direction's columns)
   bf16_t* dgates[2];
   const int* lengths;
-  float forget_bias;
+  float forget_bias, cell_clip;
   u64* xbuf;                      // [chains][2][16][granules per row]
   int* status;
   int dbg;                        // timing experiments only (NS_CLUSTER_DBG), 0 in production
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(CTHREADS) void lstm_cluster_fwd_kernel(LstmClusterA
       const float zo = __shfl_down(accB[r], 8, 64);
       const bool masked = t >= len[r];
       const float gi = sigmoidf_(accA[r]), gj = tanhf_(zj), gf = sigmoidf_(accB[r] + a.forget_bias), go = sigmoidf_(zo);
-      float cn = gf * cst[r] + gi * gj;
+      float cn = ns_cell_clip(gf * cst[r] + gi * gj, a.cell_clip);
       float hn = go * tanhf_(cn);
       if (masked) { cn = 0.f; hn = 0.f; }
       cst[r] = cn;
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(FW_WAVES * 64) void lstm_cluster2_fwd_kernel(LstmCl
         for (int r = 0; r < 4; ++r) {
           const float gi = sigmoidf_(acc[0][r]), gj = tanhf_(acc[1][r]);
           const float gf = sigmoidf_(acc[2][r] + a.forget_bias), go = sigmoidf_(acc[3][r]);
-          float cn = gf * cst[rg][r] + gi * gj;
+          float cn = ns_cell_clip(gf * cst[rg][r] + gi * gj, a.cell_clip);
           float hn = go * tanhf_(cn);
           if (masked) { cn = 0.f; hn = 0.f; }
           cst[rg][r] = cn;
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(X3_WAVES * 64) void lstm_cluster3_fwd_kernel(LstmCl
           const float zj = __shfl_down(accA[r], 8, 64), zo = __shfl_down(accB[r], 8, 64);
           const bool masked = t >= len[rg][r];
           const float gi = sigmoidf_(accA[r]), gj = tanhf_(zj), gf = sigmoidf_(accB[r] + a.forget_bias), go = sigmoidf_(zo);
-          float cn = gf * cst[rg][r] + gi * gj;
+          float cn = ns_cell_clip(gf * cst[rg][r] + gi * gj, a.cell_clip);
           float hn = go * tanhf_(cn);
           if (masked) { cn = 0.f; hn = 0.f; }
           cst[rg][r] = cn;
@@ -1532,7 +1532,7 @@ static void fill(LstmClusterArgs& a, const ns_lstm_seq_params* p0, const ns_lstm
   const ns_lstm_seq_params* pp[2] = {p0, p1};
   a.N = p0->N; a.T = p0->T; a.H = p0->H; a.P = p0->P; a.padl = p0->padl; a.CS = p0->H / 64;
   a.ld_xg = p0->ld_xg; a.ld_h = p0->ld_h; a.ld_dh = p0->ld_dh;
-  a.lengths = p0->lengths; a.forget_bias = p0->forget_bias;
+  a.lengths = p0->lengths; a.forget_bias = p0->forget_bias; a.cell_clip = p0->cell_clip;
   for (int d = 0; d < 2; ++d) {
     a.xg[d] = pp[d]->xg; a.whT[d] = (const bf16_t*)pp[d]->whT; a.wh[d] = (const bf16_t*)pp[d]->wh;
     a.h[d] = (bf16_t*)pp[d]->h; a.c[d] = pp[d]->c; a.gates[d] = (bf16_t*)pp[d]->gates;

@@ -17,6 +17,7 @@ struct LstmStep {
   const int* lengths; int t;
   int N, H;
   float forget_bias;
+  float cell_clip;                   // > 0: the new cell state is clipped to [-cell_clip, cell_clip] (ns_cell_clip)
   int passes;                        // fp32 operands: 0 exact FMA, 1/3 split-bf16 MFMA
   const bf16_t* wT_hi; const bf16_t* wT_lo;   // optional pre-split copies of an fp32 wT
   // zoneout (ns_lstm_seq_params): zmode 0 = plain cell, 1 = masks (training), 2 = expectation with rates zc / zh

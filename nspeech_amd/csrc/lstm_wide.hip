@@ -325,10 +325,10 @@ __global__ __launch_bounds__(WTF) void lstm_wide_fwd_kernel(WideArgs a) {
     float gi = sigmoidf_(z[0]), gj = tanhf_(z[1]), gf = sigmoidf_(z[2] + p.forget_bias), go = sigmoidf_(z[3]);
     float hv;
     if (!zone) {
-      cst = gf * cst + gi * gj;
+      cst = ns_cell_clip(gf * cst + gi * gj, p.cell_clip);
       hv = go * tanhf_(cst);
     } else {                  // ns_lstm_seq_params: a kept unit carries c / h of step t-1 on, h' comes from the plain c'
-      const float cn = gf * cst + gi * gj;
+      const float cn = ns_cell_clip(gf * cst + gi * gj, p.cell_clip);
       hv = go * tanhf_(cn);
       if (!ns_zone_keep(p.zoneout_seed_cell, (uint32_t)t, (uint32_t)en, (uint32_t)(u0 + eu), p.zoneout_thr_cell)) cst = cn;
       if (ns_zone_keep(p.zoneout_seed_output, (uint32_t)t, (uint32_t)en, (uint32_t)(u0 + eu), p.zoneout_thr_output)) hv = hprev;

@@ -38,7 +38,7 @@ struct Rows32Args {
   int H;
   const float* c_prev; long c_sn;
   float* c_out; long co_sn;
-  float forget_bias, zc, zh;
+  float forget_bias, zc, zh, cell_clip;
   const float* h_prev; long hp_sn;
 };
 
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(RW * 64) void rows32_kernel(Rows32Args a) {
       if (n < a.N && u < H) {
         const float gi = sigmoidf_(zs[n][ul]), gj = tanhf_(zs[n][4 + ul]);
         const float gf = sigmoidf_(zs[n][8 + ul] + a.forget_bias), go = sigmoidf_(zs[n][12 + ul]);
-        float c = gf * e_cp + gi * gj;
+        float c = ns_cell_clip(gf * e_cp + gi * gj, a.cell_clip);
         float h = go * tanhf_(c);
         if (a.zc > 0.f || a.zh > 0.f) {       // zoneout at inference = the expectation of the training masks
           c = a.zc * e_cp + (1.f - a.zc) * c;
@@ -269,7 +269,7 @@ extern "C" int ns_rows32(const ns_rows32_params* p, ns_stream_t s_) {
   NS_CHECK_ARG(!a.pk1 || p->rows_out_col + (H ? H : p->C) <= a.pk1_nkc * 32, "ns_rows32: rows_out columns out of range");
   NS_CHECK_ARG(!a.pk2 || p->rows_out2_col + (H ? H : p->C) <= a.pk2_nkc * 32, "ns_rows32: rows_out2 columns out of range");
   a.H = H; a.c_prev = p->c_prev; a.c_sn = p->c_sn; a.c_out = p->c_out; a.co_sn = p->co_sn;
-  a.forget_bias = p->forget_bias; a.zc = p->zoneout_cell; a.zh = p->zoneout_output;
+  a.forget_bias = p->forget_bias; a.zc = p->zoneout_cell; a.zh = p->zoneout_output; a.cell_clip = p->cell_clip;
   a.h_prev = p->h_prev; a.hp_sn = p->hp_sn;
   const int tiles = tiles_of(p->C, H);
   a.tiles = tiles;

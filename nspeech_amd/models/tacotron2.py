@@ -108,6 +108,14 @@ class Tacotron2(object):
         env = os.environ.get("NS_DETERMINISTIC")
         self.deterministic = (env == "1") if env is not None else bool(getattr(hparams, "deterministic_gradients", False))
         self.zoneout_rate = float(getattr(hparams, "zoneout_rate", 0.0) or 0.0)
+        # LSTMBlockCell's cell_clip (hparam lstm_cell_clip, default 0 = off: the reference constructs its cells without it,
+        # modules.py:41-42, tacotron2.py:69-70, and this build reads TF 1.7's default as "no clipping" - a [3P] assumption
+        # that cannot be checked here, oracle/taco2_oracle.py: lstm_block_cell).  With a value every LSTM of the model
+        # (encoder / expand BiLSTMs, attention cell, decoder cells; training and synthesis) clips its cell state in the
+        # forward pass as the fused TF op does; the op's gradient ignores the clip, so do the backward kernels.
+        self.cell_clip = float(getattr(hparams, "lstm_cell_clip", 0.0) or 0.0)
+        if self.cell_clip > 0.0 and self.zoneout_rate > 0.0:
+            raise ValueError("lstm_cell_clip together with zoneout_rate is not supported (the zoneout backward pass recomputes the unclipped cell state)")
         self.zoneout_base_seed = (int(seed) * 2654435761 + 97) & 0xFFFFFFFF
         self._status_words = {}
         self._bwd_sums = {}       # conv tag -> (sum dy, sum dy*xhat) left by the product that formed that layer's dy
@@ -880,6 +888,7 @@ class Tacotron2(object):
             self._sig = sig
         self._tick("start")
         ops.F32_PASSES = self.passes_fwd
+        ops.CELL_CLIP = self.cell_clip
         Tx = self.Tx
 
         # ---- encoder (tacotron2.py:37-60)

@@ -37,6 +37,7 @@ def _lstm_step(m, a, a_off, a_sn, K, wT, bias_off, c_prev, c_prev_off, c_sn, h_o
         p.zoneout_cell = p.zoneout_output = float(zoneout)
         p.h_prev, p.hp_sn = ops.ptr(a, a_off + K - H), a_sn
     p.dtype, p.N, p.H, p.K = ops.dt(a), N, H, K
+    p.cell_clip = float(ops.CELL_CLIP)
     p.a, p.a_sn, p.wT = ops.ptr(a, a_off), a_sn, ops.ptr(wT)
     p.bias = ops.ptr(m.flat_p, bias_off)
     p.c_prev = ops.ptr(c_prev, c_prev_off) if c_prev is not None else None
@@ -322,6 +323,7 @@ def _infer_body(m):
         m._bufs.clear()
         m._sig = sig
     ops.F32_PASSES = m.passes_fwd
+    ops.CELL_CLIP = m.cell_clip
     _infer_shadows(m)
     W = m._W(T_)
     buf = m._buf

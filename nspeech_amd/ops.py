@@ -14,6 +14,9 @@ from ._lib import NS_BF16, NS_F32
 
 # fp32-operand GEMM precision (see ns_gemm_params.f32_passes); models set it per call
 F32_PASSES = 0
+# LSTMBlockCell's cell_clip for every LSTM parameter block built below (hparam lstm_cell_clip; 0 = off = the reference's
+# cells); the model sets it at the top of a pass, like F32_PASSES
+CELL_CLIP = 0.0
 
 
 def stream():
@@ -332,7 +335,8 @@ def lstm_seq_params(N, T, H, P, padl, xg, ld_xg, whT, wh, lengths, reverse, h, l
           whT=ptr(whT, whT_off), wh=ptr(wh, wh_off), lengths=ptr(lengths), reverse=int(reverse),
           forget_bias=forget_bias, h=ptr(h, h_off), ld_h=ld_h, c=ptr(c), gates=ptr(gates),
           dh=ptr(dh, dh_off), ld_dh=ld_dh, dgates=ptr(dgates), work=ptr(work), f32_passes=F32_PASSES,
-          whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off), dgates_bf16=ptr(dgates_bf16))
+          whT_hi=ptr(whT_hi), whT_lo=ptr(whT_lo), wh_bf16=ptr(wh_bf16, wh_bf16_off), dgates_bf16=ptr(dgates_bf16),
+          cell_clip=float(CELL_CLIP))
     return p
 
 
@@ -400,6 +404,7 @@ def _attn_params(kw):
             v = ptr(v)
         setattr(p, k, v)
     p.f32_passes = F32_PASSES
+    p.cell_clip = float(CELL_CLIP)
     return p
 
 
@@ -616,7 +621,8 @@ def rows32(a, a_sn, packed, N, K, Cc, out=None, out_sn=0, bias=None, add=None, a
     _fill(p, N=N, K=K, C=Cc, a=_pp(a), a_sn=a_sn, packed=ptr(packed), f32_passes=f32_passes, bias=_pp(bias), add=_pp(add),
           add_sn=add_sn, act=act, out=_pp(out), out_sn=out_sn, out2=_pp(out2), out2_sn=out2_sn, cell_units=cell_units,
           c_prev=_pp(c_prev), c_sn=c_sn, c_out=_pp(c_out), co_sn=co_sn, forget_bias=forget_bias,
-          zoneout_cell=float(zoneout), zoneout_output=float(zoneout), h_prev=_pp(h_prev), hp_sn=hp_sn)
+          zoneout_cell=float(zoneout), zoneout_output=float(zoneout), h_prev=_pp(h_prev), hp_sn=hp_sn,
+          cell_clip=float(CELL_CLIP))
     if a_rows is not None:
         _fill(p, a_rows=ptr(a_rows[0]), a_rows_K=a_rows[1], a_rows_col=a_rows[2])
     if rows_out is not None:

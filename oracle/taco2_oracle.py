@@ -41,6 +41,8 @@ FLIP_LOG = None
 # Test aid: the `zoneout` argument taco2_forward() uses when its caller passes none (tests/test_zoneout_gpu.py sets it
 # around the shared oracle drivers of tests/util.py).  None = the reference's plain decoder cells.
 ZONEOUT = None
+# LSTMBlockCell's cell_clip for every cell below; taco2_forward() sets it from hp["lstm_cell_clip"] (0 / absent = None = off)
+CELL_CLIP = None
 
 
 def _relu(x):
@@ -107,6 +109,10 @@ def lstm_block_cell(x, c, h, kernel, bias):
     z = torch.cat([x, h], dim=-1) @ kernel + bias
     i, j, f, o = z.chunk(4, dim=-1)
     c2 = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+    if CELL_CLIP:
+        # the fused op clips cs in the forward pass (lstm_ops: cs = cs.cwiseMin(cell_clip).cwiseMax(-cell_clip)) and its
+        # gradient kernel (LSTMBlockCellBprop) has no term for it: clip with a straight-through gradient  [3P, recalled]
+        c2 = c2 + (c2.clamp(-CELL_CLIP, CELL_CLIP) - c2).detach()
     h2 = torch.sigmoid(o) * torch.tanh(c2)
     return c2, h2
 
@@ -240,6 +246,8 @@ def taco2_forward(p, hp, inputs, input_lengths, mel_targets=None, linear_targets
     Returns dict with mel_outputs, linear_outputs, alignments [N,T_in,steps], decoder_outputs
     and bn_updates (the UPDATE_OPS moving-average assignments, tacotron2.py:157-161)."""
     training = linear_targets is not None
+    global CELL_CLIP
+    CELL_CLIP = float(hp.get("lstm_cell_clip", 0.0) or 0.0) or None      # read by lstm_block_cell for every cell of this pass
     if zoneout is None:
         zoneout = ZONEOUT
     N, Ti = inputs.shape
