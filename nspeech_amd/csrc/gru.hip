@@ -166,39 +166,42 @@ template <typename T, int NR> __device__ __forceinline__ void store_vals(T* p, c
 // The poller waves' gather: W granules per batch row, 16 rows; granule index = row * W + k, lane-linear, so poller pw's
 // instruction j covers row 8 pw + 64 j / W, columns 64 j % W + lane: every image offset is the lane's base + a constant.
 // Returns false when the wave gave up (status raised / wall-clock bound).
-template <int W, int NPL>
+template <int W, int NPL, int ILD = W + 8>       // ILD: row stride of the image (a gather may fill a column range of a wider one)
 __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
-  constexpr int PPG = 16 * W / 128, ILD = W + 8;
+  constexpr int PPG = 16 * W / 128;
   // uniform base (scalar registers) + one 32-bit lane offset: the loads take the saddr form, no 64-bit address per granule
   const NS_GLOBAL char* src = (const NS_GLOBAL char*)((const NS_GLOBAL u64*)src_ + pw * PPG * 64);
   const unsigned lo8 = (unsigned)lane * 8u;
   unsigned short* dst = (unsigned short*)img + pw * 8 * ILD + lane;
   bool gave_up = false;
+  constexpr int CH = PPG < 32 ? PPG : 32;        // granules in flight per lane: a pass is one memory round trip, so as few
+                                                 // passes as the registers allow (16 in flight cost the H = 256 forward step
+                                                 // two serial round trips per gather)
 #pragma unroll
-  for (int j0 = 0; j0 < PPG; j0 += 16) {         // 16 granules in flight per lane
-    u64 v[16];
+  for (int j0 = 0; j0 < PPG; j0 += CH) {
+    u64 v[CH];
     unsigned spins = 0, clk0 = 0;
     bool ok;
     unsigned lo = lo8;
-    asm volatile("" : "+v"(lo));          // opaque: the 16 addresses are formed here, not hoisted out of the step loop as 64-bit pairs
+    asm volatile("" : "+v"(lo));          // opaque: the addresses are formed here, not hoisted out of the step loop as 64-bit pairs
     do {
       ok = true;
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
+      for (int j = 0; j < CH; ++j)
         v[j] = __hip_atomic_load((const NS_GLOBAL u64*)(src + (j0 + j) * 512 + lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
+      for (int j = 0; j < CH; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
       if (!ok && (++spins & 1023u) == 0) {
         if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = gave_up = true;
         else if (ns_spin_timed_out(clk0)) { atomicExch(status, 1); ok = gave_up = true; }
       }
     } while (!ok);
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
+    for (int j = 0; j < CH; ++j) {
       const int o = ((j0 + j) * 64 / W) * ILD + ((j0 + j) * 64) % W;
       const unsigned pay = (unsigned)v[j];
       dst[o] = (unsigned short)pay;
-      if (NPL == 2) dst[16 * ILD + o] = (unsigned short)(pay >> 16);
+      if (NPL == 2) dst[16 * ILD + o] = (unsigned short)(pay >> 16);      // (the lo plane follows the 16 rows of the hi plane)
     }
   }
   return !gave_up;
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
   const int T_ = a.T;
   const int col = lane & 15, q4 = lane >> 4;
   u64* xc_ = a.xbuf + (size_t)chain * 3 * 16 * H;     // dzc granules [16][H]
-  u64* xg_ = xc_ + 16 * H;                            // dzg granules [16][2H]
+  u64* xg_ = xc_ + 16 * H;                            // dzr granules [16][H], then dzu granules [16][H]
   if (tid == 0) abortf[0] = 0;
 
   if (wave < GW) {
@@ -490,7 +493,10 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         cn[i] = masked ? carry[i] : dh * u;
       }
       if constexpr (G == 1) put_image<NR, NPL>(dzcimg, PSC, swz(col, un, H), dzcv);
-      else publish<NR>(xc_ + col * H + un, (unsigned)(s + 1), dzcv);
+      else {
+        publish<NR>(xc_ + col * H + un, (unsigned)(s + 1), dzcv);
+        publish<NR>(xg_ + 16 * H + col * H + un, (unsigned)(s + 1), dzuv);       // not needed before the second product: gathered off the chain
+      }
       if (nvalid) {
         store_vals<T, NR>(dzc + rowi * (unsigned)H + un, dzcv);
         store_vals<T, NR>(dzg + rowi * (unsigned)(2 * H) + H + un, dzuv);
@@ -526,8 +532,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         put_image<NR, NPL>(dzgimg, PSG, swz(col, un, 2 * H), dzrv);
         put_image<NR, NPL>(dzgimg, PSG, swz(col, H + un, 2 * H), dzuv);
       } else {
-        publish<NR>(xg_ + col * 2 * H + un, (unsigned)(s + 1), dzrv);
-        publish<NR>(xg_ + col * 2 * H + H + un, (unsigned)(s + 1), dzuv);
+        publish<NR>(xg_ + col * H + un, (unsigned)(s + 1), dzrv);
       }
       if (nvalid) store_vals<T, NR>(dzg + rowi * (unsigned)(2 * H) + un, dzrv);
       wg_barrier();                                        // B2: dzg image complete (and the next slot's stage)
@@ -619,7 +624,9 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         wg_barrier();                                      // B1
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bpa: the own compute waves publish dzr / dzu behind it
-        if (!gather<2 * H, NPL>(xg_, (unsigned)(s + 1), dzgimg, pw, lane, a.status)) abortf[0] = 1;
+        // dzu went out in phase 1: this pass finds it at once, under the compute waves' first product; then dzr
+        if (!gather<H, NPL, 2 * H + 8>(xg_ + 16 * H, (unsigned)(s + 1), dzgimg + H, pw, lane, a.status)) abortf[0] = 1;
+        if (!gather<H, NPL, 2 * H + 8>(xg_, (unsigned)(s + 1), dzgimg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B2
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bpb

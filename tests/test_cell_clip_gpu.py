@@ -20,32 +20,32 @@ def _max_cell(m, names):
 
 
 def test_step_kernels_clip_like_the_oracle(dev):
-    """Small widths, exact fp32 (launch-per-step LSTM kernels everywhere), clip 0.004: active in every cell from the first
-    steps on.  Outputs, loss and every gradient."""
+    """Small widths, exact fp32 (launch-per-step LSTM kernels everywhere), clip 0.005: active in every cell family.  Outputs
+    against the oracle's free pass, loss and every gradient on the GPU pass' own ReLU branches (util.oracle_report: with
+    every state pinned to +-0.005 many pre-activations sit within rounding of zero)."""
+    from test_taco2_fullwidth_gpu import BOUNDS
     from nspeech_amd.models import create_model
-    hp = small_hparams(lstm_cell_clip=0.004)
+    hp = small_hparams(lstm_cell_clip=0.005)
     m = create_model("taco2", hp, device="cuda:0", dtype="fp32", seed=3)
     N, Ti, To = 3, 12, 20
-    inputs, lengths, mel, lin = same_branch_batch(m, hp, N, Ti, To, seed=11)
-    out, (loss, _, _), grads = oracle_run(hp, m.numpy_params(), m.numpy_stats(), inputs, lengths, mel, lin)
-    m.initialize(inputs, lengths, None, mel, lin)
-    m.backward()
-    m.read_losses()
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=11)
+    rep = oracle_report(m, hp, inputs, lengths, mel, lin, stabilise=2e-3)
     cells = _max_cell(m, ("dec_c1", "dec_c2", "dec_ca", "expl_c_fw", "expl_c_bw", "encl_c_fw", "encl_c_bw"))
-    assert len(cells) == 7 and all(abs(v - 0.004) < 1e-8 for v in cells.values()), cells      # every cell family hit the clip
-    for k in ("decoder_outputs", "mel_outputs", "linear_outputs", "alignments"):
-        got, ref = getattr(m, k).float().cpu().numpy(), out[k].detach().numpy()
-        assert np.abs(got - ref).max() < 5e-4 * max(1.0, np.abs(ref).max()), k
-    assert abs(m.loss - loss) < 1e-5 * abs(loss)
-    got = m.numpy_grads()
-    bad = [(k, float(np.abs(got[k] - grads[k]).max()), float(np.abs(grads[k]).max())) for k in grads
-           if np.abs(got[k] - grads[k]).max() > 2e-3 * np.abs(grads[k]).max() + 2e-6]
+    assert len(cells) == 7 and all(abs(v - 0.005) < 1e-8 for v in cells.values()), cells      # every cell family hit the clip
+    assert all(rep["paths"][k] == "step" for k in rep["paths"] if not k.startswith("attn")), rep["paths"]   # the LSTM step kernels
+    b = BOUNDS["fp32"]
+    for k, (l2, mx, l1) in rep["out"].items():
+        assert mx < 5e-4, (k, l2, mx, l1)
+    got, want = rep["loss"]
+    assert abs(got - want) < 1e-5 * abs(want)
+    bad = [(k, v) for k, v in rep["grad"].items() if not (v[0] < 2e-3 and v[1] < 4e-3)]
     assert not bad, bad[:6]
     # and the clip changes the function: the same batch without it gives other outputs
+    mel_clip = m.mel_outputs.float().clone()
     hp0 = small_hparams()
     m0 = create_model("taco2", hp0, device="cuda:0", dtype="fp32", seed=3)
     m0.initialize(inputs, lengths, None, mel, lin)
-    assert (m0.mel_outputs - m.mel_outputs).abs().max().item() > 1e-3
+    assert (m0.mel_outputs - mel_clip).abs().max().item() > 1e-3
 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "mixed"])
