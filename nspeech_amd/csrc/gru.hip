@@ -163,11 +163,49 @@ template <typename T, int NR> __device__ __forceinline__ void store_vals(T* p, c
   }
 }
 
-// The poller waves' gather: W granules per batch row, 16 rows; granule index = row * W + k, lane-linear, so poller pw's
+// The poller waves' gather: W granules per batch row, 16 rows; granule index = row * W + k.  A lane fetches PAIRS of
+// neighbouring granules with 16-byte L2-bypassing buffer loads (the two 8-byte halves arrive untorn; both tags are
+// checked) - poller pw's instruction j covers row 8 pw + 128 j / W, columns 128 j % W + 2 lane, so every image offset is
+// the lane's base + a constant and a pair goes into each plane as ONE 4-byte LDS write.  All PPG / 2 loads of a pass are in
+// flight together: a pass is one memory round trip.  Returns false when the wave gave up (status raised / wall-clock bound).
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+template <int W, int NPL, int ILD = W + 8>       // ILD: row stride of the image (a gather may fill a column range of a wider one)
+__device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
+  constexpr int NLD = 16 * W / 256;              // 16-byte loads per lane and gather (2 pollers x 64 lanes x 2 granules)
+  const uintptr_t base = (uintptr_t)(src_ + (size_t)pw * NLD * 128);
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, NLD * 1024, 0x00020000);
+  unsigned* dst = (unsigned*)(img + pw * 8 * ILD + 2 * lane);
+  bool gave_up = false;
+  u32x4 v[NLD];
+  unsigned spins = 0, clk0 = 0;
+  bool ok;
+  do {
+    ok = true;
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, j * 1024, 16);
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) ok = ok && v[j][1] == tag && v[j][3] == tag;
+    if (!ok && (++spins & 1023u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = gave_up = true;
+      else if (ns_spin_timed_out(clk0)) { atomicExch(status, 1); ok = gave_up = true; }
+    }
+  } while (!ok);
+#pragma unroll
+  for (int j = 0; j < NLD; ++j) {
+    const int o = ((j * 128 / W) * ILD + (j * 128) % W) / 2;          // in 4-byte units
+    const unsigned p0 = v[j][0], p1 = v[j][2];
+    dst[o] = (p0 & 0xffffu) | (p1 << 16);
+    if (NPL == 2) dst[16 * ILD / 2 + o] = (p0 >> 16) | (p1 & 0xffff0000u);
+  }
+  return !gave_up;
+}
+
+// The first form of the gather (8-byte loads, one granule each; kept behind NS_GRU_DBG bit 4 for A/B timing): W granules per batch row, 16 rows; granule index = row * W + k, lane-linear, so poller pw's
 // instruction j covers row 8 pw + 64 j / W, columns 64 j % W + lane: every image offset is the lane's base + a constant.
 // Returns false when the wave gave up (status raised / wall-clock bound).
 template <int W, int NPL, int ILD = W + 8>       // ILD: row stride of the image (a gather may fill a column range of a wider one)
-__device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
+__device__ __forceinline__ bool gather8(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
   constexpr int PPG = 16 * W / 128;
   // uniform base (scalar registers) + one 32-bit lane offset: the loads take the saddr form, no 64-bit address per granule
   const NS_GLOBAL char* src = (const NS_GLOBAL char*)((const NS_GLOBAL u64*)src_ + pw * PPG * 64);
@@ -205,6 +243,16 @@ __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* im
     }
   }
   return !gave_up;
+}
+
+// Which form: measured on one box, A/B in one process (us per step, H = 256, three passes / one pass):
+//   forward   8-byte loads 6.21 / 5.69    16-byte pairs 8.55 / 6.90
+//   backward  8-byte loads 8.44 / 7.95    16-byte pairs 7.08 / 6.95
+// so the forward kernel polls single granules and the backward kernel pairs; NS_GRU_DBG bit 4 swaps them.
+template <int W, int NPL, int ILD, bool PAIRS>
+__device__ __forceinline__ bool gather_sel(int dbg, const u64* src, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
+  return (PAIRS != ((dbg & 4) != 0)) ? gather<W, NPL, ILD>(src, tag, img, pw, lane, status)
+                                     : gather8<W, NPL, ILD>(src, tag, img, pw, lane, status);
 }
 
 // ===================================================================================================== forward
@@ -397,11 +445,11 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     if constexpr (G > 1) {
       const int pw = wave - GW - 1;
       for (int s = 0; s < T_; ++s) {
-        if (s > 0 && !gather<H, NPL>(xh, (unsigned)s, himg, pw, lane, a.status)) abortf[0] = 1;
+        if (s > 0 && !gather_sel<H, NPL, H + 8, false>(a.dbg, xh, (unsigned)s, himg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B0
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bp1: the own compute waves publish behind it
-        if (!gather<H, NPL>(xr, (unsigned)(s + 1), rhimg, pw, lane, a.status)) abortf[0] = 1;
+        if (!gather_sel<H, NPL, H + 8, false>(a.dbg, xr, (unsigned)(s + 1), rhimg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B1
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bp2
@@ -620,13 +668,13 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
       const int pw = wave - GW - 2;
       wg_barrier();
       for (int s = 0; s < T_; ++s) {
-        if (!gather<H, NPL>(xc_, (unsigned)(s + 1), dzcimg, pw, lane, a.status)) abortf[0] = 1;
+        if (!gather_sel<H, NPL, H + 8, true>(a.dbg, xc_, (unsigned)(s + 1), dzcimg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B1
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bpa: the own compute waves publish dzr / dzu behind it
         // dzu went out in phase 1: this pass finds it at once, under the compute waves' first product; then dzr
-        if (!gather<H, NPL, 2 * H + 8>(xg_ + 16 * H, (unsigned)(s + 1), dzgimg + H, pw, lane, a.status)) abortf[0] = 1;
-        if (!gather<H, NPL, 2 * H + 8>(xg_, (unsigned)(s + 1), dzgimg, pw, lane, a.status)) abortf[0] = 1;
+        if (!gather_sel<H, NPL, 2 * H + 8, true>(a.dbg, xg_ + 16 * H, (unsigned)(s + 1), dzgimg + H, pw, lane, a.status)) abortf[0] = 1;
+        if (!gather_sel<H, NPL, 2 * H + 8, true>(a.dbg, xg_, (unsigned)(s + 1), dzgimg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B2
         if (abortf[0]) return;
         if (KSPLIT == 2) wg_barrier();                     // Bpb
