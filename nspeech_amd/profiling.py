@@ -15,7 +15,7 @@ def _last_kernel():
     return fn().decode()
 
 
-PROFILE_ROUND = "r04"
+PROFILE_ROUND = "r05"
 
 
 def pmc_traffic(key):
