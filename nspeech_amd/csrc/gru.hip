@@ -44,7 +44,6 @@ typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
 namespace {
-constexpr int GW = 8;                 // compute waves per workgroup
 
 struct GruArgs {
   int N, T, P, padl, ndir, nrg;
@@ -70,7 +69,12 @@ template <int H_> struct GCfg {
   static constexpr int G = H == 128 ? 1 : 4;        // workgroups per chain
   static constexpr int U = H / G;                   // units per workgroup
   static constexpr int NB = U / 16;                 // 16-unit blocks per workgroup
-  static constexpr int KSPLIT = GW / NB;            // compute waves per block (each takes 1 / KSPLIT of K)
+  // compute waves: eight in both shapes (96 weight registers per wave: at H = 256 a block's K is split over two waves).
+  // Measured and dropped (GW = NB: four waves x 192 weight registers with the whole K, no partner barrier): a lone wave per
+  // SIMD spends 1.3 us in the gate / publish / store segment of a slot where two waves per SIMD take 0.55 - 1.15:
+  // forward 7.6 against 6.2 us per step, backward (one pass) 6.35 against 6.9.
+  static constexpr int GW = 8;
+  static constexpr int KSPLIT = GW / NB;            // compute waves per block (each takes 1 / KSPLIT of K); 2 = the first form
   static constexpr int KS = H / 32;                 // k-steps of a product over H
   static constexpr int KSW = KS / KSPLIT;           // ... per wave
   static constexpr int NR = 4 / KSPLIT;             // accumulator registers (units) a wave finishes per lane
@@ -137,18 +141,26 @@ __device__ __forceinline__ void put_image(bf16_t* img, int plane_stride, int off
   }
 }
 
-// A granule = {step tag, bf16 hi | bf16 lo << 16}: the publishing lane splits its 2 - 4 values, the pollers copy halves
-// into the operand images without touching the VALU.
-template <int NR>
-__device__ __forceinline__ void publish(u64* g_, unsigned tag, const float (&v)[NR]) {
-  NS_GLOBAL u64* g = (NS_GLOBAL u64*)g_;
+// A granule = {step tag, bf16 hi | bf16 lo << 16}: the publishing lane splits its values, the pollers copy halves into the
+// operand images without touching the VALU.  Layout of an exchange buffer (16 rows x W values): LANE-LINEAR in the
+// publishers' order - [16-unit block][K half kh][lane = (row, unit quad)][2 granules] - so that a compute wave's publish is
+// ONE 16-byte write-through store per lane and 1 KB of consecutive bytes per wave (with [row][unit] order a wave wrote
+// 64 scattered 8-byte pieces per instruction, two instructions per exchange: the store path, not the fabric, set the
+// publish time).  `slot` = (block * 2 + kh) * 64 + lane.
+typedef __attribute__((ext_vector_type(4))) unsigned gru_u32x4;
+__device__ __forceinline__ void publish2(u64* buf, int nslots, int slot, unsigned tag, const float (&v)[2]) {
+  unsigned pay[2];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
+  for (int i = 0; i < 2; ++i) {
     const bf16_t hi = (bf16_t)v[i], lo = (bf16_t)(v[i] - (float)hi);
-    const unsigned pay = (unsigned)(*(const unsigned short*)&hi) | ((unsigned)(*(const unsigned short*)&lo) << 16);
-    __hip_atomic_store(g + i, ((u64)tag << 32) | (u64)pay, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pay[i] = (unsigned)(*(const unsigned short*)&hi) | ((unsigned)(*(const unsigned short*)&lo) << 16);
   }
+  const uintptr_t base = (uintptr_t)buf;
+  const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
+  const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, nslots * 16, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128((gru_u32x4){pay[0], tag, pay[1], tag}, rs, (unsigned)slot * 16u, 0, 16);      // aux 16 = sc1
 }
+template <int NR> __device__ __forceinline__ void publish2(u64*, int, int, unsigned, const float (&)[NR]) {}      // (NR = 4: one workgroup per chain, nothing is published)
 
 template <typename T, int NR> __device__ __forceinline__ void store_vals(T* p, const float (&v)[NR]) {
   if constexpr (sizeof(T) == 4) {
@@ -163,19 +175,22 @@ template <typename T, int NR> __device__ __forceinline__ void store_vals(T* p, c
   }
 }
 
-// The poller waves' gather: W granules per batch row, 16 rows; granule index = row * W + k.  A lane fetches PAIRS of
-// neighbouring granules with 16-byte L2-bypassing buffer loads (the two 8-byte halves arrive untorn; both tags are
-// checked) - poller pw's instruction j covers row 8 pw + 128 j / W, columns 128 j % W + 2 lane, so every image offset is
-// the lane's base + a constant and a pair goes into each plane as ONE 4-byte LDS write.  All PPG / 2 loads of a pass are in
-// flight together: a pass is one memory round trip.  Returns false when the wave gave up (status raised / wall-clock bound).
+// The poller waves' gather of one exchange buffer (16 rows x W values in the publishers' lane-linear order, see publish2)
+// into a [16][ILD] operand image.  Two forms, both with every load of a pass in flight (a pass is one memory round trip)
+// and every image offset = the lane's base + a compile-time constant:
+//   gather   16-byte L2-bypassing buffer loads = one publishing lane's two granules (the 8-byte halves arrive untorn, both
+//            tags are checked), one 4-byte LDS write per plane;
+//   gather8  8-byte loads, one granule each, 2-byte LDS writes.
+// Poller pw takes the second half of the slots.  Returns false when the wave gave up (status raised / wall-clock bound).
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 template <int W, int NPL, int ILD = W + 8>       // ILD: row stride of the image (a gather may fill a column range of a wider one)
 __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
-  constexpr int NLD = 16 * W / 256;              // 16-byte loads per lane and gather (2 pollers x 64 lanes x 2 granules)
+  constexpr int NLD = W / 16;                    // 16-byte loads per lane: (W / 16 blocks x 2 halves x 64 lanes) / 2 pollers / 64
   const uintptr_t base = (uintptr_t)(src_ + (size_t)pw * NLD * 128);
   const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)base), bhi = __builtin_amdgcn_readfirstlane((unsigned)(base >> 32));
   const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)bhi << 32) | blo), 0, NLD * 1024, 0x00020000);
-  unsigned* dst = (unsigned*)(img + pw * 8 * ILD + 2 * lane);
+  // slot jj = pw * NLD + j of lane l: row l & 15, units 16 (jj >> 1) + 4 (l >> 4) + 2 (jj & 1) + {0, 1}
+  unsigned* dst = (unsigned*)(img + (lane & 15) * ILD + 4 * (lane >> 4) + 16 * ((pw * NLD) >> 1));
   bool gave_up = false;
   u32x4 v[NLD];
   unsigned spins = 0, clk0 = 0;
@@ -193,7 +208,7 @@ __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* im
   } while (!ok);
 #pragma unroll
   for (int j = 0; j < NLD; ++j) {
-    const int o = ((j * 128 / W) * ILD + (j * 128) % W) / 2;          // in 4-byte units
+    const int o = (16 * (j >> 1) + 2 * (j & 1)) / 2;                  // in 4-byte units (NLD is even: pw * NLD is too)
     const unsigned p0 = v[j][0], p1 = v[j][2];
     dst[o] = (p0 & 0xffffu) | (p1 << 16);
     if (NPL == 2) dst[16 * ILD / 2 + o] = (p0 >> 16) | (p1 & 0xffff0000u);
@@ -201,46 +216,37 @@ __device__ __forceinline__ bool gather(const u64* src_, unsigned tag, bf16_t* im
   return !gave_up;
 }
 
-// The first form of the gather (8-byte loads, one granule each; kept behind NS_GRU_DBG bit 4 for A/B timing): W granules per batch row, 16 rows; granule index = row * W + k, lane-linear, so poller pw's
-// instruction j covers row 8 pw + 64 j / W, columns 64 j % W + lane: every image offset is the lane's base + a constant.
-// Returns false when the wave gave up (status raised / wall-clock bound).
-template <int W, int NPL, int ILD = W + 8>       // ILD: row stride of the image (a gather may fill a column range of a wider one)
+template <int W, int NPL, int ILD = W + 8>
 __device__ __forceinline__ bool gather8(const u64* src_, unsigned tag, bf16_t* img, int pw, int lane, int* status) {
-  constexpr int PPG = 16 * W / 128;
-  // uniform base (scalar registers) + one 32-bit lane offset: the loads take the saddr form, no 64-bit address per granule
+  constexpr int PPG = W / 8;                     // granules per lane: 16 W / 128
   const NS_GLOBAL char* src = (const NS_GLOBAL char*)((const NS_GLOBAL u64*)src_ + pw * PPG * 64);
   const unsigned lo8 = (unsigned)lane * 8u;
-  unsigned short* dst = (unsigned short*)img + pw * 8 * ILD + lane;
+  // granule jj * 64 + l (jj = pw * PPG + j): row (l / 2) & 15, unit 16 (jj >> 2) + 8 (jj & 1) + 4 (l >> 5) + 2 ((jj >> 1) & 1) + (l & 1)
+  unsigned short* dst = (unsigned short*)img + ((lane >> 1) & 15) * ILD + 4 * (lane >> 5) + (lane & 1) + 16 * ((pw * PPG) >> 2);
   bool gave_up = false;
-  constexpr int CH = PPG < 32 ? PPG : 32;        // granules in flight per lane: a pass is one memory round trip, so as few
-                                                 // passes as the registers allow (16 in flight cost the H = 256 forward step
-                                                 // two serial round trips per gather)
+  u64 v[PPG];
+  unsigned spins = 0, clk0 = 0;
+  bool ok;
+  unsigned lo = lo8;
+  asm volatile("" : "+v"(lo));          // opaque: the addresses are formed here, not hoisted out of the step loop as 64-bit pairs
+  do {
+    ok = true;
 #pragma unroll
-  for (int j0 = 0; j0 < PPG; j0 += CH) {
-    u64 v[CH];
-    unsigned spins = 0, clk0 = 0;
-    bool ok;
-    unsigned lo = lo8;
-    asm volatile("" : "+v"(lo));          // opaque: the addresses are formed here, not hoisted out of the step loop as 64-bit pairs
-    do {
-      ok = true;
+    for (int j = 0; j < PPG; ++j)
+      v[j] = __hip_atomic_load((const NS_GLOBAL u64*)(src + j * 512 + lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-      for (int j = 0; j < CH; ++j)
-        v[j] = __hip_atomic_load((const NS_GLOBAL u64*)(src + (j0 + j) * 512 + lo), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int j = 0; j < CH; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
-      if (!ok && (++spins & 1023u) == 0) {
-        if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = gave_up = true;
-        else if (ns_spin_timed_out(clk0)) { atomicExch(status, 1); ok = gave_up = true; }
-      }
-    } while (!ok);
-#pragma unroll
-    for (int j = 0; j < CH; ++j) {
-      const int o = ((j0 + j) * 64 / W) * ILD + ((j0 + j) * 64) % W;
-      const unsigned pay = (unsigned)v[j];
-      dst[o] = (unsigned short)pay;
-      if (NPL == 2) dst[16 * ILD + o] = (unsigned short)(pay >> 16);      // (the lo plane follows the 16 rows of the hi plane)
+    for (int j = 0; j < PPG; ++j) ok = ok && ((unsigned)(v[j] >> 32) == tag);
+    if (!ok && (++spins & 1023u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ok = gave_up = true;
+      else if (ns_spin_timed_out(clk0)) { atomicExch(status, 1); ok = gave_up = true; }
     }
+  } while (!ok);
+#pragma unroll
+  for (int j = 0; j < PPG; ++j) {
+    const int o = 16 * (j >> 2) + 8 * (j & 1) + 2 * ((j >> 1) & 1);   // (PPG is a multiple of 4: pw * PPG is too)
+    const unsigned pay = (unsigned)v[j];
+    dst[o] = (unsigned short)pay;
+    if (NPL == 2) dst[16 * ILD + o] = (unsigned short)(pay >> 16);
   }
   return !gave_up;
 }
@@ -265,8 +271,8 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
   bf16_t* himg = (bf16_t*)smem;                       // [NPL][16][H] the state, swizzled
   bf16_t* rhimg = himg + NPL * PS;                    // [NPL][16][H] r * h
   float* xs = (float*)(rhimg + NPL * PS);             // [NBUF][XS_F] stage, filled by LDS-DMA
-  float* pbuf = xs + C::NBUF * XS_F;                  // [GW][64][4] (K split)
-  int* abortf = (int*)(pbuf + (KSPLIT == 2 ? GW * 64 * 4 : 0));
+  float* pbuf = xs + C::NBUF * XS_F;                  // [C::GW][64][4] (K split)
+  int* abortf = (int*)(pbuf + (KSPLIT == 2 ? C::GW * 64 * 4 : 0));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chain = blockIdx.x / G, g = blockIdx.x % G;
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
     if (NPL == 2) himg[PS + swz(row, k, H)] = (bf16_t)(v - (float)hi);
   }
 
-  if (wave < GW) {
+  if (wave < C::GW) {
     // ================================================================ compute role
     const int b = wave % NB, kh = wave / NB;
     const int ul0 = b * 16, ug0 = g * U + ul0;
@@ -339,7 +345,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         const float4 give = kh ? make_float4(ar[0], ar[1], au[0], au[1]) : make_float4(ar[2], ar[3], au[2], au[3]);
         *(float4*)(pbuf + (wave * 64 + lane) * 4) = give;
         wg_barrier();                                      // Bp1
-        const float4 take = *(const float4*)(pbuf + (((wave + NB) % GW) * 64 + lane) * 4);
+        const float4 take = *(const float4*)(pbuf + (((wave + NB) % C::GW) * 64 + lane) * 4);
         pr[0] = (kh ? ar[2] : ar[0]) + take.x; pr[1] = (kh ? ar[3] : ar[1]) + take.y;
         pu[0] = (kh ? au[2] : au[0]) + take.z; pu[1] = (kh ? au[3] : au[1]) + take.w;
       } else {
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
 #pragma unroll
       for (int i = 0; i < NR; ++i) { r[i] = sigmoidf_(pr[i]); u[i] = sigmoidf_(pu[i]); rhv[i] = r[i] * hst[i]; }
       if constexpr (G == 1) put_image<NR, NPL>(rhimg, PS, swz(col, un, H), rhv);
-      else publish<NR>(xr + col * H + un, (unsigned)(s + 1), rhv);
+      else publish2(xr, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), rhv);
       if (nvalid && !(a.dbg & 2)) {
         store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + un, r);
         store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + H + un, u);
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         const float2 give = kh ? make_float2(ac[0], ac[1]) : make_float2(ac[2], ac[3]);
         *(float2*)(pbuf + (wave * 64 + lane) * 4) = give;
         wg_barrier();                                      // Bp2
-        const float2 take = *(const float2*)(pbuf + (((wave + NB) % GW) * 64 + lane) * 4);
+        const float2 take = *(const float2*)(pbuf + (((wave + NB) % C::GW) * 64 + lane) * 4);
         pc[0] = (kh ? ac[2] : ac[0]) + take.x; pc[1] = (kh ? ac[3] : ac[1]) + take.y;
       } else {
 #pragma unroll
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
       }
       if (s + 1 < T_) {
         if constexpr (G == 1) put_image<NR, NPL>(himg, PS, swz(col, un, H), hst);
-        else publish<NR>(xh + col * H + un, (unsigned)(s + 1), hst);
+        else publish2(xh, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), hst);
       }
       if (nvalid && !(a.dbg & 2)) {
         store_vals<float, NR>(a.c[d] + rowi * (unsigned)H + un, cv);
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
 #undef GRU_STAMP
     if (TRACE && a.trace && blockIdx.x == 0 && lane == 0)
       for (int k = 0; k < 8; ++k) a.trace[wave * 8 + k] = tsum[k];
-  } else if (wave == GW) {
+  } else if (wave == C::GW) {
     // ================================================================ prefetcher role: LDS-DMA, two slots ahead
     // Uniform parts of every address stay in scalar registers; a lane keeps two 32-bit offsets (xg and xc rows).  Rows past
     // N fetch row N - 1 again (their results are never stored): every slot issues exactly FW_NI instructions, which is
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
   } else {
     // ================================================================ poller role (H = 256)
     if constexpr (G > 1) {
-      const int pw = wave - GW - 1;
+      const int pw = wave - C::GW - 1;
       for (int s = 0; s < T_; ++s) {
         if (s > 0 && !gather_sel<H, NPL, H + 8, false>(a.dbg, xh, (unsigned)s, himg, pw, lane, a.status)) abortf[0] = 1;
         wg_barrier();                                      // B0
@@ -476,8 +482,8 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
   bf16_t* dzcimg = (bf16_t*)smem;                     // [NPL][16][H]
   bf16_t* dzgimg = dzcimg + NPL * PSC;                // [NPL][16][2H]
   float* st = (float*)(dzgimg + NPL * PSG);           // [NBUF][ST_F] stage, filled by LDS-DMA
-  float* pbuf = st + C::NBUF * ST_F;                  // [GW][64][2] (K split)
-  int* abortf = (int*)(pbuf + (KSPLIT == 2 ? GW * 64 * 2 : 0));
+  float* pbuf = st + C::NBUF * ST_F;                  // [C::GW][64][2] (K split)
+  int* abortf = (int*)(pbuf + (KSPLIT == 2 ? C::GW * 64 * 2 : 0));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chain = blockIdx.x / G, g = blockIdx.x % G;
@@ -489,7 +495,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
   u64* xg_ = xc_ + 16 * H;                            // dzr granules [16][H], then dzu granules [16][H]
   if (tid == 0) abortf[0] = 0;
 
-  if (wave < GW) {
+  if (wave < C::GW) {
     // ================================================================ compute role
     const int b = wave % NB, kh = wave / NB;
     const int ul0 = b * 16, ug0 = g * U + ul0;
@@ -542,8 +548,8 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
       }
       if constexpr (G == 1) put_image<NR, NPL>(dzcimg, PSC, swz(col, un, H), dzcv);
       else {
-        publish<NR>(xc_ + col * H + un, (unsigned)(s + 1), dzcv);
-        publish<NR>(xg_ + 16 * H + col * H + un, (unsigned)(s + 1), dzuv);       // not needed before the second product: gathered off the chain
+        publish2(xc_, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), dzcv);
+        publish2(xg_ + 16 * H, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), dzuv);       // not needed before the second product: gathered off the chain
       }
       if (nvalid) {
         store_vals<T, NR>(dzc + rowi * (unsigned)H + un, dzcv);
@@ -564,7 +570,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         const float2 give = kh ? make_float2(acc[0], acc[1]) : make_float2(acc[2], acc[3]);
         *(float2*)(pbuf + (wave * 64 + lane) * 2) = give;
         wg_barrier();                                      // Bpa
-        const float2 take = *(const float2*)(pbuf + (((wave + NB) % GW) * 64 + lane) * 2);
+        const float2 take = *(const float2*)(pbuf + (((wave + NB) % C::GW) * 64 + lane) * 2);
         drh[0] = (kh ? acc[2] : acc[0]) + take.x; drh[1] = (kh ? acc[3] : acc[1]) + take.y;
       } else {
 #pragma unroll
@@ -580,7 +586,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         put_image<NR, NPL>(dzgimg, PSG, swz(col, un, 2 * H), dzrv);
         put_image<NR, NPL>(dzgimg, PSG, swz(col, H + un, 2 * H), dzuv);
       } else {
-        publish<NR>(xg_ + col * H + un, (unsigned)(s + 1), dzrv);
+        publish2(xg_, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), dzrv);
       }
       if (nvalid) store_vals<T, NR>(dzg + rowi * (unsigned)(2 * H) + un, dzrv);
       wg_barrier();                                        // B2: dzg image complete (and the next slot's stage)
@@ -597,7 +603,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         const float2 give = kh ? make_float2(acc[0], acc[1]) : make_float2(acc[2], acc[3]);
         *(float2*)(pbuf + (wave * 64 + lane) * 2) = give;
         wg_barrier();                                      // Bpb
-        const float2 take = *(const float2*)(pbuf + (((wave + NB) % GW) * 64 + lane) * 2);
+        const float2 take = *(const float2*)(pbuf + (((wave + NB) % C::GW) * 64 + lane) * 2);
         carry[0] = cn[0] + (kh ? acc[2] : acc[0]) + take.x;
         carry[1] = cn[1] + (kh ? acc[3] : acc[1]) + take.y;
       } else {
@@ -606,13 +612,13 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
       }
     }
     if (a.dh_init[d] && nvalid) store_vals<float, NR>(a.dh_init[d] + (long)n * a.ld_dhi + un, carry);
-  } else if (wave < GW + 2) {
+  } else if (wave < C::GW + 2) {
     // ================================================================ prefetcher role (two waves): LDS-DMA, two slots ahead
     // Instruction j of a slot: j < 4 * IPS -> section j / IPS (r, u from ru; c; dh), else the h_prev rows of the history
     // (type T: 8 bf16 or 4 fp32 per 16-byte chunk).  Wave pw issues the instructions j = pw, pw + 2, ...; rows past N and a
     // h_prev step outside the sequence fetch a valid row instead (never used): the count per slot is constant.
     constexpr int IPS = (U / 4) / 4, EPC = 16 / (int)sizeof(T);
-    const int pw = wave - GW;
+    const int pw = wave - C::GW;
     const T* hist = (const T*)a.h[d];
     const int lrow = lane & 15, lq = lane >> 4;
     const int nrow = min(rg * 16 + lrow, a.N - 1);
@@ -665,7 +671,7 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
   } else {
     // ================================================================ poller role (H = 256)
     if constexpr (G > 1) {
-      const int pw = wave - GW - 2;
+      const int pw = wave - C::GW - 2;
       wg_barrier();
       for (int s = 0; s < T_; ++s) {
         if (!gather_sel<H, NPL, H + 8, true>(a.dbg, xc_, (unsigned)(s + 1), dzcimg, pw, lane, a.status)) abortf[0] = 1;
@@ -687,13 +693,13 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
 template <int H> size_t fwd_lds(int P) {
   using C = GCfg<H>;
   const int npl = P == 3 ? 2 : 1;
-  return (size_t)2 * npl * 16 * (H + 8) * 2 + sizeof(float) * C::NBUF * C::XS_F + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 4 : 0) + 16;
+  return (size_t)2 * npl * 16 * (H + 8) * 2 + sizeof(float) * C::NBUF * C::XS_F + (C::KSPLIT == 2 ? sizeof(float) * C::GW * 64 * 4 : 0) + 16;
 }
 template <int H> size_t bwd_lds(int P, bool bf16_hist) {
   using C = GCfg<H>;
   const int npl = P == 3 ? 2 : 1;
   const size_t st_f = 4 * C::SECF + (bf16_hist ? C::SECF / 2 : C::SECF);
-  return (size_t)npl * 16 * (3 * H + 16) * 2 + sizeof(float) * C::NBUF * st_f + (C::KSPLIT == 2 ? sizeof(float) * GW * 64 * 2 : 0) + 16;
+  return (size_t)npl * 16 * (3 * H + 16) * 2 + sizeof(float) * C::NBUF * st_f + (C::KSPLIT == 2 ? sizeof(float) * C::GW * 64 * 2 : 0) + 16;
 }
 
 int passes_of(const ns_gru_seq_params* p) { return p->dtype == NS_BF16 ? 1 : p->f32_passes; }
