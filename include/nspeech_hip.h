@@ -563,8 +563,11 @@ typedef struct {
   const void* wg; int ld_wg;        /* (dtype) [H][2H] row-major recurrent rows of gates/kernel                      bwd */
   const void* wc; int ld_wc;        /* (dtype) [H][H]                                                                bwd */
   void* h; int ld_h;                /* (dtype) history, this cell's H columns of row n * P + padl + t */
-  float* ru;                        /* [N*P, 2H] */
-  float* c;                         /* [N*P, H] */
+  /* saved gates, PRIVATE to this pair of calls (the forward call writes them in the order the backward call's LDS stage
+   * wants, 1 KB of consecutive bytes per wave): [row group][t][workgroup][r | u sections][16-byte chunk][16 rows][4],
+   * ceil(N / 16) * 16 * T * 2H floats (c: ... * H).  Every row group is written whole. */
+  float* ru;
+  float* c;
   void* rh;                         /* (dtype) [N*P, H] */
   const float* h_init; int ld_hi;   /* nullable [N, H] */
   const float* dh; int ld_dh;       /* bwd: gradient wrt h, addressed as h */

@@ -357,10 +357,13 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
       for (int i = 0; i < NR; ++i) { r[i] = sigmoidf_(pr[i]); u[i] = sigmoidf_(pu[i]); rhv[i] = r[i] * hst[i]; }
       if constexpr (G == 1) put_image<NR, NPL>(rhimg, PS, swz(col, un, H), rhv);
       else publish2(xr, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), rhv);
-      if (nvalid && !(a.dbg & 2)) {
-        store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + un, r);
-        store_vals<float, NR>(a.ru[d] + rowi * (unsigned)(2 * H) + H + un, u);
-        store_vals<T, NR>(rhout + rowi * (unsigned)H + un, rhv);
+      if (!(a.dbg & 2)) {
+        // the saved gates go out in the BACKWARD stage's layout (see ns_gru_seq_params.ru): 16 bytes per lane, 1 KB of
+        // consecutive bytes per wave, every row (rows past N hold finite values nobody uses)
+        float* sv = a.ru[d] + ((size_t)(rg * T_ + t) * G + g) * (2 * SECF) + xoff + mo;
+        store_vals<float, NR>(sv, r);
+        store_vals<float, NR>(sv + SECF, u);
+        if (nvalid) store_vals<T, NR>(rhout + rowi * (unsigned)H + un, rhv);
       }
       GRU_STAMP(2);
       wg_barrier();                                        // B1: r * h image complete
@@ -401,9 +404,9 @@ __global__ __launch_bounds__(GCfg<H>::FW_WAVES * 64) void gru_fwd_kernel(GruArgs
         if constexpr (G == 1) put_image<NR, NPL>(himg, PS, swz(col, un, H), hst);
         else publish2(xh, 16 * H / 2, ((g * NB + b) * KSPLIT + kh) * 64 + lane, (unsigned)(s + 1), hst);
       }
-      if (nvalid && !(a.dbg & 2)) {
-        store_vals<float, NR>(a.c[d] + rowi * (unsigned)H + un, cv);
-        store_vals<T, NR>(hout + rowi * (unsigned)a.ld_h + un, ho);
+      if (!(a.dbg & 2)) {
+        store_vals<float, NR>(a.c[d] + ((size_t)(rg * T_ + t) * G + g) * SECF + xoff + mo, cv);
+        if (nvalid) store_vals<T, NR>(hout + rowi * (unsigned)a.ld_h + un, ho);
       }
       GRU_STAMP(5);
     }
@@ -622,14 +625,14 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
     const T* hist = (const T*)a.h[d];
     const int lrow = lane & 15, lq = lane >> 4;
     const int nrow = min(rg * 16 + lrow, a.N - 1);
-    const unsigned vo_ru = (unsigned)(nrow * a.P) * (unsigned)(2 * H) + lq * 4, vo_c = (unsigned)(nrow * a.P) * (unsigned)H + lq * 4;
     const unsigned vo_dh = (unsigned)(nrow * a.P) * (unsigned)a.ld_dh + lq * 4, vo_h = (unsigned)(nrow * a.P) * (unsigned)a.ld_h + lq * EPC;
     auto issue = [&](int s) {
       const int t = rev ? s : T_ - 1 - s;
       const int tp = min(max(rev ? t + 1 : t - 1, 0), T_ - 1);
       const size_t r0 = (size_t)(a.padl + t);
-      const float* bru = a.ru[d] + r0 * (2 * H) + g * U;
-      const float* bc = a.c[d] + r0 * H + g * U;
+      // the saved gates lie in this stage's own order (the forward kernel wrote them so): a straight lane-linear copy
+      const float* bru = a.ru[d] + ((size_t)(rg * T_ + t) * G + g) * (2 * SECF) + lane * 4;
+      const float* bc = a.c[d] + ((size_t)(rg * T_ + t) * G + g) * SECF + lane * 4;
       const float* bdh = a.dh[d] + r0 * a.ld_dh + g * U;
       const T* bh = hist + (size_t)(a.padl + tp) * a.ld_h + g * U;
       float* dst = st + (s % C::NBUF) * ST_F;
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(GCfg<H>::BW_WAVES * 64) void gru_bwd_kernel(GruArgs
         if (j >= NI) break;
         const int sec = j / IPS, jc = (j % IPS) * 16;
         const void* src;
-        if (sec < 2) src = bru + sec * H + jc + vo_ru;
-        else if (sec == 2) src = bc + jc + vo_c;
+        if (sec < 2) src = bru + j * 256;
+        else if (sec == 2) src = bc + (j - 2 * IPS) * 256;
         else if (sec == 3) src = bdh + jc + vo_dh;
         else src = bh + (j - 4 * IPS) * 4 * EPC + vo_h;
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + j * 256), 16, 0, 0);

@@ -251,8 +251,11 @@ class Tacotron(Tacotron2):
             ops.gemm(x.buf, W, dd["xg"], rows, 2 * H, cin, cin, 2 * H, 2 * H, b_mode=1, b_off=dd["og"], bias=self.flat_p,
                      bias_off=dd["bg"])
             ops.gemm(x.buf, W, dd["xc"], rows, H, cin, cin, H, H, b_mode=1, b_off=dd["oc"], bias=self.flat_p, bias_off=dd["bc"])
-            dd["ru"] = self._buf("gru:%s_ru" % tag, rows * 2 * H, torch.float32)
-            dd["cc"] = self._buf("gru:%s_c" % tag, rows * H, torch.float32)
+            # saved gates: [rows, 2H] / [rows, H] for the step launches; the persistent kernels keep them in an order of their
+            # own over whole 16-row groups (ns_gru_seq_params.ru) - the buffers serve either
+            srows = max(rows, (N + 15) // 16 * 16 * T)
+            dd["ru"] = self._buf("gru:%s_ru" % tag, srows * 2 * H, torch.float32)
+            dd["cc"] = self._buf("gru:%s_c" % tag, srows * H, torch.float32)
             dd["rh"] = self._buf("gru:%s_rh" % tag, rows * H, self.T)
             dd["gT"], dd["cT"] = self.tsh[dd["key"] + "_gT"], self.tsh[dd["key"] + "_cT"]
             dd["first"] = [int(lens[n]) - 1 if dd["reverse"] else 0 for n in range(N)]
@@ -301,6 +304,8 @@ class Tacotron(Tacotron2):
                 self._status_words[(label, "bwd")] = work
                 self.last_paths["%s:bwd" % label] = "seq"
             else:
+                if self.last_paths.get("%s:fwd" % label) == "seq":
+                    raise RuntimeError("GRU %s: the persistent forward kernel's saved gates are private to ns_gru_seq_bwd" % label)
                 self.last_paths["%s:bwd" % label] = "step"
                 for dd in dirs:
                     self._gru_steps_bwd(dd, N, P, padl, T, H, ldh, lengths, hb, out.grad, cin, h0f)

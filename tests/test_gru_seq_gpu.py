@@ -54,6 +54,7 @@ def _case(dev, N, T, H, ndir, masked, with_h0, dtype, passes, seed):
         if Tt == torch.bfloat16:            # the kernel sees bf16 weights: so does the reference
             wg, wc = wg.to(Tt).float(), wc.to(Tt).float()
         dirs.append(dict(reverse=di == 1, xg=rnd(N, T, 2 * H), xc=rnd(N, T, H), wg=wg, wc=wc, dh=rnd(N, T, H, sc=0.3)))
+    srows = (N + 15) // 16 * 16 * T          # the saved gates cover whole 16-row groups (ns_gru_seq_params.ru)
     ldh = ndir * H + 8                       # the history is a column block of a wider buffer
     hb = torch.zeros(rows * ldh, dtype=Tt, device=dev)
     dh = torch.zeros(rows * ldh, dtype=torch.float32, device=dev)
@@ -69,7 +70,7 @@ def _case(dev, N, T, H, ndir, masked, with_h0, dtype, passes, seed):
         b = dict(xg=padded(d["xg"], 2 * H), xc=padded(d["xc"], H),
                  wg=d["wg"].to(Tt).to(dev).contiguous(), wc=d["wc"].to(Tt).to(dev).contiguous(),
                  wgT=d["wg"].t().contiguous().to(Tt).to(dev), wcT=d["wc"].t().contiguous().to(Tt).to(dev),
-                 ru=torch.full((rows * 2 * H,), 7.0, device=dev), c=torch.full((rows * H,), 7.0, device=dev),
+                 ru=torch.full((srows * 2 * H,), 7.0, device=dev), c=torch.full((srows * H,), 7.0, device=dev),
                  rh=torch.zeros(rows * H, dtype=Tt, device=dev), dzg=torch.zeros(rows * 2 * H, dtype=Tt, device=dev),
                  dzc=torch.zeros(rows * H, dtype=Tt, device=dev), dh0=torch.zeros(N * H, device=dev))
         dview = dh.view(N, P, ldh)
@@ -99,7 +100,15 @@ def _case(dev, N, T, H, ndir, masked, with_h0, dtype, passes, seed):
     for di, (d, b) in enumerate(zip(dirs, bufs)):
         ref = _reference(d, H, T, N, lengths, h0)
         cut = lambda x, C: x.float().cpu().view(N, P, C)[:, padl:padl + T]
-        got = dict(h=hv[:, padl:padl + T, di * H:(di + 1) * H], ru=cut(b["ru"], 2 * H), c=cut(b["c"], H), rh=cut(b["rh"], H),
+
+        def saved(x, nsec):
+            """ns_gru_seq's own order [row group][t][workgroup][section][chunk][row][4] -> [N, T, nsec * H]"""
+            G = 1 if H == 128 else 4
+            U = H // G
+            v = x.float().cpu().view((N + 15) // 16, T, G, nsec, U // 4, 16, 4)
+            v = v.permute(0, 5, 1, 3, 2, 4, 6).reshape((N + 15) // 16 * 16, T, nsec * H)       # row group, row | t | section, workgroup, chunk, 4
+            return v[:N]
+        got = dict(h=hv[:, padl:padl + T, di * H:(di + 1) * H], ru=saved(b["ru"], 2), c=saved(b["c"], 1), rh=cut(b["rh"], H),
                    dzg=cut(b["dzg"], 2 * H), dzc=cut(b["dzc"], H), dh0=b["dh0"].cpu().view(N, H) if with_h0 else None)
         out.append((got, ref))
     return out
