@@ -687,7 +687,7 @@ int ns_taco2_attn_cluster_bwd(const ns_taco2_attn_params* p, void* work, ns_stre
  * pass da0 = dhc[:, :, A:] . values^T before it).  An utterance runs on a cluster of 8 workgroups that keep the prenet-2 /
  * GRU / query weights in registers as fp32 (matrix-vector products: exact FMAs), the utterance's keys and pv rows in LDS,
  * and exchange three (backward: four) small vectors per step through `work` as tagged 8-byte granules.
- * Shipped widths only: A = E-independent 256 units, D1 = 256, D2 = 128, T_in <= 256, no speaker rows.
+ * Shipped widths only: A = 256 units, D1 = 256, D2 = 128, T_in <= 256 (any memory width E, any speaker width Dsp).
  * Per-step buffers are [N, S+1, X]: step s in slot s+1, slot 0 = the zero initial state (zero on entry).
  * work: ns_taco1_attn_cluster_work_bytes(); work[0] (int) is a status word (non-zero after the call completes = an
  * exchange timed out, outputs invalid). */
@@ -710,6 +710,10 @@ typedef struct {
   const float* da0;                  /* fp32 [N,S+1,Tia] */
   void* df1; void* dp2; void* dzg; void* dzc; void* dq;   /* (dtype) [N,S+1,D1 | D2 | 2A | A | A] out */
   float* de;                         /* fp32 [N,S+1,Tia] out: energy gradients */
+  /* Multi-speaker (rnn_wrappers.py:28-30): Dsp > 0 widens the GRU input to [prenet(D2) | speaker projection(Dsp) | h(A)]: xa / xc
+   * rows are D2+Dsp+A wide with the per-utterance projection written into columns D2..D2+Dsp of every xa slot by the caller,
+   * wg / wc hold all D2+Dsp+A rows, and the caller forms the projection's gradient from dzg / dzc after the backward call. */
+  int Dsp;
 } ns_taco1_attn_params;
 int ns_taco1_attn_cluster_supported(const ns_taco1_attn_params* p);
 size_t ns_taco1_attn_cluster_work_bytes(const ns_taco1_attn_params* p);

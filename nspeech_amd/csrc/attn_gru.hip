@@ -37,7 +37,6 @@ constexpr int KPAD = 4;            // row pad of the keys image (16 rows x one b
 constexpr int A = 256, D1 = 256, D2 = 128;
 constexpr int UPW = A / CG;        // 32 GRU units per workgroup
 constexpr int K = D2 + A;          // input rows of both GRU kernels
-constexpr int XA = D2 + A;         // row of xa / xc
 // forward thread maps
 constexpr int P2G = CT / D2, P2K = D1 / P2G;             // prenet 2: 4 k groups x 64
 constexpr int GC = 2 * UPW, GG = CT / GC;                // gates: 64 columns (r | u of the own units), 8 k groups
@@ -140,6 +139,9 @@ __global__ __launch_bounds__(CT) void taco1_attn_fwd_kernel(TArgs a) {
   const int n = blockIdx.x / CG, g = blockIdx.x % CG;
   const long S1 = p.S + 1;
   const int HC = A + p.E;
+  // multi-speaker (rnn_wrappers.py:28-30): the GRU's input row is [p2 | speaker projection (Dsp) | h]; the projection is
+  // the same in every step, so its products with the Dsp kernel rows join the biases and the loop never sees it
+  const int Dsp = p.Dsp, XA = D2 + Dsp + A;
   const int L = min(p.lengths ? p.lengths[n] : p.Ti, p.Ti);
   const int ts = max(1, (L + CG - 1) / CG);
   const int t0 = g * ts, tn = max(0, min(L, t0 + ts) - t0);
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(CT) void taco1_attn_fwd_kernel(TArgs a) {
   float wgp[GKP], wgh[GKH];
   {
     const T* bp = Wg + (long)((tid / GC) * GKP) * 2 * A + gcol;
-    const T* bh = Wg + (long)(D2 + (tid / GC) * GKH) * 2 * A + gcol;
+    const T* bh = Wg + (long)(D2 + Dsp + (tid / GC) * GKH) * 2 * A + gcol;
 #pragma unroll
     for (int i = 0; i < GKP; ++i) wgp[i] = ldf(bp + i * 2 * A);
 #pragma unroll
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(CT) void taco1_attn_fwd_kernel(TArgs a) {
   {
     const int ccol = g * UPW + tid % UPW;
     const T* bp = Wc + (long)((tid / UPW) * CKP) * A + ccol;
-    const T* bh = Wc + (long)(D2 + (tid / UPW) * CKH) * A + ccol;
+    const T* bh = Wc + (long)(D2 + Dsp + (tid / UPW) * CKH) * A + ccol;
 #pragma unroll
     for (int i = 0; i < CKP; ++i) wcp[i] = ldf(bp + i * A);
 #pragma unroll
@@ -183,8 +185,16 @@ __global__ __launch_bounds__(CT) void taco1_attn_fwd_kernel(TArgs a) {
   }
   for (int i = tid; i < UPW * A; i += CT) wq_s[i] = ldf(Wq + (long)g * UPW * A + i);
   for (int i = tid; i < A; i += CT) vs[i] = p.v[i];
-  const float gbias = tid < GC ? p.bg[gcol] : 0.f;
-  const float cbias = tid < UPW ? p.bc[g * UPW + tid] : 0.f;
+  float gbias = tid < GC ? p.bg[gcol] : 0.f;
+  float cbias = tid < UPW ? p.bc[g * UPW + tid] : 0.f;
+  if (Dsp) {
+    const T* spk = (const T*)p.xa + ((long)n * S1 + 1) * XA + D2;       // written into every slot by the caller
+    for (int k = 0; k < Dsp; ++k) {
+      const float sk = ldf(spk + k);
+      if (tid < GC) gbias = fmaf(sk, ldf(Wg + (long)(D2 + k) * 2 * A + gcol), gbias);
+      if (tid < UPW) cbias = fmaf(sk, ldf(Wc + (long)(D2 + k) * A + g * UPW + tid), cbias);
+    }
+  }
   const float b2c = tid < D2 ? p.b2[tid] : 0.f;
   float hpart = 0.f;                       // h(s-1) . Wg[h rows of this k group]: h(-1) = 0
 
@@ -315,9 +325,9 @@ __global__ __launch_bounds__(CT) void taco1_attn_fwd_kernel(TArgs a) {
       p.ru[rowS * 2 * A + u] = sv_r;
       p.ru[rowS * 2 * A + A + u] = sv_u;
       p.cc[rowS * A + u] = sv_c;
-      stf((T*)p.xc + rowS * XA + D2 + u, sv_rh);
+      stf((T*)p.xc + rowS * XA + D2 + Dsp + u, sv_rh);
       stf((T*)p.hc + rowS * HC + u, sv_h);
-      if (st + 1 < p.S) stf((T*)p.xa + (rowS + 1) * XA + D2 + u, sv_h);
+      if (st + 1 < p.S) stf((T*)p.xa + (rowS + 1) * XA + D2 + Dsp + u, sv_h);
     }
     if (wave == 1) {
       float e = -INFINITY;
@@ -424,6 +434,7 @@ __global__ __launch_bounds__(CT) void taco1_attn_bwd_kernel(TArgs a) {
   const int n = blockIdx.x / CG, g = blockIdx.x % CG;
   const long S1 = p.S + 1;
   const int HC = A + p.E;
+  const int Dsp = p.Dsp, XA = D2 + Dsp + A;                // the loop's K rows skip the speaker rows of both kernels (see the forward kernel)
   const int L = min(p.lengths ? p.lengths[n] : p.Ti, p.Ti);
   const int ts = max(1, (L + CG - 1) / CG);
   const int t0 = g * ts, tn = max(0, min(L, t0 + ts) - t0);
@@ -441,7 +452,8 @@ __global__ __launch_bounds__(CT) void taco1_attn_bwd_kernel(TArgs a) {
   float wcr[PPT][CPQ_C], wgr[PPT][CPQ_G];  // W[row k][own columns of group qr] for this thread's (k, qr) pairs
 #pragma unroll
   for (int jj = 0; jj < PPT; ++jj) {
-    const int pi = tid + CT * jj, k = pi % K, qr = pi / K;
+    const int pi = tid + CT * jj, kl = pi % K, qr = pi / K;
+    const int k = kl < D2 ? kl : kl + Dsp;               // kernel row of loop row kl
 #pragma unroll
     for (int i = 0; i < CPQ_C; ++i) wcr[jj][i] = ldf(Wc + (long)k * A + g * UPW + qr * CPQ_C + i);
 #pragma unroll
@@ -486,7 +498,7 @@ __global__ __launch_bounds__(CT) void taco1_attn_bwd_kernel(TArgs a) {
     } else if (tid >= 384 && tid < 384 + UPW) {
       const int u = g * UPW + tid - 384;
       h_c = p.cc[rowS * A + u];
-      h_hp = ldf((const T*)p.xa + rowS * XA + D2 + u);
+      h_hp = ldf((const T*)p.xa + rowS * XA + D2 + Dsp + u);
       h_dhc = p.dhc[rowS * HC + u];
     }
   };
@@ -721,7 +733,7 @@ size_t bwd_granules(int N) { return (size_t)N * CG * (1 + A + 2 * K); }
 
 extern "C" int ns_taco1_attn_cluster_supported(const ns_taco1_attn_params* p) {
   if (!p) return 0;
-  if (!(p->A == A && p->D1 == D1 && p->D2 == D2 && p->E > 0 && p->Ti >= 1 && p->Ti <= 256 && p->Tia >= p->Ti && p->S >= 1 && p->N >= 1)) return 0;
+  if (!(p->A == A && p->D1 == D1 && p->D2 == D2 && p->E > 0 && p->Ti >= 1 && p->Ti <= 256 && p->Tia >= p->Ti && p->S >= 1 && p->N >= 1 && p->Dsp >= 0)) return 0;
   if (!(p->dtype == NS_F32 || p->dtype == NS_BF16)) return 0;
   if (!p->keys || !p->pv || !p->f1 || !p->w2 || !p->wg || !p->wc || !p->wq || !p->b2 || !p->bg || !p->bc || !p->v) return 0;
   if (!p->p1 || !p->xa || !p->xc || !p->hc || !p->ru || !p->cc || !p->q || !p->align) return 0;

@@ -629,21 +629,23 @@ class Tacotron(Tacotron2):
         ag, ac_ = o("decoder/attention_gru/gates/kernel"), o("decoder/attention_gru/candidate/kernel")
         abg, abc = o("decoder/attention_gru/gates/bias"), o("decoder/attention_gru/candidate/bias")
         ov = o("decoder/attention/attention_v")
-        # The whole loop as ONE persistent launch (csrc/attn_gru.hip) where the shape allows: the shipped widths, no speaker
-        # rows, T_in <= 256, 8 N workgroups resident.  Projected-memory form: pv = values . W1c, so the loop yields the
+        # The whole loop as ONE persistent launch (csrc/attn_gru.hip) where the shape allows: the shipped widths,
+        # T_in <= 256, 8 N workgroups resident.  Projected-memory form: pv = values . W1c, so the loop yields the
         # next step's prenet layer directly and the 256-wide contexts are formed after it by one product per utterance.
         self._attn_args = None
-        if self.use_attn_cluster and not Dsp:
+        if self.use_attn_cluster:
             wg_, wc_ = (W, ag), (W, ac_)
             pvb = self._buf("dec_pv", N * Pi * 256, T_)
             args = dict(dtype=ops.dt(hc), N=N, S=S, Ti=Ti, Pi=Pi, padl_i=self.padl, Tia=Tia, A=A, E=E, D1=256, D2=128,
                         lengths=lengths, keys=keys, pv=pvb, f1=f1, w2=(W, w2), wg=wg_, wc=wc_,
                         wq=(W, o("decoder/attention/query_layer/kernel")), b2=(self.flat_p, b2), bg=(self.flat_p, abg),
                         bc=(self.flat_p, abc), v=(self.flat_p, ov), p1=p1, xa=xa, xc=xc, hc=hc, ru=ru, cc=cc, q=q, align=al,
-                        align_t=al_t)
+                        align_t=al_t, Dsp=Dsp)
             if ops.taco1_attn_cluster_supported(**args):
                 self._attn_args = args
         if self._attn_args is not None:
+            if Dsp:      # the candidate kernel's operand rows [p2 | speaker projection | r * h]: the kernel fills the outer parts
+                ops.copy3d(self._spk_dec.buf, xc, N, S1, Dsp, (Dsp, 0), (S1 * XA, XA), dst_off=128)
             ops.gemm(enc.buf, W, pvb, N * Pi, 256, E, E, 256, 256, b_mode=1, b_off=w1 + M * 256)
             cw = self._buf("attn_cluster_work", ops.taco1_attn_cluster_work_floats(**self._attn_args), torch.float32)
             ops.taco1_attn_cluster("fwd", cw, **self._attn_args)

@@ -56,12 +56,14 @@ def _model_masks(m):
 
     out = [act("a:pre1", Pi, Ti, hp.encoder_prenet[0]), act("a:pre2", Pi, Ti, hp.encoder_prenet[1])]
 
-    def cbhg(name, P, T, K, proj):
+    def cbhg(name, P, T, K, proj, widths=(128, 128, 128, 128)):
         o = [act("c:%s_b%d_z" % (name, k), P, T, 128) for k in range(1, K + 1)]
         o += [act("c:%s_p%d_z" % (name, i + 1), P, T, size) for i, size in enumerate(proj[:-1])]
-        o += [act("a:%s_hw%d_h" % (name, i), P, T, 128) for i in range(4)]
+        o += [act("a:%s_hw%d_h" % (name, i), P, T, widths[i]) for i in range(4)]
         return o
-    out += cbhg("enc", Pi, Ti, hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes))
+    # with a speaker embedding every encoder highway layer reads [h | projection]: the width doubles per layer
+    ew = (256, 512, 1024, 2048) if m.Dsp else (128, 128, 128, 128)
+    out += cbhg("enc", Pi, Ti, hp.encoder_cbhg_banks, list(hp.encoder_cbhg_bank_sizes), ew)
     A = hp.attention_dim
     XA = 128 + m.Dsp + A
     p1 = B["dec_p1"][:N * (S + 1) * 256].float().view(N, S + 1, 256)
@@ -73,7 +75,7 @@ def _model_masks(m):
     return out
 
 
-def _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=True, force=None, log=False):
+def _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=True, force=None, log=False, spk=None):
     from oracle import taco1_oracle as O1, taco2_oracle as O2
     p = {k: torch.tensor(v, dtype=torch.float64, requires_grad=need_grad) for k, v in params.items()}
     p.update({k: torch.tensor(v, dtype=torch.float64) for k, v in stats.items()})
@@ -83,7 +85,8 @@ def _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=True, force=
     try:
         with torch.set_grad_enabled(need_grad):
             out = O1.taco1_forward(p, hp.values(), torch.tensor(inputs), torch.tensor(lengths),
-                                   torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64))
+                                   torch.tensor(mel, dtype=torch.float64), torch.tensor(lin, dtype=torch.float64),
+                                   speaker_ids=None if spk is None else torch.tensor(spk))
             loss, ml, ll = O1.taco1_loss(hp.values(), out, torch.tensor(mel, dtype=torch.float64),
                                          torch.tensor(lin, dtype=torch.float64))
         masks, flips = O2.MASK_LOG, O2.FLIP_LOG
@@ -96,21 +99,21 @@ def _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=True, force=
     return out, float(loss.detach()), grads, masks, flips
 
 
-def _report(m, hp, inputs, lengths, mel, lin, margin=2e-3):
+def _report(m, hp, inputs, lengths, mel, lin, margin=2e-3, spk=None):
     params, stats = m.numpy_params(), m.numpy_stats()
     mel, lin = mel.copy(), lin.copy()
     free = None
     for _ in range(3):                              # L1 targets off the free pass' predictions (sign() gradients)
-        free, _, _, _, _ = _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=False)
+        free, _, _, _, _ = _oracle(hp, params, stats, inputs, lengths, mel, lin, need_grad=False, spk=spk)
         bm = np.abs(free["mel_outputs"].numpy() - mel) < margin
         bl = np.abs(free["linear_outputs"].numpy() - lin) < margin
         if not bm.any() and not bl.any():
             break
         mel[bm] -= 10 * margin
         lin[bl] -= 10 * margin
-    m.initialize(inputs, lengths, None, mel, lin)
+    m.initialize(inputs, lengths, spk, mel, lin)
     got_masks = _model_masks(m)
-    out, loss, grads, _, flog = _oracle(hp, params, stats, inputs, lengths, mel, lin, force=got_masks)
+    out, loss, grads, _, flog = _oracle(hp, params, stats, inputs, lengths, mel, lin, force=got_masks, spk=spk)
     names = _families(hp, m.dims["S"])
     assert len(names) == len(flog) == len(got_masks), (len(names), len(flog), len(got_masks))
     fams = {}
@@ -167,6 +170,40 @@ def test_taco1_shipped_widths_match_oracle(dev, mode, shape):
     assert not bad, bad
     assert float(np.median([v[0] for v in rep["grad"].values()])) < b["grad_l2_median"]
     assert rep["bn"] < (1e-4 if mode != "bf16" else 2e-2)
+
+
+def test_taco1_multi_speaker_at_shipped_widths(dev):
+    """num_speakers > 1 at the shipped widths (tacotron.py:41-66, modules.py:157-169, rnn_wrappers.py:28-30): the encoder
+    CBHG's highway widths double per layer (256 .. 2048), the BiGRU(128) starts from the speaker projection (the persistent
+    kernel's h_init, per-row lengths: the backward direction meets it at a different step per utterance) and the attention
+    GRU's input row is [prenet | speaker | h] - the persistent attention clusters fold the speaker rows into their biases.
+    Every output and gradient against the float64 oracle in split-bf16 arithmetic."""
+    from test_taco1_gpu import _spread_speaker_path
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models import create_model
+    hp = hparams_mod.load("taco1")
+    hp.num_speakers = 3
+    N, Ti, To = 4, 22, 30
+    m = create_model("taco1", hp, device="cuda:0", dtype="bf16x3", seed=6)
+    assert m.layout.shape("decoder/attention_gru/gates/kernel") == (128 + 128 + 256, 512)
+    _spread_speaker_path(m)
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=61)
+    lengths = np.asarray(lengths).copy()
+    lengths[0], lengths[-1] = Ti, Ti // 2
+    spk = np.array([2, 0, 2, 1], np.int32)
+    rep = _report(m, hp, inputs, lengths, mel, lin, spk=spk)
+    m.check_status()
+    for k, v in PATHS["bf16x3"].items():
+        assert rep["paths"].get(k) == v, (k, rep["paths"])
+    b = BOUNDS["bf16x3"]
+    for k, (l2, mx, l1) in rep["out"].items():
+        assert mx < b["out"], (k, l2, mx, l1)
+    got, want = rep["loss"]
+    assert abs(got - want) < b["loss"] * abs(want), rep["loss"]
+    bad = [(k, v) for k, v in rep["grad"].items() if not (v[0] < b["grad_l2"] and v[1] < b["grad_max"])]
+    assert not bad, bad[:6]
+    for k in ("speaker/speaker_embed", "encoder_cbhg/dense/kernel", "decoder/dense/kernel"):
+        assert rep["grad"][k][0] < b["grad_l2"]
 
 
 def test_persistent_paths_equal_the_step_launches_in_the_model(dev, monkeypatch):
