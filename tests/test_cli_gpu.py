@@ -85,6 +85,29 @@ def test_taco1_config1_plumbing(tmp_path):
     assert os.path.exists(os.path.join(run, "eval-3-0.wav"))
 
 
+def test_taco1_config1_at_the_shipped_widths(tmp_path):
+    """BASELINE configs[0] with hparams/taco1.yaml as it ships (16-bank / 8-bank CBHG, 256-unit GRUs, 1025 bins): the
+    persistent Tacotron-1 kernels (GRU recurrences, attention clusters) under train.py's own loop - feeder with silence
+    trimming, checkpoint - then eval.py on the checkpoint.  The paths train.py logs must name the persistent forms."""
+    data = str(tmp_path / "lj")
+    os.makedirs(data)
+    _corpus(data)
+    logs = str(tmp_path / "logs")
+    hps = "batch_size=2,batch_group_size=2,outputs_per_step=5,max_iters=12"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--ljspeech", data, "--model", "taco1",
+                        "--log_dir", logs, "--hparams", hps, "--checkpoint_interval", "3", "--max_steps", "3",
+                        "--precision", "mixed"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "attn:fwd=cluster" in r.stdout and "post_gru:bwd=seq" in r.stdout and "gru_1:fwd=seq" in r.stdout, r.stdout[-3000:]
+    run = os.path.join(logs, "logs-taco1")
+    assert os.path.exists(os.path.join(run, "model.ckpt-3")) and "Step 3 " in r.stdout
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "eval.py"), "--checkpoint", os.path.join(run, "model.ckpt-3"),
+                        "--model", "taco1", "--hparams", hps, "--precision", "mixed"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert os.path.exists(os.path.join(run, "eval-3-0.wav"))
+
+
 def test_multi_speaker_train_and_eval(tmp_path):
     """LJSpeech + a VCTK-layout corpus (wav48/pNNN/*.wav + txt/pNNN/*.txt, corpus/vctk.py:11-20) give
     three speakers; train.py sizes the speaker table from the feeder (train.py:45), eval.py synthesises a chosen one."""
