@@ -623,21 +623,29 @@ __global__ __launch_bounds__(256, BK == 64 ? 2 : 3) void gemm_mfma_kernel(ns_gem
 // 128 rows x 64 k (16 KB each, 128-B rows, 16-B chunk index XOR ((row >> 1) & 7) as in the 128^2 kernel), filled by
 // global_load_lds_dwordx4 (LDS image lane-linear per wave -> the swizzle sits on the SOURCE address).
 // Wave (wr, wc) owns rows wr*64.. of BOTH A halves and columns wc*32.. of BOTH B halves, so a phase touches one
-// half-tile per operand for all waves and half-tiles free up one by one:
-//   phase 1: read A0, B0 | A0 x B0      phase 2: read B1 | A0 x B1
-//   phase 3: read A1     | A1 x B1      phase 4: -        | A1 x B0 (B0 fragments kept)
-// and are restaged one phase after their last read: P1 <- A1(t+1), P2 <- A0(t+2), P3 <- B0(t+2), P4 <- B1(t+2).
-// One counted wait per K-tile (phase 4): everything but the three newest half-tiles has landed = tile t+1 complete.
-// Each phase is [ds_read + stage + lgkmcnt(0)] barrier [16 MFMA] barrier; the wr = 1 waves run one barrier behind
-// the wr = 0 waves, so on every SIMD one wave feeds the matrix core while the other one loads.
-// Hazards: a read completes before its phase's first barrier (lgkmcnt(0) in front of it), so the restage one phase
-// later is behind a barrier both groups passed after their reads; the counted vmcnt sits in front of phase 4's first
-// barrier and the data is read from phase 1 of the next tile on, at least two barriers later for either group.
+// half-tile per operand for all waves and half-tiles free up one by one.  Fragment reads are spread 8 / 4 / 8 / 4 over the
+// phases (a wave group's reads of one phase then take the LDS 256 cycles - the length of the other group's 16 MFMAs):
+//   phase 1: read A0       | A0 x B0      phase 2: read B1       | A0 x B1
+//   phase 3: read A1       | A1 x B1      phase 4: read B0(t+1)  | A1 x B0   (into the registers B1 just left: the two
+//                                                                             B fragment sets swap roles every tile)
+// Half-tiles are restaged TWO phases after their last read: P1 <- A1(t+1), P2 <- B0(t+2), P3 <- A0(t+2), P4 <- B1(t+2),
+// and every phase carries one counted wait, vmcnt(10): everything but the five newest half-tiles has landed = the
+// half-tile the NEXT phase reads (each load has five phases to arrive).
+// Each phase is [ds_read + stage + vmcnt] barrier [lgkmcnt(0), 16 MFMA] barrier; the wr = 1 waves run one barrier behind
+// the wr = 0 waves, so on every SIMD one wave feeds the matrix core while the other one loads, and a group's fragment
+// reads complete in the shadow of the other group's MFMAs rather than in front of the barrier (round 5; rounds 2 - 4
+// waited in front of it and read 12 / 4 / 8 / 0: 1090 -> 1177 TFLOP/s at 4096^3 for the wait alone, A/B in one box).
+// Hazards.  RAW: the wait that retires a half-tile sits in front of phase p's first barrier, the read behind phase p's
+// second: two barriers, one of which the staggered group has also passed behind its own wait.  WAR: a read retires at
+// the lgkmcnt(0) behind its phase's first barrier, in front of that phase's MFMAs; the restage two phases later is
+// issued behind two more barriers of the issuing group, i.e. at least one that the other group reaches only after its
+// MFMAs of the reading phase.
 // NSEG = 3: split-bf16 product of pre-split operands, K-tiles walk (A, B), (A, B_lo), (A_lo, B).
 // NSEG = 2 (f32_passes = 2 with pre-split operands): (A, B), (A_lo, B) - B (the weights) rounded to bf16, A exact to
 // ~16 bits; for products whose error budget allows it (the non-recurrent postnet convolutions).
-// Measured on MI355X (random operands): 4096^3 989 TFLOP/s, 8192^3 1010, conv data gradient 32124 x 512 x 2560
-// 838 (128^2 kernel: 662 / - / 610); three-segment product 344 algorithmic = 1032 issued (in-kernel split: 239).
+// Measured on MI355X (uniform random operands, profiles/r05_x256_ab.txt): 4096^3 1203 TFLOP/s, 8192^3 1212, conv data
+// gradient 32124 x 512 x 2560 1044 (rounds 2 - 4, same box: 1082 / 1157 / 988; 128^2 kernel: 662 / - / 610);
+// three-segment product at 4096^3 434 algorithmic = 1302 issued (round 4: 383; in-kernel split: 239).
 constexpr int XHALF = 16384, XBUF = 65536;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -716,7 +724,7 @@ __global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[h][g][i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-  bf16x8 fa[4][2], fb0r[2][2], fb1r[2][2];
+  bf16x8 fa[4][2], fbe[2][2], fbo[2][2];     // B fragments: even tiles keep B0 in fbe and B1 in fbo, odd tiles the other way round
 
 #define X_READ_A(BUF, H)                                                                   \
   _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                          \
@@ -737,12 +745,22 @@ __global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
           acc[H][G][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BR[j][kk], fa[i][kk], acc[H][G][i][j], 0, 0, 0); \
     __builtin_amdgcn_s_setprio(0);                                                                         \
   } while (0)
-#define X_SYNC_LOADS()                              \
-  do {                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-    __builtin_amdgcn_sched_barrier(0);              \
-    __builtin_amdgcn_s_barrier();                   \
-    __builtin_amdgcn_sched_barrier(0);              \
+  // the counted wait of a phase: everything but the newest FULL / 2 loads has landed while tile t + 2 exists, PEN / 2 when
+  // t + 1 is the last tile, LAST / 2 when t is
+#define X_WAIT(FULL, PEN, LAST)                                                  \
+  do {                                                                           \
+    if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(" #FULL ")" ::: "memory");     \
+    else if (t + 1 < NT) asm volatile("s_waitcnt vmcnt(" #PEN ")" ::: "memory"); \
+    else asm volatile("s_waitcnt vmcnt(" #LAST ")" ::: "memory");                \
+  } while (0)
+  // first barrier of a phase; the fragment reads issued in front of it are waited for behind it, in the shadow of the
+  // other wave group's MFMA phase
+#define X_SYNC_LOADS()                                                 \
+  do {                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    __builtin_amdgcn_s_barrier();                                      \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
   } while (0)
 #define X_SYNC_MFMA()                               \
   do {                                              \
@@ -751,56 +769,67 @@ __global__ __launch_bounds__(512, 1) void gemm_x256_kernel(ns_gemm_params p) {
     __builtin_amdgcn_sched_barrier(0);              \
   } while (0)
 
-  // prologue: tile 0 whole, tile 1 without its A1 (phase 1 of tile 0 brings it)
-  X_ISSUE_A0(0); X_ISSUE_B0(0); X_ISSUE_B1(0); X_ISSUE_A1(0);
-  X_ISSUE_A0(1); X_ISSUE_B0(1); X_ISSUE_B1(1);
-  if (NT > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // prologue: the loads a steady-state phase 1 of tile 0 finds issued (tile 0, and tile 1 without its A1), the first two
+  // half-tiles landed, B0 of tile 0 in registers
+  X_ISSUE_B0(0); X_ISSUE_A0(0); X_ISSUE_B1(0); X_ISSUE_A1(0);
+  X_ISSUE_B0(1); X_ISSUE_A0(1); X_ISSUE_B1(1);
+  if (NT > 1) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_sched_barrier(0);
+  X_READ_B(fbe, 0, 0)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
   if (wr == 1) __builtin_amdgcn_s_barrier();          // the stagger
   __builtin_amdgcn_sched_barrier(0);
 
-#define X_TILE(BUF)                                                     \
+  // B0R holds B0 of tile t on entry; B1R takes B1 of tile t in phase 2 and B0 of tile t + 1 in phase 4
+#define X_TILE(BUF, B0R, B1R)                                           \
   do {                                                                  \
     /* phase 1 */                                                       \
-    X_READ_B(fb0r, BUF, 0) X_READ_A(BUF, 0)                             \
+    X_READ_A(BUF, 0)                                                    \
     X_ISSUE_A1(t + 1);                                                  \
+    if (t + 1 < NT) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   \
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");               \
     X_SYNC_LOADS();                                                     \
-    X_MFMA(0, 0, fb0r);                                                 \
+    X_MFMA(0, 0, B0R);                                                  \
     X_SYNC_MFMA();                                                      \
     /* phase 2 */                                                       \
-    X_READ_B(fb1r, BUF, 1)                                              \
-    X_ISSUE_A0(t + 2);                                                  \
+    X_READ_B(B1R, BUF, 1)                                               \
+    X_ISSUE_B0(t + 2);                                                  \
+    X_WAIT(10, 8, 0);                                                   \
     X_SYNC_LOADS();                                                     \
-    X_MFMA(0, 1, fb1r);                                                 \
+    X_MFMA(0, 1, B1R);                                                  \
     X_SYNC_MFMA();                                                      \
     /* phase 3 */                                                       \
     X_READ_A(BUF, 1)                                                    \
-    X_ISSUE_B0(t + 2);                                                  \
+    X_ISSUE_A0(t + 2);                                                  \
+    X_WAIT(10, 6, 0);                                                   \
     X_SYNC_LOADS();                                                     \
-    X_MFMA(1, 1, fb1r);                                                 \
+    X_MFMA(1, 1, B1R);                                                  \
     X_SYNC_MFMA();                                                      \
     /* phase 4 */                                                       \
+    X_READ_B(B1R, 1 - (BUF), 0)                                         \
     X_ISSUE_B1(t + 2);                                                  \
-    if (t + 2 < NT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    \
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               \
+    X_WAIT(10, 4, 0);                                                   \
     X_SYNC_LOADS();                                                     \
-    X_MFMA(1, 0, fb0r);                                                 \
+    X_MFMA(1, 0, B0R);                                                  \
     X_SYNC_MFMA();                                                      \
   } while (0)
 
   int t = 0;
   for (; t + 1 < NT; t += 2) {
-    X_TILE(0);
+    X_TILE(0, fbe, fbo);
     ++t;
-    X_TILE(1);
+    X_TILE(1, fbo, fbe);
     --t;
   }
-  if (t < NT) X_TILE(0);
+  if (t < NT) X_TILE(0, fbe, fbo);
   if (wr == 0) __builtin_amdgcn_s_barrier();          // pairs with the stagger
 #undef X_TILE
 #undef X_SYNC_MFMA
 #undef X_SYNC_LOADS
+#undef X_WAIT
 #undef X_MFMA
 #undef X_READ_B
 #undef X_READ_A
