@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One line per ns_gemm call of a Tacotron-2 training step at the benchmark shape: shape, operand modes, the kernel
-that ran, its HIP-event time and rate.  Usage: python profiles/tools/gemm_calls.py [mixed|bf16|fp32]"""
+that ran, its HIP-event time and rate.  Usage: python profiles/tools/gemm_calls.py [mixed|bf16|fp32] [another build of
+the library, for an A/B in one box]"""
 import os
 import sys
 
@@ -8,7 +9,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch  # noqa: E402
 
 import bench  # noqa: E402
-from nspeech_amd import hparams as hparams_mod, ops, profiling  # noqa: E402
+from nspeech_amd import _lib, hparams as hparams_mod, ops, profiling  # noqa: E402
+
+if len(sys.argv) > 2:
+    _lib.LIB_PATH = os.path.abspath(sys.argv[2])
 from nspeech_amd.models import create_model  # noqa: E402
 
 
