@@ -2,8 +2,9 @@
 """Waveform generation from a simple_wavenet checkpoint, the reference's generate_wavenet.py surface (:48-224): positional
 checkpoint, --samples --temperature --wav_out_path --save_every --fast_generation --wav_seed.
 
-The reference script builds the conditioned WaveNetModel and needs a wavenet_params.json that the repository does not
-ship (generate_wavenet.py:21,51); here the network is the simple_wavenet the build trains (wavenet.yaml), restored from
+The reference script builds WaveNetModel and needs a wavenet_params.json that the repository does not ship
+(generate_wavenet.py:21,51); here the network is wavenet.yaml's (+ --hparams; --gc_channels / --gc_cardinality / --gc_id
+for a speaker-conditioned checkpoint of train_wavenet.py --model wavenet, :214-231), restored from
 train_wavenet.py's model.ckpt-<step>.  --fast_generation true (default) at temperature 1.0 = the persistent incremental
 generator on the GPU (one workgroup per waveform; float64 softmax and inverse-CDF draw in the kernel).  Any other
 temperature, or --fast_generation false, takes the full-window path of generate_wavenet.py:104-142: predict_proba over the
@@ -59,7 +60,14 @@ def scale_prediction(prediction, temperature):
 def main(args):
     hp = hparams_mod.load("wavenet")
     hp.parse(args.hparams)
-    net = create_model("simple_wavenet", hp, device="cuda:0", dtype=args.precision)
+    gc = None
+    if args.gc_channels is not None:                # generate_wavenet.py:221-231: the speaker whose voice is drawn
+        hp.gc_channels, hp.gc_category_cardinality = args.gc_channels, args.gc_cardinality
+        gc = np.asarray([args.gc_id])
+    full = bool(hp.use_biases or hp.scalar_input or hp.gc_channels or hp.lc_channels)
+    net = create_model("wavenet" if full else "simple_wavenet", hp, device="cuda:0", dtype=args.precision)
+    cond = dict(global_conditions=gc) if full else {}
+    cond1 = dict(global_condition=None if gc is None else gc[0]) if full else {}
     print("Restoring model from {}".format(args.checkpoint))
     net.load_state_dict(torch.load(args.checkpoint, map_location="cpu", weights_only=True))
     q, rf = hp.quantization_channels, net.rf
@@ -75,7 +83,7 @@ def main(args):
         done = 0
         while done < args.samples:                  # in chunks, so that --save_every can write partial results
             n = min(args.samples - done, args.save_every or args.samples)
-            ids = net.generate(np.asarray(waveform[-rf:], np.int32), n, uniforms=rng.random((1, n)))
+            ids = net.generate(np.asarray(waveform[-rf:], np.int32), n, uniforms=rng.random((1, n)), **cond)
             waveform.extend(int(x) for x in ids[0, rf:].cpu().numpy())
             done += n
             print("Sample {:3<d}/{:3<d}".format(done, args.samples), end="\r")
@@ -84,7 +92,7 @@ def main(args):
     else:
         for step in range(args.samples):
             window = waveform[-rf:] if len(waveform) > rf else waveform
-            prediction = net.predict_proba(window).double().cpu().numpy()
+            prediction = net.predict_proba(window, **cond1).double().cpu().numpy()
             scaled = scale_prediction(prediction, args.temperature)
             if args.temperature == 1.0:             # the reference's own check (:133-138)
                 np.testing.assert_allclose(prediction, scaled, atol=1e-5,
@@ -129,6 +137,11 @@ if __name__ == "__main__":
     parser.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     parser.add_argument("--seed", type=int, default=0)
     a = parser.parse_args()
-    if a.gc_channels is not None:
-        sys.exit("generate_wavenet.py: global conditioning is not built (DESIGN 9)")
+    if a.gc_channels is not None:                   # generate_wavenet.py:221-231
+        if a.gc_cardinality is None:
+            raise ValueError("Globally conditioning but gc_cardinality not specified. Use --gc_cardinality=377 for full "
+                             "VCTK corpus.")
+        if a.gc_id is None:
+            raise ValueError("Globally conditioning, but global condition was not specified. Use --gc_id to specify global "
+                             "condition.")
     main(a)

@@ -799,6 +799,13 @@ typedef struct {
   int* ids; const float* uniform; float* queues; float* probs;
   const void* fgT; const void* deT;
   int engine;   /* with fgT / deT: 0 / 1 = single-wave VALU chain, 2 = MFMA chain + concurrent skip waves (R == Dc == 32) */
+  /* The full WaveNetModel's incremental generator (neural_speech/models/wavenet.py:398-437, 487-557), all optional and
+   * fp32; with any of them the per-layer kernel runs (fgT / deT must be NULL):
+   *   cond [B, L, 2Dc]  added to a layer's [filter | gate] pre-activations: the global condition's 1x1 convolution
+   *                     (:409-419) and filter_bias | gate_bias (:421-423), formed once per call by the caller;
+   *   dense_bias [L, R] (:428-429);  skip_bias [S] = the sum of the layers' skip biases (:432-434, summed :543);
+   *   post1_bias [S], post2_bias [Q] (:546-553). */
+  const float* cond; const float* dense_bias; const float* skip_bias; const float* post1_bias; const float* post2_bias;
 } ns_wavenet_generate_params;
 int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t stream);
 

@@ -282,7 +282,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_gen
       }
       __syncthreads();
       if (tid < 2 * Dc) {
-        float v = 0.f;
+        float v = p.cond ? p.cond[((long)b * p.L + l) * 2 * Dc + tid] : 0.f;      // condition + filter | gate bias
         for (int i = 0; i < kzs; ++i) v += part[i * 2 * Dc + tid];
         z[tid] = v;
       }
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_gen
       __syncthreads();
       float xn = 0.f;
       if (tid < R) {
-        xn = xin[R + tid];
+        xn = xin[R + tid] + (p.dense_bias ? p.dense_bias[(long)l * R + tid] : 0.f);
         for (int i = 0; i < kds; ++i) xn += part[i * R + tid];
       }
       __syncthreads();                                           // every reader of xin[R..2R), out and part is done
@@ -315,16 +315,16 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_kernel(ns_wavenet_gen
       if (l + 1 < p.L) layer(l + 1, wbuf, wa);
     }
     if (!emit) continue;
-    if (tid < S) h0[tid] = fmaxf(skip, 0.f);
+    if (tid < S) h0[tid] = fmaxf(skip + (p.skip_bias ? p.skip_bias[tid] : 0.f), 0.f);
     __syncthreads();
     for (int j = tid; j < S; j += GEN_THREADS) {
-      float acc = 0.f;
+      float acc = p.post1_bias ? p.post1_bias[j] : 0.f;
       for (int k = 0; k < S; ++k) acc = fmaf(h0[k], ldf(wb + p.off_post1 + (long)k * S + j), acc);
       h1[j] = fmaxf(acc, 0.f);
     }
     __syncthreads();
     for (int j = tid; j < Q; j += GEN_THREADS) {
-      float acc = 0.f;
+      float acc = p.post2_bias ? p.post2_bias[j] : 0.f;
       for (int k = 0; k < S; ++k) acc = fmaf(h1[k], ldf(wb + p.off_post2 + (long)k * Q + j), acc);
       lg[j] = acc;
     }
@@ -843,6 +843,8 @@ extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_strea
                "ns_wavenet_generate: channel counts outside the kernel's register plan");
   const size_t lds = sizeof(float) * (2 * p->R + 3 * p->Dc + GEN_THREADS + 2 * p->S + ((p->Q + 1) & ~1)) + sizeof(double) * p->Q;
   NS_CHECK_ARG(lds <= 60 * 1024, "ns_wavenet_generate: state does not fit in LDS");
+  const bool full = p->cond || p->dense_bias || p->skip_bias || p->post1_bias || p->post2_bias;
+  NS_CHECK_ARG(!full || (!p->fgT && !p->deT), "ns_wavenet_generate: conditions / biases run on the per-layer kernel (fgT, deT = NULL)");
   if (p->fgT && p->deT) {
     NS_CHECK_ARG(p->w_dtype == NS_BF16 && p->R == p->Dc && (p->R == 32 || p->R == 16) && p->S % 8 == 0 && p->Q % 8 == 0 && p->S / 8 <= GEN_THREADS &&
                      GEN_THREADS % (p->S / 8) == 0 && GEN_THREADS % (p->Q / 8) == 0,

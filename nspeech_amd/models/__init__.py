@@ -8,9 +8,10 @@ def create_model(name, hparams, **kw):
     if name == "taco1":
         from .tacotron import Tacotron
         return Tacotron(hparams, **kw)
-    if name in ("simple_wavenet", "wavenet"):
-        # models/__init__.py:13-16 maps both names; the full WaveNetModel's extra options (scalar input, biases,
-        # conditioning) are off in the shipped wavenet.yaml, where the two graphs coincide
+    if name == "wavenet":          # models/__init__.py:13-14: the full model (biases, scalar input, conditioning)
+        from .wavenet import WaveNetModel
+        return WaveNetModel(hparams, **kw)
+    if name == "simple_wavenet":   # :15-16
         from .wavenet import SimpleWaveNet
         return SimpleWaveNet(hparams, **kw)
     raise Exception("Unknown model: " + name)

@@ -690,8 +690,10 @@ def wavenet_softmax(logits, ld, rows, Q, probs, logits_off=0):
 
 
 def wavenet_generate(weights, offs, dilations, L_, R, Dc, S, Q, B, n_seed, total, queue_rows, ids, uniform, queues, probs=None,
-                     fgT=None, deT=None, engine=0):
+                     fgT=None, deT=None, engine=0, cond=None, dense_bias=None, skip_bias=None, post1_bias=None, post2_bias=None):
     p = L.struct("ns_wavenet_generate_params")
+    _fill(p, cond=ptr(cond), dense_bias=ptr(dense_bias), skip_bias=ptr(skip_bias), post1_bias=ptr(post1_bias),
+          post2_bias=ptr(post2_bias))
     _fill(p, weights=ptr(weights), w_dtype=dt(weights), off_causal=offs["causal"], off_layer0=offs["layer0"],
           layer_stride=offs["layer_stride"], off_dense_in_layer=offs["dense_in_layer"], off_skip=offs["skip"],
           off_post1=offs["post1"], off_post2=offs["post2"], dilations=ptr(dilations), L=L_, R=R, Dc=Dc, S=S, Q=Q, B=B,

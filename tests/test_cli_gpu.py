@@ -163,8 +163,8 @@ def test_wavenet_train_then_generate(tmp_path):
     logs = str(tmp_path / "logs")
     small = "dilations_length=4,dilations_depth=2,skip_channels=64,sample_size=400,batch_size=4,queue_size=16"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_wavenet.py"), "--ljspeech", data, "--log-dir", logs,
-                        "--hparams", small, "--max-steps", "3", "--checkpoint-interval", "3", "--summary-interval", "1"],
-                       capture_output=True, text=True, timeout=600)
+                        "--model", "simple_wavenet", "--hparams", small, "--max-steps", "3", "--checkpoint-interval", "3",
+                        "--summary-interval", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     run = os.path.join(logs, "simple_wavenet")
     ckpt = os.path.join(run, "model.ckpt-3")
@@ -177,3 +177,32 @@ def test_wavenet_train_then_generate(tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         with wave.open(out, "rb") as f:
             assert f.getframerate() == 16000 and f.getnframes() >= int(n)
+
+
+def test_speaker_conditioned_wavenet_train_then_generate(tmp_path):
+    """--model wavenet (the reference's default, train_wavenet.py:108) with gc_channels: every piece conditioned on its
+    speaker id from the feeder (:40-49), biases on; generate_wavenet.py --gc_channels / --gc_cardinality / --gc_id
+    (:214-231) draws one speaker's voice through the incremental generator and through the full-window path."""
+    lj = str(tmp_path / "lj")
+    os.makedirs(lj)
+    _corpus(lj)
+    logs = str(tmp_path / "logs")
+    small = ("dilations_length=4,dilations_depth=2,skip_channels=64,sample_size=400,batch_size=4,queue_size=16,"
+             "gc_channels=8,use_biases=true")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_wavenet.py"), "--ljspeech", lj, "--log-dir", logs,
+                        "--hparams", small, "--max-steps", "3", "--checkpoint-interval", "3"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    ckpt = os.path.join(logs, "wavenet", "model.ckpt-3")
+    assert os.path.exists(ckpt) and "Loaded 1 different speaker(s)" in r.stdout
+    for fast, n in (("true", "200"), ("false", "8")):
+        out = str(tmp_path / ("gen_%s.wav" % fast))
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "generate_wavenet.py"), ckpt, "--samples", n, "--hparams", small,
+                            "--gc_channels", "8", "--gc_cardinality", "1", "--gc_id", "0", "--fast_generation", fast,
+                            "--wav_out_path", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        with wave.open(out, "rb") as f:
+            assert f.getnframes() >= int(n)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train_wavenet.py"), "--ljspeech", lj, "--log-dir", logs,
+                        "--hparams", small + ",lc_channels=4", "--max-steps", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and "lc_channels" in (r.stdout + r.stderr)

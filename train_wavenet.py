@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
-"""simple_wavenet training CLI with the reference's flags (train_wavenet.py:19-135) on the MI355X-native model.
+"""WaveNet training CLI with the reference's flags (train_wavenet.py:19-135) on the MI355X-native models.
 
-  python3 train_wavenet.py --ljspeech DIR [--model simple_wavenet] [--hparams sample_size=8000,batch_size=8] ...
+  python3 train_wavenet.py --ljspeech DIR [--model wavenet | simple_wavenet] [--hparams sample_size=8000,batch_size=8] ...
+
+--model wavenet (the reference's default, :108) is WaveNetModel with its options - e.g. --hparams gc_channels=32 conditions
+every piece on its speaker (the feeder's speaker ids, :40-46; the embedding table is sized from the corpora BEFORE the
+model is built - the reference builds the model first, with the yaml's cardinality 0); with the shipped options it is
+simple_wavenet.  lc_channels > 0 is refused here: the reference's pieces carry a mel image of receptive_field rows
+(WavenetDataFeeder.py:127-135), which no layer's output length equals - its graph does not build either.
 
 LOGDIR/RUN/train.log, model.ckpt-STEP (torch.save of a name -> tensor dict under the TF variable names), a scalars line
 in events.jsonl every --summary-interval steps.  The shipped train.yaml has sample_size = 1 (one predicted sample per
@@ -28,13 +34,16 @@ def train_wavenet(log_dir, args, hp):
     log("Checkpoint path: %s" % os.path.join(log_dir, "model.ckpt"), logf)
     log("Using model: %s" % args.model, logf)
     log(hparams_mod.debug_string(hp), logf)
-    model = create_model(args.model, hp, device="cuda:0", dtype=args.precision)
-    feeder = WavenetFeeder(hp, model.rf, ljspeech=args.ljspeech or None, vctk=args.vctk or None,
+    from nspeech_amd.models.wavenet import receptive_field
+    full = args.model == "wavenet"
+    feeder = WavenetFeeder(hp, receptive_field(hp, full), ljspeech=args.ljspeech or None, vctk=args.vctk or None,
                            librispeech=args.librispeech or None, seed=1234)
     log("Loaded data refs for %d examples" % len(feeder.items), logf)
     log("Loaded %d different speaker(s)" % len(feeder.speaker2id), logf)
     hp.num_speakers = len(feeder.speaker2id)            # train_wavenet.py:40-41
     hp.gc_category_cardinality = hp.num_speakers
+    model = create_model(args.model, hp, device="cuda:0", dtype=args.precision)
+    use_gc = full and (hp.gc_channels or 0) > 0         # :46
     step0 = 0
     if args.restore_step:
         path = "%s-%d" % (os.path.join(log_dir, "model.ckpt"), args.restore_step)
@@ -51,7 +60,8 @@ def train_wavenet(log_dir, args, hp):
     events = os.path.join(log_dir, "events.jsonl")
     while args.max_steps is None or model.global_step < args.max_steps:
         t0 = time.time()
-        loss = model.step(feeder.next_batch())           # train_wavenet.py:75
+        batch = feeder.next_batch()
+        loss = model.step(batch, feeder.speaker_ids if use_gc else None)        # train_wavenet.py:46-49, 75
         step = model.global_step
         time_window.append(time.time() - t0)
         loss_window.append(loss)
@@ -74,7 +84,7 @@ def main():
     ap.add_argument("--vctk", default="")
     ap.add_argument("--ljspeech", default="")
     ap.add_argument("--librispeech", default="")
-    ap.add_argument("--model", default="simple_wavenet")       # the reference's default 'wavenet' (WaveNetModel) is not built
+    ap.add_argument("--model", default="wavenet", choices=["wavenet", "simple_wavenet"])       # train_wavenet.py:108
     ap.add_argument("--name", default=None)
     ap.add_argument("--hparams", default="")
     ap.add_argument("--restore-step", "--restore_step", type=int, default=None)
@@ -88,15 +98,15 @@ def main():
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--max-steps", "--max_steps", type=int, default=None)
     args = ap.parse_args()
-    if args.model == "wavenet":
-        sys.exit("train_wavenet.py: only --model simple_wavenet is built (wavenet_simple.py); WaveNetModel with global / "
-                 "local conditioning is out of scope (DESIGN 9)")
     os.environ.setdefault("HIP_VISIBLE_DEVICES", str(args.gpu))
     run_name = args.name or args.model
     log_dir = os.path.join(args.log_dir, run_name)
     os.makedirs(log_dir, exist_ok=True)
     hp = hparams_mod.load("wavenet")
     hp.parse(args.hparams)
+    if (hp.lc_channels or 0) > 0:
+        sys.exit("train_wavenet.py: lc_channels > 0 - the feeder's local-condition images have receptive_field rows "
+                 "(WavenetDataFeeder.py:127-135) and fit no layer; pass local conditions to WaveNetModel.initialize yourself")
     train_wavenet(log_dir, args, hp)
 
 
