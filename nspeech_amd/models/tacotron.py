@@ -309,36 +309,187 @@ class Tacotron(Tacotron2):
                 self.last_paths["%s:bwd" % label] = "step"
                 for dd in dirs:
                     self._gru_steps_bwd(dd, N, P, padl, T, H, ldh, lengths, hb, out.grad, cin, h0f)
-            sk = self._splitk
             for dd in reversed(dirs):
-                og, oc, dzg, dzc, rh = dd["og"], dd["oc"], dd["dzg"], dd["dzc"], dd["rh"]
-                # hoisted weight gradients: x parts, h parts (h_prev = history shifted by one row), biases
-                ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
-                         split_k=sk(rows, cin, 2 * H))
-                ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
-                         split_k=sk(rows, cin, H))
-                if dd["reverse"]:
-                    ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + dd["col"],
-                             c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-                else:
-                    ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=dd["col"], b_off=2 * H,
-                             c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-                ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
-                         split_k=sk(rows, H, H))
-                if h0 is not None:
-                    # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
-                    ops.copy3d(dd["dh0"], h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
-                    dz0 = self._buf("gru:%s_dz0" % dd["tag"], N * 2 * H, self.T)
-                    for n in range(N):
-                        ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + dd["first"][n]) * 2 * H,
-                                   dst_off=n * 2 * H)
-                    ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
-                             accumulate=2)
-                ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=dd["bg"])
-                ops.colsum(dzc, H, rows, H, g, out_off=dd["bc"])
-                ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
-                ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
+                self._gru_hoisted_bwd(dd, x, H, hb, ldh, h0)
         self._tape.append(bwd)
+
+    # ---- the decoder's two residual GRUs as a pipeline in time (round 5)
+    use_gru_pipeline = os.environ.get("NS_GRU_PIPE", "1") != "0"
+    GRU_PIPE_CHUNKS = int(os.environ.get("NS_GRU_PIPE_CHUNKS", "4"))
+
+    def _gru_pair(self, x1, H):
+        """y1 = x1 + GRU_1(x1); y2 = y1 + GRU_2(y1) (tacotron.py:72-76) under teacher forcing.  Step s of GRU_2 needs only
+        step s of GRU_1, and a persistent GRU(256) launch occupies 8 of the 256 CUs - so the time axis is cut into
+        GRU_PIPE_CHUNKS windows and GRU_2 runs window c on a second stream while GRU_1 runs window c + 1 on the first
+        (each window is one ns_gru_seq launch on the rows [t0, t1) with the state at t0 - 1 as its initial state; GRU_2's
+        input products of a window are a batched GEMM over the window's rows).  Backward the same in reverse: GRU_2's
+        window c, its input gradients, then GRU_1's window c on the other stream while GRU_2 runs window c - 1; the
+        gradient wrt a window's initial state is added to the history gradient of the row in front of it.  The hoisted
+        weight gradients stay whole-sequence products.  Returns None when the persistent kernels do not take the shape
+        (the caller then runs the two GRUs one after the other)."""
+        N, P, padl, T = x1.N, x1.P, x1.padl, x1.T
+        rows, D = x1.rows, x1.C
+        if not self.use_gru_seq or D != H or T < 2 * self.GRU_PIPE_CHUNKS or self.device.type != "cuda":
+            return None
+        W, T_ = self._W(self.T), self.T
+        f32 = torch.float32
+        nch = self.GRU_PIPE_CHUNKS
+        edges = [T * c // nch for c in range(nch + 1)]
+        wins = [(edges[c], edges[c + 1]) for c in range(nch)]
+        N16 = (N + 15) // 16 * 16
+        h1 = self._new("dec_h1", x1, H); y1 = self._new("dec_y1", x1, H)
+        h2 = self._new("dec_h2", x1, H); y2 = self._new("dec_y2", x1, H)
+        gr = []
+        for k, (tag, xin) in enumerate((("gru_1", x1), ("gru_2", y1))):
+            scope = "decoder/" + tag
+            dd = dict(tag=tag, key=tag, reverse=False, col=0, x=xin, out=(h1, h2)[k])
+            dd["og"], dd["oc"] = self._o(scope + "/gates/kernel"), self._o(scope + "/candidate/kernel")
+            dd["bg"], dd["bc"] = self._o(scope + "/gates/bias"), self._o(scope + "/candidate/bias")
+            dd["xg"] = self._buf("gru:%s_xg" % tag, rows * 2 * H, f32)
+            dd["xc"] = self._buf("gru:%s_xc" % tag, rows * H, f32)
+            dd["ru"] = self._buf("gru:%s_ru" % tag, max(rows, N16 * T) * 2 * H, f32)
+            dd["cc"] = self._buf("gru:%s_c" % tag, max(rows, N16 * T) * H, f32)
+            dd["rh"] = self._buf("gru:%s_rh" % tag, rows * H, T_)
+            dd["gT"], dd["cT"] = self.tsh[tag + "_gT"], self.tsh[tag + "_cT"]
+            dd["hi"] = [None] + [self._buf("gru:%s_hi%d" % (tag, c), N * H, f32) for c in range(1, nch)]
+            dd["work"] = self._buf("gru:%s_work" % tag, 1, f32)
+            gr.append(dd)
+
+        def params(dd, c, bwd):
+            t0, t1 = wins[c]
+            hb = dd["out"].buf
+            kw = {}
+            if bwd:
+                kw = dict(dh=(dd["out"].grad, 0), ld_dh=H, dzg=dd["dzg"], dzc=dd["dzc"])
+                if c > 0:
+                    kw.update(dh_init=dd["dhi"], ld_dhi=H)
+            # a window = the same arrays with the first row moved to t0: every [N*P, .] array is addressed as row n * P + padl + t
+            return ops.gru_seq_params(hb, N, t1 - t0, H, P, padl + t0, False, None, dd["xg"], dd["xc"], dd["gT"], dd["cT"],
+                                      (W, dd["og"] + D * 2 * H), 2 * H, (W, dd["oc"] + D * H), H, (hb, 0), H,
+                                      (dd["ru"], N16 * t0 * 2 * H), (dd["cc"], N16 * t0 * H), dd["rh"],
+                                      h_init=dd["hi"][c], ld_hi=H, **kw)
+
+        for dd in gr:
+            p0 = params(dd, 1, False)
+            if not ops.gru_seq_supported(p0, None, backward=False):
+                return None
+            dd["work"] = self._buf("gru:%s_work" % dd["tag"], ops.gru_seq_work_floats(p0), f32)
+        g1, g2 = gr
+        ops.zero_many((h1.buf, h2.buf, y1.buf))       # (y1's pad rows: the windows below write the steps' rows only)
+        ops.gemm(x1.buf, W, g1["xg"], rows, 2 * H, D, D, 2 * H, 2 * H, b_mode=1, b_off=g1["og"], bias=self.flat_p, bias_off=g1["bg"])
+        ops.gemm(x1.buf, W, g1["xc"], rows, H, D, D, H, H, b_mode=1, b_off=g1["oc"], bias=self.flat_p, bias_off=g1["bc"])
+        # (a batched product takes no bias: GRU_2's input products add onto rows that hold the biases)
+        ops.copy3d(self.flat_p, g2["xg"], 1, rows, 2 * H, (0, 0), (0, 2 * H), src_off=g2["bg"])
+        ops.copy3d(self.flat_p, g2["xc"], 1, rows, H, (0, 0), (0, H), src_off=g2["bc"])
+        if getattr(self, "_pipe", None) is None:
+            self._pipe = torch.cuda.Stream(device=self.device)
+        main, side = torch.cuda.current_stream(self.device), self._pipe
+
+        def hand_over(src, dst):            # dst goes on behind everything src holds so far
+            ev = torch.cuda.Event()
+            ev.record(src)
+            dst.wait_event(ev)
+
+        def window(dd, c, direction):
+            t0, _ = wins[c]
+            if direction == "fwd" and c > 0:        # the state in front of the window is its initial state
+                ops.copy3d(dd["out"].buf, dd["hi"][c], N, 1, H, (P * H, 0), (H, 0), src_off=(padl + t0 - 1) * H)
+            ops.gru_seq(direction, params(dd, c, direction == "bwd"), None, dd["work"])
+            if direction == "bwd" and c > 0:        # ... and its gradient belongs to the row in front of the window
+                ops.copy3d(dd["dhi"], dd["out"].grad, N, 1, H, (H, 0), (P * H, 0), dst_off=(padl + t0 - 1) * H, accumulate=1)
+
+        def rows_of(c, C):                  # (I, J, strides, offset) of a window's rows in a [N*P, C] array
+            t0, t1 = wins[c]
+            return N, t1 - t0, (P * C, C), (padl + t0) * C
+
+        hand_over(main, side)
+        for c in range(nch):
+            window(g1, c, "fwd")
+            hand_over(main, side)
+            with torch.cuda.stream(side):
+                I, J, st, off = rows_of(c, H)
+                ops.copy3d(x1.buf, y1.buf, I, J, H, st, st, src_off=off, dst_off=off)
+                ops.copy3d(h1.buf, y1.buf, I, J, H, st, st, src_off=off, dst_off=off, accumulate=1)
+                ops.gemm(y1.buf, W, g2["xg"], J, 2 * H, H, H, 2 * H, 2 * H, b_mode=1, a_off=off, b_off=g2["og"], c_off=2 * off,
+                         accumulate=1, batch=N, batch_strides=(P * H, 0, P * 2 * H))
+                ops.gemm(y1.buf, W, g2["xc"], J, H, H, H, H, H, b_mode=1, a_off=off, b_off=g2["oc"], c_off=off,
+                         accumulate=1, batch=N, batch_strides=(P * H, 0, P * H))
+                window(g2, c, "fwd")
+        hand_over(side, main)
+        ops.copy3d(y1.buf, y2.buf, 1, rows, H, (0, H), (0, H))
+        ops.copy3d(h2.buf, y2.buf, 1, rows, H, (0, H), (0, H), accumulate=1)
+        for dd in gr:
+            self._status_words[(dd["tag"], "fwd")] = dd["work"]
+            self.last_paths["%s:fwd" % dd["tag"]] = "seq"
+        self.last_paths["gru_pair"] = "pipelined x%d" % nch
+
+        def bwd():
+            main = torch.cuda.current_stream(self.device)
+            # y2 = y1 + h2
+            ops.copy3d(y2.grad, y1.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
+            ops.copy3d(y2.grad, h2.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
+            for dd in gr:
+                dd["dzg"] = self._buf("gru:%s_dzg" % dd["tag"], rows * 2 * H, T_)
+                dd["dzc"] = self._buf("gru:%s_dzc" % dd["tag"], rows * H, T_)
+                dd["dhi"] = self._buf("gru:%s_dhi" % dd["tag"], N * H, f32)
+            ops.zero_many((g1["dzg"], g1["dzc"], g2["dzg"], g2["dzc"]))      # pad rows must hold zeros for the hoisted products
+            hand_over(main, side)
+            for c in range(nch - 1, -1, -1):
+                window(g2, c, "bwd")
+                I, J, st, off = rows_of(c, H)
+                # the window's gradient wrt GRU_2's input y1
+                ops.gemm(g2["dzg"], W, y1.grad, J, H, 2 * H, 2 * H, 2 * H, H, a_mode=0, b_mode=0, a_off=2 * off, b_off=g2["og"],
+                         c_off=off, accumulate=1, batch=N, batch_strides=(P * 2 * H, 0, P * H))
+                ops.gemm(g2["dzc"], W, y1.grad, J, H, H, H, H, H, a_mode=0, b_mode=0, a_off=off, b_off=g2["oc"], c_off=off,
+                         accumulate=1, batch=N, batch_strides=(P * H, 0, P * H))
+                hand_over(main, side)
+                with torch.cuda.stream(side):
+                    ops.copy3d(y1.grad, h1.grad, I, J, H, st, st, src_off=off, dst_off=off, accumulate=1)      # y1 = x1 + h1
+                    window(g1, c, "bwd")
+            hand_over(side, main)
+            ops.copy3d(y1.grad, x1.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
+            for dd in (g2, g1):
+                self._status_words[(dd["tag"], "bwd")] = dd["work"]
+                self.last_paths["%s:bwd" % dd["tag"]] = "seq"
+                self._gru_hoisted_bwd(dd, dd["x"], H, dd["out"].buf, H, None, input_grads=dd is g1)
+        self._tape.append(bwd)
+        return y2
+
+    def _gru_hoisted_bwd(self, dd, x, H, hb, ldh, h0=None, input_grads=True):
+        """What the backward pass of one GRU direction hoists out of its time loop, given the gate gradients dzg / dzc of
+        every step: weight gradients - x parts, h parts (h_prev = history shifted by one row), biases - and the gradient
+        wrt the input (input_grads=False: the caller has formed it already)."""
+        N, P, padl = x.N, x.P, x.padl
+        rows, cin = x.rows, x.C
+        W, g = self._W(self.T), self.flat_g
+        sk = self._splitk
+        og, oc, dzg, dzc, rh = dd["og"], dd["oc"], dd["dzg"], dd["dzc"], dd["rh"]
+        ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
+                 split_k=sk(rows, cin, 2 * H))
+        ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
+                 split_k=sk(rows, cin, H))
+        if dd["reverse"]:
+            ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + dd["col"],
+                     c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+        else:
+            ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=dd["col"], b_off=2 * H,
+                     c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+        ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
+                 split_k=sk(rows, H, H))
+        if h0 is not None:
+            # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
+            ops.copy3d(dd["dh0"], h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
+            dz0 = self._buf("gru:%s_dz0" % dd["tag"], N * 2 * H, self.T)
+            for n in range(N):
+                ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + dd["first"][n]) * 2 * H,
+                           dst_off=n * 2 * H)
+            ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
+                     accumulate=2)
+        ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=dd["bg"])
+        ops.colsum(dzc, H, rows, H, g, out_off=dd["bc"])
+        if input_grads:
+            ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
+            ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
 
     def _gru_steps_fwd(self, dd, N, P, padl, T, H, ldh, lengths, hb, h0, h0f):
         """The launch-per-step form of one direction: two gate products + two element-wise kernels per step."""
@@ -682,12 +833,14 @@ class Tacotron(Tacotron2):
 
         # ---- projection, residual GRUs, output projection (tacotron.py:69-76)
         x1 = self._dense("attproj", hcA, "decoder/attention_projection", D, ACT_NONE, mask=True)
-        h1 = self._new("dec_h1", x1, D); ops.zero(h1.buf)
-        self._gru_seq("gru_1", x1, "decoder/gru_1", "gru_1", D, None, False, h1, 0)
-        y1 = self._add("dec_y1", x1, h1)
-        h2 = self._new("dec_h2", y1, D); ops.zero(h2.buf)
-        self._gru_seq("gru_2", y1, "decoder/gru_2", "gru_2", D, None, False, h2, 0)
-        y2 = self._add("dec_y2", y1, h2)
+        y2 = self._gru_pair(x1, D) if self.use_gru_pipeline else None
+        if y2 is None:
+            h1 = self._new("dec_h1", x1, D); ops.zero(h1.buf)
+            self._gru_seq("gru_1", x1, "decoder/gru_1", "gru_1", D, None, False, h1, 0)
+            y1 = self._add("dec_y1", x1, h1)
+            h2 = self._new("dec_h2", y1, D); ops.zero(h2.buf)
+            self._gru_seq("gru_2", y1, "decoder/gru_2", "gru_2", D, None, False, h2, 0)
+            y2 = self._add("dec_y2", y1, h2)
         decA = Act(self, "dec_out", N, S1, 1, S, M * r, dtype=torch.float32)
         op_, ob_ = o("decoder/output_projection/kernel"), o("decoder/output_projection/bias")
         ops.gemm(y2.buf, W, decA.buf, y2.rows, M * r, D, D, M * r, M * r, b_mode=1, b_off=op_, bias=self.flat_p, bias_off=ob_)

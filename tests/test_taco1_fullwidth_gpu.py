@@ -154,6 +154,9 @@ def test_taco1_shipped_widths_match_oracle(dev, mode, shape):
     m.check_status()
     for k, v in PATHS[mode].items():
         assert rep["paths"].get(k) == v, (k, rep["paths"])
+    if mode != "fp32":      # the two residual GRUs ran as a pipeline in time (Tacotron._gru_pair) where the steps allow four windows
+        steps = -(-To // hp.outputs_per_step)
+        assert ("gru_pair" in rep["paths"]) == (steps >= 8), (steps, rep["paths"])
     b = BOUNDS[mode]
     worst = sorted(rep["grad"].items(), key=lambda kv: -kv[1][0])[:3]
     print("\ntaco1 %s %s: ReLU flips %s; outputs (rel L2, rel max, L1) %s; BN stats %.1e; worst gradients %s; median %.2e" % (
@@ -237,3 +240,32 @@ def test_persistent_paths_equal_the_step_launches_in_the_model(dev, monkeypatch)
                   if not k.endswith("conv1d/bias") and np.linalg.norm(res[False][2][k]) > 1e-9 * gn)
     assert errs[len(errs) // 2][0] < 1e-4, errs[len(errs) // 2]
     assert errs[-1][0] < 3e-2, errs[-1]
+
+
+def test_pipelined_residual_grus_equal_the_sequential_ones(dev):
+    """Tacotron._gru_pair cuts the two residual GRUs into time windows on two streams; with NS_GRU_PIPE=0 they run one
+    after the other over the whole sequence.  Same kernels, same arithmetic per step: outputs and gradients agree to the
+    last bits of the products whose summation order the windows change (the batched input products of GRU_2)."""
+    from nspeech_amd import hparams as hparams_mod
+    from nspeech_amd.models import create_model
+    from nspeech_amd.models.tacotron import Tacotron
+    hp = hparams_mod.load("taco1")
+    N, Ti, To = 4, 24, 60
+    inputs, lengths, mel, lin = make_batch(hp, N, Ti, To, seed=3)
+    res = []
+    for pipe in (True, False):
+        Tacotron.use_gru_pipeline = pipe
+        try:
+            m = create_model("taco1", hp, device="cuda:0", dtype="mixed", seed=5)
+            m.initialize(inputs, lengths, None, mel, lin)
+            m.backward()
+            m.check_status()
+            assert ("gru_pair" in m.last_paths) == pipe
+            res.append((m.mel_outputs.float().cpu().numpy(), m.linear_outputs.float().cpu().numpy(), m.numpy_grads()))
+        finally:
+            Tacotron.use_gru_pipeline = True
+    (ma, la, ga), (mb, lb, gb) = res
+    assert np.abs(ma - mb).max() < 1e-5 * max(1.0, np.abs(mb).max()) and np.abs(la - lb).max() < 1e-5 * max(1.0, np.abs(lb).max())
+    rel = {k: np.abs(ga[k] - gb[k]).max() / (np.abs(gb[k]).max() + 1e-12) for k in gb}
+    worst = max(rel.values())
+    assert float(np.median(list(rel.values()))) < 1e-4 and worst < 3e-2, sorted(rel.items(), key=lambda kv: -kv[1])[:4]
