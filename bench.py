@@ -326,7 +326,7 @@ def real_dynamics_bench(hp, model, args, one_step):
             "note": "targets = features of the same synthetic speech with min_level_db = -100 (not saturated)"}
 
 
-def e2e_bench(hp, model, args, device):
+def e2e_bench(hp, model, args, device, modes=("hbm_cache", "hbm_cache_sync_loss", "host_cache")):
     """train.py's own loop at the benchmark shape on synthetic FILES: an LJSpeech-layout corpus of 64
     utterances of 12.45 s (-> T_out 1000) and 80-159 characters is written to a temporary directory; the feeder thread
     reads the wavs, extracts the features on the GPU, sorts / pads / deals batches as the reference does, and
@@ -356,6 +356,8 @@ def e2e_bench(hp, model, args, device):
         hpf = copy.deepcopy(hp)
         hpf.batch_size, hpf.batch_group_size = args.batch, 2
         for key, dev_cache, sync in (("hbm_cache", True, False), ("hbm_cache_sync_loss", True, True), ("host_cache", False, False)):
+            if key not in modes:
+                continue
             feeder = DataFeeder(hpf, ljspeech=tmp, seed=7, pinned=True, device_cache=dev_cache).start()
             batches = DeviceStager(feeder, device)
             pipe = None if sync else train_cli.LossPipeline(model, batches)
@@ -377,6 +379,8 @@ def e2e_bench(hp, model, args, device):
             To = int(model.mel_targets.shape[1])
             out[key] = {"e2e_ms_per_step": dt * 1e3, "mel_frames_per_s": args.batch * To / dt, "t_out": To,
                         "t_in": int(model.inputs.shape[1]), "loss": loss}
+            feeder.stop()                               # (its thread, queued batches and pinned memory would outlive this block)
+            del feeder, batches, pipe, run
         out["note"] = ("train.py's loop (feeder thread -> batch on the GPU -> step -> EVERY step's loss read back) on %d "
                        "synthetic wav files; hbm_cache: features stay in HBM, batches assembled on the device, the loss "
                        "read-back one step behind the launches (train.py's defaults); hbm_cache_sync_loss: the same with "

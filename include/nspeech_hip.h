@@ -265,6 +265,13 @@ int ns_zero(void* p, size_t bytes, ns_stream_t stream);
 /* The same for n buffers in one launch per NS_ZERO_MANY_MAX of them (ptrs / bytes: host arrays, read before the call returns). */
 #define NS_ZERO_MANY_MAX 24
 int ns_zero_many(void* const* ptrs, const size_t* bytes, int n, ns_stream_t stream);
+/* Do two streams run side by side?  HIP deals its hardware queues to streams in turn, so a second stream shares the
+ * first one's queue whenever the process has created a multiple of the queue count in between - its launches then
+ * queue BEHIND the first stream's and an overlap planned on it is silently lost (measured: the seventh stream of a
+ * process).  The probe: a one-thread kernel on `a` waits up to 200 us for a word that a one-thread kernel launched on
+ * `b` right behind it sets.  Returns 1 (concurrent), 0 (b ran only after a's kernel gave up) or a negative error;
+ * synchronises both streams.  work: 16 bytes of device memory. */
+int ns_streams_concurrent(ns_stream_t a, ns_stream_t b, void* work);
 
 /* hi[i] = bf16(src[i]), lo[i] = bf16(src[i] - hi[i]): pre-split operands for f32_passes = 3. */
 typedef struct { const float* src; void* hi; void* lo; int64_t n; } ns_split_params;

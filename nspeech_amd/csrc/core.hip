@@ -125,3 +125,35 @@ extern "C" int ns_wait_counter(const int* counter, int target, double timeout_us
   NS_CHECK_LAUNCH("ns_wait_counter");
   return NS_OK;
 }
+
+// ------------------------------------------------------------------ do two streams share a hardware queue?
+__global__ void ns_probe_wait_kernel(int* w) {      // w[0]: the word, w[1]: seen
+  const long long t0 = wall_clock64();
+  int seen = 0;
+  while (wall_clock64() - t0 < 20000) {             // 200 us at 100 MHz
+    if (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { seen = 1; break; }
+  }
+  w[1] = seen;
+}
+__global__ void ns_probe_set_kernel(int* w) { __hip_atomic_store(w, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+extern "C" int ns_streams_concurrent(ns_stream_t a_, ns_stream_t b_, void* work) {
+  hipStream_t a = (hipStream_t)a_, b = (hipStream_t)b_;
+  NS_CHECK_ARG(work && (((uintptr_t)work) & 15) == 0, "ns_streams_concurrent: 16 bytes of device memory");
+  if (a == b) return 0;
+  int rc = ns_zero_async(work, 16, a);
+  if (rc) return rc;
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) {
+    ns_set_error("ns_streams_concurrent: synchronize failed");
+    return NS_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(ns_probe_wait_kernel, dim3(1), dim3(1), 0, a, (int*)work);
+  hipLaunchKernelGGL(ns_probe_set_kernel, dim3(1), dim3(1), 0, b, (int*)work);
+  NS_CHECK_LAUNCH("ns_streams_concurrent");
+  int host[2] = {0, 0};
+  if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess ||
+      hipMemcpy(host, work, sizeof(host), hipMemcpyDeviceToHost) != hipSuccess) {
+    ns_set_error("ns_streams_concurrent: synchronize / copy failed");
+    return NS_ERR_LAUNCH;
+  }
+  return host[1] ? 1 : 0;
+}

@@ -183,6 +183,7 @@ class DataFeeder(object):
         self._trim = trim         # False: the corpus is already trimmed (the reference always trims, process.py:27)
         self.speaker_ids = None
         self._queue = queue.Queue(maxsize=8) if prefetch else None
+        self._stop = False
         self._thread = None
         self._pending = []
         self._error = None
@@ -265,15 +266,39 @@ class DataFeeder(object):
             if self.device is not None:
                 import torch
                 torch.cuda.set_device(self.device)
-            while True:
+            while not self._stop:
                 for b in self._next_group():
-                    self._queue.put(b)
+                    while not self._stop:
+                        try:
+                            self._queue.put(b, timeout=0.1)
+                            break
+                        except queue.Full:
+                            pass
+                    if self._stop:
+                        break
         except Exception as e:              # surfaced by next_batch()
             self._error = e
             self._queue.put(None)
 
+    def stop(self):
+        """End the background thread (the reference's coord.request_stop, datafeeder.py:96-101) and drop what it had queued:
+        a feeder that is merely abandoned keeps its thread, its queued batches and their pinned / device memory alive."""
+        self._stop = True
+        t, self._thread = self._thread, None
+        if t is not None:
+            while t.is_alive():
+                try:
+                    self._queue.get_nowait()
+                except queue.Empty:
+                    pass
+                t.join(timeout=0.05)
+        if self._queue is not None:
+            while not self._queue.empty():
+                self._queue.get_nowait()
+
     def start(self):
         if self._queue is not None and self._thread is None:
+            self._stop = False
             self._thread = threading.Thread(target=self._worker, name="datafeeder", daemon=True)
             self._thread.start()
         return self
@@ -314,7 +339,8 @@ class DeviceStager(object):
         import torch
         self.feeder, self.torch = feeder, torch
         self.device = torch.device(device)
-        self.copy_stream = torch.cuda.Stream(device=self.device)
+        from .. import ops
+        self.copy_stream = ops.concurrent_stream(self.device)      # one that really runs beside the compute stream
         self.speaker_ids = None
         self._next = None
 

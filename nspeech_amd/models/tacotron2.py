@@ -378,7 +378,7 @@ class Tacotron2(object):
     def _side_stream(self):
         """The second stream, made to wait for everything enqueued on the main stream so far."""
         if self._side is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = ops.concurrent_stream(self.device)        # one that does not share the main stream's hardware queue
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.device))
         self._side.wait_event(ev)

@@ -256,6 +256,31 @@ def zero(t):
     L.check(L.lib().ns_zero(C.c_void_p(ptr(t)), C.c_size_t(nbytes), C.c_void_p(stream())), "ns_zero")
 
 
+def streams_concurrent(a, b):
+    """True when launches on torch streams a and b can run side by side (ns_streams_concurrent: they do not share a
+    hardware queue).  Synchronises both."""
+    work = torch.zeros(4, dtype=torch.int32, device=a.device)
+    rc = L.lib().ns_streams_concurrent(C.c_void_p(a.cuda_stream), C.c_void_p(b.cuda_stream), C.c_void_p(ptr(work)))
+    if rc < 0:
+        L.check(rc, "ns_streams_concurrent")
+    return rc == 1
+
+
+def concurrent_stream(device, tries=8):
+    """A new stream that runs beside the CURRENT one.  HIP hands its hardware queues to streams in turn; a stream that
+    lands on the current stream's queue (every queue-count-th one of a process) serialises behind it and an overlap
+    planned on it is silently lost - so candidates are probed, and the rejected ones are kept alive until one passes (a
+    released queue slot would be dealt out again)."""
+    cur = torch.cuda.current_stream(device)
+    rejected = []
+    for _ in range(tries):
+        s = torch.cuda.Stream(device=device)
+        if streams_concurrent(cur, s):
+            return s
+        rejected.append(s)
+    return rejected[-1]
+
+
 def zero_many(tensors):
     """Clear several tensors with one launch per 24 of them (ns_zero_many)."""
     ts = [t for t in tensors if t is not None and t.numel()]

@@ -286,3 +286,19 @@ def test_feeder_takes_its_features_from_the_trimmed_wav(tmp_path):
         assert any(np.array_equal(s, w) for w in want)
     assert all(len(w) < len(wavs[i]) for i, w in enumerate(want))
     assert sorted(int(v) for v in mel[:, :, 0].sum(axis=1) * 4) == sorted(1 + len(w) // 250 for w in want)
+
+
+def test_stop_ends_the_background_thread_and_start_resumes(tmp_path):
+    """DataFeeder.stop(): the thread ends, nothing stays queued; next_batch() afterwards starts a new thread."""
+    import threading
+    hp = _hp()
+    root = _corpus(tmp_path, 24)
+    loader, features, _ = _stubs(hp)
+    f = DataFeeder(hp, ljspeech=root, seed=3, features=features, loader=loader).start()
+    a = f.next_batch()
+    before = threading.active_count()
+    f.stop()
+    assert f._thread is None and f._queue.empty() and threading.active_count() == before - 1
+    b = f.next_batch()
+    assert b[0].shape[0] == a[0].shape[0]
+    f.stop()
