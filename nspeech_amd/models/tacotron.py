@@ -49,6 +49,26 @@ class Tacotron(Tacotron2):
     # data parallel: one whole-buffer all-reduce once backward() has been enqueued (parallel.whole_buffer_range)
     _BUCKET_AFTER = {"backward": "all"}
 
+    # Weight gradients of the non-recurrent layers are QUEUED and released onto a second stream where the backward pass
+    # reaches a recurrence (ns_gru_seq / the attention clusters occupy 4 - 16 CUs, or wait on their hops): the post CBHG's
+    # ~2 ms of k-long split-K products then run beside the decoder's GRUs instead of in front of them (round 5).
+    WG = "taco1"
+
+    @property
+    def queue_groups(self):
+        return (self.WG,)
+
+    def _make_streams(self):
+        """The weight-gradient stream and the GRU pipeline's two: three streams that run beside the main one AND beside
+        one another (ops.concurrent_streams: four hardware queues, four streams)."""
+        if self._side is None:
+            self._side, sa, sb = ops.concurrent_streams(self.device, 3)
+            self._pipe = (sa, sb)
+
+    def _side_stream(self):
+        self._make_streams()
+        return Tacotron2._side_stream(self)
+
     padl, padr = 8, 8     # bank widths up to 16: 'same' needs 7 left / 8 right; the data gradient the mirror
     use_attn_cluster = os.environ.get("NS_TACO1_ATTN_CLUSTER", "1") != "0"     # persistent attention loop (csrc/attn_gru.hip)
     LAYOUT = staticmethod(P_.taco1_layout)
@@ -125,12 +145,16 @@ class Tacotron(Tacotron2):
                  bias_off=boff, act=act, row_mask=rm)
 
         def bwd():
-            dpre = self._buf("t:dpre", x.rows * cout, self.T)
+            # (a queued weight gradient reads dpre later: a buffer of the layer's own then)
+            dpre = self._buf("t:dpre" + (":" + name if self.overlap_wgrads else ""), x.rows * cout, self.T)
             ops.act_bwd(y.grad, y.buf, dpre, x.rows, cout, act, row_mask=x.mask if mask else None)
             g = self.flat_g
-            ops.gemm(x.buf, dpre, g, x.C, cout, x.rows, x.C, cout, cout, a_mode=1, b_mode=1, c_off=woff, accumulate=2,
-                     split_k=self._splitk(x.rows, x.C, cout))
-            ops.colsum(dpre, cout, x.rows, cout, g, out_off=boff)
+
+            def wgrad():
+                ops.gemm(x.buf, dpre, g, x.C, cout, x.rows, x.C, cout, cout, a_mode=1, b_mode=1, c_off=woff, accumulate=2,
+                         split_k=self._splitk(x.rows, x.C, cout))
+                ops.colsum(dpre, cout, x.rows, cout, g, out_off=boff)
+            self._defer(self.WG, wgrad)
             ops.gemm(dpre, Wb, x.grad, x.rows, x.C, cout, cout, cout, x.C, a_mode=0, b_mode=0, b_off=woff, accumulate=1)
         self._tape.append(bwd)
         return y
@@ -141,7 +165,7 @@ class Tacotron(Tacotron2):
 
         def bwd():
             self._conv_bwd(scope, x.buf, y.grad, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, x.grad,
-                           dx_accumulate=True)
+                           dx_accumulate=True, defer=self.WG)
         self._tape.append(bwd)
         return y
 
@@ -200,15 +224,20 @@ class Tacotron(Tacotron2):
         ops.highway(h.buf, t.buf, x.buf, x.rows * C, y=y.buf)
 
         def bwd():
-            dh = self._buf("t:hw_dh", x.rows * C, self.T)
-            dt_ = self._buf("t:hw_dt", x.rows * C, self.T)
+            own = (":" + name) if self.overlap_wgrads else ""          # the queued weight gradients read them later
+            dh = self._buf("t:hw_dh" + own, x.rows * C, self.T)
+            dt_ = self._buf("t:hw_dt" + own, x.rows * C, self.T)
             dx = self._buf("t:hw_dx", x.rows * C, torch.float32)
             ops.highway(h.buf, t.buf, x.buf, x.rows * C, dy=y.grad, dhpre=dh, dtpre=dt_, dx=dx)
             g = self.flat_g
-            for dpre, ow, ob in ((dh, oh, bh), (dt_, ot, bt)):
-                ops.gemm(x.buf, dpre, g, C, C, x.rows, C, C, C, a_mode=1, b_mode=1, c_off=ow, accumulate=2,
-                         split_k=self._splitk(x.rows, C, C))
-                ops.colsum(dpre, C, x.rows, C, g, out_off=ob)
+
+            def wgrad():
+                for dpre, ow, ob in ((dh, oh, bh), (dt_, ot, bt)):
+                    ops.gemm(x.buf, dpre, g, C, C, x.rows, C, C, C, a_mode=1, b_mode=1, c_off=ow, accumulate=2,
+                             split_k=self._splitk(x.rows, C, C))
+                    ops.colsum(dpre, C, x.rows, C, g, out_off=ob)
+            self._defer(self.WG, wgrad)
+            for dpre, ow in ((dh, oh), (dt_, ot)):
                 ops.gemm(dpre, W, dx, x.rows, C, C, C, C, C, a_mode=0, b_mode=0, b_off=ow, accumulate=1)
             ops.copy3d(dx, x.grad, 1, x.rows, C, (0, C), (0, C), accumulate=1)
         self._tape.append(bwd)
@@ -290,6 +319,7 @@ class Tacotron(Tacotron2):
                 self._gru_steps_fwd(dd, N, P, padl, T, H, ldh, lengths, hb, h0, h0f)
 
         def bwd():
+            self._flush_deferred()          # queued weight gradients run beside this recurrence
             for dd in dirs:
                 dd["dzg"] = self._buf("gru:%s_dzg" % dd["tag"], rows * 2 * H, self.T)
                 dd["dzc"] = self._buf("gru:%s_dzc" % dd["tag"], rows * H, self.T)
@@ -381,13 +411,11 @@ class Tacotron(Tacotron2):
         # (a batched product takes no bias: GRU_2's input products add onto rows that hold the biases)
         ops.copy3d(self.flat_p, g2["xg"], 1, rows, 2 * H, (0, 0), (0, 2 * H), src_off=g2["bg"])
         ops.copy3d(self.flat_p, g2["xc"], 1, rows, H, (0, 0), (0, H), src_off=g2["bc"])
-        # Both chains run on streams of their own, created one after the other: HIP deals its hardware queues to streams
-        # in turn, so two consecutive streams never share one, while a single side stream shares the main stream's queue
-        # whenever the process has made a multiple of the queue count before it (measured: the seventh stream of a
-        # process - 22.0 instead of 20.8 ms per step, the two chains serialised and the events on top).  The main
-        # stream only waits.
-        if getattr(self, "_pipe", None) is None:
-            self._pipe = (torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device))
+        # Both chains run on streams of their own that were probed to run side by side (_make_streams): HIP deals its
+        # hardware queues to streams in turn, and a single side stream shares the main stream's queue whenever the
+        # process has made a multiple of the queue count before it (measured: the seventh stream of a process - 22.0
+        # instead of 20.8 ms per step, the two chains serialised and the events on top).  The main stream only waits.
+        self._make_streams()
         main = torch.cuda.current_stream(self.device)
         sa, sb = self._pipe
 
@@ -431,6 +459,7 @@ class Tacotron(Tacotron2):
         self.last_paths["gru_pair"] = "pipelined x%d" % nch
 
         def bwd():
+            self._flush_deferred()          # the weight gradients queued so far (the post CBHG's) run beside the windows below
             main = torch.cuda.current_stream(self.device)
             # y2 = y1 + h2
             ops.copy3d(y2.grad, y1.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
@@ -472,29 +501,33 @@ class Tacotron(Tacotron2):
         W, g = self._W(self.T), self.flat_g
         sk = self._splitk
         og, oc, dzg, dzc, rh = dd["og"], dd["oc"], dd["dzg"], dd["dzc"], dd["rh"]
-        ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
-                 split_k=sk(rows, cin, 2 * H))
-        ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
-                 split_k=sk(rows, cin, H))
-        if dd["reverse"]:
-            ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + dd["col"],
-                     c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-        else:
-            ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=dd["col"], b_off=2 * H,
-                     c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
-        ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
-                 split_k=sk(rows, H, H))
+
+        def wgrad():        # queued (self.WG): every operand is a buffer of this GRU's own and stays as it is until the join
+            ops.gemm(x.buf, dzg, g, cin, 2 * H, rows, cin, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og, accumulate=2,
+                     split_k=sk(rows, cin, 2 * H))
+            ops.gemm(x.buf, dzc, g, cin, H, rows, cin, H, H, a_mode=1, b_mode=1, c_off=oc, accumulate=2,
+                     split_k=sk(rows, cin, H))
+            if dd["reverse"]:
+                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=ldh + dd["col"],
+                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+            else:
+                ops.gemm(hb, dzg, g, H, 2 * H, rows - 1, ldh, 2 * H, 2 * H, a_mode=1, b_mode=1, a_off=dd["col"], b_off=2 * H,
+                         c_off=og + cin * 2 * H, accumulate=2, split_k=sk(rows, H, 2 * H))
+            ops.gemm(rh, dzc, g, H, H, rows, H, H, H, a_mode=1, b_mode=1, c_off=oc + cin * H, accumulate=2,
+                     split_k=sk(rows, H, H))
+            if h0 is not None:          # the first steps' h_prev was h0
+                dz0 = self._buf("gru:%s_dz0" % dd["tag"], N * 2 * H, self.T)
+                for n in range(N):
+                    ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + dd["first"][n]) * 2 * H,
+                               dst_off=n * 2 * H)
+                ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
+                         accumulate=2)
+            ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=dd["bg"])
+            ops.colsum(dzc, H, rows, H, g, out_off=dd["bc"])
+        self._defer(self.WG, wgrad)
         if h0 is not None:
-            # what is left in the carry is the gradient wrt the initial state; the first steps' h_prev was h0
+            # what is left in the carry is the gradient wrt the initial state
             ops.copy3d(dd["dh0"], h0.grad, 1, N, H, (0, H), (0, H), accumulate=1)
-            dz0 = self._buf("gru:%s_dz0" % dd["tag"], N * 2 * H, self.T)
-            for n in range(N):
-                ops.copy3d(dzg, dz0, 1, 1, 2 * H, (0, 0), (0, 0), src_off=(n * P + padl + dd["first"][n]) * 2 * H,
-                           dst_off=n * 2 * H)
-            ops.gemm(h0.buf, dz0, g, H, 2 * H, N, H, 2 * H, 2 * H, a_mode=1, b_mode=1, c_off=og + cin * 2 * H,
-                     accumulate=2)
-        ops.colsum(dzg, 2 * H, rows, 2 * H, g, out_off=dd["bg"])
-        ops.colsum(dzc, H, rows, H, g, out_off=dd["bc"])
         if input_grads:
             ops.gemm(dzg, W, x.grad, rows, cin, 2 * H, 2 * H, 2 * H, cin, a_mode=0, b_mode=0, b_off=og, accumulate=1)
             ops.gemm(dzc, W, x.grad, rows, cin, H, H, H, cin, a_mode=0, b_mode=0, b_off=oc, accumulate=1)
@@ -921,6 +954,7 @@ class Tacotron(Tacotron2):
         # ---- everything else: the tape, newest first
         while self._tape:
             self._tape.pop()()
+        self._join_deferred()               # the queued weight gradients are in flat_g behind this
         self._tick("backward")
 
     def _attention_backward(self):

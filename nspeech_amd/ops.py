@@ -266,19 +266,29 @@ def streams_concurrent(a, b):
     return rc == 1
 
 
-def concurrent_stream(device, tries=8):
-    """A new stream that runs beside the CURRENT one.  HIP hands its hardware queues to streams in turn; a stream that
-    lands on the current stream's queue (every queue-count-th one of a process) serialises behind it and an overlap
-    planned on it is silently lost - so candidates are probed, and the rejected ones are kept alive until one passes (a
-    released queue slot would be dealt out again)."""
+def concurrent_streams(device, n=1, tries=16):
+    """n new streams that run beside the CURRENT one and beside one another.  HIP hands its hardware queues to streams in
+    turn; a stream that lands on another one's queue (every queue-count-th one of a process) serialises behind it and an
+    overlap planned on the pair is silently lost - so candidates are probed against the current stream and against the
+    ones already accepted, and the rejected ones are kept alive until the set is complete (a released queue slot would
+    be dealt out again).  With fewer free queues than asked for, the last candidates fill the set."""
     cur = torch.cuda.current_stream(device)
-    rejected = []
+    chosen, rejected = [], []
     for _ in range(tries):
+        if len(chosen) == n:
+            break
         s = torch.cuda.Stream(device=device)
-        if streams_concurrent(cur, s):
-            return s
-        rejected.append(s)
-    return rejected[-1]
+        if streams_concurrent(cur, s) and all(streams_concurrent(c, s) for c in chosen):
+            chosen.append(s)
+        else:
+            rejected.append(s)
+    while len(chosen) < n:
+        chosen.append(rejected.pop() if rejected else torch.cuda.Stream(device=device))
+    return chosen
+
+
+def concurrent_stream(device, tries=8):
+    return concurrent_streams(device, 1, tries)[0]
 
 
 def zero_many(tensors):
