@@ -51,7 +51,7 @@ def run(N, T, H, ndir, dtype, passes, reps=5):
         torch.cuda.synchronize()
         tr = work.view(torch.int64)[-16 * 8:].view(16, 8).cpu().numpy()
         names = ["B0 wait", "phase-1 reads + MFMA", "gates, r*h, stores", "B1 wait", "phase-2 reads + MFMA", "tail"]
-        for w in (0, 3, 7):
+        for w in (range(8) if os.environ.get("NS_GRU_TRACE_ALL") else (0, 3, 7)):
             print("   wave %d, us per step: %s" % (w, ", ".join("%s %.2f" % (nm, tr[w, k] * 0.01 / T) for k, nm in enumerate(names))))
 
 
