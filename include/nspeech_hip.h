@@ -813,7 +813,18 @@ typedef struct {
    *   dense_bias [L, R] (:428-429);  skip_bias [S] = the sum of the layers' skip biases (:432-434, summed :543);
    *   post1_bias [S], post2_bias [Q] (:546-553). */
   const float* cond; const float* dense_bias; const float* skip_bias; const float* post1_bias; const float* post2_bias;
+  /* engine 3 (round 5) = engine 2 with the post-processing products of a drawn sample - relu -> post1 -> relu -> post2,
+   * 768 KB of weights that ONE workgroup streamed per sample (16 - 18 of 41 us) - on NS_WN_HELPERS helper workgroups per
+   * waveform that keep their quarter of both kernels in REGISTERS for the whole call: the chain workgroup hands over the
+   * 512 skip sums, the helpers exchange the 512 hidden values among themselves and return 256 logits - three hand-offs
+   * of self-flagging {tag, value} granules through post_x instead of two matrix-vector products from L2.
+   * post_x: ns_wavenet_post_bytes(B) of device memory, zeroed by the call; helper_stream: a stream that runs BESIDE the
+   * call's own (ns_streams_concurrent) - the helper kernel is launched on it first; post_x[0] (int) is a status word
+   * (non-zero after the call = a wait timed out, the samples are invalid).  S = 512, Q = 256, B * (1 + 4) <= the CUs. */
+  void* post_x; void* helper_stream;   /* helper_stream: an ns_stream_t */
 } ns_wavenet_generate_params;
+#define NS_WN_HELPERS 4
+size_t ns_wavenet_post_bytes(int B);
 int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_stream_t stream);
 
 /* ------------------------------------------------------------------ audio DSP (utils/audio.py)

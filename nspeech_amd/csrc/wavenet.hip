@@ -543,6 +543,109 @@ constexpr int MF_AHEAD = 2;
   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, (float)(old_)), __builtin_bit_cast(int, (float)(src_)), (ctrl_), 0xF, 0xF, false))
 #define MF_DPP_ZERO(src_, ctrl_) \
   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(src_)), (ctrl_), 0xF, 0xF, true))
+// ------------------------------------------------------------------ engine 3: post-processing helpers
+// See ns_wavenet_generate_params.post_x.  Per waveform b the exchange region holds, as 8-byte {tag, value} granules,
+// h0 [512] (chain workgroup -> helpers), h1 [512] (helper h writes its 128), logits [256] (helper h writes its 64); the tag
+// is the index of the drawn sample (1, 2, ...), so a granule is its own flag and nothing is ever reset.  One buffer per
+// array is enough: h0 of sample e + 1 is published only after every logit of sample e has come back, and a helper
+// publishes its logits only after it has read all of h1.
+typedef unsigned long long wn_u64;
+constexpr int WN_S = 512, WN_Q = 256, WN_XW = WN_S + WN_S + WN_Q;       // granules per waveform
+__device__ __forceinline__ wn_u64 wn_pack(unsigned tag, float v) { return ((wn_u64)tag << 32) | (wn_u64)__float_as_uint(v); }
+__device__ __forceinline__ void wn_put(wn_u64* p, unsigned tag, float v) {
+  __hip_atomic_store((NS_GLOBAL wn_u64*)p, wn_pack(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// polls one granule until it carries `tag`; false = gave up (status raised, or `ticks` of the 100 MHz clock went by)
+__device__ __forceinline__ bool wn_get(const wn_u64* p, unsigned tag, float& v, int* status, unsigned ticks) {
+  unsigned spins = 0, t0 = 0;
+  for (;;) {
+    const wn_u64 g = __hip_atomic_load((const NS_GLOBAL wn_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(g >> 32) == tag) { v = __uint_as_float((unsigned)g); return true; }
+    if ((++spins & 255u) == 0) {
+      if (__hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return false;
+      const unsigned now = (unsigned)wall_clock64() | 1u;
+      if (t0 == 0u) t0 = now;
+      else if (now - t0 > ticks) { atomicExch(status, 1); return false; }
+    }
+  }
+}
+
+// helper h of waveform b = block b * NS_WN_HELPERS + h.  512 threads.  post1: thread (n = tid % 128, kq = tid / 128) keeps
+// W1[128 kq .. +128][128 h + n] (64 registers of bf16 pairs), post2: thread (q = tid % 64, k8 = tid / 64) keeps
+// W2[64 k8 .. +64][64 h + q] (32 registers).
+__global__ __launch_bounds__(512) void wn_post_helper_kernel(ns_wavenet_generate_params p) {
+  __shared__ float hv[WN_S];
+  __shared__ float part[512];
+  __shared__ int abortf;
+  const int tid = threadIdx.x, b = blockIdx.x / NS_WN_HELPERS, h = blockIdx.x % NS_WN_HELPERS;
+  int* status = (int*)p.post_x;
+  wn_u64* x = (wn_u64*)((char*)p.post_x + 256) + (size_t)b * WN_XW;
+  wn_u64 *xh0 = x, *xh1 = x + WN_S, *xlg = x + 2 * WN_S;
+  const bf16_t* wb = (const bf16_t*)p.weights;
+  const int n1 = tid & 127, kq = tid >> 7, q2 = tid & 63, k8 = tid >> 6;
+  unsigned w1[64], w2[32];
+  {
+    const bf16_t* W1 = wb + p.off_post1 + 128 * h + n1;          // [k][n], row stride S
+    const bf16_t* W2 = wb + p.off_post2 + 64 * h + q2;           // [k][q], row stride Q
+#pragma unroll
+    for (int i = 0; i < 64; ++i) {
+      const int k = 128 * kq + 2 * i;
+      w1[i] = (unsigned)*(const unsigned short*)(W1 + (long)k * WN_S) | ((unsigned)*(const unsigned short*)(W1 + (long)(k + 1) * WN_S) << 16);
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const int k = 64 * k8 + 2 * i;
+      w2[i] = (unsigned)*(const unsigned short*)(W2 + (long)k * WN_Q) | ((unsigned)*(const unsigned short*)(W2 + (long)(k + 1) * WN_Q) << 16);
+    }
+  }
+  if (tid == 0) abortf = 0;
+  __syncthreads();
+  const int n_emit = p.total - p.n_seed;
+  // the first hand-over arrives behind the seed walk (~23 us per seed sample): its bound grows with the seed
+  const unsigned first_ticks = NS_SPIN_TICKS + (unsigned)min((long)p.n_seed * 10000L, 3000000000L);
+  for (int e = 1; e <= n_emit; ++e) {
+    float v;
+    if (!wn_get(xh0 + tid, (unsigned)e, v, status, e == 1 ? first_ticks : NS_SPIN_TICKS)) abortf = 1;
+    hv[tid] = v;
+    __syncthreads();
+    if (abortf) return;
+    {   // post1 slice: relu(h0 . W1[:, 128 h + n])
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 64; ++i) {
+        acc = fmaf(hv[128 * kq + 2 * i], pk_lo(w1[i]), acc);
+        acc = fmaf(hv[128 * kq + 2 * i + 1], pk_hi(w1[i]), acc);
+      }
+      part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) wn_put(xh1 + 128 * h + tid, (unsigned)e, fmaxf((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]), 0.f));
+    if (!wn_get(xh1 + tid, (unsigned)e, v, status, NS_SPIN_TICKS)) abortf = 1;
+    __syncthreads();                        // every reader of hv (h0) is done
+    hv[tid] = v;
+    __syncthreads();
+    if (abortf) return;
+    {   // post2 slice: h1 . W2[:, 64 h + q]
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < 32; ++i) {
+        acc = fmaf(hv[64 * k8 + 2 * i], pk_lo(w2[i]), acc);
+        acc = fmaf(hv[64 * k8 + 2 * i + 1], pk_hi(w2[i]), acc);
+      }
+      part[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s += part[64 * i + tid];
+      wn_put(xlg + 64 * h + tid, (unsigned)e, s);
+    }
+    __syncthreads();                        // part and hv are free for the next sample
+  }
+}
+extern "C" size_t ns_wavenet_post_bytes(int B) { return 256 + (size_t)(B > 0 ? B : 0) * WN_XW * sizeof(wn_u64); }
+
 struct GenMf { uint4 fg[8]; uint4 de[2]; float4 r0, r1; };
 
 __device__ __forceinline__ bf16x8 mf_pack(float4 a, float4 b) {
@@ -589,7 +692,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
   // the sample loop is written out once per role: the chain wave and the skip waves then get register allocations of
   // their own (one loop with a role branch inside made the allocator spill ~300 registers, and every scratch access
   // forces vmcnt(0) behind the prefetches); both loops execute the same sequence of workgroup barriers
-  auto gen_post = [&](int t) {
+  auto gen_post = [&](int t) -> bool {
         for (int j = tid; j < S; j += GEN_THREADS) {
           float v = 0.f;
     #pragma unroll
@@ -597,8 +700,22 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
           h0[j] = fmaxf(v, 0.f);
         }
         __syncthreads();
-        gen_matvec8(wb + p.off_post1, S, S, h0, h1, part, true, tid);
-        gen_matvec8(wb + p.off_post2, S, Q, h1, lg, part, false, tid);
+        if (p.post_x) {        // engine 3: the helpers of this waveform hold post1 / post2 in registers
+          int* status = (int*)p.post_x;
+          wn_u64* x = (wn_u64*)((char*)p.post_x + 256) + (size_t)b * WN_XW;
+          const unsigned e = (unsigned)(t + 2 - p.n_seed);       // index of the sample being drawn
+          wn_put(x + tid, e, h0[tid]);                           // (S == GEN_THREADS == 512)
+          if (tid < Q) {
+            float v = 0.f;
+            if (!wn_get(x + 2 * WN_S + tid, e, v, status, NS_SPIN_TICKS)) ns_lds_poke(&chain_pos, -1);
+            lg[tid] = v;
+          }
+          __syncthreads();
+          if (ns_lds_peek(&chain_pos) < 0) return false;
+        } else {
+          gen_matvec8(wb + p.off_post1, S, S, h0, h1, part, true, tid);
+          gen_matvec8(wb + p.off_post2, S, Q, h1, lg, part, false, tid);
+        }
         float m = -3.0e38f;
         for (int j = tid; j < Q; j += GEN_THREADS) m = fmaxf(m, lg[j]);
         m = block_max(m, red);
@@ -652,7 +769,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
             for (int j = 0; j < Q; ++j) p.probs[(long)b * Q + j] = (float)(ex[j] / se);
         }
         __syncthreads();
-
+        return true;
   };
   if (wave == 0) {
     for (int t = 1; t < p.total; ++t) {
@@ -768,7 +885,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
 #undef MF_RROW
       __syncthreads();
       if (!emit) continue;
-      gen_post(t);
+      if (!gen_post(t)) return;                              // (engine 3: a hand-over timed out)
     }
   } else {
     for (int t = 1; t < p.total; ++t) {
@@ -830,7 +947,7 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
       }
       __syncthreads();
       if (!emit) continue;
-      gen_post(t);
+      if (!gen_post(t)) return;                              // (engine 3: a hand-over timed out)
     }
   }
 }
@@ -851,8 +968,26 @@ extern "C" int ns_wavenet_generate(const ns_wavenet_generate_params* p, ns_strea
                  "ns_wavenet_generate: the single-wave chain needs bf16 weights and R == Dc in {16, 32}");
     const size_t lds2 = sizeof(float) * ((size_t)p->L * p->R + 2 * p->S + ((p->Q + 1) & ~1) + 16 + GEN_THREADS * 8) + sizeof(double) * p->Q;
     NS_CHECK_ARG(lds2 <= 60 * 1024 && ((size_t)p->L * p->R) % 2 == 0, "ns_wavenet_generate: state does not fit in LDS");
-    if (p->engine == 2) {
+    NS_CHECK_ARG(p->engine == 3 || !p->post_x, "ns_wavenet_generate: post_x belongs to engine 3");
+    if (p->engine == 2 || p->engine == 3) {
       NS_CHECK_ARG(p->R == 32 && p->S / 8 <= 64 && p->S * 7 <= GEN_THREADS * 8, "ns_wavenet_generate: the MFMA chain needs R == Dc == 32, S <= 512");
+      if (p->engine == 3) {
+        NS_CHECK_ARG(p->post_x && p->helper_stream && p->helper_stream != s && p->S == WN_S && p->Q == WN_Q &&
+                         (((uintptr_t)p->post_x) & 15) == 0 && (long)p->B * (1 + NS_WN_HELPERS) <= ns_device_cus(),
+                     "ns_wavenet_generate: engine 3 needs post_x, a helper stream of its own, S = 512, Q = 256 and B * 5 workgroups resident");
+        const int zrc = ns_zero_async(p->post_x, (ns_wavenet_post_bytes(p->B) + 15) & ~(size_t)15, (hipStream_t)s);
+        if (zrc) return zrc;
+        // the helpers start behind the clearing of the exchange region and run beside the chain kernel
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, (hipStream_t)s) != hipSuccess ||
+            hipStreamWaitEvent((hipStream_t)p->helper_stream, ev, 0) != hipSuccess) {
+          ns_set_error("ns_wavenet_generate: could not order the helper stream behind the call's");
+          return NS_ERR_LAUNCH;
+        }
+        (void)hipEventDestroy(ev);
+        hipLaunchKernelGGL(wn_post_helper_kernel, dim3(p->B * NS_WN_HELPERS), dim3(512), 0, (hipStream_t)p->helper_stream, *p);
+        NS_CHECK_LAUNCH("wavenet_post_helper");
+      }
       const size_t lds3 = lds2 + sizeof(float) * 32;
       hipLaunchKernelGGL(wn_generate_mfma_kernel, dim3(p->B), dim3(GEN_THREADS), lds3, (hipStream_t)s, *p);
       NS_CHECK_LAUNCH("wavenet_generate_mfma");

@@ -627,14 +627,25 @@ class SimpleWaveNet(object):
             fgT, deT = fg.contiguous().to(torch.bfloat16), de.contiguous().to(torch.bfloat16)
         if engine is None:          # MFMA chain + concurrent skip waves at the shipped widths, else the single-wave VALU chain
             engine = 2 if (fgT is not None and self.R == 32 and self.S <= 512) else 1
-        if engine == 2:
+            if engine == 2 and self.S == 512 and self.Q == 256 and B * 5 <= torch.cuda.get_device_properties(dev).multi_processor_count:
+                engine = 3          # + the post-processing products on four helper workgroups per waveform (weights in registers)
+        if engine in (2, 3):
             # the MFMA chain keeps the activations in fragment layout between layers: operand slot 8 g + j of a
             # 32-wide K block holds channel 4 g + (j & 3) + 16 (j >> 2) (wavenet.hip, wn_generate_mfma_kernel)
             perm = torch.tensor([4 * (i // 8) + (i % 4) + 16 * ((i % 8) // 4) for i in range(32)], device=dev)
             fgT = torch.cat([fgT[:, :, :32][:, :, perm], fgT[:, :, 32:][:, :, perm]], dim=2).contiguous()
             deT = deT[:, :, perm].contiguous()
+        if engine == 3:
+            if getattr(self, "_helper_stream", None) is None:
+                self._helper_stream = ops.concurrent_stream(dev)         # runs BESIDE the call's stream (probed)
+            post_x = torch.empty(ops.wavenet_post_floats(B), dtype=torch.float32, device=dev)
+            extra = dict(extra, post_x=post_x, helper_stream=self._helper_stream)
         ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
                              probs=self.last_probs, fgT=fgT, deT=deT, engine=engine, **extra)
+        if engine == 3:             # the call's stream takes the helpers' end in: post_x is free behind it
+            torch.cuda.current_stream(dev).wait_stream(self._helper_stream)
+            self.last_status = extra["post_x"][:1].view(torch.int32)     # non-zero: a hand-over timed out, the samples are invalid
+        self.last_engine = engine
         self._gen_keep = (fgT, deT, un, queues, dil, extra)  # keep the operands alive until the stream has used them
         return ids
 

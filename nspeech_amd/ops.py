@@ -696,6 +696,12 @@ def attention_post_bwd(N, S, Ti, Tia, A, kw, lengths, keys_t, q, align, de, wcl,
     L.call("ns_attention_post_bwd", p, stream())
 
 
+def wavenet_post_floats(B):
+    fn = L.lib().ns_wavenet_post_bytes
+    fn.restype = C.c_size_t
+    return (int(fn(int(B))) + 3) // 4
+
+
 def wavenet_input(ids, w, x, N, T, C, Q, w_off=0, dx=None, dw=None, dw_off=0, start=0):
     p = L.struct("ns_wavenet_input_params")
     _fill(p, ids=ptr(ids), w=ptr(w, w_off), x=ptr(x), dtype=dt(x) if x is not None else 0, dx=ptr(dx),
@@ -725,8 +731,11 @@ def wavenet_softmax(logits, ld, rows, Q, probs, logits_off=0):
 
 
 def wavenet_generate(weights, offs, dilations, L_, R, Dc, S, Q, B, n_seed, total, queue_rows, ids, uniform, queues, probs=None,
-                     fgT=None, deT=None, engine=0, cond=None, dense_bias=None, skip_bias=None, post1_bias=None, post2_bias=None):
+                     fgT=None, deT=None, engine=0, cond=None, dense_bias=None, skip_bias=None, post1_bias=None, post2_bias=None,
+                     post_x=None, helper_stream=None):
     p = L.struct("ns_wavenet_generate_params")
+    if post_x is not None:
+        p.post_x, p.helper_stream = ptr(post_x), helper_stream.cuda_stream
     _fill(p, cond=ptr(cond), dense_bias=ptr(dense_bias), skip_bias=ptr(skip_bias), post1_bias=ptr(post1_bias),
           post2_bias=ptr(post2_bias))
     _fill(p, weights=ptr(weights), w_dtype=dt(weights), off_causal=offs["causal"], off_layer0=offs["layer0"],
