@@ -627,7 +627,8 @@ class SimpleWaveNet(object):
             fgT, deT = fg.contiguous().to(torch.bfloat16), de.contiguous().to(torch.bfloat16)
         if engine is None:          # MFMA chain + concurrent skip waves at the shipped widths, else the single-wave VALU chain
             engine = 2 if (fgT is not None and self.R == 32 and self.S <= 512) else 1
-            if engine == 2 and self.S == 512 and self.Q == 256 and B * 5 <= torch.cuda.get_device_properties(dev).multi_processor_count:
+            if engine == 2 and self.S == 512 and self.Q == 256 and B * 5 <= torch.cuda.get_device_properties(dev).multi_processor_count \
+                    and self._helper(dev) is not None:
                 engine = 3          # + the post-processing products on four helper workgroups per waveform (weights in registers)
         if engine in (2, 3):
             # the MFMA chain keeps the activations in fragment layout between layers: operand slot 8 g + j of a
@@ -636,18 +637,29 @@ class SimpleWaveNet(object):
             fgT = torch.cat([fgT[:, :, :32][:, :, perm], fgT[:, :, 32:][:, :, perm]], dim=2).contiguous()
             deT = deT[:, :, perm].contiguous()
         if engine == 3:
-            if getattr(self, "_helper_stream", None) is None:
-                self._helper_stream = ops.concurrent_stream(dev)         # runs BESIDE the call's stream (probed)
+            assert self._helper(dev) is not None, "engine 3 needs a stream that runs beside the current one"
             post_x = torch.empty(ops.wavenet_post_floats(B), dtype=torch.float32, device=dev)
             extra = dict(extra, post_x=post_x, helper_stream=self._helper_stream)
         ops.wavenet_generate(W, offs, dil, self.L, self.R, self.Dc, self.S, self.Q, B, n_seed, total, qrows, ids, un, queues,
                              probs=self.last_probs, fgT=fgT, deT=deT, engine=engine, **extra)
         if engine == 3:             # the call's stream takes the helpers' end in: post_x is free behind it
             torch.cuda.current_stream(dev).wait_stream(self._helper_stream)
-            self.last_status = extra["post_x"][:1].view(torch.int32)     # non-zero: a hand-over timed out, the samples are invalid
+            self.last_status = extra["post_x"][:1].view(torch.int32)
+            if int(self.last_status.item()) != 0:        # (the caller reads the samples next anyway: one wait here)
+                raise RuntimeError("ns_wavenet_generate: a hand-over between the chain and its helper workgroups timed out "
+                                   "(their workgroups were not resident together?) - the samples are invalid; engine=2 "
+                                   "runs without helpers")
         self.last_engine = engine
         self._gen_keep = (fgT, deT, un, queues, dil, extra)  # keep the operands alive until the stream has used them
         return ids
+
+    def _helper(self, dev):
+        """The helper kernel's stream: one that was seen to run BESIDE the current stream (ns_streams_concurrent), or None
+        (then the helpers would start only after the chain kernel: engine 2 it is)."""
+        if getattr(self, "_helper_stream", None) is None:
+            s = ops.concurrent_stream(dev)
+            self._helper_stream = s if ops.streams_concurrent(torch.cuda.current_stream(dev), s) else False
+        return self._helper_stream or None
 
     def _generator_terms(self, B, W, global_conditions):
         """What the full model's incremental generator adds per layer (wavenet.py:398-437), formed once per call:
