@@ -297,7 +297,10 @@ def wavenet_bench(seed=1234):
         warm = time.perf_counter() - t0                      # the seed walk alone
         gen = max(dt - warm, 1e-9)
         out["generate_batch_%d" % B] = {"samples_per_s": B * 2000 / gen, "us_per_drawn_sample": gen / 2000 * 1e6,
-                                        "seed_walk_ms": warm * 1e3, "realtime_factor_16k": (B * 2000 / gen) / 16000.0}
+                                        "seed_walk_ms": warm * 1e3, "realtime_factor_16k": (B * 2000 / gen) / 16000.0,
+                                        "engine": {1: "single-wave VALU chain", 2: "MFMA chain + skip waves",
+                                                   3: "MFMA chain + skip waves + 4 post-processing helper workgroups per waveform"
+                                                   }.get(getattr(m, "last_engine", 0), "per-layer kernel")}
     return out
 
 
