@@ -816,8 +816,9 @@ typedef struct {
   /* engine 3 (round 5) = engine 2 with the post-processing products of a drawn sample - relu -> post1 -> relu -> post2,
    * 768 KB of weights that ONE workgroup streamed per sample (16 - 18 of 41 us) - on NS_WN_HELPERS helper workgroups per
    * waveform that keep their quarter of both kernels in REGISTERS for the whole call: the chain workgroup hands over the
-   * 512 skip sums, the helpers exchange the 512 hidden values among themselves and return 256 logits - three hand-offs
-   * of self-flagging {tag, value} granules through post_x instead of two matrix-vector products from L2.
+   * 512 skip sums, helper h forms hidden units 128 h .. 128 h + 127 (its columns of post1) and their share of all 256
+   * logits (its rows of post2), the chain workgroup adds the four partial vectors in a fixed order - two hand-offs of
+   * self-flagging {tag, value} granules through post_x instead of two matrix-vector products from L2.
    * post_x: ns_wavenet_post_bytes(B) of device memory, zeroed by the call; helper_stream: a stream that runs BESIDE the
    * call's own (ns_streams_concurrent) - the helper kernel is launched on it first; post_x[0] (int) is a status word
    * (non-zero after the call = a wait timed out, the samples are invalid).  S = 512, Q = 256, B * (1 + 4) <= the CUs. */

@@ -545,12 +545,14 @@ constexpr int MF_AHEAD = 2;
   __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (float)(src_)), (ctrl_), 0xF, 0xF, true))
 // ------------------------------------------------------------------ engine 3: post-processing helpers
 // See ns_wavenet_generate_params.post_x.  Per waveform b the exchange region holds, as 8-byte {tag, value} granules,
-// h0 [512] (chain workgroup -> helpers), h1 [512] (helper h writes its 128), logits [256] (helper h writes its 64); the tag
-// is the index of the drawn sample (1, 2, ...), so a granule is its own flag and nothing is ever reset.  One buffer per
-// array is enough: h0 of sample e + 1 is published only after every logit of sample e has come back, and a helper
-// publishes its logits only after it has read all of h1.
+// h0 [512] (chain workgroup -> helpers) and the helpers' PARTIAL logits [4][256] (helper h -> chain workgroup): helper h
+// owns hidden units 128 h .. 128 h + 127 - it forms them from all of h0 (post1, its 128 columns) and, without handing
+// them to anyone, their contribution to ALL 256 logits (post2, its 128 rows); the chain workgroup adds the four partial
+// vectors in a fixed order.  Two hand-offs per sample.  The tag is the index of the drawn sample (1, 2, ...), so a
+// granule is its own flag and nothing is ever reset; one buffer per array is enough: h0 of sample e + 1 is published
+// only after every partial logit of sample e has come back.
 typedef unsigned long long wn_u64;
-constexpr int WN_S = 512, WN_Q = 256, WN_XW = WN_S + WN_S + WN_Q;       // granules per waveform
+constexpr int WN_S = 512, WN_Q = 256, WN_XW = WN_S + NS_WN_HELPERS * WN_Q;       // granules per waveform
 __device__ __forceinline__ wn_u64 wn_pack(unsigned tag, float v) { return ((wn_u64)tag << 32) | (wn_u64)__float_as_uint(v); }
 __device__ __forceinline__ void wn_put(wn_u64* p, unsigned tag, float v) {
   __hip_atomic_store((NS_GLOBAL wn_u64*)p, wn_pack(tag, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -571,22 +573,23 @@ __device__ __forceinline__ bool wn_get(const wn_u64* p, unsigned tag, float& v, 
 }
 
 // helper h of waveform b = block b * NS_WN_HELPERS + h.  512 threads.  post1: thread (n = tid % 128, kq = tid / 128) keeps
-// W1[128 kq .. +128][128 h + n] (64 registers of bf16 pairs), post2: thread (q = tid % 64, k8 = tid / 64) keeps
-// W2[64 k8 .. +64][64 h + q] (32 registers).
+// W1[128 kq .. +128][128 h + n] (64 registers of bf16 pairs); post2: thread (q = tid % 256, kh = tid / 256) keeps
+// W2[128 h + 64 kh .. +64][q] (32 registers).
 __global__ __launch_bounds__(512) void wn_post_helper_kernel(ns_wavenet_generate_params p) {
   __shared__ float hv[WN_S];
+  __shared__ float h1v[128];
   __shared__ float part[512];
   __shared__ int abortf;
   const int tid = threadIdx.x, b = blockIdx.x / NS_WN_HELPERS, h = blockIdx.x % NS_WN_HELPERS;
   int* status = (int*)p.post_x;
   wn_u64* x = (wn_u64*)((char*)p.post_x + 256) + (size_t)b * WN_XW;
-  wn_u64 *xh0 = x, *xh1 = x + WN_S, *xlg = x + 2 * WN_S;
+  wn_u64 *xh0 = x, *xlg = x + WN_S + h * WN_Q;
   const bf16_t* wb = (const bf16_t*)p.weights;
-  const int n1 = tid & 127, kq = tid >> 7, q2 = tid & 63, k8 = tid >> 6;
+  const int n1 = tid & 127, kq = tid >> 7, q2 = tid & 255, kh = tid >> 8;
   unsigned w1[64], w2[32];
   {
     const bf16_t* W1 = wb + p.off_post1 + 128 * h + n1;          // [k][n], row stride S
-    const bf16_t* W2 = wb + p.off_post2 + 64 * h + q2;           // [k][q], row stride Q
+    const bf16_t* W2 = wb + p.off_post2 + q2;                    // [k][q], row stride Q
 #pragma unroll
     for (int i = 0; i < 64; ++i) {
       const int k = 128 * kq + 2 * i;
@@ -594,7 +597,7 @@ __global__ __launch_bounds__(512) void wn_post_helper_kernel(ns_wavenet_generate
     }
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-      const int k = 64 * k8 + 2 * i;
+      const int k = 128 * h + 64 * kh + 2 * i;
       w2[i] = (unsigned)*(const unsigned short*)(W2 + (long)k * WN_Q) | ((unsigned)*(const unsigned short*)(W2 + (long)(k + 1) * WN_Q) << 16);
     }
   }
@@ -604,12 +607,12 @@ __global__ __launch_bounds__(512) void wn_post_helper_kernel(ns_wavenet_generate
   // the first hand-over arrives behind the seed walk (~23 us per seed sample): its bound grows with the seed
   const unsigned first_ticks = NS_SPIN_TICKS + (unsigned)min((long)p.n_seed * 10000L, 3000000000L);
   for (int e = 1; e <= n_emit; ++e) {
-    float v;
+    float v = 0.f;
     if (!wn_get(xh0 + tid, (unsigned)e, v, status, e == 1 ? first_ticks : NS_SPIN_TICKS)) abortf = 1;
     hv[tid] = v;
     __syncthreads();
     if (abortf) return;
-    {   // post1 slice: relu(h0 . W1[:, 128 h + n])
+    {   // post1, own 128 columns: relu(h0 . W1[:, 128 h + n])
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < 64; ++i) {
@@ -619,29 +622,20 @@ __global__ __launch_bounds__(512) void wn_post_helper_kernel(ns_wavenet_generate
       part[tid] = acc;
     }
     __syncthreads();
-    if (tid < 128) wn_put(xh1 + 128 * h + tid, (unsigned)e, fmaxf((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]), 0.f));
-    if (!wn_get(xh1 + tid, (unsigned)e, v, status, NS_SPIN_TICKS)) abortf = 1;
-    __syncthreads();                        // every reader of hv (h0) is done
-    hv[tid] = v;
+    if (tid < 128) h1v[tid] = fmaxf((part[tid] + part[128 + tid]) + (part[256 + tid] + part[384 + tid]), 0.f);
     __syncthreads();
-    if (abortf) return;
-    {   // post2 slice: h1 . W2[:, 64 h + q]
+    {   // post2, own 128 rows: partial logits of all 256 outputs
       float acc = 0.f;
 #pragma unroll
       for (int i = 0; i < 32; ++i) {
-        acc = fmaf(hv[64 * k8 + 2 * i], pk_lo(w2[i]), acc);
-        acc = fmaf(hv[64 * k8 + 2 * i + 1], pk_hi(w2[i]), acc);
+        acc = fmaf(h1v[64 * kh + 2 * i], pk_lo(w2[i]), acc);
+        acc = fmaf(h1v[64 * kh + 2 * i + 1], pk_hi(w2[i]), acc);
       }
       part[tid] = acc;
     }
     __syncthreads();
-    if (tid < 64) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s += part[64 * i + tid];
-      wn_put(xlg + 64 * h + tid, (unsigned)e, s);
-    }
-    __syncthreads();                        // part and hv are free for the next sample
+    if (tid < 256) wn_put(xlg + tid, (unsigned)e, part[tid] + part[256 + tid]);
+    __syncthreads();                        // part, hv and h1v are free for the next sample
   }
 }
 extern "C" size_t ns_wavenet_post_bytes(int B) { return 256 + (size_t)(B > 0 ? B : 0) * WN_XW * sizeof(wn_u64); }
@@ -705,13 +699,18 @@ __global__ __launch_bounds__(GEN_THREADS) void wn_generate_mfma_kernel(ns_wavene
           wn_u64* x = (wn_u64*)((char*)p.post_x + 256) + (size_t)b * WN_XW;
           const unsigned e = (unsigned)(t + 2 - p.n_seed);       // index of the sample being drawn
           wn_put(x + tid, e, h0[tid]);                           // (S == GEN_THREADS == 512)
-          if (tid < Q) {
-            float v = 0.f;
-            if (!wn_get(x + 2 * WN_S + tid, e, v, status, NS_SPIN_TICKS)) ns_lds_poke(&chain_pos, -1);
-            lg[tid] = v;
+          {   // thread (q = tid % 256, pair = tid / 256) takes helpers 2 pair and 2 pair + 1: the four partial vectors add up
+              // as (h0 + h1) + (h2 + h3), always in that order
+            const int q = tid & 255, pr = tid >> 8;
+            float v0 = 0.f, v1 = 0.f;
+            if (!wn_get(x + WN_S + (2 * pr) * WN_Q + q, e, v0, status, NS_SPIN_TICKS) ||
+                !wn_get(x + WN_S + (2 * pr + 1) * WN_Q + q, e, v1, status, NS_SPIN_TICKS)) ns_lds_poke(&chain_pos, -1);
+            h1[tid] = v0 + v1;                                   // (h1 [S] is free in this engine)
           }
           __syncthreads();
           if (ns_lds_peek(&chain_pos) < 0) return false;
+          if (tid < Q) lg[tid] = h1[tid] + h1[256 + tid];
+          __syncthreads();
         } else {
           gen_matvec8(wb + p.off_post1, S, S, h0, h1, part, true, tid);
           gen_matvec8(wb + p.off_post2, S, Q, h1, lg, part, false, tid);
