@@ -49,14 +49,23 @@ class Tacotron(Tacotron2):
     # data parallel: one whole-buffer all-reduce once backward() has been enqueued (parallel.whole_buffer_range)
     _BUCKET_AFTER = {"backward": "all"}
 
-    # Weight gradients of the non-recurrent layers are QUEUED and released onto a second stream where the backward pass
-    # reaches a recurrence (ns_gru_seq / the attention clusters occupy 4 - 16 CUs, or wait on their hops): the post CBHG's
-    # ~2 ms of k-long split-K products then run beside the decoder's GRUs instead of in front of them (round 5).
+    # Weight gradients of the non-recurrent layers run on a second stream, on operand buffers of their layers' own: ~2.8 ms
+    # of k-long split-K products per step leave the main stream's dependent chain and fill what the recurrences (ns_gru_seq /
+    # the attention clusters: 4 - 16 CUs, or waiting on their hops) and the small launches leave idle (round 5).
     WG = "taco1"
+
+    # eager: released as the backward pass forms their operands (19.1 ms per step at the benchmark shape); queue: held back
+    # for the next recurrence (19.5 - a burst of chip-filling products starves the small launches of the OTHER streams
+    # while it lasts, the GRU windows among them, and what is queued behind the last recurrence ends as a serial tail);
+    # after: queue, released behind the first window's launch (19.4)
+    WG_POLICY = os.environ.get("NS_T1_WG_POLICY", "eager")
 
     @property
     def queue_groups(self):
-        return (self.WG,)
+        return () if self.WG_POLICY == "eager" else (self.WG,)
+
+    def _defer(self, group, fn, eager=False):
+        return Tacotron2._defer(self, group, fn, eager=eager or self.WG_POLICY == "eager")
 
     def _make_streams(self):
         """The weight-gradient stream and the GRU pipeline's two: three streams that run beside the main one AND beside
@@ -459,7 +468,8 @@ class Tacotron(Tacotron2):
         self.last_paths["gru_pair"] = "pipelined x%d" % nch
 
         def bwd():
-            self._flush_deferred()          # the weight gradients queued so far (the post CBHG's) run beside the windows below
+            if self.WG_POLICY != "after":
+                self._flush_deferred()      # the weight gradients queued so far (the post CBHG's) run beside the windows below
             main = torch.cuda.current_stream(self.device)
             # y2 = y1 + h2
             ops.copy3d(y2.grad, y1.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
@@ -483,6 +493,8 @@ class Tacotron(Tacotron2):
                 with torch.cuda.stream(sb):
                     ops.copy3d(y1.grad, h1.grad, I, J, H, st, st, src_off=off, dst_off=off, accumulate=1)      # y1 = x1 + h1
                     window(g1, c, "bwd")
+                if c == nch - 1 and self.WG_POLICY == "after":
+                    self._flush_deferred()  # behind the first windows' launches
             hand_over(sb, main)
             ops.copy3d(y1.grad, x1.grad, 1, rows, H, (0, H), (0, H), accumulate=1)
             for dd in (g2, g1):

@@ -296,8 +296,19 @@ def forward_infer(m):
         if st["graph"] is None:
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                _infer_body(m)
+            # No garbage collection while the stream captures: a collection that falls into the capture destroys whatever
+            # cyclic garbage the process holds - another model's buffers, events, captured graphs - and a destructor that
+            # calls into HIP then (hipGraphExecDestroy, an event record of the allocator) aborts the process (seen: a
+            # Tacotron-1 model of an earlier test collected inside this capture).  torch.cuda.graph collects once on entry.
+            import gc
+            was_enabled = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    _infer_body(m)
+            finally:
+                if was_enabled:
+                    gc.enable()
             st["graph"] = g
         st["graph"].replay()
         return m
