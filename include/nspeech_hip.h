@@ -176,6 +176,8 @@ typedef struct {
   /* optional (dtype NS_F32): the output also / instead as a pre-split bf16 pair y_hi = bf16(y), y_lo = bf16(y - y_hi),
    * the operand form of the three-segment 256-tile product (ns_gemm A_lo / B_lo); with them `y` may be NULL */
   void* y_hi; void* y_lo;
+  int64_t ld_y;     /* row stride of y in elements; 0 = C.  A wider one writes the output as a column block of a concatenated
+                       activation (the CBHG convolution bank, modules.py:121-128, without the copy) */
 } ns_bn_fwd_params;
 int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t stream);
 
@@ -198,6 +200,7 @@ typedef struct {
   int dpre_dtype;   /* 0: dpre has `dtype`; NS_BF16 with dtype NS_F32: dpre is written as bf16 (single-pass backward
                        products read it at half the bytes; the bias gradient is summed on the rounded values) */
   const float* sum_dy; const float* sum_dyxh;
+  int64_t ld_dy;    /* row stride of dy in elements; 0 = C (dy as a column block of a concatenated activation's gradient) */
 } ns_bn_bwd_params;
 int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t stream);
 

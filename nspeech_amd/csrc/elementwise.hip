@@ -167,7 +167,7 @@ __global__ void bn_apply_kernel(ns_bn_fwd_params p) {
     }
     float v = 0.f;
     if (valid) v = (ldf(z + idx) - p.mean_out[c]) * p.istd_out[c] * p.gamma[c] + p.beta[c];
-    stf(y + idx, v);
+    stf(y + (p.ld_y ? (long)row * p.ld_y + c : idx), v);
   }
 }
 // vector form: 4 adjacent channels per thread (16-byte accesses), optional pre-split bf16 outputs
@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) void bn_apply4_kernel(ns_bn_fwd_params p) {
       v.z = (x.z - m.z) * is.z * g.z + b.z; v.w = (x.w - m.w) * is.w * g.w + b.w;
     }
     if (p.y) {
-      if constexpr (sizeof(T) == 4) *(float4*)((float*)p.y + i4 * 4) = v;
+      const long yo = p.ld_y ? (long)row * p.ld_y + c : i4 * 4;
+      if constexpr (sizeof(T) == 4) *(float4*)((float*)p.y + yo) = v;
       else {
         bf16x4 o; o[0] = (bf16_t)v.x; o[1] = (bf16_t)v.y; o[2] = (bf16_t)v.z; o[3] = (bf16_t)v.w;
-        *(bf16x4*)((bf16_t*)p.y + i4 * 4) = o;
+        *(bf16x4*)((bf16_t*)p.y + yo) = o;
       }
     }
     if (p.y_hi) {
@@ -218,11 +219,12 @@ extern "C" int ns_bn_fwd(const ns_bn_fwd_params* p, ns_stream_t s) {
   NS_CHECK_ARG(!p->training || (p->col_sum && p->col_sumsq && p->count > 0), "ns_bn_fwd: training needs stats");
   NS_CHECK_ARG(p->training || (p->moving_mean && p->moving_var), "ns_bn_fwd: inference needs moving stats");
   NS_CHECK_ARG((p->y_hi != nullptr) == (p->y_lo != nullptr), "ns_bn_fwd: y_hi and y_lo come together");
+  NS_CHECK_ARG(p->ld_y == 0 || (p->ld_y >= p->C && p->y), "ns_bn_fwd: ld_y < C, or no y");
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(ceil_div(p->C, 256)), dim3(256), 0, (hipStream_t)s, *p);
   const long total = (long)p->rows * p->C;
   auto al = [](const void* q, int b) { return ((uintptr_t)q % b) == 0; };
   const int esz = p->dtype == NS_BF16 ? 2 : 4;
-  const bool vec = p->C % 4 == 0 && al(p->z, 4 * esz) && al(p->y, 4 * esz) && al(p->mean_out, 16) && al(p->istd_out, 16) &&
+  const bool vec = p->C % 4 == 0 && p->ld_y % 4 == 0 && al(p->z, 4 * esz) && al(p->y, 4 * esz) && al(p->mean_out, 16) && al(p->istd_out, 16) &&
                    al(p->gamma, 16) && al(p->beta, 16) && al(p->y_hi, 8) && al(p->y_lo, 8);
   if (vec) {
     const int grid = (int)min((long)4096, (total / 4 + 255) / 256);
@@ -259,7 +261,7 @@ __global__ void bn_bwd_reduce_kernel(ns_bn_bwd_params p) {
         if (t < p.row_lo || t >= p.row_hi) continue;
       }
       const long idx = (long)row * p.C + c;
-      const float dy = p.dy[idx];
+      const float dy = p.dy[p.ld_dy ? (long)row * p.ld_dy + c : idx];
       const float xh = (ldf(z + idx) - mean) * istd;
       s1 += dy;
       s2 += dy * xh;
@@ -294,7 +296,7 @@ __global__ void bn_bwd_apply_kernel(ns_bn_bwd_params p) {
       if (valid) {
         const float zv = ldf(z + idx);
         const float xh = (zv - mean) * istd;
-        d = g * istd * (p.dy[idx] - m1 - xh * m2);
+        d = g * istd * (p.dy[p.ld_dy ? (long)row * p.ld_dy + c : idx] - m1 - xh * m2);
         if (p.act == NS_ACT_RELU) d = zv > 0.f ? d : 0.f;
         else if (p.act == NS_ACT_TANH) d *= (1.f - zv * zv);
         else if (p.act == NS_ACT_SIGMOID) d *= zv * (1.f - zv);
@@ -364,7 +366,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce4_kernel(ns_bn_bwd_params p)
         }
         if (ok[u]) {
           const long idx = (long)row * p.C + 4 * q;
-          d[u] = *(const float4*)(p.dy + idx);
+          d[u] = *(const float4*)(p.dy + (p.ld_dy ? (long)row * p.ld_dy + 4 * q : idx));
           zz[u] = ld4(z + idx);
         }
       }
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply4_kernel(ns_bn_bwd_params p, 
         }
         if (ok[u]) {
           const long idx = (long)row * p.C + 4 * q;
-          d[u] = *(const float4*)(p.dy + idx);
+          d[u] = *(const float4*)(p.dy + (p.ld_dy ? (long)row * p.ld_dy + 4 * q : idx));
           zz[u] = ld4(z + idx);
         }
       }
@@ -511,7 +513,8 @@ extern "C" int ns_bn_bwd(const ns_bn_bwd_params* p, ns_stream_t s_) {
                     ((uintptr_t)p->work % 16 == 0) && (p->dtype == NS_BF16 || ((uintptr_t)p->z % 16 == 0 &&
                     (uintptr_t)p->dpre % (p->dpre_dtype == NS_BF16 ? 8 : 16) == 0)) &&
                     (!p->sum_dy || ((uintptr_t)p->sum_dy % 16 == 0 && (uintptr_t)p->sum_dyxh % 16 == 0));
-  if (p->C % 4 == 0 && al16) {
+  NS_CHECK_ARG(p->ld_dy == 0 || p->ld_dy >= p->C, "ns_bn_bwd: ld_dy < C");
+  if (p->C % 4 == 0 && p->ld_dy % 4 == 0 && al16) {
     // work: [0, C) sum dy | [C, 2C) sum dy*xhat (fallback only) | [2C, 2C + RB*C) bias-gradient partials |
     //       [2C + 64C, 2C + 64C + 2*RB*C) the fallback reduction's partials
     const int rb = max(1, min(BN4_MAX_RB, ceil_div(p->rows, 128)));

@@ -168,12 +168,22 @@ class Tacotron(Tacotron2):
         self._tape.append(bwd)
         return y
 
-    def _conv(self, name, x, scope, k, cout, act, training):
-        yb = self._conv_fwd(scope, x.buf, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, training=training)
-        y = Act(self, name, x.N, x.P, x.padl, x.T, cout, buf=yb)
+    def _conv(self, name, x, scope, k, cout, act, training, into=None):
+        """into = (Act, first column): the layer's output IS that column block of the wider activation (a convolution bank's
+        concatenation, modules.py:121-128, without a copy either way: BatchNorm writes there, its backward reads the
+        block of the wide gradient)."""
+        if into is not None:
+            wide, col = into
+            self._conv_fwd(scope, x.buf, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, training=training,
+                           y_out=(wide.buf, col, wide.C))
+            y, dy = None, lambda: (wide.grad, col, wide.C)
+        else:
+            yb = self._conv_fwd(scope, x.buf, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, training=training)
+            y = Act(self, name, x.N, x.P, x.padl, x.T, cout, buf=yb)
+            dy = lambda: y.grad
 
         def bwd():
-            self._conv_bwd(scope, x.buf, y.grad, x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, x.grad,
+            self._conv_bwd(scope, x.buf, dy(), x.C, cout, k, act, x.N, x.T, x.P, "c:" + name, x.grad,
                            dx_accumulate=True, defer=self.WG)
         self._tape.append(bwd)
         return y
@@ -596,9 +606,10 @@ class Tacotron(Tacotron2):
 
     def _cbhg(self, name, x, lengths, scope, K, proj, training, spk=None):
         """spk: the speaker embedding rows (Act [N, 1, speaker_embed_dim]) for the encoder CBHG, modules.py:157-169."""
-        banks = [self._conv("%s_b%d" % (name, k), x, "%s/conv_bank/conv1d_%d" % (scope, k), k, 128, ACT_RELU, training)
-                 for k in range(1, K + 1)]
-        bank = self._concat(name + "_bank", banks)
+        bank = self._new(name + "_bank", x, 128 * K)        # the K bank outputs side by side: every layer writes its own block
+        for k in range(1, K + 1):
+            self._conv("%s_b%d" % (name, k), x, "%s/conv_bank/conv1d_%d" % (scope, k), k, 128, ACT_RELU, training,
+                       into=(bank, (k - 1) * 128))
         y = bank
         for i, size in enumerate(proj[:-1]):      # each reads the bank (SURVEY Q3), the last one wins
             y = self._conv("%s_p%d" % (name, i + 1), bank, "%s/proj_%d" % (scope, i + 1), 3, size, ACT_RELU, training)

@@ -568,7 +568,7 @@ class Tacotron2(object):
                 and ((rows + 255) // 256) * ((cout + 255) // 256) >= 96)
 
     def _conv_fwd(self, scope, xin, cin, cout, k, act, N, T, Pp, tag, training=True, D=None, xsplit=None,
-                  emit_split=False):
+                  emit_split=False, y_out=None):
         """conv1d('same') + bias + act + BN statistics in one GEMM, then BN apply (modules.py:194-198).
         xsplit = (hi, lo): the input as a pre-split bf16 pair (then the product runs as three segments on the 256-tile
         kernel); emit_split: BatchNorm writes its output as such a pair (returned instead of the fp32 tensor)."""
@@ -593,9 +593,13 @@ class Tacotron2(object):
             ops.gemm(xin, self._W(D), z, Mg, cout, k * cin, cin, cout, cout, a_mode=0, b_mode=1,
                      b_off=self._o(scope + "/conv1d/kernel"), **common)
         y = yh = yl = None
+        ykw = {}
         if emit_split:
             yh = self._buf(tag + "_yhi", rows * cout, torch.bfloat16)
             yl = self._buf(tag + "_ylo", rows * cout, torch.bfloat16)
+        elif y_out is not None:         # (buffer, first column, row stride): the output as a column block of a wider activation
+            y = y_out[0]
+            ykw = dict(y_off=y_out[1], ld_y=y_out[2])
         else:
             y = self._buf(tag + "_y", rows * cout, D)
         ops.bn_fwd(z, y, rows, cout, st, st[cout:], N * T, self.flat_p, self.flat_p, self.flat_stats,
@@ -603,7 +607,7 @@ class Tacotron2(object):
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    beta_off=self._o(scope + "/batch_normalization/beta"),
                    mm_off=self.stat_layout.off(scope + "/batch_normalization/moving_mean"),
-                   mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"), y_hi=yh, y_lo=yl)
+                   mv_off=self.stat_layout.off(scope + "/batch_normalization/moving_variance"), y_hi=yh, y_lo=yl, **ykw)
         return (yh, yl) if emit_split else y
 
     def _conv_bwd(self, scope, xin, dy, cin, cout, k, act, N, T, Pp, tag, dx, need_dx=True, dx_accumulate=False,
@@ -632,8 +636,11 @@ class Tacotron2(object):
             xin = x16
         work = self._buf("bn_work", 200 * max(1024, cout), torch.float32)
         g = self.flat_g
+        dykw = {}
+        if isinstance(dy, tuple):           # (buffer, first column, row stride): dy as a column block of a wider gradient
+            dy, dykw = dy[0], dict(dy_off=dy[1], ld_dy=dy[2])
         ops.bn_bwd(dy, z, dpre, rows, cout, st[2 * cout:], st[3 * cout:], self.flat_p, g, g, g, work, N * T, act,
-                   sums=self._bwd_sums.pop(tag, None), row_mask=(Pp, self.padl, self.padl + T),
+                   sums=self._bwd_sums.pop(tag, None), row_mask=(Pp, self.padl, self.padl + T), **dykw,
                    gamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dgamma_off=self._o(scope + "/batch_normalization/gamma"),
                    dbeta_off=self._o(scope + "/batch_normalization/beta"),

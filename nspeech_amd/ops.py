@@ -163,11 +163,13 @@ def embedding_bwd(ids, dout, dtable, N, T, P, padl, D, V, dtable_off=0):
 
 def bn_fwd(z, y, rows, C, col_sum, col_sumsq, count, gamma, beta, moving_mean, moving_var, mean_out, istd_out,
            training, row_mask=None, eps=1e-3, momentum=0.99, gamma_off=0, beta_off=0, mm_off=0, mv_off=0,
-           y_hi=None, y_lo=None):
+           y_hi=None, y_lo=None, y_off=0, ld_y=0):
+    """y_off / ld_y: y as a column block of a wider [rows, ld_y] array (element offset of its first column)."""
     p = L.struct("ns_bn_fwd_params")
     if y_hi is not None:
         p.y_hi, p.y_lo = ptr(y_hi), ptr(y_lo)
-    _fill(p, z=ptr(z), y=ptr(y), dtype=dt(z), rows=rows, C=C, col_sum=ptr(col_sum), col_sumsq=ptr(col_sumsq),
+    p.ld_y = ld_y
+    _fill(p, z=ptr(z), y=ptr(y, y_off), dtype=dt(z), rows=rows, C=C, col_sum=ptr(col_sum), col_sumsq=ptr(col_sumsq),
           count=float(count), gamma=ptr(gamma, gamma_off), beta=ptr(beta, beta_off),
           moving_mean=ptr(moving_mean, mm_off), moving_var=ptr(moving_var, mv_off),
           mean_out=ptr(mean_out), istd_out=ptr(istd_out), eps=eps, momentum=momentum, training=int(training))
@@ -177,13 +179,15 @@ def bn_fwd(z, y, rows, C, col_sum, col_sumsq, count, gamma, beta, moving_mean, m
 
 
 def bn_bwd(dy, z, dpre, rows, C, mean, istd, gamma, dgamma, dbeta, dbias, work, count, act, row_mask=None,
-           gamma_off=0, dgamma_off=0, dbeta_off=0, dbias_off=0, sums=None):
-    """sums = (sum dy, sum dy * xhat) per column as left by the product that formed dy (gemm(..., stat_z=...))."""
+           gamma_off=0, dgamma_off=0, dbeta_off=0, dbias_off=0, sums=None, dy_off=0, ld_dy=0):
+    """sums = (sum dy, sum dy * xhat) per column as left by the product that formed dy (gemm(..., stat_z=...)).
+    dy_off / ld_dy: dy as a column block of a wider [rows, ld_dy] gradient."""
     p = L.struct("ns_bn_bwd_params")
+    p.ld_dy = ld_dy
     if sums is not None:
         p.sum_dy, p.sum_dyxh = ptr(sums[0]), ptr(sums[1])
     assert work.numel() >= 200 * C, "ns_bn_bwd: work needs 200 * C floats"
-    _fill(p, dy=ptr(dy), z=ptr(z), dpre=ptr(dpre), dtype=dt(z), rows=rows, C=C, mean=ptr(mean), istd=ptr(istd),
+    _fill(p, dy=ptr(dy, dy_off), z=ptr(z), dpre=ptr(dpre), dtype=dt(z), rows=rows, C=C, mean=ptr(mean), istd=ptr(istd),
           gamma=ptr(gamma, gamma_off), dgamma=ptr(dgamma, dgamma_off), dbeta=ptr(dbeta, dbeta_off),
           dbias=ptr(dbias, dbias_off), work=ptr(work), count=float(count), act=act)
     if dpre.dtype != z.dtype:
