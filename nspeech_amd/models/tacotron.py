@@ -954,6 +954,7 @@ class Tacotron(Tacotron2):
         ops.F32_PASSES = self.passes_bwd
         W, o, tsh = self._W(T_), self._o, self.tsh
         sk = self._splitk
+        self._x16_cache = {}                # bf16 copies of layer inputs made in this pass, by source (Tacotron2._conv_bwd)
 
         # ---- losses (tacotron.py:124-133): mel on the decoder output, linear with the 3 kHz band
         n_prio = int(3000 / (hp.sample_rate * 0.5) * F)

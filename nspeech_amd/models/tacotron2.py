@@ -631,8 +631,14 @@ class Tacotron2(object):
             assert w16 is not None
             xin = xin[0]
         elif w16 is not None:
-            x16 = self._buf("xin16_%d%s" % (cin, own), rows * cin, torch.bfloat16)
-            ops.cast2d(xin, rows, cin, cin, x16, cin, False)
+            # (layers that read the SAME input - the K convolutions of a CBHG bank - share one bf16 copy per backward pass)
+            cache, key = getattr(self, "_x16_cache", None), (xin.data_ptr(), rows, cin)
+            x16 = cache.get(key) if cache is not None else None
+            if x16 is None:
+                x16 = self._buf("xin16_%d%s" % (cin, own), rows * cin, torch.bfloat16)
+                ops.cast2d(xin, rows, cin, cin, x16, cin, False)
+                if cache is not None:
+                    cache[key] = x16
             xin = x16
         work = self._buf("bn_work", 200 * max(1024, cout), torch.float32)
         g = self.flat_g
