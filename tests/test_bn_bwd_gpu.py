@@ -112,3 +112,48 @@ def test_cast2d_forms(dev, rows, cols, transpose, dst):
     if hi is not None:
         h = want.to(torch.bfloat16)
         assert torch.equal(hi, h) and torch.equal(lo, (want - h.float()).to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C", [128, 6])          # the vector kernels (C % 4 == 0) and the scalar ones
+def test_batchnorm_on_a_column_block_of_a_wider_activation(dev, dtype, C):
+    """ns_bn_fwd_params.ld_y / ns_bn_bwd_params.ld_dy (round 5): the output written as a column block of a [rows, LD]
+    array, the backward pass reading dy from the same block of the wide gradient - bit for bit what the contiguous
+    call gives, and nothing outside the block touched (the CBHG convolution bank without its concatenation copies)."""
+    from nspeech_amd import ops
+    g = torch.Generator().manual_seed(C)
+    rows, LD, col = 75, (3 * C + 8) // 4 * 4, C + 4
+    period, lo, hi = 25, 2, 22
+    z = torch.randn(rows, C, generator=g).to(dtype).to(dev)
+    gamma = (1.0 + 0.1 * torch.randn(C, generator=g)).to(dev)
+    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
+    mm, mv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    zf = z.float()
+    m = torch.arange(rows, device=dev)
+    valid = ((m % period) >= lo) & ((m % period) < hi)
+    count = int(valid.sum())
+    st = torch.zeros(4 * C, device=dev)
+    st[:C] = (zf * valid[:, None]).sum(0)
+    st[C:2 * C] = (zf * zf * valid[:, None]).sum(0)
+    y0 = torch.full((rows, C), 7.0, dtype=dtype, device=dev)
+    wide = torch.full((rows, LD), 7.0, dtype=dtype, device=dev)
+    for y, kw in ((y0, {}), (wide, dict(y_off=col, ld_y=LD))):
+        ops.bn_fwd(z, y, rows, C, st, st[C:], count, gamma, beta, mm.clone(), mv.clone(), st[2 * C:], st[3 * C:], True,
+                   row_mask=(period, lo, hi), **kw)
+    assert torch.equal(wide[:, col:col + C], y0)
+    out = wide.clone()
+    out[:, col:col + C] = 7.0
+    assert bool((out == 7.0).all())                                   # nothing outside the block was written
+    dy = (torch.randn(rows, C, generator=g) * 0.3).to(dev)
+    dwide = torch.full((rows, LD), float("nan"), device=dev)
+    dwide[:, col:col + C] = dy
+    res = []
+    for d, kw in ((dy, {}), (dwide, dict(dy_off=col, ld_dy=LD))):
+        dpre = torch.zeros(rows, C, dtype=dtype, device=dev)
+        grads = torch.zeros(3 * C, device=dev)
+        work = torch.zeros(200 * max(1024, C), device=dev)
+        ops.bn_bwd(d, z, dpre, rows, C, st[2 * C:], st[3 * C:], gamma, grads, grads, grads, work, count, ACT_RELU,
+                   row_mask=(period, lo, hi), dgamma_off=0, dbeta_off=C, dbias_off=2 * C, **kw)
+        res.append((dpre.clone(), grads.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][1].abs().max()) > 0
