@@ -15,7 +15,8 @@ def test_probe_and_picked_stream(dev):
     keep = [torch.cuda.Stream() for _ in range(16)]
     pattern = [ops.streams_concurrent(cur, s) for s in keep]
     print("\nstreams 1..16 of this process beside the current one:", "".join("c" if c else "S" for c in pattern))
-    assert any(pattern)                                          # the device has more than one hardware queue
+    if not any(pattern):                                         # one hardware queue (GPU_MAX_HW_QUEUES=1?): nothing to pick from
+        pytest.skip("no second hardware queue on this device / runtime configuration")
     s = ops.concurrent_stream(torch.device("cuda:0"))
     assert ops.streams_concurrent(cur, s)
     # and the probe does what it says: a kernel queued on a NON-concurrent stream starts only after the current stream's
