@@ -262,6 +262,8 @@ def test_wavenet_helper_engine_equals_the_chain_engine(dev):
     p = m.numpy_params()
     p["wavenet/postprocessing/postprocess2"] = p["wavenet/postprocessing/postprocess2"] * 10.0
     m.load_numpy_params(p)
+    if m._helper(torch.device("cuda:0")) is None:
+        pytest.skip("no stream runs beside the current one on this runtime configuration: engine 2 is what generate() takes")
     for B, n_new in ((1, 40), (3, 24), (32, 6), (3, 24)):
         seeds = mu_law_encode(_audio(B, rf + 5, seed=4 + B), hp.quantization_channels)
         un = np.random.default_rng(2).random((B, n_new))
